@@ -1,0 +1,429 @@
+"""Host-side plan of the SynthesisModelCNN forward / backward on MI355X.
+
+Owns the geometry (padded row strides per stage), the HBM workspaces and the order in which the
+HIP entry points of ``libtonal_hip.so`` are enqueued.  Everything numerical happens inside those
+kernels; torch is used for buffer allocation, the label de-duplication (``torch.unique``) and the
+current stream only.
+
+Data layout: activations are channels-last, sequence-major: one *sequence* is one
+(batch element, ECoG channel) pair, ``seq = b*C + c``; a stage's tensor is a row-major matrix
+``[seq*Tp + t][channel]`` with ``Tp`` (rows per sequence) padded so every max-pool pair is
+row-aligned.  In that layout the (k,1) convolution of the reference
+(models/synthesis_models.py:86-105) is a GEMM whose A rows are overlapping windows of the
+activation matrix - no im2col copy exists anywhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_LRELU, EPI_MASK, EPI_POOL, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, NtParams, TnParams,
+                   check, ptr)
+
+
+def _r4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class _Stage:
+    """One ecog_conv_block stage (conv (k,1) + LeakyReLU [+ MaxPool (2,1)])."""
+
+    def __init__(self, idx, cin, cout, k, pool, tin, tp_in):
+        self.idx, self.cin, self.cout, self.k, self.pool = idx, cin, cout, k, pool
+        self.tin, self.tp_in = tin, tp_in
+        self.tc = tin - k + 1
+        self.tout = self.tc // 2 if pool else self.tc
+        self.tp_out = tp_in // 2 if pool else tp_in
+
+
+class CnnEngine:
+    def __init__(self, output_dim: int, n_channels: int, n_timepoints: int, lstm_channels: int,
+                 conv_channels: int, dropout: float, negative_slope: float, stage_defs, concat_widths):
+        if negative_slope < 0:
+            raise ValueError("the MI355X path needs negative_slope >= 0 (max-pool / LeakyReLU are fused)")
+        self.lib = _lib.load()
+        self.out_dim = output_dim
+        self.C = n_channels
+        self.T = n_timepoints
+        self.Lc = lstm_channels
+        self.Cc = conv_channels
+        self.p_drop = float(dropout)
+        self.slope = float(negative_slope)
+        self.cslope = 0.1                      # concat block slope, models/synthesis_models.py:118-130
+        # ---- geometry ----
+        k1 = stage_defs[0][1]
+        npool_after = sum(1 for s in stage_defs[1:] if s[2])
+        tc1 = n_timepoints - k1 + 1
+        self.k1 = k1
+        self.c1 = stage_defs[0][0]
+        self.tout1 = tc1 // 2
+        if not stage_defs[0][2]:
+            raise ValueError("first stage must pool")
+        align = 1 << npool_after
+        self.tp1 = max(align, (self.tout1 + align - 1) // align * align)
+        self.stages: List[_Stage] = []
+        cin, tin, tp = self.c1, self.tout1, self.tp1
+        for i, (cout, k, pool) in enumerate(stage_defs[1:], start=2):
+            st = _Stage(i, cin, cout, k, pool, tin, tp)
+            if st.tout < 1:
+                raise ValueError("n_timepoints too small for the conv stack")
+            self.stages.append(st)
+            cin, tin, tp = cout, st.tout, st.tp_out
+        self.lat = tin
+        self.tp5 = tp
+        self.H = self.lat * n_channels * lstm_channels
+        self.ld5 = _r4(conv_channels)
+        self.ldx = _r4(conv_channels + lstm_channels)
+        self.concat_dims = []                  # (cin_true, cin_ld, cout_true, cout_ld)
+        cin_t, cin_ld = conv_channels + lstm_channels, self.ldx
+        for w in concat_widths:
+            self.concat_dims.append((cin_t, cin_ld, w, _r4(w)))
+            cin_t, cin_ld = w, _r4(w)
+        self.ldy5 = self.concat_dims[-1][3]
+        self.kflat = n_channels * self.tp5 * self.ldy5
+        self.ldd = _r4(output_dim)
+        self.lowrank_param = "label_lstm.weight_hh_l0"   # reduced via gathered factors under DP
+        self._B = None
+        self.generation = 0
+        self._saved_generation = -1
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, B: int, dev):
+        if self._B == B and self._dev == dev:
+            return
+        self._B, self._dev = B, dev
+        S = B * self.C
+        self.S = S
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = lambda *s: torch.zeros(*s, **f32)
+        zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        self.P = {1: z(S * self.tp1, self.c1)}
+        self.bits = {1: zi(S * self.tp1, self.c1 // 32)}
+        for st in self.stages:
+            rows = S * st.tp_out
+            ld = st.cout if st.pool else self.ld5
+            self.P[st.idx] = z(rows, ld)
+            if st.pool:
+                self.bits[st.idx] = zi(rows, st.cout // 32)
+        rows5 = S * self.tp5
+        self.rows5 = rows5
+        self.Xc = z(rows5, self.ldx)
+        self.Y = [z(rows5, d[3]) for d in self.concat_dims]
+        self.out_slab = None
+        self.G = None          # gradient workspaces are allocated lazily on the first backward
+
+    def _alloc_bwd(self):
+        if self.G is not None:
+            return
+        dev = self._dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = lambda *s: torch.zeros(*s, **f32)
+        S = self.S
+        self.G = {1: z(S * self.tp1, self.c1)}
+        for st in self.stages:
+            self.G[st.idx] = z(S * st.tp_out, st.cout if st.pool else self.ld5)
+        self.GY = [z(self.rows5, d[3]) for d in self.concat_dims]
+        self.dXc = z(self.rows5, self.ldx)
+
+    # ------------------------------------------------------------------ ABI helpers
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _permute(self, src, dst, dims, strides, lims=None, nz=1, zs=0, src_off=0, bias=None):
+        d = (C.c_int64 * 4)(*dims)
+        s = (C.c_int64 * 4)(*strides)
+        l = (C.c_int64 * 4)(*(lims if lims is not None else dims))
+        check(self.lib.tl_permute_reduce(src.data_ptr() + 4 * src_off, dst.data_ptr(), d, s, l, nz, zs, ptr(bias),
+                                         self._stream()), "tl_permute_reduce")
+
+    def _nt(self, **kw):
+        p = NtParams()
+        p.splitk, p.bm, p.J, p.Tp, p.slope = 1, 128, 1, 1, 0.0
+        for k, v in kw.items():
+            setattr(p, k, v)
+        check(self.lib.tl_gemm_nt_window(C.byref(p), self._stream()), "tl_gemm_nt_window")
+
+    def _tn(self, **kw):
+        p = TnParams()
+        p.splitk, p.J, p.Tp, p.Tvalid = 1, 1, 1, 1
+        for k, v in kw.items():
+            setattr(p, k, v)
+        check(self.lib.tl_gemm_tn_window(C.byref(p), self._stream()), "tl_gemm_tn_window")
+
+    @staticmethod
+    def _splitk(tiles: int, ksteps: int, target: int = 2048) -> int:
+        return int(max(1, min(ksteps, (target + tiles - 1) // tiles, 1024)))
+
+    # ------------------------------------------------------------------ weight packing
+    def _pack_conv(self, w, cin_ld, flip_for_dgrad):
+        """torch (O, I, J, 1) -> forward pack [J][O][cin_ld] or dgrad pack [J'][I_ld][O_ld] (J flipped)."""
+        O, I, J, _ = w.shape
+        if not flip_for_dgrad:
+            dst = torch.empty(J, O, cin_ld, dtype=torch.float32, device=w.device)
+            self._permute(w, dst, (1, J, O, cin_ld), (0, 1, I * J, J), (1, J, O, I))
+            return dst
+        old = _r4(O)
+        dst = torch.empty(J, cin_ld, old, dtype=torch.float32, device=w.device)
+        # dst[j'][i][o] = w[o][i][J-1-j']
+        self._permute(w, dst, (1, J, cin_ld, old), (0, -1, J, I * J), (1, J, I, O), src_off=J - 1)
+        return dst
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,
+                save: bool, seed: int = 0) -> torch.Tensor:
+        B, Cn, T = x.shape
+        if Cn != self.C or T != self.T:
+            raise ValueError(f"expected ECoG input (B, {self.C}, {self.T}), got {tuple(x.shape)}")
+        if labels.dim() != 3 or labels.shape[0] != B or labels.shape[1] != 2:
+            raise ValueError(f"expected labels (B, 2, L), got {tuple(labels.shape)}")
+        x = x.contiguous().float()
+        labels = labels.contiguous().float()
+        dev = x.device
+        self._alloc(B, dev)
+        lib, st_ = self.lib, self._stream()
+        S = self.S
+        self.generation += 1
+        p_drop = self.p_drop if training else 0.0
+        self._p_drop_used, self._seed_used = p_drop, seed
+        self._x = x
+        # ---- stage 1 (C_in = 1) ----
+        w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
+        check(lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]), ptr(self.P[1]), ptr(self.bits[1]),
+                               S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd")
+        # ---- stages 2..5: windowed implicit GEMM on fp32 MFMA ----
+        self._wp = {}
+        names = {2: "ecog_conv_block.3", 3: "ecog_conv_block.6", 4: "ecog_conv_block.9", 5: "ecog_conv_block.12"}
+        for st in self.stages:
+            w = prm[names[st.idx] + ".weight"]
+            bia = prm[names[st.idx] + ".bias"]
+            wp = self._pack_conv(w, st.cin, False)
+            src = self.P[st.idx - 1]
+            kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(self.P[st.idx]), M=S * st.tp_in,
+                      A_rows=src.shape[0], N=st.cout, K=st.cin, lda=src.shape[1], ldb=st.cin,
+                      ldo=self.P[st.idx].shape[1], J=st.k, row_shift=0, Tp=st.tp_in, slope=self.slope,
+                      loader=LOAD_DIRECT)
+            if st.pool:
+                kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
+            else:
+                kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
+            self._nt(**kw)
+        # ---- label LSTM on the distinct label sequences ----
+        L = labels.shape[2]
+        flat = labels.reshape(B, 2 * L)
+        uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
+        U = uniq.shape[0]
+        self._U, self._L = U, L
+        self._uid = inv.to(torch.int32).contiguous()
+        H = self.H
+        xu = uniq.reshape(U, 2, L).permute(2, 0, 1).contiguous()          # (L, U, 2) time-major
+        self._xu = xu
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._act = torch.empty(L, U, 4 * H, **f32)
+        self._c = torch.empty(L, U, H, **f32)
+        self._h = torch.empty(L, U, H, **f32)
+        hh = torch.empty(U, 4 * H, **f32) if L > 1 else None
+        w_ih, w_hh = prm["label_lstm.weight_ih_l0"], prm["label_lstm.weight_hh_l0"]
+        b_ih, b_hh = prm["label_lstm.bias_ih_l0"], prm["label_lstm.bias_hh_l0"]
+        bm = 32 if U <= 64 else 128
+        for t in range(L):
+            if t > 0:
+                self._nt(A=ptr(self._h[t - 1]), Bw=ptr(w_hh), out=ptr(hh), M=U, A_rows=U, N=4 * H, K=H, lda=H,
+                         ldb=H, ldo=4 * H, loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm)
+            check(lib.tl_lstm_cell_fwd(ptr(hh) if t > 0 else None, ptr(xu[t]), ptr(w_ih), ptr(b_ih), ptr(b_hh),
+                                       ptr(self._c[t - 1]) if t > 0 else None, ptr(self._act[t]), ptr(self._c[t]),
+                                       ptr(self._h[t]), U, H, 2, 4 * H, st_), "tl_lstm_cell_fwd")
+        # ---- dropout + concat ----
+        check(lib.tl_concat_pack(ptr(self.P[5]), ptr(self._h[L - 1]), ptr(self._uid), ptr(self.Xc), B, self.C,
+                                 self.tp5, self.lat, self.Cc, self.Lc, self.ld5, H, self.ldx, p_drop, seed, st_),
+              "tl_concat_pack")
+        # ---- concat 1x1 stack ----
+        src = self.Xc
+        self._wc = []
+        for i, (cin_t, cin_ld, cout_t, cout_ld) in enumerate(self.concat_dims):
+            w = prm[f"concat_conv_block.{2 * i}.weight"]
+            bia = prm[f"concat_conv_block.{2 * i}.bias"]
+            wp = self._pack_conv(w, cin_ld, False)
+            self._nt(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(self.Y[i]), M=self.rows5, A_rows=self.rows5,
+                     N=cout_t, K=cin_ld, lda=cin_ld, ldb=cin_ld, ldo=cout_ld, loader=LOAD_DIRECT,
+                     epilogue=EPI_LRELU, slope=self.cslope, Tp=self.tp5, Tvalid=self.lat)
+            src = self.Y[i]
+        # ---- output Linear: (B, kflat) x (out_dim, kflat)^T, split-K ----
+        wo = prm["output_layer.weight"]
+        wpo = torch.empty(self.out_dim, self.kflat, **f32)
+        latC = self.lat * self.C
+        self._permute(wo, wpo, (self.out_dim, self.C, self.tp5, self.ldy5), (self.Cc * latC, 1, self.C, latC),
+                      (self.out_dim, self.C, self.lat, self.Cc))
+        self._wpo = wpo
+        nkc = (self.kflat + 31) // 32
+        tiles = ((B + 127) // 128) * ((self.out_dim + 127) // 128)
+        sk = self._splitk(tiles, nkc, 1024)
+        slab = torch.empty(sk, B, self.out_dim, **f32)
+        self._nt(A=ptr(self.Y[-1]), Bw=ptr(wpo), out=ptr(slab), M=B, A_rows=B, N=self.out_dim, K=self.kflat,
+                 lda=self.kflat, ldb=self.kflat, ldo=self.out_dim, loader=LOAD_DIRECT, epilogue=EPI_STORE,
+                 splitk=sk, slab_stride=B * self.out_dim)
+        out = torch.empty(B, self.out_dim, **f32)
+        self._permute(slab, out, (1, 1, B, self.out_dim), (0, 0, self.out_dim, 1), nz=sk, zs=B * self.out_dim,
+                      bias=prm["output_layer.bias"])
+        if save:
+            self._saved_generation = self.generation
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, prm: Dict[str, torch.Tensor], dout: torch.Tensor, grads: Dict[str, torch.Tensor],
+                 gather_whh=None) -> None:
+        """dout: (B, ldd) gradient of the loss w.r.t. the output (pad columns zero).
+        Fills ``grads[name]`` (torch layouts) for every parameter.  ``gather_whh(dg, h)`` may
+        return the low-rank factors of every data-parallel rank (parallel.gather_lowrank): the
+        W_hh gradient written is then already the sum over ranks."""
+        if self._saved_generation != self.generation:
+            raise RuntimeError("SynthesisModelCNN backward: the forward intermediates were overwritten by a later "
+                               "forward pass (one forward/backward pair at a time per model)")
+        self._alloc_bwd()
+        lib, st_ = self.lib, self._stream()
+        B, S, dev = self._B, self.S, self._dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        H, U, L = self.H, self._U, self._L
+        rows5 = self.rows5
+
+        def colsum(Gm, rows, ncols, ld, Tp, Tvalid, dst):
+            nblk = int(min(512, max(1, rows // 64)))
+            part = torch.empty(nblk, ncols, **f32)
+            check(lib.tl_colsum(ptr(Gm), ptr(part), nblk, rows, ncols, ld, Tp, Tvalid, st_), "tl_colsum")
+            self._permute(part, dst, (1, 1, 1, ncols), (0, 0, 0, 1), nz=nblk, zs=ncols)
+
+        # ---- output layer ----
+        gw = grads["output_layer.weight"]
+        slab = torch.empty(self.ldd, self.kflat, **f32)
+        self._tn(A=ptr(dout), B=ptr(self.Y[-1]), slab=ptr(slab), Krows=B, A_rows=B, B_rows=B, Mdim=self.ldd,
+                 Ndim=self.kflat, lda=self.ldd, ldb=self.kflat, ldc=self.kflat, loader=LOAD_DIRECT)
+        latC = self.lat * self.C
+        self._permute(slab, gw, (self.out_dim, self.Cc, self.lat, self.C),
+                      (self.kflat, 1, self.ldy5, self.tp5 * self.ldy5))
+        colsum(dout, B, self.out_dim, self.ldd, 1, 1, grads["output_layer.bias"])
+        # dY5 = dout . Wp_out, masked by lrelu'(Y5)
+        wpt = torch.empty(self.kflat, self.ldd, **f32)
+        self._permute(prm["output_layer.weight"], wpt, (self.C, self.tp5, self.ldy5, self.ldd),
+                      (1, self.C, latC, self.Cc * latC), (self.C, self.lat, self.Cc, self.out_dim))
+        self._nt(A=ptr(dout), Bw=ptr(wpt), aux=ptr(self.Y[-1]), out=ptr(self.GY[-1]), M=B, A_rows=B, N=self.kflat,
+                 K=self.ldd, lda=self.ldd, ldb=self.ldd, ldo=self.kflat, ldaux=self.kflat, loader=LOAD_DIRECT,
+                 epilogue=EPI_MASK, slope=self.cslope)
+        del wpt
+        # ---- concat 1x1 stack, last to first ----
+        for i in range(len(self.concat_dims) - 1, -1, -1):
+            cin_t, cin_ld, cout_t, cout_ld = self.concat_dims[i]
+            src = self.Xc if i == 0 else self.Y[i - 1]
+            Gi = self.GY[i]
+            name = f"concat_conv_block.{2 * i}"
+            tiles = ((cin_ld + 127) // 128) * ((cout_ld + 127) // 128)
+            sk = self._splitk(tiles, (rows5 + 31) // 32)
+            slab = torch.empty(sk, cin_ld, cout_ld, **f32)
+            self._tn(A=ptr(src), B=ptr(Gi), slab=ptr(slab), Krows=rows5, A_rows=rows5, B_rows=rows5, Mdim=cin_ld,
+                     Ndim=cout_ld, lda=cin_ld, ldb=cout_ld, ldc=cout_ld, loader=LOAD_DIRECT, Tp=self.tp5,
+                     Tvalid=self.lat, splitk=sk, slab_stride=cin_ld * cout_ld)
+            self._permute(slab, grads[name + ".weight"], (1, 1, cout_t, cin_t), (0, 0, 1, cout_ld), nz=sk,
+                          zs=cin_ld * cout_ld)
+            colsum(Gi, rows5, cout_t, cout_ld, self.tp5, self.lat, grads[name + ".bias"])
+            wd = self._pack_conv(prm[name + ".weight"], cin_ld, True)          # [1][cin_ld][cout_ld]
+            if i > 0:
+                self._nt(A=ptr(Gi), Bw=ptr(wd), aux=ptr(src), out=ptr(self.GY[i - 1]), M=rows5, A_rows=rows5,
+                         N=cin_ld, K=cout_ld, lda=cout_ld, ldb=cout_ld, ldo=cin_ld, ldaux=cin_ld, loader=LOAD_DIRECT,
+                         epilogue=EPI_MASK, slope=self.cslope)
+            else:
+                self._nt(A=ptr(Gi), Bw=ptr(wd), out=ptr(self.dXc), M=rows5, A_rows=rows5, N=cin_ld, K=cout_ld,
+                         lda=cout_ld, ldb=cout_ld, ldo=cin_ld, loader=LOAD_DIRECT, epilogue=EPI_STORE)
+        # ---- un-concat: G5 (dropout + lrelu') and dh summed over duplicates ----
+        order = torch.argsort(self._uid, stable=True).to(torch.int32)
+        counts = torch.bincount(self._uid, minlength=U)
+        offsets = torch.zeros(U + 1, dtype=torch.int32, device=dev)
+        offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        dh_ext = torch.empty(U, H, **f32)
+        check(lib.tl_concat_unpack_bwd(ptr(self.dXc), ptr(self.P[5]), ptr(order), ptr(offsets), ptr(self.G[5]),
+                                       ptr(dh_ext), B, U, self.C, self.tp5, self.lat, self.Cc, self.Lc, self.ld5, H,
+                                       self.ldx, self.slope, self._p_drop_used, self._seed_used, st_),
+              "tl_concat_unpack_bwd")
+        # ---- LSTM BPTT on the distinct rows ----
+        w_hh = prm["label_lstm.weight_hh_l0"]
+        ldt = (U + 31) // 32 * 32
+        dg = torch.empty(L, U, 4 * H, **f32)
+        dgt = torch.zeros(4 * H, ldt, **f32) if L > 1 else None
+        dc = [torch.empty(U, H, **f32), torch.empty(U, H, **f32)]
+        dhrec = torch.empty(U, H, **f32) if L > 1 else None
+        if L > 1:
+            tiles = (ldt + 127) // 128 * ((H + 127) // 128)
+            sk_h = self._splitk(tiles, (4 * H + 31) // 32, 1024)
+            slab_h = torch.empty(sk_h, ldt, H, **f32)
+        for t in range(L - 1, -1, -1):
+            check(lib.tl_lstm_cell_bwd(ptr(dh_ext) if t == L - 1 else None, ptr(dhrec) if t < L - 1 else None,
+                                       ptr(dc[(t + 1) & 1]) if t < L - 1 else None, ptr(self._act[t]), ptr(self._c[t]),
+                                       ptr(self._c[t - 1]) if t > 0 else None, ptr(dg[t]),
+                                       ptr(dgt) if t > 0 else None, ptr(dc[t & 1]), U, H, ldt, st_), "tl_lstm_cell_bwd")
+            if t > 0:
+                self._tn(A=ptr(dgt), B=ptr(w_hh), slab=ptr(slab_h), Krows=4 * H, A_rows=4 * H, B_rows=4 * H, Mdim=ldt,
+                         Ndim=H, lda=ldt, ldb=H, ldc=H, loader=LOAD_DIRECT, splitk=sk_h, slab_stride=ldt * H)
+                self._permute(slab_h, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=sk_h, zs=ldt * H)
+        gwhh = grads["label_lstm.weight_hh_l0"]
+        if L > 1:
+            kr = (L - 1) * U
+            fa, fb = dg[1:].reshape(kr, 4 * H), self._h[:L - 1].reshape(kr, H)
+            if gather_whh is not None:
+                fa, fb = gather_whh(fa, fb)
+                kr = fa.shape[0]
+            self._tn(A=ptr(fa), B=ptr(fb), slab=ptr(gwhh), Krows=kr, A_rows=kr, B_rows=kr, Mdim=4 * H, Ndim=H,
+                     lda=4 * H, ldb=H, ldc=H, loader=LOAD_DIRECT)
+            del fa, fb
+        else:
+            gwhh.zero_()
+        gb = grads["label_lstm.bias_ih_l0"]
+        check(lib.tl_lstm_ih_grad(ptr(dg), ptr(self._xu), ptr(grads["label_lstm.weight_ih_l0"]), ptr(gb), L, U, H, 2,
+                                  st_), "tl_lstm_ih_grad")
+        grads["label_lstm.bias_hh_l0"].copy_(gb)
+        del dg, dgt
+        # ---- ecog stages 5..2 ----
+        names = {2: "ecog_conv_block.3", 3: "ecog_conv_block.6", 4: "ecog_conv_block.9", 5: "ecog_conv_block.12"}
+        for st in reversed(self.stages):
+            name = names[st.idx]
+            Xin = self.P[st.idx - 1]
+            Gs = self.G[st.idx]
+            rows_in = S * st.tp_in
+            ldg = Gs.shape[1]
+            nd = _r4(st.cout)
+            tiles = st.k * ((st.cin + 127) // 128) * ((nd + 127) // 128)
+            sk = self._splitk(tiles, (rows_in + 31) // 32)
+            slab = torch.empty(sk, st.k * st.cin, ldg, **f32)
+            kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0],
+                      Mdim=st.cin, Ndim=nd, lda=st.cin, ldb=ldg, ldc=ldg, J=st.k, Tp=st.tp_in, splitk=sk,
+                      slab_stride=st.k * st.cin * ldg)
+            if st.pool:
+                kw.update(loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
+            else:
+                kw.update(loader=LOAD_DIRECT, Tvalid=st.tout)
+            self._tn(**kw)
+            # slab[z][j][i][o] -> torch (O, I, J, 1)
+            self._permute(slab, grads[name + ".weight"], (1, st.cout, st.cin, st.k), (0, 1, ldg, st.cin * ldg), nz=sk,
+                          zs=st.k * st.cin * ldg)
+            colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, grads[name + ".bias"])
+            wd = self._pack_conv(prm[name + ".weight"], st.cin, True)           # [J][cin][r4(cout)]
+            kd = wd.shape[2]
+            kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=ptr(self.G[st.idx - 1]), M=rows_in, A_rows=Gs.shape[0],
+                      N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k, row_shift=-(st.k - 1),
+                      Tp=st.tp_in, epilogue=EPI_MASK, slope=self.slope)
+            if st.pool:
+                kw.update(loader=LOAD_UNPOOL, abits=ptr(self.bits[st.idx]), ld_abits=st.cout // 32,
+                          Tvalid_in=2 * st.tout)
+            else:
+                kw.update(loader=LOAD_DIRECT)
+            self._nt(**kw)
+        # ---- stage 1 weight / bias gradient ----
+        nblk = int(min(1024, S))
+        part = torch.empty(nblk, (self.k1 + 1) * self.c1, **f32)
+        check(lib.tl_conv1_wgrad(ptr(self._x), ptr(self.G[1]), ptr(self.bits[1]), ptr(part), nblk, S, self.T, self.k1,
+                                 self.c1, self.tp1, self.tout1, st_), "tl_conv1_wgrad")
+        zs = (self.k1 + 1) * self.c1
+        self._permute(part, grads["ecog_conv_block.0.weight"], (1, 1, self.c1, self.k1), (0, 0, 1, self.c1), nz=nblk,
+                      zs=zs)
+        self._permute(part, grads["ecog_conv_block.0.bias"], (1, 1, 1, self.c1), (0, 0, 0, 1), nz=nblk, zs=zs,
+                      src_off=self.k1 * self.c1)

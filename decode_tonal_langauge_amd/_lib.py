@@ -1,0 +1,121 @@
+"""ctypes binding of ``libtonal_hip.so`` (the C ABI declared in ``include/tonal_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile``.  There is no CPU
+fallback anywhere in this package: if the shared object is missing, or a kernel entry point
+reports an error, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtonal_hip.so")
+
+# epilogue / loader codes of tl_gemm_nt_window (include/tonal_hip.h)
+LOAD_DIRECT, LOAD_UNPOOL = 0, 1
+EPI_STORE, EPI_LRELU, EPI_POOL, EPI_MASK = 0, 1, 2, 3
+
+
+class NtParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("abits", C.c_void_p), ("Bw", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p),
+        ("out", C.c_void_p), ("obits", C.c_void_p),
+        ("M", C.c_int64), ("A_rows", C.c_int64),
+        ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldb", C.c_int), ("ldo", C.c_int), ("ldaux", C.c_int), ("ld_abits", C.c_int),
+        ("ld_obits", C.c_int),
+        ("J", C.c_int), ("row_shift", C.c_int),
+        ("Tp", C.c_int), ("Tvalid", C.c_int), ("Tvalid_in", C.c_int),
+        ("slope", C.c_float),
+        ("loader", C.c_int), ("epilogue", C.c_int),
+        ("splitk", C.c_int), ("slab_stride", C.c_int64),
+        ("bm", C.c_int),
+    ]
+
+
+class TnParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("bbits", C.c_void_p), ("slab", C.c_void_p),
+        ("Krows", C.c_int64), ("A_rows", C.c_int64), ("B_rows", C.c_int64),
+        ("Mdim", C.c_int), ("Ndim", C.c_int),
+        ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ld_bbits", C.c_int),
+        ("J", C.c_int), ("Tp", C.c_int), ("Tvalid", C.c_int), ("loader", C.c_int),
+        ("splitk", C.c_int), ("slab_stride", C.c_int64),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+
+#: every symbol include/tonal_hip.h declares -> (restype, argtypes)
+SIGNATURES = {
+    "tl_last_error": (C.c_char_p, []),
+    "tl_version": (_I, []),
+    "tl_device_count": (_I, []),
+    "tl_gemm_nt_window": (_I, [C.POINTER(NtParams), _P]),
+    "tl_gemm_tn_window": (_I, [C.POINTER(TnParams), _P]),
+    "tl_conv1_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
+    "tl_conv1_wgrad": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P]),
+    "tl_permute_reduce": (_I, [_P, _P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _L, _P, _P]),
+    "tl_colsum": (_I, [_P, _P, _I, _L, _I, _I, _I, _I, _P]),
+    "tl_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "tl_lstm_ih_grad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tl_concat_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint64, _P]),
+    "tl_concat_unpack_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F,
+                                  C.c_uint64, _P]),
+    "tl_l1_mcd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "tl_nadam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "tl_tone_dynamics": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "tl_gauss_envelope": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
+    "tl_filtfilt_f64": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
+    "tl_sosfilt_f64": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),
+    "tl_fir_bank": (_I, [_P, _I, _P, _P, _I, _I, _L, _I, _I, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared object (once) and type every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C decode_tonal_langauge_amd/csrc`). This package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().tl_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on '{t.device}'. The MI355X path runs HIP kernels only and has no CPU "
+            "fallback; move the model and its inputs to a 'cuda' device.")

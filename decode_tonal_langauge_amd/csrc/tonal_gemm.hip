@@ -1,0 +1,506 @@
+// fp32 MFMA implicit-GEMM kernels for gfx950 (MI355X): windowed NT (forward / input-gradient
+// of the (k,1) convolutions, Linear, LSTM h.W_hh^T) and windowed TN (weight gradients).
+//
+// Both use v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  A single accumulator chain
+// already issues back to back (64-cycle issue = 64-cycle dependent latency), so the design
+// effort goes into keeping the matrix pipe fed: register-staged global loads issued one K-step
+// ahead, LDS double buffering with one barrier per K-step, 2 workgroups (8 waves) per CU.
+#include "tonal_common.h"
+
+namespace tl {
+
+constexpr int BN = 128;   // column tile
+constexpr int BK = 32;    // K depth of one LDS stage
+constexpr int LDS_LD = BK + 4;   // 36 floats = 144 B rows: conflict-free ds_read_b128 (9 odd)
+
+enum { LOAD_DIRECT = 0, LOAD_UNPOOL = 1 };
+enum { EPI_STORE = 0, EPI_LRELU = 1, EPI_POOL = 2, EPI_MASK = 3 };
+
+// ------------------------------------------------------------------------------------------
+// NT window kernel
+// ------------------------------------------------------------------------------------------
+template <int BM, int LOADER, int EPI>
+__global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p) {
+  constexpr int WM = (BM == 128) ? 2 : 1;          // waves along M
+  constexpr int WN = 4 / WM;                       // waves along N
+  constexpr int MI = BM / (32 * WM);               // 32x32 tiles per wave along M
+  constexpr int NI = BN / (32 * WN);
+  constexpr int AROWS = BM + 2;                    // staged rows incl. the tap window (J <= 3)
+  constexpr int A_F4 = (LOADER == LOAD_DIRECT) ? ((AROWS * 8 + 255) / 256) : ((AROWS / 2 * 8 + 255) / 256);
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * AROWS * LDS_LD + 2 * BN * LDS_LD];
+  float* As = lds;                                 // [2][AROWS][LDS_LD]
+  float* Bs = lds + 2 * AROWS * LDS_LD;            // [2][BN][LDS_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD/L2, so give each XCD a contiguous
+  // run of logical tiles; consecutive logical tiles walk N first and share the A panel.
+  const int ntn = (p.N + BN - 1) / BN;
+  const long long ntm = (p.M + BM - 1) / BM;
+  const long long nwg = ntm * ntn;
+  long long bid = blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const long long tm = bid / ntn;
+  const int tn = (int)(bid % ntn);
+  const long long R0 = tm * BM;
+  const int n0 = tn * BN;
+  const int J = p.J;
+  const int arows_used = BM + J - 1;
+
+  // K range (split-K only meaningful for J == 1 plain GEMMs, but handled generally)
+  const int nkc_all = (p.K + BK - 1) / BK;
+  const int z = blockIdx.y;
+  const int kc_per = (nkc_all + p.splitk - 1) / p.splitk;
+  const int kc_begin = z * kc_per;
+  const int kc_end = min(nkc_all, kc_begin + kc_per);
+  const int nchunks = max(0, kc_end - kc_begin);
+  const int nsteps = nchunks * J;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 ra[A_F4];          // staged A (DIRECT) or G (UNPOOL)
+  uint32_t rbits[A_F4];    // UNPOOL: 4-bit arg nibble (bit set -> odd row of the pair)
+  f32x4 rb[4];
+
+  const long long Abase = R0 + p.row_shift;        // first staged A row (even for UNPOOL)
+
+  auto load_a = [&](int chunk) {
+    const int kc = (kc_begin + chunk) * BK;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 3, c4 = idx & 7;
+      const int k = kc + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      uint32_t nib = 0;
+      if constexpr (LOADER == LOAD_DIRECT) {
+        const long long row = Abase + r;
+        if (r < arows_used && row >= 0 && row < p.A_rows && k < p.K)
+          v = *reinterpret_cast<const f32x4*>(p.A + row * (long long)p.lda + k);
+      } else {
+        const long long prow = (Abase >> 1) + r;   // Abase is even
+        const bool ok = (r < (arows_used + 1) / 2) && prow >= 0 && prow < p.A_rows && k < p.K &&
+                        (int)((2 * prow) % p.Tp) < p.Tvalid_in;
+        if (ok) {
+          v = *reinterpret_cast<const f32x4*>(p.A + prow * (long long)p.lda + k);
+          const uint32_t w = p.abits[prow * (long long)p.ld_abits + (k >> 5)];
+          nib = (w >> (k & 31)) & 0xFu;
+        }
+      }
+      ra[i] = v;
+      rbits[i] = nib;
+    }
+  };
+  auto store_a = [&](int buf) {
+    float* dst = As + buf * AROWS * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 3, c4 = idx & 7;
+      if constexpr (LOADER == LOAD_DIRECT) {
+        if (r < AROWS) *reinterpret_cast<f32x4*>(dst + r * LDS_LD + c4 * 4) = ra[i];
+      } else {
+        if (r < AROWS / 2) {
+          f32x4 e, o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool odd = (rbits[i] >> q) & 1u;
+            e[q] = odd ? 0.f : ra[i][q];
+            o[q] = odd ? ra[i][q] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(dst + (2 * r) * LDS_LD + c4 * 4) = e;
+          *reinterpret_cast<f32x4*>(dst + (2 * r + 1) * LDS_LD + c4 * 4) = o;
+        }
+      }
+    }
+  };
+  auto load_b = [&](int chunk, int j) {
+    const int kc = (kc_begin + chunk) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 3, c4 = idx & 7;
+      const int n = n0 + r, k = kc + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < p.N && k < p.K)
+        v = *reinterpret_cast<const f32x4*>(p.Bw + ((long long)j * p.N + n) * (long long)p.ldb + k);
+      rb[i] = v;
+    }
+  };
+  auto store_b = [&](int buf) {
+    float* dst = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<f32x4*>(dst + r * LDS_LD + c4 * 4) = rb[i];
+    }
+  };
+
+  if (nsteps > 0) {
+    load_a(0);
+    load_b(0, 0);
+    store_a(0);
+    store_b(0);
+  }
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int chunk = s / J, j = s - chunk * J;
+    const int s1 = s + 1;
+    const int chunk1 = s1 / J, j1 = s1 - chunk1 * J;
+    const bool more = s1 < nsteps;
+    const bool newa = more && (j1 == 0);
+    if (more) {
+      load_b(chunk1, j1);
+      if (newa) load_a(chunk1);
+    }
+    const float* a_s = As + (chunk & 1) * AROWS * LDS_LD + (wm * (MI * 32) + lr + j) * LDS_LD + lh * 4;
+    const float* b_s = Bs + (s & 1) * BN * LDS_LD + (wn * (NI * 32) + lr) * LDS_LD + lh * 4;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fb[i] = *reinterpret_cast<const f32x4*>(b_s + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][q], fb[ni][q], acc[mi][ni], 0, 0, 0);
+    }
+    if (more) {
+      store_b(s1 & 1);
+      if (newa) store_a(chunk1 & 1);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------- epilogue ----------------------------------
+  // C/D map of 32x32x2: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = n0 + wn * (NI * 32) + ni * 32 + lr;
+      const bool colok = col < p.N;
+      const long long rbase = R0 + wm * (MI * 32) + mi * 32;
+      if constexpr (EPI == EPI_POOL) {
+        const float bv = (colok && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long long Rq = rbase + 8 * q + 4 * lh;        // even conv row of this lane's 4 rows
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float y0 = lrelu(acc[mi][ni][4 * q + 2 * e] + bv, p.slope);
+            const float y1 = lrelu(acc[mi][ni][4 * q + 2 * e + 1] + bv, p.slope);
+            const bool rowok = (Rq + 2 * e) < p.M;              // Tp, Tvalid even: the pair shares validity
+            const bool valid_e = rowok && (int)((Rq + 2 * e) % p.Tp) < p.Tvalid;
+            const bool sel = valid_e && colok && (y1 > y0);
+            const float o = valid_e ? (sel ? y1 : y0) : 0.f;
+            const long long prow = (Rq >> 1) + e;
+            if (rowok && colok) p.out[prow * (long long)p.ldo + col] = o;
+            const unsigned long long m = __ballot(sel);
+            if (lr == 0 && rowok && (n0 + wn * (NI * 32) + ni * 32) < p.N)
+              p.obits[prow * (long long)p.ld_obits + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] =
+                  (uint32_t)(m >> (32 * lh));
+          }
+        }
+      } else {
+        float bv = 0.f;
+        if constexpr (EPI == EPI_STORE || EPI == EPI_LRELU) bv = (colok && p.bias && p.splitk == 1) ? p.bias[col] : 0.f;
+        float* outp = p.out + (long long)z * p.slab_stride;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long R = rbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (R < p.M && colok) {
+            float v = acc[mi][ni][e] + bv;
+            if constexpr (EPI == EPI_LRELU) v = lrelu(v, p.slope);
+            if constexpr (EPI == EPI_MASK) {
+              const float a = p.aux[R * (long long)p.ldaux + col];
+              v = a > 0.f ? v : v * p.slope;
+            }
+            outp[R * (long long)p.ldo + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int LOADER, int EPI>
+static int launch_nt(const tl_nt_params& p, hipStream_t st) {
+  const long long ntm = (p.M + BM - 1) / BM;
+  const long long ntn = (p.N + BN - 1) / BN;
+  const long long nwg = ntm * ntn;
+  if (nwg <= 0) return TL_OK;
+  TL_REQUIRE(nwg < (1LL << 31), "nt_window: grid too large");
+  dim3 grid((unsigned)nwg, (unsigned)p.splitk, 1);
+  hipLaunchKernelGGL((nt_window_kernel<BM, LOADER, EPI>), grid, dim3(256), 0, st, p);
+  return check_launch("nt_window");
+}
+
+template <int BM>
+static int dispatch_nt(const tl_nt_params& p, hipStream_t st) {
+  if (p.loader == LOAD_DIRECT) {
+    switch (p.epilogue) {
+      case EPI_STORE: return launch_nt<BM, LOAD_DIRECT, EPI_STORE>(p, st);
+      case EPI_LRELU: return launch_nt<BM, LOAD_DIRECT, EPI_LRELU>(p, st);
+      case EPI_POOL: return launch_nt<BM, LOAD_DIRECT, EPI_POOL>(p, st);
+      case EPI_MASK: return launch_nt<BM, LOAD_DIRECT, EPI_MASK>(p, st);
+    }
+  } else {
+    switch (p.epilogue) {
+      case EPI_STORE: return launch_nt<BM, LOAD_UNPOOL, EPI_STORE>(p, st);
+      case EPI_MASK: return launch_nt<BM, LOAD_UNPOOL, EPI_MASK>(p, st);
+    }
+  }
+  set_error("nt_window: unsupported loader/epilogue combination %d/%d", p.loader, p.epilogue);
+  return TL_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------
+// TN window kernel: slab[z][j*Mdim + m][n] = sum_R A[R + j][m] * Bz[R][n]
+// LDS tiles are k-major ([BK][128 + 4]); fragments are conflict-free ds_read_b32.
+// ------------------------------------------------------------------------------------------
+constexpr int TN_LD = 128 + 4;
+
+template <int LOADER>
+__global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * TN_LD];
+  float* As = lds;                        // [2][BK][TN_LD]
+  float* Bs = lds + 2 * BK * TN_LD;       // [2][BK][TN_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int ntm1 = (p.Mdim + 127) / 128;          // m tiles per tap
+  const int ntn = (p.Ndim + 127) / 128;
+  // blockIdx.x -> (tap j, m tile, n tile): n fastest so that neighbours share the A panel
+  int bid = blockIdx.x;
+  const int tn = bid % ntn;
+  bid /= ntn;
+  const int tm = bid % ntm1;
+  const int j = bid / ntm1;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int z = blockIdx.y;
+
+  const long long ksteps_all = (p.Krows + BK - 1) / BK;
+  const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const long long nsteps = ks_end > ks_begin ? ks_end - ks_begin : 0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  uint32_t rnib[2];
+  (void)rnib;
+
+  auto load_tiles = [&](long long step) {
+    const long long k0 = (ks_begin + step) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 5, c4 = idx & 31;
+      const long long row = k0 + r + j;
+      const int m = m0 + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < p.A_rows && (k0 + r) < p.Krows && m < p.Mdim)
+        v = *reinterpret_cast<const f32x4*>(p.A + row * (long long)p.lda + m);
+      ra[i] = v;
+    }
+    if constexpr (LOADER == LOAD_DIRECT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;
+        const int r = idx >> 5, c4 = idx & 31;
+        const long long row = k0 + r;
+        const int n = n0 + c4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < p.Krows && row < p.B_rows && n < p.Ndim && (int)(row % p.Tp) < p.Tvalid)
+          v = *reinterpret_cast<const f32x4*>(p.B + row * (long long)p.ldb + n);
+        rb[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        const int pr = idx >> 5, c4 = idx & 31;
+        const long long prow = (k0 >> 1) + pr;        // k0 is a multiple of BK (even)
+        const int n = n0 + c4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        uint32_t nib = 0;
+        if (2 * prow < p.Krows && prow < p.B_rows && n < p.Ndim && (int)((2 * prow) % p.Tp) < p.Tvalid) {
+          v = *reinterpret_cast<const f32x4*>(p.B + prow * (long long)p.ldb + n);
+          const uint32_t w = p.bbits[prow * (long long)p.ld_bbits + (n >> 5)];
+          nib = (w >> (n & 31)) & 0xFu;
+        }
+        rb[i] = v;
+        rnib[i] = nib;
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* da = As + buf * BK * TN_LD;
+    float* db = Bs + buf * BK * TN_LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<f32x4*>(da + r * TN_LD + c4 * 4) = ra[i];
+    }
+    if constexpr (LOADER == LOAD_DIRECT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256;
+        const int r = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<f32x4*>(db + r * TN_LD + c4 * 4) = rb[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        const int pr = idx >> 5, c4 = idx & 31;
+        f32x4 e, o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool odd = (rnib[i] >> q) & 1u;
+          e[q] = odd ? 0.f : rb[i][q];
+          o[q] = odd ? rb[i][q] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(db + (2 * pr) * TN_LD + c4 * 4) = e;
+        *reinterpret_cast<f32x4*>(db + (2 * pr + 1) * TN_LD + c4 * 4) = o;
+      }
+    }
+  };
+
+  if (nsteps > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (long long s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    if (more) load_tiles(s + 1);
+    const float* a_s = As + (s & 1) * BK * TN_LD + lh * TN_LD + wm * 64 + lr;
+    const float* b_s = Bs + (s & 1) * BK * TN_LD + lh * TN_LD + wn * 64 + lr;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float fa[2], fb[2];
+      fa[0] = a_s[kk * 2 * TN_LD];
+      fa[1] = a_s[kk * 2 * TN_LD + 32];
+      fb[0] = b_s[kk * 2 * TN_LD];
+      fb[1] = b_s[kk * 2 * TN_LD + 32];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (more) store_tiles((s + 1) & 1);
+    __syncthreads();
+  }
+
+  float* out = p.slab + (long long)z * p.slab_stride;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + ni * 32 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.Mdim && col < p.Ndim)
+          out[((long long)j * p.Mdim + m) * (long long)p.ldc + col] = acc[mi][ni][e];
+      }
+    }
+}
+
+}  // namespace tl
+
+extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "nt_window: null params");
+  tl_nt_params p = *pp;
+  if (p.splitk < 1) p.splitk = 1;
+  if (p.bm == 0) p.bm = 128;
+  TL_REQUIRE(p.A && p.Bw && p.out, "nt_window: null A/Bw/out");
+  TL_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0, "nt_window: bad M/N/K %lld/%d/%d", (long long)p.M, p.N, p.K);
+  TL_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "nt_window: K, lda, ldb must be multiples of 4");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K, "nt_window: lda/ldb smaller than K");
+  TL_REQUIRE(p.J >= 1 && p.J <= 3, "nt_window: J must be 1..3");
+  TL_REQUIRE(p.row_shift == 0 || p.row_shift == -(p.J - 1), "nt_window: row_shift must be 0 or -(J-1)");
+  TL_REQUIRE(p.bm == 128 || p.bm == 32, "nt_window: bm must be 128 or 32");
+  TL_REQUIRE(p.Tp > 0, "nt_window: Tp must be positive");
+  TL_REQUIRE(p.splitk == 1 || p.epilogue == EPI_STORE, "nt_window: split-K needs the STORE epilogue");
+  TL_REQUIRE(p.splitk <= 65535, "nt_window: splitk too large");
+  if (p.loader == LOAD_UNPOOL) {
+    TL_REQUIRE(p.abits != nullptr, "nt_window: UNPOOL loader needs abits");
+    TL_REQUIRE((p.row_shift % 2) == 0 && p.Tp % 2 == 0 && p.Tvalid_in % 2 == 0, "nt_window: UNPOOL needs even shift/Tp/Tvalid_in");
+    TL_REQUIRE(p.K % 32 == 0 || p.ld_abits * 32 >= p.K, "nt_window: abits row too short");
+    TL_REQUIRE(p.bm == 128, "nt_window: UNPOOL loader needs bm = 128");
+  }
+  if (p.epilogue == EPI_POOL) {
+    TL_REQUIRE(p.obits != nullptr, "nt_window: POOL epilogue needs obits");
+    TL_REQUIRE(p.Tp % 2 == 0 && p.Tvalid % 2 == 0, "nt_window: POOL needs even Tp/Tvalid");
+    TL_REQUIRE(p.N % 32 == 0 && p.ld_obits * 32 >= p.N, "nt_window: POOL needs N %% 32 == 0");
+  }
+  if (p.epilogue == EPI_MASK) TL_REQUIRE(p.aux != nullptr, "nt_window: MASK epilogue needs aux");
+  hipStream_t st = (hipStream_t)stream;
+  return p.bm == 128 ? dispatch_nt<128>(p, st) : dispatch_nt<32>(p, st);
+}
+
+extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "tn_window: null params");
+  tl_tn_params p = *pp;
+  if (p.splitk < 1) p.splitk = 1;
+  TL_REQUIRE(p.A && p.B && p.slab, "tn_window: null A/B/slab");
+  TL_REQUIRE(p.Krows > 0 && p.Mdim > 0 && p.Ndim > 0, "tn_window: bad sizes");
+  TL_REQUIRE(p.Mdim % 4 == 0 && p.Ndim % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "tn_window: dims/ld must be multiples of 4");
+  TL_REQUIRE(p.J >= 1 && p.J <= 3, "tn_window: J must be 1..3");
+  TL_REQUIRE(p.Tp > 0, "tn_window: Tp must be positive");
+  TL_REQUIRE(p.splitk <= 65535, "tn_window: splitk too large");
+  if (p.loader == LOAD_UNPOOL) {
+    TL_REQUIRE(p.bbits != nullptr, "tn_window: UNPOOL loader needs bbits");
+    TL_REQUIRE(p.Tp % 2 == 0 && p.Tvalid % 2 == 0, "tn_window: UNPOOL needs even Tp/Tvalid");
+    TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim, "tn_window: bbits row too short");
+  }
+  const long long ntm = (p.Mdim + 127) / 128, ntn = (p.Ndim + 127) / 128;
+  const long long nwg = ntm * ntn * p.J;
+  TL_REQUIRE(nwg < (1LL << 31), "tn_window: grid too large");
+  dim3 grid((unsigned)nwg, (unsigned)p.splitk, 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (p.loader == LOAD_DIRECT)
+    hipLaunchKernelGGL((tn_window_kernel<LOAD_DIRECT>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((tn_window_kernel<LOAD_UNPOOL>), grid, dim3(256), 0, st, p);
+  return check_launch("tn_window");
+}

@@ -1,0 +1,578 @@
+// HBM-bound kernels of the synthesis train step (gfx950): first conv stage (C_in = 1), layout
+// packs / split-K reductions, bias-gradient column sums, LSTM cell, concat + dropout glue,
+// L1 + MCD, fused NAdam, tone-dynamics gather.  All are streaming kernels: coalesced loads
+// along the channel axis, one pass over each tensor, no atomics (deterministic sums).
+#include "tonal_common.h"
+#include <math.h>
+
+namespace tl {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// counter-based uniform in [0,1): splitmix64 finaliser over (seed, index)
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
+  uint64_t zz = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+  zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+  zz ^= zz >> 31;
+  return (float)(zz >> 40) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 forward: one workgroup per sequence, thread = output channel(s)
+// ------------------------------------------------------------------------------------------
+constexpr int MAXKT = 8;
+
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ P,
+                                                        uint32_t* __restrict__ bits, long long S, int T, int kt,
+                                                        int C1, int Tp, int Tout, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const long long seq = blockIdx.x;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for (int o = threadIdx.x; o < C1; o += blockDim.x) {   // C1 % 64 == 0 -> whole waves stay active
+    float wv[MAXKT];
+#pragma unroll
+    for (int j = 0; j < MAXKT; ++j) wv[j] = j < kt ? w[o * kt + j] : 0.f;
+    const float bv = b[o];
+    for (int p = 0; p < Tp; ++p) {
+      float out = 0.f;
+      bool sel = false;
+      if (p < Tout) {
+        float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXKT; ++j)
+          if (j < kt) {
+            z0 = fmaf(wv[j], xs[2 * p + j], z0);
+            z1 = fmaf(wv[j], xs[2 * p + 1 + j], z1);
+          }
+        const float y0 = lrelu(z0 + bv, slope), y1 = lrelu(z1 + bv, slope);
+        sel = y1 > y0;
+        out = sel ? y1 : y0;
+      }
+      const long long row = seq * Tp + p;
+      P[row * C1 + o] = out;
+      const unsigned long long m = __ballot(sel);
+      if (lane == 0) {
+        bits[row * (C1 >> 5) + (o >> 5)] = (uint32_t)m;
+        bits[row * (C1 >> 5) + (o >> 5) + 1] = (uint32_t)(m >> 32);
+      }
+    }
+  }
+}
+
+// conv1 weight/bias gradient partials: block handles a contiguous range of sequences;
+// thread owns channels tid and tid + 256 (C1 <= 512), barriers are outside every guard.
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ G,
+                                                          const uint32_t* __restrict__ bits, float* __restrict__ partial,
+                                                          long long S, int T, int kt, int C1, int Tp, int Tout) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const long long per = (S + gridDim.x - 1) / gridDim.x;
+  const long long s0 = blockIdx.x * per;
+  const long long s1 = s0 + per < S ? s0 + per : S;
+  float acc[2][MAXKT + 1];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j <= MAXKT; ++j) acc[h][j] = 0.f;
+  for (long long seq = s0; seq < s1; ++seq) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int o = threadIdx.x + h * 256;
+      if (o < C1) {
+        for (int p = 0; p < Tout; ++p) {
+          const long long row = seq * Tp + p;
+          const float g = G[row * C1 + o];
+          const uint32_t wbit = bits[row * (C1 >> 5) + (o >> 5)];
+          const int a = (wbit >> (o & 31)) & 1;
+#pragma unroll
+          for (int j = 0; j < MAXKT; ++j)
+            if (j < kt) acc[h][j] = fmaf(g, xs[2 * p + a + j], acc[h][j]);
+          acc[h][MAXKT] += g;
+        }
+      }
+    }
+  }
+  float* dst = partial + (long long)blockIdx.x * (kt + 1) * C1;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int o = threadIdx.x + h * 256;
+    if (o < C1) {
+#pragma unroll
+      for (int j = 0; j < MAXKT; ++j)
+        if (j < kt) dst[j * C1 + o] = acc[h][j];
+      dst[kt * C1 + o] = acc[h][MAXKT];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic 4-D permute + slab reduction
+// ------------------------------------------------------------------------------------------
+struct perm_args {
+  long long d[4], s[4], lim[4];
+  long long zs;
+  int nz;
+};
+__global__ __launch_bounds__(256) void permute_reduce_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             const float* __restrict__ bias_last, perm_args a,
+                                                             long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const long long i3 = r % a.d[3]; r /= a.d[3];
+    const long long i2 = r % a.d[2]; r /= a.d[2];
+    const long long i1 = r % a.d[1]; r /= a.d[1];
+    const long long i0 = r;
+    float acc = 0.f;
+    if (i0 < a.lim[0] && i1 < a.lim[1] && i2 < a.lim[2] && i3 < a.lim[3]) {
+      const long long off = i0 * a.s[0] + i1 * a.s[1] + i2 * a.s[2] + i3 * a.s[3];
+      for (int z = 0; z < a.nz; ++z) acc += src[off + z * a.zs];
+      if (bias_last) acc += bias_last[i3];
+    }
+    dst[i] = acc;
+  }
+}
+
+// masked column sums (bias gradients): partial[blk][ncols]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G, float* __restrict__ partial,
+                                                     long long rows, int ncols, int ld, int Tp, int Tvalid) {
+  const long long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long long r0 = blockIdx.x * per;
+  const long long r1 = r0 + per < rows ? r0 + per : rows;
+  for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+    float acc = 0.f;
+    for (long long r = r0; r < r1; ++r)
+      if ((int)(r % Tp) < Tvalid) acc += G[r * ld + c];
+    partial[(long long)blockIdx.x * ncols + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LSTM cell (torch gate order i, f, g, o)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restrict__ hh, const float* __restrict__ x_t,
+                                                            const float* __restrict__ w_ih, const float* __restrict__ b_ih,
+                                                            const float* __restrict__ b_hh, const float* __restrict__ c_prev,
+                                                            float* __restrict__ act, float* __restrict__ c,
+                                                            float* __restrict__ h, int U, int H, int in_dim, int ld_hh) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)U * H) return;
+  const int u = (int)(i / H), k = (int)(i % H);
+  float pre[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long long row = (long long)q * H + k;
+    float ih = 0.f;
+    for (int d = 0; d < in_dim; ++d) ih = fmaf(x_t[u * in_dim + d], w_ih[row * in_dim + d], ih);
+    ih += b_ih[row];
+    float hv = b_hh[row];
+    if (hh) hv += hh[(long long)u * ld_hh + row];
+    pre[q] = ih + hv;
+  }
+  const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+  const float cp = c_prev ? c_prev[i] : 0.f;
+  const float cn = fg * cp + ig * gg;
+  const long long ab = (long long)u * 4 * H + k;
+  act[ab] = ig;
+  act[ab + H] = fg;
+  act[ab + 2LL * H] = gg;
+  act[ab + 3LL * H] = og;
+  c[i] = cn;
+  h[i] = og * tanhf(cn);
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh_rec,
+                                                            const float* __restrict__ dc_next, const float* __restrict__ act,
+                                                            const float* __restrict__ c, const float* __restrict__ c_prev,
+                                                            float* __restrict__ dgates, float* __restrict__ dgates_t,
+                                                            float* __restrict__ dc_prev, int U, int H, int ldt) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)U * H) return;
+  const int u = (int)(i / H), k = (int)(i % H);
+  float dht = 0.f;
+  if (dh) dht += dh[i];
+  if (dh_rec) dht += dh_rec[i];
+  const long long ab = (long long)u * 4 * H + k;
+  const float ig = act[ab], fg = act[ab + H], gg = act[ab + 2LL * H], og = act[ab + 3LL * H];
+  const float tc = tanhf(c[i]);
+  const float dog = dht * tc;
+  float dc = dht * og * (1.f - tc * tc);
+  if (dc_next) dc += dc_next[i];
+  const float cp = c_prev ? c_prev[i] : 0.f;
+  const float d_i = dc * gg * ig * (1.f - ig);
+  const float d_f = dc * cp * fg * (1.f - fg);
+  const float d_g = dc * ig * (1.f - gg * gg);
+  const float d_o = dog * og * (1.f - og);
+  dgates[ab] = d_i;
+  dgates[ab + H] = d_f;
+  dgates[ab + 2LL * H] = d_g;
+  dgates[ab + 3LL * H] = d_o;
+  if (dgates_t) {
+    dgates_t[((long long)k) * ldt + u] = d_i;
+    dgates_t[((long long)H + k) * ldt + u] = d_f;
+    dgates_t[(2LL * H + k) * ldt + u] = d_g;
+    dgates_t[(3LL * H + k) * ldt + u] = d_o;
+  }
+  dc_prev[i] = dc * fg;
+}
+
+__global__ __launch_bounds__(256) void lstm_ih_grad_kernel(const float* __restrict__ dgates, const float* __restrict__ x,
+                                                           float* __restrict__ dw_ih, float* __restrict__ db, int L, int U,
+                                                           int H, int in_dim) {
+  const long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (r >= 4LL * H) return;
+  float accw[MAXKT];
+#pragma unroll
+  for (int d = 0; d < MAXKT; ++d) accw[d] = 0.f;
+  float accb = 0.f;
+  for (int tu = 0; tu < L * U; ++tu) {
+    const float g = dgates[(long long)tu * 4 * H + r];
+    accb += g;
+#pragma unroll
+    for (int d = 0; d < MAXKT; ++d)
+      if (d < in_dim) accw[d] = fmaf(g, x[tu * in_dim + d], accw[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < MAXKT; ++d)
+    if (d < in_dim) dw_ih[r * in_dim + d] = accw[d];
+  db[r] = accb;
+}
+
+// ------------------------------------------------------------------------------------------
+// concat + dropout glue
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void concat_pack_kernel(const float* __restrict__ O5, const float* __restrict__ h,
+                                                          const int32_t* __restrict__ uid, float* __restrict__ Xc, int B,
+                                                          int C, int Tp, int lat, int Cc, int Lc, int ld5, int ldh, int ldx,
+                                                          float p_drop, uint64_t seed) {
+  const long long total = (long long)B * C * Tp * ldx;
+  const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ldx);
+    const long long row = i / ldx;
+    const int t = (int)(row % Tp);
+    const long long seq = row / Tp;
+    const int cch = (int)(seq % C);
+    const int b = (int)(seq / C);
+    float v = 0.f;
+    if (t < lat) {
+      if (col < Cc) {
+        v = O5[row * ld5 + col];
+        if (p_drop > 0.f) v = u01(seed, (uint64_t)(row * Cc + col)) >= p_drop ? v * keep_scale : 0.f;
+      } else if (col < Cc + Lc) {
+        v = h[(long long)uid[b] * ldh + ((long long)(col - Cc) * lat + t) * C + cch];
+      }
+    }
+    Xc[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void concat_g5_kernel(const float* __restrict__ dXc, const float* __restrict__ O5,
+                                                        float* __restrict__ G5, long long rows, int Cc, int ld5, int ldx,
+                                                        float slope, float p_drop, uint64_t seed) {
+  const long long total = rows * Cc;
+  const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % Cc);
+    const long long row = i / Cc;
+    float g = dXc[row * ldx + col];
+    if (p_drop > 0.f) g = u01(seed, (uint64_t)(row * Cc + col)) >= p_drop ? g * keep_scale : 0.f;
+    const float a = O5[row * ld5 + col];
+    G5[row * ld5 + col] = a > 0.f ? g : g * slope;
+  }
+}
+
+__global__ __launch_bounds__(256) void concat_dh_kernel(const float* __restrict__ dXc, const int32_t* __restrict__ members,
+                                                        const int32_t* __restrict__ offsets, float* __restrict__ dh, int U,
+                                                        int C, int Tp, int lat, int Cc, int Lc, int ldh, int ldx) {
+  const long long per_u = (long long)Lc * lat * C;
+  const long long total = (long long)U * per_u;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int u = (int)(i / per_u);
+    long long r = i % per_u;
+    const int cch = (int)(r % C); r /= C;
+    const int t = (int)(r % lat);
+    const int lc = (int)(r / lat);
+    float acc = 0.f;
+    for (int q = offsets[u]; q < offsets[u + 1]; ++q) {
+      const int b = members[q];
+      acc += dXc[(((long long)b * C + cch) * Tp + t) * ldx + Cc + lc];
+    }
+    dh[(long long)u * ldh + ((long long)lc * lat + t) * C + cch] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// L1 loss gradient + L1 / MCD statistics: one workgroup, thread per row, fixed-order reduction
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l1_mcd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                     float* __restrict__ dout, float* __restrict__ stats, int B, int D,
+                                                     int ldd, int trunc_targets, float grad_scale) {
+  __shared__ float s1[256], s2[256];
+  float l1 = 0.f, mcd = 0.f;
+  const float gs = grad_scale / ((float)B * (float)D);
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int d = 0; d < D; ++d) {
+      float t = tgt[(long long)b * D + d];
+      if (trunc_targets) t = truncf(t);
+      const float df = out[(long long)b * D + d] - t;
+      a1 += fabsf(df);
+      a2 = fmaf(df, df, a2);
+      if (dout) dout[(long long)b * ldd + d] = df > 0.f ? gs : (df < 0.f ? -gs : 0.f);
+    }
+    l1 += a1;
+    mcd += 4.342944819032518f * sqrtf(2.f * a2);   // 10 / ln(10)
+  }
+  s1[threadIdx.x] = l1;
+  s2[threadIdx.x] = mcd;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      s1[threadIdx.x] += s1[threadIdx.x + off];
+      s2[threadIdx.x] += s2[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    stats[0] += s1[0] / ((float)B * (float)D);
+    stats[1] += s2[0] / (float)B;
+    stats[2] = s1[0] / ((float)B * (float)D);    // last-step values
+    stats[3] = s2[0] / (float)B;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused NAdam: 4 reads + 3 writes of 4 B per element, float4 wide
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void nadam_one(float& p, float g, float& m, float& v, float cg, float cm, float b1,
+                                          float b2, float bc2, float eps, float wd, float gscale) {
+  g = fmaf(wd, p, g * gscale);
+  m = m + (g - m) * (1.f - b1);
+  v = fmaf(v, b2, (1.f - b2) * g * g);
+  const float denom = sqrtf(v / bc2) + eps;
+  p = p - cg * (g / denom);
+  p = p - cm * (m / denom);
+}
+__global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long long n, float cg,
+                                                    float cm, float b1, float b2, float bc2, float eps, float wd,
+                                                    float gscale) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float pq = pv[q], mq = mv[q], vq = vv[q];
+      nadam_one(pq, gv[q], mq, vq, cg, cm, b1, b2, bc2, eps, wd, gscale);
+      pv[q] = pq;
+      mv[q] = mq;
+      vv[q] = vq;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  for (long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride)
+    nadam_one(p[i], g[i], m[i], v[i], cg, cm, b1, b2, bc2, eps, wd, gscale);
+}
+
+__global__ void tone_dynamics_kernel(const long long* __restrict__ tone, const long long* __restrict__ syl,
+                                     const float* __restrict__ table, float* __restrict__ labels, int32_t* err, int B,
+                                     int n_tones, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * L) return;
+  const int b = i / L, l = i % L;
+  const long long t = tone[b];
+  labels[((long long)b * 2) * L + l] = (float)syl[b];
+  if (t < 0 || t >= n_tones) {
+    *err = 1;
+    labels[((long long)b * 2 + 1) * L + l] = 0.f;
+  } else {
+    labels[((long long)b * 2 + 1) * L + l] = table[t * L + l];
+  }
+}
+
+static inline unsigned grid_for(long long total, int block = 256, long long cap = 256LL * 32) {
+  long long g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+}  // namespace tl
+
+using namespace tl;
+
+extern "C" const char* tl_last_error(void) { return tl::g_err; }
+extern "C" int tl_version(void) { return 100; }
+extern "C" int tl_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return TL_ENODEV;
+  }
+  return n;
+}
+
+extern "C" int tl_conv1_fwd(const float* x, const float* w, const float* b, float* P, uint32_t* bits, int64_t S,
+                            int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream) {
+  TL_REQUIRE(x && w && b && P && bits, "conv1_fwd: null pointer");
+  TL_REQUIRE(S > 0 && S < (1LL << 31), "conv1_fwd: bad S");
+  TL_REQUIRE(ktaps >= 1 && ktaps <= MAXKT, "conv1_fwd: ktaps must be 1..%d", MAXKT);
+  TL_REQUIRE(C1 % 64 == 0, "conv1_fwd: C1 must be a multiple of 64");
+  TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_fwd: Tout/Tp/T inconsistent (%d,%d,%d)", Tout, Tp, T);
+  TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_fwd: T too large for the LDS window");
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,
+                     bits, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+  return check_launch("conv1_fwd");
+}
+
+extern "C" int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial, int nblk,
+                              int64_t S, int T, int ktaps, int C1, int Tp, int Tout, void* stream) {
+  TL_REQUIRE(x && G && bits && partial, "conv1_wgrad: null pointer");
+  TL_REQUIRE(nblk > 0 && S > 0, "conv1_wgrad: bad sizes");
+  TL_REQUIRE(ktaps >= 1 && ktaps <= MAXKT, "conv1_wgrad: ktaps must be 1..%d", MAXKT);
+  TL_REQUIRE(C1 % 32 == 0 && C1 <= 512, "conv1_wgrad: C1 must be a multiple of 32 and <= 512");
+  TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_wgrad: Tout/Tp/T inconsistent");
+  TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_wgrad: T too large for the LDS window");
+  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)nblk), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, G,
+                     bits, partial, (long long)S, T, ktaps, C1, Tp, Tout);
+  return check_launch("conv1_wgrad");
+}
+
+extern "C" int tl_permute_reduce(const float* src, float* dst, const int64_t dims[4], const int64_t strides[4],
+                                 const int64_t lims[4], int nz, int64_t zs, const float* bias_last, void* stream) {
+  TL_REQUIRE(src && dst && dims && strides && lims, "permute_reduce: null pointer");
+  TL_REQUIRE(nz >= 1, "permute_reduce: nz must be >= 1");
+  perm_args a;
+  long long total = 1;
+  for (int i = 0; i < 4; ++i) {
+    TL_REQUIRE(dims[i] >= 1, "permute_reduce: dims must be >= 1");
+    a.d[i] = dims[i];
+    a.s[i] = strides[i];
+    a.lim[i] = lims[i];
+    total *= dims[i];
+  }
+  a.zs = zs;
+  a.nz = nz;
+  hipLaunchKernelGGL(permute_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     bias_last, a, total);
+  return check_launch("permute_reduce");
+}
+
+extern "C" int tl_colsum(const float* G, float* partial, int nblk, int64_t rows, int ncols, int ld, int Tp,
+                         int Tvalid, void* stream) {
+  TL_REQUIRE(G && partial && nblk > 0 && rows > 0 && ncols > 0 && ld >= ncols && Tp > 0, "colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, G, partial,
+                     (long long)rows, ncols, ld, Tp, Tvalid);
+  return check_launch("colsum");
+}
+
+extern "C" int tl_lstm_cell_fwd(const float* hh, const float* x_t, const float* w_ih, const float* b_ih,
+                                const float* b_hh, const float* c_prev, float* act, float* c, float* h, int U, int H,
+                                int in_dim, int ld_hh, void* stream) {
+  TL_REQUIRE(x_t && w_ih && b_ih && b_hh && act && c && h, "lstm_cell_fwd: null pointer");
+  TL_REQUIRE(U > 0 && H > 0 && in_dim > 0, "lstm_cell_fwd: bad sizes");
+  const long long total = (long long)U * H;
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     hh, x_t, w_ih, b_ih, b_hh, c_prev, act, c, h, U, H, in_dim, ld_hh);
+  return check_launch("lstm_cell_fwd");
+}
+
+extern "C" int tl_lstm_cell_bwd(const float* dh, const float* dh_rec, const float* dc_next, const float* act,
+                                const float* c, const float* c_prev, float* dgates, float* dgates_t, float* dc_prev,
+                                int U, int H, int ldt, void* stream) {
+  TL_REQUIRE(act && c && dgates && dc_prev, "lstm_cell_bwd: null pointer");
+  TL_REQUIRE(U > 0 && H > 0 && (!dgates_t || ldt >= U), "lstm_cell_bwd: bad sizes");
+  const long long total = (long long)U * H;
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dh, dh_rec, dc_next, act, c, c_prev, dgates, dgates_t, dc_prev, U, H, ldt);
+  return check_launch("lstm_cell_bwd");
+}
+
+extern "C" int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih, float* db, int L, int U, int H,
+                               int in_dim, void* stream) {
+  TL_REQUIRE(dgates && x && dw_ih && db, "lstm_ih_grad: null pointer");
+  TL_REQUIRE(in_dim >= 1 && in_dim <= MAXKT, "lstm_ih_grad: in_dim must be 1..%d", MAXKT);
+  const long long total = 4LL * H;
+  hipLaunchKernelGGL(lstm_ih_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dgates, x, dw_ih, db, L, U, H, in_dim);
+  return check_launch("lstm_ih_grad");
+}
+
+extern "C" int tl_concat_pack(const float* O5, const float* h, const int32_t* uid, float* Xc, int B, int C, int Tp,
+                              int lat, int Cc, int Lc, int ld5, int ldh, int ldx, float p_drop, uint64_t seed,
+                              void* stream) {
+  TL_REQUIRE(O5 && h && uid && Xc, "concat_pack: null pointer");
+  TL_REQUIRE(ldx >= Cc + Lc && ld5 >= Cc && lat <= Tp && p_drop >= 0.f && p_drop < 1.f, "concat_pack: bad arguments");
+  const long long total = (long long)B * C * Tp * ldx;
+  hipLaunchKernelGGL(concat_pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, O5, h, uid, Xc, B,
+                     C, Tp, lat, Cc, Lc, ld5, ldh, ldx, p_drop, seed);
+  return check_launch("concat_pack");
+}
+
+extern "C" int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int32_t* members, const int32_t* offsets,
+                                    float* G5, float* dh, int B, int U, int C, int Tp, int lat, int Cc, int Lc, int ld5,
+                                    int ldh, int ldx, float slope, float p_drop, uint64_t seed, void* stream) {
+  TL_REQUIRE(dXc && O5 && members && offsets && G5 && dh, "concat_unpack_bwd: null pointer");
+  TL_REQUIRE(ldx >= Cc + Lc && ld5 >= Cc && lat <= Tp && p_drop >= 0.f && p_drop < 1.f, "concat_unpack_bwd: bad arguments");
+  const long long rows = (long long)B * C * Tp;
+  hipLaunchKernelGGL(concat_g5_kernel, dim3(grid_for(rows * Cc)), dim3(256), 0, (hipStream_t)stream, dXc, O5, G5, rows,
+                     Cc, ld5, ldx, slope, p_drop, seed);
+  int rc = check_launch("concat_g5");
+  if (rc) return rc;
+  const long long total = (long long)U * Lc * lat * C;
+  hipLaunchKernelGGL(concat_dh_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dXc, members, offsets,
+                     dh, U, C, Tp, lat, Cc, Lc, ldh, ldx);
+  return check_launch("concat_dh");
+}
+
+extern "C" int tl_l1_mcd(const float* out, const float* targets, float* dout, float* stats, int B, int D, int ldd,
+                         int trunc_targets, float grad_scale, void* stream) {
+  TL_REQUIRE(out && targets && stats && B > 0 && D > 0 && ldd >= D, "l1_mcd: bad arguments");
+  hipLaunchKernelGGL(l1_mcd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, targets, dout, stats, B, D, ldd,
+                     trunc_targets, grad_scale);
+  return check_launch("l1_mcd");
+}
+
+extern "C" int tl_nadam(float* p, const float* g, float* m, float* v, int64_t n, float coef_grad, float coef_mom,
+                        float beta1, float beta2, float bias_corr2, float eps, float weight_decay, float grad_scale,
+                        void* stream) {
+  TL_REQUIRE(p && g && m && v && n > 0, "nadam: bad arguments");
+  TL_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "nadam: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(nadam_kernel, dim3(grid_for(n / 4 + 1, 256, 256LL * 8)), dim3(256), 0, (hipStream_t)stream, p, g,
+                     m, v, (long long)n, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps, weight_decay, grad_scale);
+  return check_launch("nadam");
+}
+
+extern "C" int tl_tone_dynamics(const int64_t* tone, const int64_t* syl, const float* table, float* labels,
+                                int32_t* err, int B, int n_tones, int L, void* stream) {
+  TL_REQUIRE(tone && syl && table && labels && err && B > 0 && n_tones > 0 && L > 0, "tone_dynamics: bad arguments");
+  const int total = B * L;
+  hipLaunchKernelGGL(tone_dynamics_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)tone, (const long long*)syl, table, labels, err, B, n_tones, L);
+  return check_launch("tone_dynamics");
+}

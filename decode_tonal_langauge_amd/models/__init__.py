@@ -1,0 +1,4 @@
+from .classifier import ClassifierModel
+from .simple_classifiers import LogisticRegressionClassifier, ShallowNNClassifier
+from .synthesis_models import SynthesisModel, SynthesisModelCNN, SynthesisLite
+from .synthesis_trainer import SynthesisTrainer, compute_mcd

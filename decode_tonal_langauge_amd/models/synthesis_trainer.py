@@ -1,0 +1,220 @@
+"""``SynthesisTrainer`` on MI355X (mirror of reference models/synthesis_trainer.py:46-302).
+
+Same constructor keywords, ``train(loader, epochs, verbose) -> [(loss, mcd)]`` and
+``evaluate(loader) -> (mcd, recon, origin)``.  What changes is where the work happens:
+
+* the label dynamics are gathered on the device (``tl_tone_dynamics``) instead of the
+  ``.cpu().numpy()`` -> Python loop -> ``torch.Tensor`` round trip (:212-218);
+* for the models of this package the step is fused: forward, L1 (+ MCD statistics), backward and
+  NAdam run as HIP kernels on one stream with no autograd graph and no host sync per step
+  (the reference syncs three times per step, :214-215,228,229); loss / MCD are accumulated on
+  the device and read once per epoch;
+* under ``torch.distributed`` (one process per GPU) every rank takes its row shard of each
+  global batch and gradients are reduced over RCCL (parallel.py).
+
+Reference quirks kept on purpose: training targets are truncated to integers (:222), evaluation
+targets are not (:290); the classifiers are never updated (their parameters are not in the
+optimizer, :131-137) - ``train_classifiers`` only toggles ``.train()``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader
+
+from .. import _lib, parallel
+from .._lib import check, ptr
+from ..optim import FusedNAdam
+from .classifier import ClassifierModel
+from .synthesis_models import SynthesisModel
+
+
+def compute_mcd(true_mcc: torch.Tensor, pred_mcc: torch.Tensor) -> float:
+    """Mean over the batch of 10/ln10 * sqrt(2 * sum_k (t - p)^2) (reference :14-43), computed by
+    the ``tl_l1_mcd`` kernel."""
+    t = true_mcc.float().contiguous()
+    p = pred_mcc.detach().float().contiguous()
+    _lib.require_gpu(p, "compute_mcd")
+    stats = torch.zeros(4, dtype=torch.float32, device=p.device)
+    B, D = p.shape
+    check(_lib.load().tl_l1_mcd(ptr(p), ptr(t.to(p.device)), None, ptr(stats), B, D, D, 0, 1.0,
+                                torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
+    return float(stats[3].item())
+
+
+class SynthesisTrainer:
+    def __init__(self, synthesize_model: SynthesisModel, tone_model: ClassifierModel, syllable_model: ClassifierModel,
+                 tone_dynamic_mapping: Dict[str, List[int]], device: torch.device = torch.device("cpu"),
+                 learning_rate: float = 0.0005, beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-08,
+                 schedule_decay: float = 0.004, verbose: bool = True, train_classifiers: bool = False) -> None:
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("SynthesisTrainer (MI355X build) needs a 'cuda' device: the synthesis path runs "
+                               "hand-written HIP kernels and has no CPU fallback")
+        self.lib = _lib.load()
+        self.train_classifiers = train_classifiers
+        self.tone_dynamic_mapping = tone_dynamic_mapping
+        self.model = synthesize_model.to(self.device)
+        if verbose:
+            print(f"Number of trainable parameters in the synthesis model: {self.model.get_nparams():,}")
+        self.optimizer = FusedNAdam(self.model.parameters(), lr=learning_rate, betas=(beta_1, beta_2), eps=epsilon,
+                                    weight_decay=schedule_decay)
+        self.criterion = nn.L1Loss()          # generic (autograd) path only
+        self.tone_model = tone_model.to(self.device)
+        self.syllable_model = syllable_model.to(self.device)
+        if not train_classifiers:
+            self.tone_model.eval()
+            self.syllable_model.eval()
+        elif verbose:
+            for nm, m in (("tone", self.tone_model), ("syllable", self.syllable_model)):
+                n = sum(p.numel() for p in m.parameters() if p.requires_grad)
+                print(f"Number of trainable parameters in the {nm} model: {n:,}")
+        # tone dynamics table: row t = mapping[str(t)]
+        keys = sorted(int(k) for k in tone_dynamic_mapping)
+        lens = {len(v) for v in tone_dynamic_mapping.values()}
+        if len(lens) != 1:
+            raise ValueError("every entry of tone_dynamic_mapping must have the same length")
+        self._L = lens.pop()
+        self._n_rows = (max(keys) + 1) if keys else 0
+        table = torch.full((max(self._n_rows, 1), self._L), float("nan"))
+        for k in keys:
+            if k >= 0:
+                table[k] = torch.tensor(tone_dynamic_mapping[str(k)], dtype=torch.float32)
+        self._table_host = table
+        n_cls = getattr(self.tone_model, "n_classes", None)
+        self._need_check = n_cls is None or any(str(t) not in tone_dynamic_mapping for t in range(n_cls))
+        self._table = table.to(self.device)
+        self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._grads = None
+        self.rank, self.world = parallel.world()
+
+    # ------------------------------------------------------------------ helpers
+    def _labels(self, inputs_tone, inputs_syllable) -> torch.Tensor:
+        """argmax of both classifiers + device gather of the dynamics (reference :207-218)."""
+        tone = torch.argmax(self.tone_model(inputs_tone), dim=1).contiguous()
+        syl = torch.argmax(self.syllable_model(inputs_syllable), dim=1).contiguous()
+        B = tone.shape[0]
+        labels = torch.empty(B, 2, self._L, dtype=torch.float32, device=self.device)
+        check(self.lib.tl_tone_dynamics(ptr(tone), ptr(syl), ptr(self._table), ptr(labels), ptr(self._err), B,
+                                        self._n_rows, self._L, torch.cuda.current_stream().cuda_stream),
+              "tl_tone_dynamics")
+        if self._need_check:
+            # a predicted tone may be absent from the mapping: keep the reference's immediate error
+            for t in tone.tolist():
+                if str(int(t)) not in self.tone_dynamic_mapping:
+                    raise ValueError(f"Tone {int(t)} not found in tone_dynamic_mapping."
+                                     f"Available tones in mapping: {list(self.tone_dynamic_mapping.keys())}")
+        return labels
+
+    def _shard(self, *tensors):
+        if self.world == 1:
+            return tensors
+        sl = parallel.shard_rows(tensors[0].shape[0], self.rank, self.world)
+        return tuple(t[sl] for t in tensors)
+
+    def _fused_step(self, inputs_non, inputs_label, targets) -> None:
+        model = self.model
+        eng = model._engine
+        names = model._pnames
+        params = dict(model.named_parameters())
+        prm = {k: params[k].detach() for k in names}
+        if self._grads is None:
+            self._grads = {k: torch.empty_like(v) for k, v in prm.items()}
+        out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True, seed=model._next_seed())
+        B, D = out.shape
+        dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)
+        check(self.lib.tl_l1_mcd(ptr(out), ptr(targets), ptr(dout), ptr(self._stats), B, D, eng.ldd, 1, 1.0,
+                                 torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
+        gather = parallel.gather_lowrank if self.world > 1 else None
+        eng.backward(prm, dout, self._grads, gather_whh=gather)
+        scale = 1.0
+        if self.world > 1:
+            skip = getattr(eng, "lowrank_param", None)
+            parallel.allreduce_bucketed([g for k, g in self._grads.items() if k != skip])
+            scale = 1.0 / self.world
+        self.optimizer.step(grads={params[k]: self._grads[k] for k in names}, grad_scale=scale)
+
+    def _generic_step(self, inputs_non, inputs_label, targets) -> None:
+        """Any other ``SynthesisModel`` subclass: torch autograd for the model, fused NAdam."""
+        self.optimizer.zero_grad()
+        outputs = self.model(inputs_non, inputs_label)
+        tgt = targets.long()
+        loss = self.criterion(outputs, tgt)
+        loss.backward()
+        scale = 1.0
+        if self.world > 1:
+            parallel.allreduce_bucketed([p.grad for p in self.model.parameters() if p.grad is not None])
+            scale = 1.0 / self.world
+        self.optimizer.step(grad_scale=scale)
+        out = outputs.detach().float().contiguous()
+        B, D = out.shape
+        check(self.lib.tl_l1_mcd(ptr(out), ptr(targets.float().contiguous()), None, ptr(self._stats), B, D, D, 1, 1.0,
+                                 torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
+
+    def train_step(self, inputs_non, inputs_syllable, inputs_tone, targets) -> None:
+        """One body of the batch loop (reference :201-229).  Loss / MCD go to ``self._stats``."""
+        dev = self.device
+        inputs_non = inputs_non.to(dev, non_blocking=True)
+        inputs_syllable = inputs_syllable.to(dev, non_blocking=True)
+        inputs_tone = inputs_tone.to(dev, non_blocking=True)
+        targets = targets.to(dev, non_blocking=True).float().contiguous()
+        inputs_non, inputs_syllable, inputs_tone, targets = self._shard(inputs_non, inputs_syllable, inputs_tone,
+                                                                        targets)
+        with torch.no_grad():
+            inputs_label = self._labels(inputs_tone, inputs_syllable)
+        if getattr(self.model, "_engine", None) is not None and hasattr(self.model._engine, "backward"):
+            self._fused_step(inputs_non.float().contiguous(), inputs_label, targets.contiguous())
+        else:
+            self._generic_step(inputs_non, inputs_label, targets)
+
+    # ------------------------------------------------------------------ public API
+    def train(self, train_loader: DataLoader, epochs: int, verbose: bool = True) -> List[Tuple[float, float]]:
+        self.model.train()
+        if self.train_classifiers:
+            self.tone_model.train()
+            self.syllable_model.train()
+        history = []
+        for epoch in range(epochs):
+            self._stats.zero_()
+            nb = 0
+            for inputs_non, inputs_syllable, inputs_tone, targets in train_loader:
+                self.train_step(inputs_non, inputs_syllable, inputs_tone, targets)
+                nb += 1
+            stats = self._stats.clone()
+            if self.world > 1:
+                torch.distributed.all_reduce(stats)
+                stats /= self.world
+            s = stats.tolist()                                  # the one host sync of the epoch
+            epoch_loss, mcd = s[0] / max(nb, 1), s[1] / max(nb, 1)
+            history.append((epoch_loss, mcd))
+            if verbose:
+                print(f"Epoch {epoch+1}/{epochs}, Loss: {epoch_loss:.4f}, Mean MCD: {mcd:.4f}")
+        return history
+
+    def evaluate(self, test_loader: DataLoader):
+        self.model.eval()
+        self.tone_model.eval()
+        self.syllable_model.eval()
+        recon, origin = [], []
+        stats = torch.zeros(4, dtype=torch.float32, device=self.device)
+        nb = 0
+        with torch.no_grad():
+            for inputs_non, inputs_syllable, inputs_tone, targets in test_loader:
+                inputs_non = inputs_non.to(self.device)
+                inputs_syllable = inputs_syllable.to(self.device)
+                inputs_tone = inputs_tone.to(self.device)
+                targets = targets.to(self.device).float().contiguous()
+                inputs_label = self._labels(inputs_tone, inputs_syllable)
+                outputs = self.model(inputs_non, inputs_label).float().contiguous()
+                B, D = outputs.shape
+                check(self.lib.tl_l1_mcd(ptr(outputs), ptr(targets), None, ptr(stats), B, D, D, 0, 1.0,
+                                         torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
+                recon.append(outputs.cpu())
+                origin.append(targets.cpu())
+                nb += 1
+        mcd = float(stats[1].item()) / max(nb, 1)
+        return mcd, torch.cat(recon, dim=0).numpy(), torch.cat(origin, dim=0).numpy()

@@ -1,0 +1,70 @@
+"""Fused NAdam on MI355X: one HBM pass per parameter tensor (``tl_nadam``).
+
+Same update rule and defaults as ``torch.optim.NAdam`` built by the reference trainer
+(reference models/synthesis_trainer.py:131-137): coupled L2 ``weight_decay`` (the reference's
+``schedule_decay`` argument lands there), ``momentum_decay=0.004``, non-decoupled.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def nadam_scalars(step: int, mu_product: float, lr: float, beta1: float, beta2: float, momentum_decay: float):
+    """Scalar schedule of torch's ``_single_tensor_nadam`` for 1-based ``step`` (host, float64)."""
+    bc2 = 1.0 - beta2 ** step
+    mu = beta1 * (1.0 - 0.5 * (0.96 ** (step * momentum_decay)))
+    mu_next = beta1 * (1.0 - 0.5 * (0.96 ** ((step + 1) * momentum_decay)))
+    mu_product = mu_product * mu
+    coef_grad = lr * (1.0 - mu) / (1.0 - mu_product)
+    coef_mom = lr * mu_next / (1.0 - mu_product * mu_next)
+    return coef_grad, coef_mom, bc2, mu_product
+
+
+class FusedNAdam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, momentum_decay: float = 4e-3):
+        if lr < 0 or eps < 0 or weight_decay < 0 or momentum_decay < 0:
+            raise ValueError("FusedNAdam: negative hyper-parameter")
+        if not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError(f"Invalid beta parameters: {betas}")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      momentum_decay=momentum_decay))
+        self._lib = _lib.load()
+
+    def _state_for(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["mu_product"] = 1.0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None, grads: Optional[Dict[torch.nn.Parameter, torch.Tensor]] = None,
+             grad_scale: float = 1.0):
+        """``grads`` optionally maps parameter -> gradient tensor (fused trainer path, no ``.grad``)."""
+        loss = closure() if closure is not None else None
+        stream = torch.cuda.current_stream().cuda_stream
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                g = grads.get(p) if grads is not None else p.grad
+                if g is None:
+                    continue
+                _lib.require_gpu(p, "FusedNAdam.step")
+                if not (p.is_contiguous() and g.is_contiguous()):
+                    raise RuntimeError("FusedNAdam needs contiguous parameters and gradients")
+                st = self._state_for(p)
+                st["step"] += 1
+                cg, cm, bc2, st["mu_product"] = nadam_scalars(st["step"], st["mu_product"], group["lr"], b1, b2,
+                                                              group["momentum_decay"])
+                check(self._lib.tl_nadam(ptr(p), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel(), cg, cm,
+                                         b1, b2, bc2, group["eps"], group["weight_decay"], grad_scale, stream),
+                      "tl_nadam")
+        return loss

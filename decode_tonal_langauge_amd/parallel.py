@@ -1,0 +1,109 @@
+"""Data-parallel glue: one process per GPU, ``torch.distributed`` over RCCL/xGMI (backend "nccl").
+
+Windows are independent, so a global batch is sharded by rows (rank r takes rows
+[r*B/N, (r+1)*B/N)) and the only exchange step is the gradient reduction:
+ * every parameter except ``label_lstm.weight_hh_l0``: bucketed all-reduce (sum; the 1/N of the
+   mean loss is folded into the NAdam kernel's ``grad_scale``);
+ * ``weight_hh_l0`` (98.7 % of the parameters, 5.5 GB at the north-star shape) is never
+   all-reduced: its gradient is ``dgates^T . h`` with at most (L-1)*U rows per rank, so the
+   ranks all-gather those low-rank factors (a few MB) and each computes the full-batch gradient
+   locally with the TN GEMM kernel.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise the default process group from RANK/WORLD_SIZE/LOCAL_RANK (torchrun) if needed."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_rows(n: int, rank: int, nranks: int) -> slice:
+    """Rows of a global batch owned by ``rank`` (equal shards; the remainder goes to the last ranks)."""
+    base, rem = divmod(n, nranks)
+    start = rank * base + max(0, rank - (nranks - rem)) if rem else rank * base
+    size = base + (1 if rem and rank >= nranks - rem else 0)
+    return slice(start, start + size)
+
+
+def allreduce_bucketed(tensors: List[torch.Tensor], bucket_bytes: int = 64 << 20) -> None:
+    """Sum-all-reduce ``tensors`` in place, coalesced into flat buckets (few, large messages:
+    xGMI rings are per-link bound)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    bucket: List[torch.Tensor] = []
+    size = 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        if len(bucket) == 1:
+            dist.all_reduce(bucket[0])
+        else:
+            flat = torch.cat([t.reshape(-1) for t in bucket])
+            dist.all_reduce(flat)
+            ofs = 0
+            for t in bucket:
+                n = t.numel()
+                t.copy_(flat[ofs:ofs + n].view_as(t))
+                ofs += n
+        bucket, size = [], 0
+
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if nbytes >= bucket_bytes:
+            flush()
+            dist.all_reduce(t)
+            continue
+        if size + nbytes > bucket_bytes:
+            flush()
+        bucket.append(t)
+        size += nbytes
+    flush()
+
+
+def gather_lowrank(dg: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather the factors of the W_hh gradient: dg (k, 4H), h (k, H) with a per-rank k.
+    Ranks pad to the common maximum with zero rows (which add nothing to dg^T . h)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return dg, h
+    n = dist.get_world_size()
+    k = torch.tensor([dg.shape[0]], device=dg.device, dtype=torch.int64)
+    dist.all_reduce(k, op=dist.ReduceOp.MAX)
+    kmax = int(k.item())
+
+    def pad(t):
+        if t.shape[0] == kmax:
+            return t.contiguous()
+        out = torch.zeros(kmax, t.shape[1], dtype=t.dtype, device=t.device)
+        out[:t.shape[0]] = t
+        return out
+
+    dg_all = torch.empty(n * kmax, dg.shape[1], dtype=dg.dtype, device=dg.device)
+    h_all = torch.empty(n * kmax, h.shape[1], dtype=h.dtype, device=h.device)
+    dist.all_gather_into_tensor(dg_all, pad(dg))
+    dist.all_gather_into_tensor(h_all, pad(h))
+    return dg_all, h_all

@@ -1,0 +1,234 @@
+"""Band extraction step on MI355X (mirror of reference preprocess/signal/frequency_filter.py).
+
+Same plugin ABI: ``run(data (C,T), params) -> (C', T)`` with ``params.bands`` / ``params.signal_freq``
+(:9-77) and the same three public functions with the same keyword arguments and error behaviour:
+``hilbert_filter`` (:80-184), ``butter_filter`` (:187-229), ``fir_bandpass_filter`` (:232-274).
+
+The arithmetic runs in HIP kernels (``csrc/tonal_signal.hip``):
+ * the Gaussian-bank analytic signal is evaluated as an *exact* circular convolution: the host
+   takes the inverse DFT of the reference's frequency-domain kernel ``H_b * hilbert_mult``
+   (including its ``H[0] = 0`` and the one-sided multiplier) and keeps every tap above the fp64
+   round-off floor of that inverse DFT (1e-13 of the kernel peak); the kernel then computes |sum_n h_b[n] x[(t-n) mod T]| per band and the mean
+   over bands in one pass over the recording (the reference loops n_bands x C Python-level iFFTs);
+ * ``filtfilt`` / ``sosfilt`` are fp64 direct-form-II-transposed recurrences, one lane per channel;
+ * the FIR bank is a causal convolution with zero initial state.
+Filter *design* (``butter``, ``lfilter_zi``, ``firwin``) stays on scipy: coefficient generation,
+not the hot path.
+
+Inputs may be NumPy arrays (copied to the GPU and back, like a drop-in step must) or CUDA torch
+tensors (stay resident; a CUDA tensor is returned).
+"""
+from __future__ import annotations
+
+import math
+from argparse import Namespace
+from typing import List, Tuple, Union
+
+import numpy as np
+import torch
+from scipy.signal import butter, firwin, lfilter_zi
+
+from ... import _lib
+from ..._lib import check, ptr
+
+_MAX_TAPS_LDS = 7169      # (1024 + ntap - 1) * 8 B <= 64 KiB
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("frequency_filter (MI355X build): no GPU visible; this package has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_device(data) -> Tuple[torch.Tensor, bool]:
+    """(C,T) float32/float64 device tensor and whether the caller passed a NumPy array."""
+    if isinstance(data, torch.Tensor):
+        _lib.require_gpu(data, "frequency_filter")
+        t = data
+        was_np = False
+    else:
+        arr = np.asarray(data)
+        if arr.dtype not in (np.float32, np.float64):
+            arr = arr.astype(np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(_device())
+        was_np = True
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.double()
+    if t.dim() != 2:
+        raise ValueError("expected data of shape (n_channels, n_timepoints)")
+    return t.contiguous(), was_np
+
+
+def _ret(t: torch.Tensor, was_np: bool):
+    return t.cpu().numpy() if was_np else t
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gaussian_bank(freq_ranges, sampling_rate, f0=0.018, octspace=1 / 7, filterbank_bias=math.log10(0.39),
+                  filterbank_slope=0.5):
+    """Centre frequencies / widths, including the reference's argument normalisation (:121-153)."""
+    if isinstance(freq_ranges, tuple):
+        freq_ranges = [freq_ranges]
+    if isinstance(freq_ranges[0], float):
+        freq_ranges = [tuple(freq_ranges)]
+    cfs, sds = [], []
+    for fr in freq_ranges:
+        if len(fr) != 2:
+            raise ValueError("Each frequency range must be a tuple of (min_freq, max_freq).")
+        min_freq = fr[0] if fr else 0
+        max_freq = fr[1] if fr else sampling_rate // 2
+        max_oct = math.log2(max_freq / f0)
+        f = f0
+        while math.log2(f / f0) < max_oct:
+            if f >= min_freq:
+                cfs.append(f)
+                sds.append(10 ** (filterbank_bias + filterbank_slope * math.log10(f)))
+            f = f * (2 ** octspace)
+    return np.array(cfs), np.array(sds) * np.sqrt(2)
+
+
+def analytic_taps(T: int, sampling_rate: float, cfs: np.ndarray, sds: np.ndarray, tol: float = 1e-13):
+    """Time-domain kernels of the reference's per-band DFT multiplier (:155-175).
+
+    Returns (taps (nb, ntap) complex128, half) with h_b[n], n = k - half.  ``ntap == T, half == 0``
+    means the full circular kernel is used (short recordings / slowly decaying kernels)."""
+    freqs = np.fft.fftfreq(T, d=1.0 / sampling_rate)
+    mult = np.zeros(T)
+    if T % 2 == 0:
+        mult[0] = 1
+        mult[1:T // 2] = 2
+        mult[T // 2] = 1
+    else:
+        mult[0] = 1
+        mult[1:(T + 1) // 2] = 2
+    ker = np.empty((len(cfs), T), dtype=np.complex128)
+    for i, (fc, sf) in enumerate(zip(cfs, sds)):
+        H = np.exp(-0.5 * ((freqs - fc) / sf) ** 2)
+        H[0] = 0
+        ker[i] = np.fft.ifft(H * mult)
+    # Keep every tap above the round-off floor of the DFT-domain evaluation itself: entries below
+    # `tol` x the kernel peak are indistinguishable from the reference's own fp64 FFT rounding.
+    mag = np.abs(ker)
+    dist = np.minimum(np.arange(T), T - np.arange(T))      # circular distance of index n from 0
+    live = mag > tol * mag.max(axis=1, keepdims=True)
+    half = int(dist[live.any(axis=0)].max())
+    if 2 * half + 1 >= T:
+        return ker, 0
+    idx = np.arange(-half, half + 1) % T
+    return np.ascontiguousarray(ker[:, idx]), half
+
+
+def hilbert_filter(data, sampling_rate: int, freq_ranges: Union[List[Tuple[float, float]], Tuple[float, float]],
+                   f0: float = 0.018, octspace: float = 1 / 7, filterbank_bias: float = math.log10(0.39),
+                   filterbank_slope: float = 0.5, envelope: bool = True):
+    """Gaussian Hilbert filter bank, mean over bands; float64 out (reference :80-184)."""
+    cfs, sds = gaussian_bank(freq_ranges, sampling_rate, f0, octspace, filterbank_bias, filterbank_slope)
+    x, was_np = _to_device(data)
+    C, T = x.shape
+    if len(cfs) == 0:
+        # the reference's mean over an empty band axis yields NaN
+        return _ret(torch.full((C, T), float("nan"), dtype=torch.float64, device=x.device), was_np)
+    taps, half = analytic_taps(T, sampling_rate, cfs, sds)
+    ntap = taps.shape[1]
+    if ntap > _MAX_TAPS_LDS:
+        raise ValueError(f"hilbert_filter: the band kernels need {ntap} taps at this sampling rate; "
+                         f"the MI355X kernel supports up to {_MAX_TAPS_LDS}")
+    tp = torch.from_numpy(np.ascontiguousarray(np.stack([taps.real, taps.imag], axis=-1))).to(x.device)
+    y = torch.empty(C, T, dtype=torch.float64, device=x.device)
+    check(_lib.load().tl_gauss_envelope(ptr(x), int(x.dtype == torch.float64), ptr(tp), ptr(y), C, T, len(cfs), ntap,
+                                        half, int(bool(envelope)), _stream()), "tl_gauss_envelope")
+    return _ret(y, was_np)
+
+
+def butter_filter(data, freqs: Union[Tuple[float, float], float], fs: float, order: int = 4, causal: bool = False,
+                  filter_type: str = 'bandpass'):
+    """Butterworth filter: zero-phase ``filtfilt`` or causal ``sosfilt`` (reference :187-229)."""
+    nyquist = 0.5 * fs
+    wn = np.asarray(freqs, dtype=float) / nyquist
+    squeeze = False
+    if not isinstance(data, torch.Tensor) and np.asarray(data).ndim == 1:
+        data = np.asarray(data)[None, :]
+        squeeze = True
+    x, was_np = _to_device(data)
+    C, T = x.shape
+    lib = _lib.load()
+    y = torch.empty(C, T, dtype=torch.float64, device=x.device)
+    if causal:
+        sos = np.ascontiguousarray(butter(order, wn, btype=filter_type, output='sos'), dtype=np.float64)
+        sd = torch.from_numpy(sos).to(x.device)
+        check(lib.tl_sosfilt_f64(ptr(x), int(x.dtype == torch.float64), ptr(sd), ptr(y), C, T, sos.shape[0], _stream()),
+              "tl_sosfilt_f64")
+    else:
+        b, a = butter(order, wn, btype=filter_type)
+        ntaps = max(len(a), len(b))
+        edge = 3 * ntaps
+        if T <= edge:
+            raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
+        bb = np.zeros(ntaps)
+        aa = np.zeros(ntaps)
+        bb[:len(b)] = b / a[0]
+        aa[:len(a)] = a / a[0]
+        zi = lfilter_zi(bb, aa)
+        dev = x.device
+        bd, ad, zd = (torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev) for v in (bb, aa, zi))
+        work = torch.empty(C, T + 2 * edge, dtype=torch.float64, device=dev)
+        check(lib.tl_filtfilt_f64(ptr(x), int(x.dtype == torch.float64), ptr(bd), ptr(ad), ptr(zd), ptr(y), ptr(work),
+                                  C, T, ntaps, _stream()), "tl_filtfilt_f64")
+    out = _ret(y, was_np)
+    return out[0] if squeeze else out
+
+
+def fir_bandpass_filter(data, fs: float, order: int, center_frequencies: List[float]):
+    """Causal FIR band-pass bank, mean over centre frequencies (reference :232-274), including its
+    double normalisation of the cut-offs (:265-268).  Output dtype follows the input (:261)."""
+    nyquist = 0.5 * fs
+    taps = []
+    for fc in center_frequencies:
+        taps.append(firwin(order + 1, [fc * 0.9 / nyquist, fc * 1.1 / nyquist], pass_zero=False, fs=fs))
+    taps = np.ascontiguousarray(np.array(taps), dtype=np.float64)
+    if taps.shape[1] > _MAX_TAPS_LDS:
+        raise ValueError(f"fir_bandpass_filter: order {order} exceeds the kernel limit {_MAX_TAPS_LDS - 1}")
+    squeeze = False
+    if not isinstance(data, torch.Tensor) and np.asarray(data).ndim == 1:
+        data = np.asarray(data)[None, :]
+        squeeze = True
+    x, was_np = _to_device(data)
+    C, T = x.shape
+    td = torch.from_numpy(taps).to(x.device)
+    y = torch.empty(C, T, dtype=x.dtype, device=x.device)
+    check(_lib.load().tl_fir_bank(ptr(x), int(x.dtype == torch.float64), ptr(td), ptr(y),
+                                  int(y.dtype == torch.float64), C, T, taps.shape[0], taps.shape[1], _stream()),
+          "tl_fir_bank")
+    out = _ret(y, was_np)
+    return out[0] if squeeze else out
+
+
+def run(data, params: Namespace):
+    """Plugin entry: iterate ``params.bands`` and concatenate the extracted bands as channels
+    (reference :9-77)."""
+    if "bands" not in params or params.bands is None:
+        raise ValueError("bands must be specified in params.")
+    all_channels = []
+    for freq_config in params.bands:
+        method = freq_config.get("method", "hilbert")
+        method_params = freq_config.get("params", {})
+        if method == 'hilbert':
+            if 'freq_ranges' not in method_params:
+                raise ValueError("Hilbert filter requires 'freq_ranges' in params.")
+            signals = hilbert_filter(data, params.signal_freq, **method_params)
+        elif method == 'butter':
+            if "freqs" not in method_params:
+                raise ValueError("Butterworth filter requires 'freq_range' in params.")
+            signals = butter_filter(data, fs=params.signal_freq, **method_params)
+        elif method == 'fir':
+            if "order" not in method_params or "center_frequencies" not in method_params:
+                raise ValueError("FIR filter requires 'order' and 'center_frequencies' in params.")
+            signals = fir_bandpass_filter(data, fs=params.signal_freq, order=method_params["order"],
+                                          center_frequencies=method_params["center_frequencies"])
+        all_channels.append(signals)
+    if all_channels and isinstance(all_channels[0], torch.Tensor):
+        return torch.cat([s.double() for s in all_channels], dim=0)
+    return np.concatenate(all_channels, axis=0)

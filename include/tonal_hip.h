@@ -1,0 +1,174 @@
+/* tonal_hip.h - C ABI of libtonal_hip.so (gfx950 / MI355X).
+ *
+ * The reference (Daniel-Lin-S/decode_tonal_langauge) is pure Python and has no FFI; every
+ * arithmetic call on its hot path goes to torch / scipy.  This header
+ * is therefore the boundary *we* define: each entry point names the reference call site
+ * (file:line under /root/reference) whose arithmetic it replaces.  The Python mirror of the
+ * reference's classes (decode_tonal_langauge_amd/models/..., preprocess/signal/...) binds these
+ * with ctypes (decode_tonal_langauge_amd/_lib.py); INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - the caller owns every buffer, including workspaces; no entry point allocates, frees or
+ *    synchronises; work is enqueued on `stream` (a hipStream_t passed as void*);
+ *  - return 0 on success, a negative TL_E* code otherwise; tl_last_error() gives the
+ *    thread-local message of the last failure;
+ *  - fp32 unless stated; "rows" are flattened (sequence, time) rows of channels-last
+ *    activations: row = seq * Tp + t, seq = b * C + c (data layout).
+ */
+#ifndef TONAL_HIP_H
+#define TONAL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TL_OK 0
+#define TL_EINVAL (-1)   /* bad argument / shape */
+#define TL_ELAUNCH (-2)  /* hip launch failure   */
+#define TL_ENODEV (-3)   /* no gfx950 device     */
+
+const char* tl_last_error(void);
+int tl_version(void);
+/* number of visible HIP devices, or negative error (does not initialise a context) */
+int tl_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Windowed NT GEMM  ("conv (k,1) as implicit GEMM", fp32 MFMA 32x32x2):
+ *   acc[R][n] = sum_{j<J} sum_{k<K} Arow(R + j + row_shift)[k] * Bw[j][n][k]
+ * Replaces nn.Conv2d((k,1)) + LeakyReLU + MaxPool2d((2,1)) forward and input-gradient
+ * (models/synthesis_models.py:86-105,116-131), nn.Linear forward (:133-135), and the
+ * h @ W_hh^T product of nn.LSTM (:112,164-166).
+ *
+ * loader: 0 DIRECT  A rows are read from `A` (row stride lda);
+ *         1 UNPOOL  A rows are the un-pooled gradient dZ built on the fly from the pooled
+ *                   gradient G (`A`, row stride lda) and the arg-max bits written by the
+ *                   forward epilogue (`abits`, [prow][ld_abits] 32-bit words):
+ *                   dZ[Rz][k] = G[Rz/2][k] if bit(Rz/2,k)==(Rz&1) and (Rz%Tp)<Tvalid_in else 0.
+ * epilogue: 0 STORE  out[R][n] = acc (+bias[n]); with splitk>1 partial sums go to
+ *                    out + z*slab_stride (no bias) and the caller reduces;
+ *           1 LRELU  out[R][n] = lrelu(acc + bias[n]);
+ *           2 POOL   out[R/2][n] = max over the row pair of lrelu(acc + bias[n]), 0 for rows
+ *                    with (R%Tp) >= Tvalid; arg-max bit -> obits[R/2][n/32];
+ *           3 MASK   out[R][n] = acc * (aux[R][n] > 0 ? 1 : slope)    (LeakyReLU backward)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* A; const uint32_t* abits; const float* Bw; const float* bias; const float* aux;
+  float* out; uint32_t* obits;
+  int64_t M;          /* output rows to compute                                   */
+  int64_t A_rows;     /* rows addressable in A (G rows for UNPOOL)                */
+  int N, K;           /* output columns, reduction length per tap (K % 4 == 0)    */
+  int lda, ldb, ldo, ldaux, ld_abits, ld_obits;
+  int J;              /* taps (1..3); Bw is [J][N][ldb]                           */
+  int row_shift;      /* 0 forward, -(J-1) input-gradient                         */
+  int Tp, Tvalid, Tvalid_in;
+  float slope;
+  int loader, epilogue;
+  int splitk; int64_t slab_stride;
+  int bm;             /* row-tile height: 128 (default) or 32 (skinny M)          */
+} tl_nt_params;
+int tl_gemm_nt_window(const tl_nt_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Windowed TN GEMM (weight gradients, reduction over rows):
+ *   slab[z][j*Mj + m][n] = sum_{R in split z} A[R + j][m] * Bz[R][n]
+ * with Bz = B (DIRECT, rows masked by (R%Tp)<Tvalid) or the un-pooled dZ (UNPOOL, as above).
+ * Replaces the weight-gradient of Conv2d/Linear/LSTM produced by loss.backward()
+ * (models/synthesis_trainer.py:226).  The caller sums the `splitk` slabs.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* A; const float* B; const uint32_t* bbits; float* slab;
+  int64_t Krows;      /* reduction rows                                            */
+  int64_t A_rows, B_rows;
+  int Mdim, Ndim;     /* A columns used (per tap), B columns                       */
+  int lda, ldb, ldc, ld_bbits;
+  int J;
+  int Tp, Tvalid;
+  int loader;
+  int splitk; int64_t slab_stride;
+} tl_tn_params;
+int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
+
+/* ---- first conv stage, C_in = 1 (models/synthesis_models.py:87-89) ----------------------
+ * x (S, T) -> P1 rows (S*Tp, C1) + arg-max bits; w (C1,3) b (C1).                          */
+int tl_conv1_fwd(const float* x, const float* w, const float* b, float* P, uint32_t* bits,
+                 int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream);
+/* its weight/bias gradient from G1 = dL/dZ at the arg-max: partial[nblk][(ktaps+1)*C1]      */
+int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial,
+                   int nblk, int64_t S, int T, int ktaps, int C1, int Tp, int Tout, void* stream);
+
+/* ---- small strided helpers --------------------------------------------------------------- */
+/* dst[i0][i1][i2][i3] (contiguous) = sum_{z<nz} src[z*zs + i0*s0 + i1*s1 + i2*s2 + i3*s3];
+ * elements whose i_d >= lim_d (source extents) read as 0. Used to pack torch-layout weights
+ * into GEMM layouts and to reduce + unpack split-K weight-gradient slabs.                   */
+int tl_permute_reduce(const float* src, float* dst, const int64_t dims[4], const int64_t strides[4],
+                      const int64_t lims[4], int nz, int64_t zs, const float* bias_last, void* stream);
+/* out[c] partial sums over valid rows: partial[nblk][ncols]; rows valid iff (r%Tp)<Tvalid   */
+int tl_colsum(const float* G, float* partial, int nblk, int64_t rows, int ncols, int ld,
+              int Tp, int Tvalid, void* stream);
+
+/* ---- label LSTM (models/synthesis_models.py:112,164-167; :249-252,288-289) --------------- */
+/* one time step, pointwise part: gates = hh + x_t W_ih^T + b_ih + b_hh -> (i,f,g,o), c, h.
+ * hh (U, 4H) may be null for t = 0 (zero state).  act (U,4H) keeps the activated gates.     */
+int tl_lstm_cell_fwd(const float* hh, const float* x_t, const float* w_ih, const float* b_ih,
+                     const float* b_hh, const float* c_prev, float* act, float* c, float* h,
+                     int U, int H, int in_dim, int ld_hh, void* stream);
+/* backward of the same step: dh, dc_next -> dgates (U,4H) row-major and transposed (4H,ldt),
+ * dc_prev.  c_prev may be null (t = 0).                                                     */
+int tl_lstm_cell_bwd(const float* dh, const float* dh_rec, const float* dc_next, const float* act,
+                     const float* c, const float* c_prev, float* dgates, float* dgates_t, float* dc_prev,
+                     int U, int H, int ldt, void* stream);
+/* dW_ih (4H,in_dim), db (4H) from dgates (L,U,4H) and x (L,U,in_dim)                        */
+int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih, float* db,
+                    int L, int U, int H, int in_dim, void* stream);
+
+/* ---- concat / dropout glue (models/synthesis_models.py:107,160-170) ----------------------- */
+/* Xc[row][0:Cc] = O5[row][0:Cc] * keep(row,ch); Xc[row][Cc+lc] = h[uid[b]][lc*lat*C + t*C + c];
+ * remaining pad columns = 0.  keep = 1 if p_drop == 0 else Bernoulli via counter hash.      */
+int tl_concat_pack(const float* O5, const float* h, const int32_t* uid, float* Xc,
+                   int B, int C, int Tp, int lat, int Cc, int Lc, int ld5, int ldh, int ldx,
+                   float p_drop, uint64_t seed, void* stream);
+/* backward: G5[row][ch] = dXc[row][ch]*keep*lrelu'(O5); dh[u][..] = sum_{b in u} dXc[..][Cc+lc] */
+int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int32_t* members, const int32_t* offsets,
+                         float* G5, float* dh, int B, int U, int C, int Tp, int lat, int Cc, int Lc,
+                         int ld5, int ldh, int ldx, float slope, float p_drop, uint64_t seed, void* stream);
+
+/* ---- loss / metric (models/synthesis_trainer.py:14-43,140,222-229) ------------------------ */
+/* targets are truncated toward zero when trunc_targets != 0 (the reference's .long()).
+ * dout (row stride ldd) = sign(out - t) / (B*D) * grad_scale; stats[0] += L1 mean,
+ * stats[1] += MCD mean, stats[2], stats[3] = this call's L1 / MCD                            */
+int tl_l1_mcd(const float* out, const float* targets, float* dout, float* stats,
+              int B, int D, int ldd, int trunc_targets, float grad_scale, void* stream);
+
+/* ---- NAdam (torch.optim.NAdam as built at models/synthesis_trainer.py:131-137) ------------ */
+int tl_nadam(float* p, const float* g, float* m, float* v, int64_t n, float coef_grad, float coef_mom,
+             float beta1, float beta2, float bias_corr2, float eps, float weight_decay, float grad_scale,
+             void* stream);
+
+/* ---- tone dynamics gather (data_loading/utils.py:32-79) ----------------------------------- */
+/* labels[b][0][l] = syl[b]; labels[b][1][l] = table[tone[b]][l]; err flag set if tone out of range */
+int tl_tone_dynamics(const int64_t* tone, const int64_t* syl, const float* table, float* labels,
+                     int32_t* err, int B, int n_tones, int L, void* stream);
+
+/* ---- preprocess/signal band extraction (preprocess/signal/frequency_filter.py) ------------ */
+/* Gaussian-bank analytic envelope, circular, exact DFT-domain taps supplied by the host:
+ * taps (nb, ntap, 2) complex float64 kernels h_b[n], n = k - half for k in [0, ntap), ntap <= T
+ * (frequency_filter.py:158-184); x (C,T) float32 or float64 (x_is_f64), y (C,T) float64 =
+ * mean_b |sum_n h_b[n] x[(t-n) mod T]| (envelope != 0) or the mean of the real parts.        */
+int tl_gauss_envelope(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T,
+                      int nb, int ntap, int half, int envelope, void* stream);
+/* zero-phase IIR (scipy filtfilt, odd padding, lfilter_zi), fp64 (frequency_filter.py:226-227) */
+int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, const double* a, const double* zi,
+                    double* y, double* work, int C, int64_t T, int ntaps, void* stream);
+/* causal cascade of biquads (sosfilt), fp64 (frequency_filter.py:223-224)                     */
+int tl_sosfilt_f64(const void* x, int x_is_f64, const double* sos, double* y, int C, int64_t T,
+                   int nsec, void* stream);
+/* causal FIR bank, mean over bands (frequency_filter.py:260-274); taps (nb, ntap) float64      */
+int tl_fir_bank(const void* x, int x_is_f64, const double* taps, void* y, int y_is_f64, int C, int64_t T,
+                int nb, int ntap, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+"""Seeded input generators shared by oracle/make_golden.py and the parity tests.
+
+The goldens under tests/golden/ hold the reference's *outputs*; the inputs are regenerated
+from these seeds (CPU torch / numpy generators are deterministic for a given version; each
+golden also stores an input checksum so RNG drift is detected rather than silently accepted).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+TONE_MAP = {"0": [3, 3, 3, 3, 3], "1": [1, 2, 3, 4, 5], "2": [3, 2, 1, 2, 4], "3": [5, 4, 3, 2, 1]}
+
+
+def tone_dynamics(tones: torch.Tensor, syls: torch.Tensor, mapping=TONE_MAP) -> torch.Tensor:
+    """(B,2,L) float tensor [[syl]*L, mapping[tone]] - what the trainer feeds the model
+    (reference models/synthesis_trainer.py:212-218)."""
+    rows = [[[int(s)] * len(mapping[str(int(t))]), list(mapping[str(int(t))])] for t, s in zip(tones, syls)]
+    return torch.tensor(rows, dtype=torch.float32)
+
+
+def train_batches(nsteps: int, B: int, C: int, T: int, seed: int = 1234, out_dim: int = 80):
+    """Synthetic batches in the layout of SURVEY.md section 8d."""
+    gen = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(B, C, T, generator=gen) for _ in range(nsteps)]
+    tones = [torch.randint(0, 4, (B,), generator=gen) for _ in range(nsteps)]
+    syls = [torch.randint(0, 2, (B,), generator=gen) for _ in range(nsteps)]
+    labs = [tone_dynamics(t, s) for t, s in zip(tones, syls)]
+    tg = [10 * torch.randn(B, out_dim, generator=gen) for _ in range(nsteps)]
+    return xs, tones, syls, labs, tg
+
+
+def g1_inputs():
+    """After torch.manual_seed(0) and model construction: x, lab drawn from the global RNG."""
+    x = torch.randn(3, 4, 100)
+    lab = torch.randn(3, 2, 5)
+    return x, lab
+
+
+def g2_inputs():
+    x = torch.randn(4, 32, 200)
+    lab = torch.randn(4, 2, 5)
+    return x, lab
+
+
+def g6_inputs():
+    x = np.random.default_rng(0).standard_normal((2, 1000))
+    x2 = np.random.default_rng(1).standard_normal((3, 777)).astype(np.float32)
+    return x, x2
+
+
+def g9_dataset(N: int = 96, C: int = 32, T: int = 200, seed: int = 1234):
+    gen = torch.Generator().manual_seed(seed)
+    e_non = torch.randn(N, C, T, generator=gen)
+    e_syl = torch.randn(N, 8, T, generator=gen)
+    e_tone = torch.randn(N, 8, T, generator=gen)
+    tgt = 10 * torch.randn(N, 80, generator=gen)
+    return e_non, e_syl, e_tone, tgt
+
+
+def checksum(*arrays) -> float:
+    s = 0.0
+    for a in arrays:
+        a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        s += float(np.abs(a.astype(np.float64)).sum())
+    return s
+
+
+def update_rel_l2(final_a, final_b, init) -> float:
+    """Relative L2 distance between two parameter *updates* (final - init).  NAdam turns a
+    gradient that is numerically ~0 into a +-lr step, so element-wise comparison of final
+    parameters is ill-conditioned; the update vector as a whole is not."""
+    da = (np.asarray(final_a, dtype=np.float64) - np.asarray(init, dtype=np.float64)).ravel()
+    db = (np.asarray(final_b, dtype=np.float64) - np.asarray(init, dtype=np.float64)).ravel()
+    return float(np.linalg.norm(da - db) / max(np.linalg.norm(db), 1e-30))

@@ -1,0 +1,159 @@
+"""GPU parity tests (run with ``-m gpu`` on the MI355X box): the HIP path, called through the
+C ABI, against the committed golden vectors of the reference and against the CPU oracle on the
+same seeded inputs.  Tolerances: fp32 paths 1e-3 relative (north_star), observed ~1e-6;
+fp64 signal paths 1e-9 relative.
+"""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+def _trainer(model, dev, T, n_ch=8):
+    from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
+    from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
+    tone = LogisticRegressionClassifier(n_ch * T, 4)
+    syl = LogisticRegressionClassifier(n_ch * T, 2)
+    return SynthesisTrainer(model, tone, syl, gi.TONE_MAP, device=dev, verbose=False)
+
+
+def test_cnn_forward_matches_reference_golden(dev):
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    g = np.load(os.path.join(GOLD, "g1_cnn_forward.npz"))
+    torch.manual_seed(0)
+    model = SynthesisModelCNN(80, 4, 100).eval()
+    x, lab = gi.g1_inputs()
+    assert abs(gi.checksum(x, lab) - float(g["in_checksum"])) < 1e-6 * float(g["in_checksum"])
+    assert abs(gi.checksum(*model.state_dict().values()) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
+    model.to(dev)
+    with torch.no_grad():
+        out = model(x.to(dev), lab.to(dev))
+    assert out.shape == (3, 80)
+    assert rel(out.cpu().numpy(), g["out"]) < 1e-4
+    # intermediate checks through the engine buffers (layout: [seq*Tp + t][channel])
+    eng = model._engine
+    e5 = eng.P[5].view(3, 4, eng.tp5, eng.ld5)[:, :, :eng.lat, :64].permute(0, 3, 2, 1).cpu().numpy()
+    assert rel(e5, g["ecog5"]) < 1e-4
+    h = eng._h[-1][eng._uid.long()].cpu().numpy()
+    assert rel(h, g["lstm_h"]) < 1e-4
+
+
+def test_cnn_train_steps_match_reference_golden(dev):
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    g = np.load(os.path.join(GOLD, "g4_cnn_train.npz"))
+    xs, _t, _s, labs, tg = gi.train_batches(3, 8, 16, 200)
+    assert abs(gi.checksum(*xs, *labs, *tg) - float(g["in_checksum"])) < 1e-6 * float(g["in_checksum"])
+    torch.manual_seed(0)
+    model = SynthesisModelCNN(80, 16, 200, dropout=0.0)
+    assert model.get_nparams() == 7169232
+    init = {k: v.detach().clone().numpy() for k, v in model.named_parameters()}
+    tr = _trainer(model, dev, 200)
+    model.train()
+    losses, mcds = [], []
+    for s in range(3):
+        tr._fused_step(xs[s].to(dev), labs[s].to(dev), tg[s].to(dev))
+        st = tr._stats.cpu().numpy()
+        losses.append(st[2])
+        mcds.append(st[3])
+        if s == 0:
+            for k, gr in tr._grads.items():
+                gr = gr.cpu().numpy()
+                if "grad1." + k in g:
+                    assert rel(gr, g["grad1." + k]) < 1e-3, k
+                else:
+                    assert rel(gr.reshape(-1)[::97], g["grad1." + k + "@s97"]) < 1e-3, k
+                    sums = g["grad1." + k + "@sum"]
+                    assert abs(np.abs(gr).astype(np.float64).sum() - sums[1]) < 1e-3 * sums[1], k
+    assert rel(losses, g["losses"]) < 1e-4
+    assert rel(mcds, g["mcds"]) < 1e-4
+    for k, p in model.named_parameters():
+        fin = p.detach().cpu().numpy()
+        if "final." + k in g:
+            assert gi.update_rel_l2(fin, g["final." + k], init[k]) < 2e-3, k
+        else:
+            assert gi.update_rel_l2(fin.reshape(-1)[::97], g["final." + k + "@s97"], init[k].reshape(-1)[::97]) < 2e-3, k
+
+
+def test_cnn_autograd_path_equals_fused_path(dev):
+    """model(x, lab) + loss.backward() (torch.autograd.Function) gives the same gradients as the
+    trainer's fused step, and they match the oracle on the same inputs."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    from oracle import synthesis_oracle as so
+    xs, _t, _s, labs, tg = gi.train_batches(1, 5, 4, 100, seed=77)
+    torch.manual_seed(3)
+    model = SynthesisModelCNN(80, 4, 100, dropout=0.0)
+    params = {k: v.detach().clone() for k, v in model.named_parameters()}
+    model.to(dev).train()
+    out = model(xs[0].to(dev), labs[0].to(dev))
+    loss = (out - tg[0].to(dev).long()).abs().mean()
+    loss.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = so.cnn_forward(leaves, xs[0], labs[0])
+    ref_loss = so.l1_loss(ref, tg[0].long())
+    ref_grads = dict(zip(leaves, torch.autograd.grad(ref_loss, list(leaves.values()))))
+    assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    for k, p in model.named_parameters():
+        assert rel(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 1e-3, k
+
+
+def test_cnn_random_labels_no_dedup(dev):
+    """Arbitrary float label sequences (every row distinct): the LSTM runs with U = B."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    from oracle import synthesis_oracle as so
+    torch.manual_seed(5)
+    model = SynthesisModelCNN(40, 8, 60, lstm_channels=2, conv_channels=16, dropout=0.0)
+    params = {k: v.detach().clone() for k, v in model.named_parameters()}
+    x = torch.randn(70, 8, 60)
+    lab = torch.randn(70, 2, 3)
+    model.to(dev).train()
+    out = model(x.to(dev), lab.to(dev))
+    out.square().mean().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = so.cnn_forward(leaves, x, lab)
+    ref_grads = dict(zip(leaves, torch.autograd.grad(ref.square().mean(), list(leaves.values()))))
+    assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    for k, p in model.named_parameters():
+        assert rel(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 1e-3, k
+
+
+def test_signal_filters_match_reference_golden(dev):
+    from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
+    g = np.load(os.path.join(GOLD, "g6_signal.npz"))
+    x, x2 = gi.g6_inputs()
+    assert abs(gi.checksum(x, x2) - float(g["in_checksum"])) < 1e-9 * float(g["in_checksum"])
+    hil = ff.hilbert_filter(x, 400, freq_ranges=[70., 150.])
+    assert hil.dtype == np.float64 and rel(hil, g["hilbert"]) < 1e-9
+    assert rel(ff.hilbert_filter(x, 400, freq_ranges=[70., 150.], envelope=False), g["hilbert_real"]) < 1e-9
+    assert rel(ff.butter_filter(x, [0.3, 100], 400), g["butter"]) < 1e-9
+    assert rel(ff.butter_filter(x, [0.3, 100], 400, causal=True), g["butter_causal"]) < 1e-9
+    assert rel(ff.fir_bandpass_filter(x, 400, 390, [100.]), g["fir"]) < 1e-9
+    assert rel(ff.fir_bandpass_filter(x, 400, 64, [60., 120.]), g["fir2"]) < 1e-9
+    # float32 input, odd length, two ranges: the reference itself computes this in complex64
+    h2 = ff.hilbert_filter(x2, 400, freq_ranges=[(70., 110.), (110., 150.)])
+    assert h2.dtype == np.float64 and rel(h2, g["hilbert2"]) < 1e-5
+    prm = Namespace(signal_freq=400, bands=[
+        {"method": "hilbert", "params": {"freq_ranges": [70., 150.], "envelope": True}},
+        {"method": "butter", "params": {"freqs": [0.3, 100], "filter_type": "bandpass"}},
+        {"method": "fir", "params": {"order": 390, "center_frequencies": [100.]}}])
+    out = ff.run(x, prm)
+    assert out.shape == (6, 1000) and rel(out, g["run"]) < 1e-9
