@@ -117,9 +117,11 @@ constexpr int MAX_TAPS = 17;
 
 template <typename TIN>
 __device__ __forceinline__ double ext_sample(const void* x, long long cbase, long long T, int edge, long long i) {
+#pragma clang fp contract(off)
   // odd extension of scipy.signal.filtfilt (padtype='odd')
-  if (i < edge) return 2.0 * ld_as_f64<TIN>(x, cbase) - ld_as_f64<TIN>(x, cbase + (edge - i));
-  if (i >= edge + T) return 2.0 * ld_as_f64<TIN>(x, cbase + T - 1) - ld_as_f64<TIN>(x, cbase + T - 2 - (i - edge - T));
+  if (i < edge) return __dsub_rn(__dmul_rn(2.0, ld_as_f64<TIN>(x, cbase)), ld_as_f64<TIN>(x, cbase + (edge - i)));
+  if (i >= edge + T)
+    return __dsub_rn(__dmul_rn(2.0, ld_as_f64<TIN>(x, cbase + T - 1)), ld_as_f64<TIN>(x, cbase + T - 2 - (i - edge - T)));
   return ld_as_f64<TIN>(x, cbase + (i - edge));
 }
 
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(const void* __restrict__ x
                                                       const double* __restrict__ a, const double* __restrict__ zi,
                                                       double* __restrict__ y, double* __restrict__ work, int C,
                                                       long long T, int ntaps) {
+#pragma clang fp contract(off)   // HIP's __dadd_rn/__dmul_rn are plain + and *: keep them un-fused
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const int edge = 3 * ntaps;
@@ -144,12 +147,15 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(const void* __restrict__ x
   {
     const double x0 = ext_sample<TIN>(x, cb, T, edge, 0);
 #pragma unroll
-    for (int k = 0; k < MAX_TAPS; ++k) z[k] = (k < ntaps - 1) ? zi[k] * x0 : 0.0;
+    for (int k = 0; k < MAX_TAPS; ++k) z[k] = (k < ntaps - 1) ? __dmul_rn(zi[k], x0) : 0.0;
     for (long long i = 0; i < next; ++i) {
       const double xv = ext_sample<TIN>(x, cb, T, edge, i);
-      const double yv = fma(bb[0], xv, z[0]);
+      // same operation order and roundings as scipy's lfilter C loop (no FMA contraction):
+      // y = z0 + b0*x;  z_k = (z_{k+1} + x*b_{k+1}) - y*a_{k+1}
+      const double yv = __dadd_rn(z[0], __dmul_rn(bb[0], xv));
 #pragma unroll
-      for (int k = 0; k < MAX_TAPS - 1; ++k) z[k] = fma(bb[k + 1], xv, z[k + 1]) - aa[k + 1] * yv;
+      for (int k = 0; k < MAX_TAPS - 1; ++k)
+        z[k] = __dsub_rn(__dadd_rn(z[k + 1], __dmul_rn(xv, bb[k + 1])), __dmul_rn(yv, aa[k + 1]));
       w[i] = yv;
     }
   }
@@ -157,12 +163,15 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(const void* __restrict__ x
   {
     const double x0 = w[next - 1];
 #pragma unroll
-    for (int k = 0; k < MAX_TAPS; ++k) z[k] = (k < ntaps - 1) ? zi[k] * x0 : 0.0;
+    for (int k = 0; k < MAX_TAPS; ++k) z[k] = (k < ntaps - 1) ? __dmul_rn(zi[k], x0) : 0.0;
     for (long long i = next - 1; i >= 0; --i) {
       const double xv = w[i];
-      const double yv = fma(bb[0], xv, z[0]);
+      // same operation order and roundings as scipy's lfilter C loop (no FMA contraction):
+      // y = z0 + b0*x;  z_k = (z_{k+1} + x*b_{k+1}) - y*a_{k+1}
+      const double yv = __dadd_rn(z[0], __dmul_rn(bb[0], xv));
 #pragma unroll
-      for (int k = 0; k < MAX_TAPS - 1; ++k) z[k] = fma(bb[k + 1], xv, z[k + 1]) - aa[k + 1] * yv;
+      for (int k = 0; k < MAX_TAPS - 1; ++k)
+        z[k] = __dsub_rn(__dadd_rn(z[k + 1], __dmul_rn(xv, bb[k + 1])), __dmul_rn(yv, aa[k + 1]));
       if (i >= edge && i < edge + T) y[cb + (i - edge)] = yv;
     }
   }
@@ -172,6 +181,7 @@ constexpr int MAX_SEC = 8;
 template <typename TIN>
 __global__ __launch_bounds__(64) void sosfilt_kernel(const void* __restrict__ x, const double* __restrict__ sos,
                                                      double* __restrict__ y, int C, long long T, int nsec) {
+#pragma clang fp contract(off)
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s[MAX_SEC][6], z0[MAX_SEC], z1[MAX_SEC];
@@ -187,9 +197,10 @@ __global__ __launch_bounds__(64) void sosfilt_kernel(const void* __restrict__ x,
 #pragma unroll
     for (int q = 0; q < MAX_SEC; ++q)
       if (q < nsec) {
-        const double yv = fma(s[q][0], v, z0[q]);
-        z0[q] = fma(s[q][1], v, z1[q]) - s[q][4] * yv;
-        z1[q] = s[q][2] * v - s[q][5] * yv;
+        // scipy _sosfilt order: y = b0*x + z0; z0 = (b1*x - a1*y) + z1; z1 = b2*x - a2*y
+        const double yv = __dadd_rn(__dmul_rn(s[q][0], v), z0[q]);
+        z0[q] = __dadd_rn(__dsub_rn(__dmul_rn(s[q][1], v), __dmul_rn(s[q][4], yv)), z1[q]);
+        z1[q] = __dsub_rn(__dmul_rn(s[q][2], v), __dmul_rn(s[q][5], yv));
         v = yv;
       }
     y[cb + i] = v;

@@ -33,10 +33,9 @@ class SynthesisModel(nn.Module, ABC):
 
 class _CnnFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, labels, model, *params):
+    def forward(ctx, x, labels, model, need_grad, *params):
         eng: CnnEngine = model._engine
         prm = dict(zip(model._pnames, (p.detach() for p in params)))
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         out = eng.forward(prm, x, labels, training=model.training, save=need_grad, seed=model._next_seed())
         ctx.model = model
         ctx.prm = prm
@@ -56,7 +55,7 @@ class _CnnFunction(torch.autograd.Function):
             dout = pad
         grads = {k: torch.empty_like(v) for k, v in ctx.prm.items()}
         eng.backward(ctx.prm, dout, grads)
-        return (None, None, None) + tuple(grads[k] for k in model._pnames)
+        return (None, None, None, None) + tuple(grads[k] for k in model._pnames)
 
 
 class SynthesisModelCNN(SynthesisModel):
@@ -117,7 +116,8 @@ class SynthesisModelCNN(SynthesisModel):
         _lib.require_gpu(inputs_ecog, "SynthesisModelCNN.forward")
         params = [p for _, p in self.named_parameters()]
         _lib.require_gpu(params[0], "SynthesisModelCNN parameters")
-        return _CnnFunction.apply(inputs_ecog, inputs_labels.to(inputs_ecog.device), self, *params)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _CnnFunction.apply(inputs_ecog, inputs_labels.to(inputs_ecog.device), self, need_grad, *params)
 
     def _compute_latent_length(self, n_timepoints: int) -> int:
         t = n_timepoints
