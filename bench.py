@@ -1,0 +1,187 @@
+"""Headline benchmark: mel-frames/sec of the SynthesisModelCNN train step on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2] / SURVEY.md section 8d, "C3"): SynthesisModelCNN 128 ch x 400
+samples -> 80 mel bins, 4 tones x 2 syllables (L = 5 dynamics), batch 256 per GPU, reference
+defaults (dropout 0.5, NAdam lr 5e-4, coupled weight decay 0.004), LogisticRegression tone /
+syllable classifiers on 8-channel slices, synthetic N(0,1) ECoG and 10*N(0,1) targets,
+random-init weights.  A "step" is the whole body of the reference's batch loop
+(models/synthesis_trainer.py:201-229): classifier forwards + argmax, label dynamics, forward,
+L1 on truncated targets, backward, (DP: gradient reduction), NAdam, loss + MCD accumulation.
+Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns 256 windows.
+
+Extra objects on the JSON line:
+  roofline     the dominant kernel family of the step (conv2 = 53 % of the forward MACs):
+               algorithmic FLOPs per launch / mean launch time measured with HIP events on the
+               launch stream, against the dense fp32 MFMA peak (157.3 TFLOP/s).
+  cpu_baseline the CPU oracle (oracle/synthesis_oracle.py, PyTorch-CPU fp32 restatement of the
+               reference) timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TONE_MAP = {"0": [3, 3, 3, 3, 3], "1": [1, 2, 3, 4, 5], "2": [3, 2, 1, 2, 4], "3": [5, 4, 3, 2, 1]}
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, dense fp32 matrix peak
+
+
+def conv_flops(eng, stage_idx: int, B: int) -> float:
+    """Algorithmic FLOPs of one conv stage pass (2 FLOP/MAC, valid rows only), SURVEY 8d."""
+    st = eng.stages[stage_idx - 2]
+    return 2.0 * B * eng.C * st.tc * st.k * st.cin * st.cout
+
+
+def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, budget_s: float = 40.0):
+    """Time the oracle's train step on the host cores (bounded sample)."""
+    from oracle import synthesis_oracle as so
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    params = {k: v.detach().to("cpu", copy=True) for k, v in model.named_parameters()}
+    state = so.NAdamState(params)
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.randn(B_cpu, C, T, generator=gen)
+    tones = torch.randint(0, 4, (B_cpu,), generator=gen)
+    syls = torch.randint(0, 2, (B_cpu,), generator=gen)
+    lab = torch.tensor([[[int(s)] * 5, TONE_MAP[str(int(t))]] for t, s in zip(tones, syls)], dtype=torch.float32)
+    tgt = 10 * torch.randn(B_cpu, out_dim, generator=gen)
+    mask = (torch.rand(B_cpu, 64, model.latent_len, C, generator=gen) >= 0.5).float() * 2.0   # Dropout(0.5)
+    times = []
+    t_all = time.perf_counter()
+    for _ in range(2):
+        t0 = time.perf_counter()
+        so.train_step("cnn", params, None, state, x, lab, tgt, dropout_mask=mask)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s:
+            break
+    best = min(times)
+    return {"value": B_cpu / best, "unit": "mel-frames/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} train step(s) of the CPU oracle at micro-batch {B_cpu} (same model, "
+                      f"C={C}, T={T}; best of {len(times)}: {best:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
+    ap.add_argument("--channels", type=int, default=128)
+    ap.add_argument("--timepoints", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.5)
+    args = ap.parse_args()
+
+    from decode_tonal_langauge_amd import parallel
+    from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    B, C, T, D = args.batch, args.channels, args.timepoints, 80
+
+    torch.manual_seed(1234)
+    model = SynthesisModelCNN(D, C, T, dropout=args.dropout)
+    tone_m = LogisticRegressionClassifier(8 * T, 4)
+    syl_m = LogisticRegressionClassifier(8 * T, 2)
+    trainer = SynthesisTrainer(model, tone_m, syl_m, TONE_MAP, device=dev, verbose=False)
+    eng = model._engine
+
+    # synthetic data, resident in HBM: every rank builds the same global batches and takes its shard
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    nb = 4
+    GB = B * world
+    data = []
+    for _ in range(nb):
+        data.append((torch.randn(GB, C, T, device=dev, generator=gen),
+                     torch.randn(GB, 8, T, device=dev, generator=gen),
+                     torch.randn(GB, 8, T, device=dev, generator=gen),
+                     10 * torch.randn(GB, D, device=dev, generator=gen)))
+    model.train()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.train_step(*data[i % nb])
+    if not args.no_kernel_timers:
+        eng.enable_timers(True)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.train_step(*data[(args.warmup + i) % nb])
+    sync()
+    dt = time.perf_counter() - t0
+    tsum = eng.timer_summary() if eng.timers is not None else {}
+    eng.enable_timers(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = GB * args.steps / dt
+
+    if rank == 0:
+        roof = None
+        if tsum:
+            fam = {}
+            for name, (n, ms) in tsum.items():
+                stage = int(name[4])
+                fam.setdefault(stage, []).append((name, n, ms))
+            # dominant family = the conv stage with the largest total time
+            stage = max(fam, key=lambda s: sum(n * ms for _, n, ms in fam[s]))
+            fl = conv_flops(eng, stage, B)
+            per = {name: {"launches": n, "ms": round(ms, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
+                   for name, n, ms in fam[stage]}
+            tot_ms = sum(ms for _, _, ms in fam[stage])
+            ach = len(fam[stage]) * fl / (tot_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": f"conv{stage} fwd+dgrad+wgrad (nt_window/tn_window, fp32 MFMA 32x32x2)",
+                    "flops_per_launch": fl, "per_kernel": per,
+                    "all_kernels_ms": {k: round(v[1], 3) for k, v in sorted(tsum.items())}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(model, 2, C, T, D)
+            except Exception as e:      # noqa: BLE001 - the baseline leg must not kill the bench line
+                cpu = {"value": None, "error": repr(e)}
+        line = {
+            "metric": "mel-frames/sec (train step) SynthesisModelCNN, 128ch x 400t batch256",
+            "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SynthesisModelCNN {C}ch x {T}t -> {D} mel, 4 tones x 2 syllables, L=5, "
+                                   f"batch {B} per GPU (global {GB}), dropout {args.dropout}, NAdam, "
+                                   f"{model.get_nparams():,} params",
+                       "per_gpu_batch": B, "global_batch": GB, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,7 @@ class CnnEngine:
         self.kflat = n_channels * self.tp5 * self.ldy5
         self.ldd = _r4(output_dim)
         self.lowrank_param = "label_lstm.weight_hh_l0"   # reduced via gathered factors under DP
+        self.timers = None
         self._B = None
         self.generation = 0
         self._saved_generation = -1
@@ -133,6 +134,28 @@ class CnnEngine:
     def _stream(self):
         return torch.cuda.current_stream().cuda_stream
 
+    def enable_timers(self, on: bool = True):
+        """Per-launch HIP-event timing of the GEMM kernels (bench.py roofline leg).  Events are
+        recorded on the stream the kernels are launched on (torch's current stream)."""
+        self.timers = {} if on else None
+
+    def _tick(self, name):
+        if getattr(self, "timers", None) is None or name is None:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.timers.setdefault(name, []).append(ev)
+        ev[0].record()
+        return ev
+
+    def timer_summary(self):
+        """{name: (launches, mean ms)} - synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for k, evs in (self.timers or {}).items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[k] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
+
     def _permute(self, src, dst, dims, strides, lims=None, nz=1, zs=0, src_off=0, bias=None):
         d = (C.c_int64 * 4)(*dims)
         s = (C.c_int64 * 4)(*strides)
@@ -140,19 +163,25 @@ class CnnEngine:
         check(self.lib.tl_permute_reduce(src.data_ptr() + 4 * src_off, dst.data_ptr(), d, s, l, nz, zs, ptr(bias),
                                          self._stream()), "tl_permute_reduce")
 
-    def _nt(self, **kw):
+    def _nt(self, tag=None, **kw):
         p = NtParams()
         p.splitk, p.bm, p.J, p.Tp, p.slope = 1, 128, 1, 1, 0.0
         for k, v in kw.items():
             setattr(p, k, v)
+        ev = self._tick(tag)
         check(self.lib.tl_gemm_nt_window(C.byref(p), self._stream()), "tl_gemm_nt_window")
+        if ev:
+            ev[1].record()
 
-    def _tn(self, **kw):
+    def _tn(self, tag=None, **kw):
         p = TnParams()
         p.splitk, p.J, p.Tp, p.Tvalid = 1, 1, 1, 1
         for k, v in kw.items():
             setattr(p, k, v)
+        ev = self._tick(tag)
         check(self.lib.tl_gemm_tn_window(C.byref(p), self._stream()), "tl_gemm_tn_window")
+        if ev:
+            ev[1].record()
 
     @staticmethod
     def _splitk(tiles: int, ksteps: int, target: int = 2048) -> int:
@@ -210,7 +239,7 @@ class CnnEngine:
                 kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
             else:
                 kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
-            self._nt(**kw)
+            self._nt(tag=f"conv{st.idx}_fwd", **kw)
         # ---- label LSTM on the distinct label sequences ----
         L = labels.shape[2]
         flat = labels.reshape(B, 2 * L)
@@ -401,7 +430,7 @@ class CnnEngine:
                 kw.update(loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
             else:
                 kw.update(loader=LOAD_DIRECT, Tvalid=st.tout)
-            self._tn(**kw)
+            self._tn(tag=f"conv{st.idx}_wgrad", **kw)
             # slab[z][j][i][o] -> torch (O, I, J, 1)
             self._permute(slab, grads[name + ".weight"], (1, st.cout, st.cin, st.k), (0, 1, ldg, st.cin * ldg), nz=sk,
                           zs=st.k * st.cin * ldg)
@@ -416,7 +445,7 @@ class CnnEngine:
                           Tvalid_in=2 * st.tout)
             else:
                 kw.update(loader=LOAD_DIRECT)
-            self._nt(**kw)
+            self._nt(tag=f"conv{st.idx}_dgrad", **kw)
         # ---- stage 1 weight / bias gradient ----
         nblk = int(min(1024, S))
         part = torch.empty(nblk, (self.k1 + 1) * self.c1, **f32)
