@@ -44,10 +44,23 @@ def conv_flops(eng, stage_idx: int, B: int) -> float:
     return 2.0 * B * eng.C * st.tc * st.k * st.cin * st.cout
 
 
+def host_threads() -> int:
+    """Threads the host leg may use: the cgroup CPU quota / affinity of this box, not the
+    machine-wide core count (a 1-GPU box owns a 16-core share of a 256-thread host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("TL_BENCH_CPU_THREADS", min(n, 32)))
+
+
 def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, budget_s: float = 40.0):
     """Time the oracle's train step on the host cores (bounded sample)."""
     from oracle import synthesis_oracle as so
-    threads = os.cpu_count() or 1
+    threads = host_threads()
     torch.set_num_threads(threads)
     params = {k: v.detach().to("cpu", copy=True) for k, v in model.named_parameters()}
     state = so.NAdamState(params)
@@ -60,7 +73,7 @@ def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, budget_s: floa
     mask = (torch.rand(B_cpu, 64, model.latent_len, C, generator=gen) >= 0.5).float() * 2.0   # Dropout(0.5)
     times = []
     t_all = time.perf_counter()
-    for _ in range(2):
+    for _ in range(1):
         t0 = time.perf_counter()
         so.train_step("cnn", params, None, state, x, lab, tgt, dropout_mask=mask)
         times.append(time.perf_counter() - t0)

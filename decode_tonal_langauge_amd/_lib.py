@@ -58,6 +58,8 @@ SIGNATURES = {
     "tl_device_count": (_I, []),
     "tl_gemm_nt_window": (_I, [C.POINTER(NtParams), _P]),
     "tl_gemm_tn_window": (_I, [C.POINTER(TnParams), _P]),
+    "tl_sizeof_nt_params": (_I, []),
+    "tl_sizeof_tn_params": (_I, []),
     "tl_conv1_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
     "tl_conv1_wgrad": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P]),
     "tl_permute_reduce": (_I, [_P, _P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _L, _P, _P]),
@@ -94,6 +96,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.tl_sizeof_nt_params() != C.sizeof(NtParams) or lib.tl_sizeof_tn_params() != C.sizeof(TnParams):
+        raise RuntimeError("libtonal_hip.so parameter structs do not match the ctypes binding; rebuild the library")
     _lib = lib
     return lib
 

@@ -504,3 +504,6 @@ extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
     hipLaunchKernelGGL((tn_window_kernel<LOAD_UNPOOL>), grid, dim3(256), 0, st, p);
   return check_launch("tn_window");
 }
+
+extern "C" int tl_sizeof_nt_params(void) { return (int)sizeof(tl_nt_params); }
+extern "C" int tl_sizeof_tn_params(void) { return (int)sizeof(tl_tn_params); }

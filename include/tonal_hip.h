@@ -89,6 +89,9 @@ typedef struct {
   int splitk; int64_t slab_stride;
 } tl_tn_params;
 int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
+/* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
+int tl_sizeof_nt_params(void);
+int tl_sizeof_tn_params(void);
 
 /* ---- first conv stage, C_in = 1 (models/synthesis_models.py:87-89) ----------------------
  * x (S, T) -> P1 rows (S*Tp, C1) + arg-max bits; w (C1,3) b (C1).                          */

@@ -379,5 +379,5 @@ def train_step(kind: str, params: Dict[str, torch.Tensor], buffers: Optional[Dic
     nadam_step(params, grads, state, lr=lr, weight_decay=weight_decay)
     mcd = compute_mcd(tgt, out.detach())
     if return_grads:
-        return float(loss), mcd, grads, out.detach()
-    return float(loss), mcd
+        return float(loss.detach()), mcd, grads, out.detach()
+    return float(loss.detach()), mcd

