@@ -201,6 +201,75 @@ class CnnEngine:
         self._permute(w, dst, (1, J, cin_ld, old), (0, -1, J, I * J), (1, J, I, O), src_off=J - 1)
         return dst
 
+
+    # ------------------------------------------------------------------ one ecog stage (2..5)
+    STAGE_NAMES = {2: "ecog_conv_block.3", 3: "ecog_conv_block.6", 4: "ecog_conv_block.9", 5: "ecog_conv_block.12"}
+
+    def stage_forward(self, st: _Stage, w: torch.Tensor, bia: torch.Tensor) -> None:
+        """conv (k,1) + bias + LeakyReLU (+ max-pool, arg-max bits): P[idx-1] -> P[idx]."""
+        S = self.S
+        wp = self._pack_conv(w, st.cin, False)
+        src = self.P[st.idx - 1]
+        kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(self.P[st.idx]), M=S * st.tp_in,
+                  A_rows=src.shape[0], N=st.cout, K=st.cin, lda=src.shape[1], ldb=st.cin,
+                  ldo=self.P[st.idx].shape[1], J=st.k, row_shift=0, Tp=st.tp_in, slope=self.slope,
+                  loader=LOAD_DIRECT)
+        if st.pool:
+            kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
+        else:
+            kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
+        self._nt(tag=f"conv{st.idx}_fwd", **kw)
+
+    def _colsum(self, Gm, rows, ncols, ld, Tp, Tvalid, dst):
+        nblk = int(min(512, max(1, rows // 64)))
+        part = torch.empty(nblk, ncols, dtype=torch.float32, device=Gm.device)
+        check(self.lib.tl_colsum(ptr(Gm), ptr(part), nblk, rows, ncols, ld, Tp, Tvalid, self._stream()), "tl_colsum")
+        self._permute(part, dst, (1, 1, 1, ncols), (0, 0, 0, 1), nz=nblk, zs=ncols)
+
+    def stage_wgrad(self, st: _Stage, gw: torch.Tensor, gb: torch.Tensor) -> None:
+        """dW, db of one stage from its input P[idx-1] and G[idx] (pooled gradient + arg-max bits)."""
+        S = self.S
+        f32 = dict(dtype=torch.float32, device=self._dev)
+        Xin = self.P[st.idx - 1]
+        Gs = self.G[st.idx]
+        rows_in = S * st.tp_in
+        ldg = Gs.shape[1]
+        nd = _r4(st.cout)
+        tiles = st.k * ((st.cin + 127) // 128) * ((nd + 127) // 128)
+        sk = self._splitk(tiles, (rows_in + 31) // 32)
+        slab = torch.empty(sk, st.k * st.cin, ldg, **f32)
+        kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0],
+                  Mdim=st.cin, Ndim=nd, lda=st.cin, ldb=ldg, ldc=ldg, J=st.k, Tp=st.tp_in, splitk=sk,
+                  slab_stride=st.k * st.cin * ldg)
+        if st.pool:
+            kw.update(loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
+        else:
+            kw.update(loader=LOAD_DIRECT, Tvalid=st.tout)
+        self._tn(tag=f"conv{st.idx}_wgrad", **kw)
+        # slab[z][j][i][o] -> torch (O, I, J, 1)
+        self._permute(slab, gw, (1, st.cout, st.cin, st.k), (0, 1, ldg, st.cin * ldg), nz=sk,
+                      zs=st.k * st.cin * ldg)
+        self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
+
+    def stage_dgrad(self, st: _Stage, w: torch.Tensor) -> None:
+        """G[idx-1] = (dZ[idx] (*) flipped W) * LeakyReLU'(P[idx-1])."""
+        S = self.S
+        Xin = self.P[st.idx - 1]
+        Gs = self.G[st.idx]
+        rows_in = S * st.tp_in
+        ldg = Gs.shape[1]
+        wd = self._pack_conv(w, st.cin, True)           # [J][cin][r4(cout)]
+        kd = wd.shape[2]
+        kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=ptr(self.G[st.idx - 1]), M=rows_in, A_rows=Gs.shape[0],
+                  N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k, row_shift=-(st.k - 1),
+                  Tp=st.tp_in, epilogue=EPI_MASK, slope=self.slope)
+        if st.pool:
+            kw.update(loader=LOAD_UNPOOL, abits=ptr(self.bits[st.idx]), ld_abits=st.cout // 32,
+                      Tvalid_in=2 * st.tout)
+        else:
+            kw.update(loader=LOAD_DIRECT)
+        self._nt(tag=f"conv{st.idx}_dgrad", **kw)
+
     # ------------------------------------------------------------------ forward
     def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,
                 save: bool, seed: int = 0) -> torch.Tensor:
@@ -224,22 +293,8 @@ class CnnEngine:
         check(lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]), ptr(self.P[1]), ptr(self.bits[1]),
                                S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd")
         # ---- stages 2..5: windowed implicit GEMM on fp32 MFMA ----
-        self._wp = {}
-        names = {2: "ecog_conv_block.3", 3: "ecog_conv_block.6", 4: "ecog_conv_block.9", 5: "ecog_conv_block.12"}
         for st in self.stages:
-            w = prm[names[st.idx] + ".weight"]
-            bia = prm[names[st.idx] + ".bias"]
-            wp = self._pack_conv(w, st.cin, False)
-            src = self.P[st.idx - 1]
-            kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(self.P[st.idx]), M=S * st.tp_in,
-                      A_rows=src.shape[0], N=st.cout, K=st.cin, lda=src.shape[1], ldb=st.cin,
-                      ldo=self.P[st.idx].shape[1], J=st.k, row_shift=0, Tp=st.tp_in, slope=self.slope,
-                      loader=LOAD_DIRECT)
-            if st.pool:
-                kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
-            else:
-                kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
-            self._nt(tag=f"conv{st.idx}_fwd", **kw)
+            self.stage_forward(st, prm[self.STAGE_NAMES[st.idx] + ".weight"], prm[self.STAGE_NAMES[st.idx] + ".bias"])
         # ---- label LSTM on the distinct label sequences ----
         L = labels.shape[2]
         flat = labels.reshape(B, 2 * L)
@@ -318,11 +373,7 @@ class CnnEngine:
         H, U, L = self.H, self._U, self._L
         rows5 = self.rows5
 
-        def colsum(Gm, rows, ncols, ld, Tp, Tvalid, dst):
-            nblk = int(min(512, max(1, rows // 64)))
-            part = torch.empty(nblk, ncols, **f32)
-            check(lib.tl_colsum(ptr(Gm), ptr(part), nblk, rows, ncols, ld, Tp, Tvalid, st_), "tl_colsum")
-            self._permute(part, dst, (1, 1, 1, ncols), (0, 0, 0, 1), nz=nblk, zs=ncols)
+        colsum = self._colsum
 
         # ---- output layer ----
         gw = grads["output_layer.weight"]
@@ -412,40 +463,10 @@ class CnnEngine:
         grads["label_lstm.bias_hh_l0"].copy_(gb)
         del dg, dgt
         # ---- ecog stages 5..2 ----
-        names = {2: "ecog_conv_block.3", 3: "ecog_conv_block.6", 4: "ecog_conv_block.9", 5: "ecog_conv_block.12"}
         for st in reversed(self.stages):
-            name = names[st.idx]
-            Xin = self.P[st.idx - 1]
-            Gs = self.G[st.idx]
-            rows_in = S * st.tp_in
-            ldg = Gs.shape[1]
-            nd = _r4(st.cout)
-            tiles = st.k * ((st.cin + 127) // 128) * ((nd + 127) // 128)
-            sk = self._splitk(tiles, (rows_in + 31) // 32)
-            slab = torch.empty(sk, st.k * st.cin, ldg, **f32)
-            kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0],
-                      Mdim=st.cin, Ndim=nd, lda=st.cin, ldb=ldg, ldc=ldg, J=st.k, Tp=st.tp_in, splitk=sk,
-                      slab_stride=st.k * st.cin * ldg)
-            if st.pool:
-                kw.update(loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
-            else:
-                kw.update(loader=LOAD_DIRECT, Tvalid=st.tout)
-            self._tn(tag=f"conv{st.idx}_wgrad", **kw)
-            # slab[z][j][i][o] -> torch (O, I, J, 1)
-            self._permute(slab, grads[name + ".weight"], (1, st.cout, st.cin, st.k), (0, 1, ldg, st.cin * ldg), nz=sk,
-                          zs=st.k * st.cin * ldg)
-            colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, grads[name + ".bias"])
-            wd = self._pack_conv(prm[name + ".weight"], st.cin, True)           # [J][cin][r4(cout)]
-            kd = wd.shape[2]
-            kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=ptr(self.G[st.idx - 1]), M=rows_in, A_rows=Gs.shape[0],
-                      N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k, row_shift=-(st.k - 1),
-                      Tp=st.tp_in, epilogue=EPI_MASK, slope=self.slope)
-            if st.pool:
-                kw.update(loader=LOAD_UNPOOL, abits=ptr(self.bits[st.idx]), ld_abits=st.cout // 32,
-                          Tvalid_in=2 * st.tout)
-            else:
-                kw.update(loader=LOAD_DIRECT)
-            self._nt(tag=f"conv{st.idx}_dgrad", **kw)
+            name = self.STAGE_NAMES[st.idx]
+            self.stage_wgrad(st, grads[name + ".weight"], grads[name + ".bias"])
+            self.stage_dgrad(st, prm[name + ".weight"])
         # ---- stage 1 weight / bias gradient ----
         nblk = int(min(1024, S))
         part = torch.empty(nblk, (self.k1 + 1) * self.c1, **f32)
