@@ -221,10 +221,12 @@ class CnnEngine:
         self._nt(tag=f"conv{st.idx}_fwd", **kw)
 
     def _colsum(self, Gm, rows, ncols, ld, Tp, Tvalid, dst):
-        nblk = int(min(512, max(1, rows // 64)))
-        part = torch.empty(nblk, ncols, dtype=torch.float32, device=Gm.device)
-        check(self.lib.tl_colsum(ptr(Gm), ptr(part), nblk, rows, ncols, ld, Tp, Tvalid, self._stream()), "tl_colsum")
-        self._permute(part, dst, (1, 1, 1, ncols), (0, 0, 0, 1), nz=nblk, zs=ncols)
+        nc4 = _r4(ncols)                       # pad columns of G are zero by construction
+        rpb = max(1, 256 // (nc4 // 4))
+        nblk = int(min(2048, max(1, rows // (rpb * 16))))
+        part = torch.empty(nblk, nc4, dtype=torch.float32, device=Gm.device)
+        check(self.lib.tl_colsum(ptr(Gm), ptr(part), nblk, rows, nc4, ld, Tp, Tvalid, self._stream()), "tl_colsum")
+        self._permute(part, dst, (1, 1, 1, ncols), (0, 0, 0, 1), nz=nblk, zs=nc4)
 
     def stage_wgrad(self, st: _Stage, gw: torch.Tensor, gb: torch.Tensor) -> None:
         """dW, db of one stage from its input P[idx-1] and G[idx] (pooled gradient + arg-max bits)."""
@@ -433,8 +435,10 @@ class CnnEngine:
         dc = [torch.empty(U, H, **f32), torch.empty(U, H, **f32)]
         dhrec = torch.empty(U, H, **f32) if L > 1 else None
         if L > 1:
-            tiles = (ldt + 127) // 128 * ((H + 127) // 128)
-            sk_h = self._splitk(tiles, (4 * H + 31) // 32, 1024)
+            if ldt <= 32:        # skinny streaming kernel: 32 x 512 tiles, 16-deep K stages
+                sk_h = self._splitk((H + 511) // 512, (4 * H + 15) // 16, 1024)
+            else:
+                sk_h = self._splitk((ldt + 127) // 128 * ((H + 127) // 128), (4 * H + 31) // 32, 1024)
             slab_h = torch.empty(sk_h, ldt, H, **f32)
         for t in range(L - 1, -1, -1):
             check(lib.tl_lstm_cell_bwd(ptr(dh_ext) if t == L - 1 else None, ptr(dhrec) if t < L - 1 else None,
@@ -468,7 +472,7 @@ class CnnEngine:
             self.stage_wgrad(st, grads[name + ".weight"], grads[name + ".bias"])
             self.stage_dgrad(st, prm[name + ".weight"])
         # ---- stage 1 weight / bias gradient ----
-        nblk = int(min(1024, S))
+        nblk = int(min(2048, S))
         part = torch.empty(nblk, (self.k1 + 1) * self.c1, **f32)
         check(lib.tl_conv1_wgrad(ptr(self._x), ptr(self.G[1]), ptr(self.bits[1]), ptr(part), nblk, S, self.T, self.k1,
                                  self.c1, self.tp1, self.tout1, st_), "tl_conv1_wgrad")

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   f32x4 ra[A_F4];          // staged A (DIRECT) or G (UNPOOL)
-  uint32_t rbits[A_F4];    // UNPOOL: 4-bit arg nibble (bit set -> odd row of the pair)
+  uint32_t rbits[A_F4];    // UNPOOL: raw 32-bit arg word (bit set -> odd row of the pair); the
+                           // nibble is extracted at LDS-store time so the load stays in flight
   f32x4 rb[4];
 
   const long long Abase = R0 + p.row_shift;        // first staged A row (even for UNPOOL)
@@ -97,8 +98,7 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
                         (int)((2 * prow) % p.Tp) < p.Tvalid_in;
         if (ok) {
           v = *reinterpret_cast<const f32x4*>(p.A + prow * (long long)p.lda + k);
-          const uint32_t w = p.abits[prow * (long long)p.ld_abits + (k >> 5)];
-          nib = (w >> (k & 31)) & 0xFu;
+          nib = p.abits[prow * (long long)p.ld_abits + (k >> 5)];
         }
       }
       ra[i] = v;
@@ -116,9 +116,10 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
       } else {
         if (r < AROWS / 2) {
           f32x4 e, o;
+          const uint32_t nibv = rbits[i] >> ((c4 * 4) & 31);     // kc is a multiple of 32
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const bool odd = (rbits[i] >> q) & 1u;
+            const bool odd = (nibv >> q) & 1u;
             e[q] = odd ? 0.f : ra[i][q];
             o[q] = odd ? ra[i][q] : 0.f;
           }
@@ -151,6 +152,30 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
     }
   };
 
+  // Fragment sets F0 / F1 (statically named): while the MFMAs of one 8-deep k-group run, the
+  // ds_read_b128 of the next group are in flight; the last group of a K-step is carried in
+  // registers ACROSS the barrier, so the matrix pipe has work the moment the barrier opens, and
+  // the LDS stores of the next stage are issued mid-step (their target buffer was released at
+  // the previous barrier), leaving nothing but the barrier itself at the end of a step.
+  f32x4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+  auto load_frag = [&](f32x4 (&fa)[MI], f32x4 (&fb)[NI], int abuf, int bbuf, int j, int kk) {
+    const float* a_s = As + abuf * AROWS * LDS_LD + (wm * (MI * 32) + lr + j) * LDS_LD + lh * 4 + kk * 8;
+    const float* b_s = Bs + bbuf * BN * LDS_LD + (wn * (NI * 32) + lr) * LDS_LD + lh * 4 + kk * 8;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * 32 * LDS_LD);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fb[i] = *reinterpret_cast<const f32x4*>(b_s + i * 32 * LDS_LD);
+  };
+  auto mfma_group = [&](const f32x4 (&fa)[MI], const f32x4 (&fb)[NI]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][q], fb[ni][q], acc[mi][ni], 0, 0, 0);
+  };
+
   if (nsteps > 0) {
     load_a(0);
     load_b(0, 0);
@@ -165,33 +190,26 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
     const int chunk1 = s1 / J, j1 = s1 - chunk1 * J;
     const bool more = s1 < nsteps;
     const bool newa = more && (j1 == 0);
+    const int abuf = chunk & 1, bbuf = s & 1;
+    load_frag(fa0, fb0, abuf, bbuf, j, 0);
     if (more) {
       load_b(chunk1, j1);
       if (newa) load_a(chunk1);
     }
-    const float* a_s = As + (chunk & 1) * AROWS * LDS_LD + (wm * (MI * 32) + lr + j) * LDS_LD + lh * 4;
-    const float* b_s = Bs + (s & 1) * BN * LDS_LD + (wn * (NI * 32) + lr) * LDS_LD + lh * 4;
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 fa[MI], fb[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * 32 * LDS_LD + kk * 8);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) fb[i] = *reinterpret_cast<const f32x4*>(b_s + i * 32 * LDS_LD + kk * 8);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][q], fb[ni][q], acc[mi][ni], 0, 0, 0);
-    }
-    if (more) {
+    if (s > 0) mfma_group(fa1, fb1);             // k-group 3 of the previous step (registers)
+    load_frag(fa1, fb1, abuf, bbuf, j, 1);
+    mfma_group(fa0, fb0);
+    load_frag(fa0, fb0, abuf, bbuf, j, 2);
+    mfma_group(fa1, fb1);
+    if (more) {                                   // global loads issued at the top have landed
       store_b(s1 & 1);
       if (newa) store_a(chunk1 & 1);
     }
+    load_frag(fa1, fb1, abuf, bbuf, j, 3);
+    mfma_group(fa0, fb0);
     __syncthreads();
   }
+  if (nsteps > 0) mfma_group(fa1, fb1);
 
   // ---------------------------------- epilogue ----------------------------------
   // C/D map of 32x32x2: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -359,8 +377,7 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
         uint32_t nib = 0;
         if (2 * prow < p.Krows && prow < p.B_rows && n < p.Ndim && (int)((2 * prow) % p.Tp) < p.Tvalid) {
           v = *reinterpret_cast<const f32x4*>(p.B + prow * (long long)p.ldb + n);
-          const uint32_t w = p.bbits[prow * (long long)p.ld_bbits + (n >> 5)];
-          nib = (w >> (n & 31)) & 0xFu;
+          nib = p.bbits[prow * (long long)p.ld_bbits + (n >> 5)];     // raw word, nibble at store time
         }
         rb[i] = v;
         rnib[i] = nib;
@@ -389,9 +406,10 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
         const int idx = tid + i * 256;
         const int pr = idx >> 5, c4 = idx & 31;
         f32x4 e, o;
+        const uint32_t nibv = rnib[i] >> ((n0 + c4 * 4) & 31);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const bool odd = (rnib[i] >> q) & 1u;
+          const bool odd = (nibv >> q) & 1u;
           e[q] = odd ? 0.f : rb[i][q];
           o[q] = odd ? rb[i][q] : 0.f;
         }
@@ -401,6 +419,30 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
     }
   };
 
+  // same software pipeline as the NT kernel: k-groups of 8 rows (4 MFMA k-steps), fragment
+  // sets F0/F1, the last group carried across the barrier, LDS stores issued mid-step
+  float ta0[4][2], tb0[4][2], ta1[4][2], tb1[4][2];
+  auto load_frag = [&](float (&fa)[4][2], float (&fb)[4][2], int buf, int g) {
+    const float* a_s = As + buf * BK * TN_LD + (g * 8 + lh) * TN_LD + wm * 64 + lr;
+    const float* b_s = Bs + buf * BK * TN_LD + (g * 8 + lh) * TN_LD + wn * 64 + lr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      fa[q][0] = a_s[q * 2 * TN_LD];
+      fa[q][1] = a_s[q * 2 * TN_LD + 32];
+      fb[q][0] = b_s[q * 2 * TN_LD];
+      fb[q][1] = b_s[q * 2 * TN_LD + 32];
+    }
+  };
+  auto mfma_group = [&](const float (&fa)[4][2], const float (&fb)[4][2]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi], fb[q][ni], acc[mi][ni], 0, 0, 0);
+  };
+
   if (nsteps > 0) {
     load_tiles(0);
     store_tiles(0);
@@ -408,25 +450,20 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
   __syncthreads();
   for (long long s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
+    const int buf = (int)(s & 1);
+    load_frag(ta0, tb0, buf, 0);
     if (more) load_tiles(s + 1);
-    const float* a_s = As + (s & 1) * BK * TN_LD + lh * TN_LD + wm * 64 + lr;
-    const float* b_s = Bs + (s & 1) * BK * TN_LD + lh * TN_LD + wn * 64 + lr;
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      float fa[2], fb[2];
-      fa[0] = a_s[kk * 2 * TN_LD];
-      fa[1] = a_s[kk * 2 * TN_LD + 32];
-      fb[0] = b_s[kk * 2 * TN_LD];
-      fb[1] = b_s[kk * 2 * TN_LD + 32];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
-    }
-    if (more) store_tiles((s + 1) & 1);
+    if (s > 0) mfma_group(ta1, tb1);
+    load_frag(ta1, tb1, buf, 1);
+    mfma_group(ta0, tb0);
+    load_frag(ta0, tb0, buf, 2);
+    mfma_group(ta1, tb1);
+    if (more) store_tiles(buf ^ 1);
+    load_frag(ta1, tb1, buf, 3);
+    mfma_group(ta0, tb0);
     __syncthreads();
   }
+  if (nsteps > 0) mfma_group(ta1, tb1);
 
   float* out = p.slab + (long long)z * p.slab_stride;
 #pragma unroll
@@ -441,6 +478,107 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
           out[((long long)j * p.Mdim + m) * (long long)p.ldc + col] = acc[mi][ni][e];
       }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// TN, skinny M (<= 32 rows of output): slab[z][m][n] = sum_k A[k][m] * B[k][n].  Used for
+// dh = dgates . W_hh on the few distinct label rows: B (5.4 GB) is streamed exactly once, so the
+// tile is 32 x 512 with a 16-deep K stage (33 KB in flight per workgroup, 2 workgroups per CU) and
+// the kernel is HBM-bound, not MFMA-bound.
+// ------------------------------------------------------------------------------------------
+constexpr int SK_BK = 16, SK_BN = 512, SK_LDB = SK_BN + 4, SK_LDA = 32 + 4;
+
+__global__ __launch_bounds__(256, 2) void tn_skinny_kernel(const tl_tn_params p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * SK_BK * SK_LDA + 2 * SK_BK * SK_LDB];
+  float* As = lds;
+  float* Bs = lds + 2 * SK_BK * SK_LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * SK_BN;
+  const int z = blockIdx.y;
+  const long long ksteps_all = (p.Krows + SK_BK - 1) / SK_BK;
+  const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const long long nsteps = ks_end > ks_begin ? ks_end - ks_begin : 0;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+  f32x4 rb[8], ra;
+  const bool mask_rows = p.Tp > 1;
+
+  auto load_tiles = [&](long long step) {
+    const long long k0 = (ks_begin + step) * SK_BK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 7, c4 = idx & 127;
+      const long long row = k0 + r;
+      const int n = n0 + c4 * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      bool ok = row < p.Krows && row < p.B_rows && n < p.Ndim;
+      if (mask_rows) ok = ok && (int)(row % p.Tp) < p.Tvalid;
+      if (ok) v = *reinterpret_cast<const f32x4*>(p.B + row * (long long)p.ldb + n);
+      rb[i] = v;
+    }
+    {
+      const int r = (tid >> 3) & 15, c4 = tid & 7;
+      const long long row = k0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (tid < 128 && row < p.Krows && row < p.A_rows && c4 * 4 < p.Mdim)
+        v = *reinterpret_cast<const f32x4*>(p.A + row * (long long)p.lda + c4 * 4);
+      ra = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* db = Bs + buf * SK_BK * SK_LDB;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 7, c4 = idx & 127;
+      *reinterpret_cast<f32x4*>(db + r * SK_LDB + c4 * 4) = rb[i];
+    }
+    if (tid < 128) {
+      const int r = tid >> 3, c4 = tid & 7;
+      *reinterpret_cast<f32x4*>(As + buf * SK_BK * SK_LDA + r * SK_LDA + c4 * 4) = ra;
+    }
+  };
+
+  if (nsteps > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (long long s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    if (more) load_tiles(s + 1);
+    const float* a_s = As + (s & 1) * SK_BK * SK_LDA + lh * SK_LDA + lr;
+    const float* b_s = Bs + (s & 1) * SK_BK * SK_LDB + lh * SK_LDB + wave * 128 + lr;
+#pragma unroll
+    for (int kk = 0; kk < SK_BK / 2; ++kk) {
+      const float fa = a_s[kk * 2 * SK_LDA];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, b_s[kk * 2 * SK_LDB + ni * 32], acc[ni], 0, 0, 0);
+    }
+    if (more) store_tiles((s + 1) & 1);
+    __syncthreads();
+  }
+  float* out = p.slab + (long long)z * p.slab_stride;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int col = n0 + wave * 128 + ni * 32 + lr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m < p.Mdim && col < p.Ndim) out[(long long)m * p.ldc + col] = acc[ni][e];
+    }
+  }
 }
 
 }  // namespace tl
@@ -493,11 +631,16 @@ extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
     TL_REQUIRE(p.Tp % 2 == 0 && p.Tvalid % 2 == 0, "tn_window: UNPOOL needs even Tp/Tvalid");
     TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim, "tn_window: bbits row too short");
   }
+  hipStream_t st = (hipStream_t)stream;
+  if (p.Mdim <= 32 && p.J == 1 && p.loader == LOAD_DIRECT) {       // skinny-M streaming variant
+    dim3 grid((unsigned)((p.Ndim + SK_BN - 1) / SK_BN), (unsigned)p.splitk, 1);
+    hipLaunchKernelGGL(tn_skinny_kernel, grid, dim3(256), 0, st, p);
+    return check_launch("tn_skinny");
+  }
   const long long ntm = (p.Mdim + 127) / 128, ntn = (p.Ndim + 127) / 128;
   const long long nwg = ntm * ntn * p.J;
   TL_REQUIRE(nwg < (1LL << 31), "tn_window: grid too large");
   dim3 grid((unsigned)nwg, (unsigned)p.splitk, 1);
-  hipStream_t st = (hipStream_t)stream;
   if (p.loader == LOAD_DIRECT)
     hipLaunchKernelGGL((tn_window_kernel<LOAD_DIRECT>), grid, dim3(256), 0, st, p);
   else

@@ -91,7 +91,26 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     for (int h = 0; h < 2; ++h) {
       const int o = threadIdx.x + h * 256;
       if (o < C1) {
-        for (int p = 0; p < Tout; ++p) {
+        int p = 0;
+        for (; p + 4 <= Tout; p += 4) {          // 4 independent loads in flight per thread
+          float g[4];
+          uint32_t wb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const long long row = seq * Tp + p + u;
+            g[u] = G[row * C1 + o];
+            wb[u] = bits[row * (C1 >> 5) + (o >> 5)];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int a = (wb[u] >> (o & 31)) & 1;
+#pragma unroll
+            for (int j = 0; j < MAXKT; ++j)
+              if (j < kt) acc[h][j] = fmaf(g[u], xs[2 * (p + u) + a + j], acc[h][j]);
+            acc[h][MAXKT] += g[u];
+          }
+        }
+        for (; p < Tout; ++p) {
           const long long row = seq * Tp + p;
           const float g = G[row * C1 + o];
           const uint32_t wbit = bits[row * (C1 >> 5) + (o >> 5)];
@@ -145,17 +164,50 @@ __global__ __launch_bounds__(256) void permute_reduce_kernel(const float* __rest
   }
 }
 
-// masked column sums (bias gradients): partial[blk][ncols]
+// masked column sums (bias gradients): partial[blk][ncols].  float4 per thread along the
+// columns, 256/(ncols/4) rows per pass, 4 independent row loads in flight per thread, LDS
+// reduction over the row lanes (fixed order -> deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G, float* __restrict__ partial,
                                                      long long rows, int ncols, int ld, int Tp, int Tvalid) {
+  __shared__ f32x4 red[256];
+  const int tpr = ncols >> 2;                 // threads per row (ncols % 4 == 0, tpr <= 256)
+  const int rpb = 256 / tpr;                  // rows per pass
+  const int c4 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const bool active = rl < rpb;
   const long long per = (rows + gridDim.x - 1) / gridDim.x;
   const long long r0 = blockIdx.x * per;
   const long long r1 = r0 + per < rows ? r0 + per : rows;
-  for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
-    float acc = 0.f;
-    for (long long r = r0; r < r1; ++r)
-      if ((int)(r % Tp) < Tvalid) acc += G[r * ld + c];
-    partial[(long long)blockIdx.x * ncols + c] = acc;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    long long r = r0 + rl;
+    int t = (int)(r % Tp);
+    const int dt = rpb % Tp;
+    for (; r + 3LL * rpb < r1; r += 4LL * rpb) {
+      f32x4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ok[u] = t < Tvalid;
+        v[u] = *reinterpret_cast<const f32x4*>(G + (r + (long long)u * rpb) * ld + c4 * 4);
+        t += dt;
+        if (t >= Tp) t -= Tp;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) acc += v[u];
+    }
+    for (; r < r1; r += rpb) {
+      if (t < Tvalid) acc += *reinterpret_cast<const f32x4*>(G + r * ld + c4 * 4);
+      t += dt;
+      if (t >= Tp) t -= Tp;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < tpr) {
+    f32x4 sum = red[threadIdx.x];
+    for (int q = 1; q < rpb; ++q) sum += red[threadIdx.x + q * tpr];
+    *reinterpret_cast<f32x4*>(partial + (long long)blockIdx.x * ncols + threadIdx.x * 4) = sum;
   }
 }
 
@@ -486,6 +538,7 @@ extern "C" int tl_permute_reduce(const float* src, float* dst, const int64_t dim
 extern "C" int tl_colsum(const float* G, float* partial, int nblk, int64_t rows, int ncols, int ld, int Tp,
                          int Tvalid, void* stream) {
   TL_REQUIRE(G && partial && nblk > 0 && rows > 0 && ncols > 0 && ld >= ncols && Tp > 0, "colsum: bad arguments");
+  TL_REQUIRE(ncols % 4 == 0 && ncols <= 1024 && ld % 4 == 0, "colsum: ncols must be a multiple of 4 and <= 1024");
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, G, partial,
                      (long long)rows, ncols, ld, Tp, Tvalid);
   return check_launch("colsum");
