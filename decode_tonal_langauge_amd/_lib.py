@@ -73,6 +73,15 @@ SIGNATURES = {
     "tl_l1_mcd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "tl_nadam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_tone_dynamics": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "tl_lite_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "tl_lite_bn_finalize": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _P]),
+    "tl_lite_bn_act_pool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "tl_lite_bn_act_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "tl_lite_conv_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "tl_lite_lstm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tl_lite_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tl_lite_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, C.c_uint64, _P]),
+    "tl_lite_uncat": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, C.c_uint64, _P]),
     "tl_gauss_envelope": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_filtfilt_f64": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
     "tl_sosfilt_f64": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),

@@ -1,1 +1,428 @@
+// SynthesisLite kernels (reference models/synthesis_models.py:201-296): Conv1d + BatchNorm1d +
+// LeakyReLU + MaxPool1d(2) blocks, the small label LSTM (whole sequence in one launch), and the
+// concat + dropout glue.  The two Linear layers reuse the MFMA GEMM kernels.  At the reference's
+// Lite sizes (32 ch x 200 samples, batch 64) every tensor is KBs-MBs: the step is launch-bound, so
+// each kernel does a whole layer stage per launch and no kernel needs more than one pass.
 #include "tonal_common.h"
+#include <math.h>
+
+namespace tl {
+
+constexpr int LT = 64;   // time tile of the direct conv kernels
+
+// z[b][o][t] = bias[o] + sum_{i,j} w[o][i][j] * x[b][i][t + j - pad]   (zero padding)
+// part[(b*ntile + tile)][o][0..1] = (sum_t z, sum_t z^2) over the tile
+__global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ z,
+                                                            float* __restrict__ part, int Cin, int Cout, int T, int k,
+                                                            int pad) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];      // [Cin][LT + k - 1]
+  const int b = blockIdx.y, tile = blockIdx.x, t0 = tile * LT;
+  const int W = LT + k - 1;
+  for (int i = threadIdx.x; i < Cin * W; i += blockDim.x) {
+    const int ci = i / W, tt = t0 + (i % W) - pad;
+    xs[i] = (tt >= 0 && tt < T) ? x[((long long)b * Cin + ci) * T + tt] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = t0 + lane;
+  for (int o = wave; o < Cout; o += 4) {
+    float acc = bias[o];
+    const float* wo = w + (long long)o * Cin * k;
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int j = 0; j < k; ++j) acc = fmaf(wo[ci * k + j], xs[ci * W + lane + j], acc);
+    const bool ok = t < T;
+    if (ok) z[((long long)b * Cout + o) * T + t] = acc;
+    float s1 = ok ? acc : 0.f, s2 = ok ? acc * acc : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s1 += __shfl_down(s1, off);
+      s2 += __shfl_down(s2, off);
+    }
+    if (lane == 0 && part) {
+      float* pp = part + (((long long)b * gridDim.x + tile) * Cout + o) * 2;
+      pp[0] = s1;
+      pp[1] = s2;
+    }
+  }
+}
+
+// mean / rstd from the partial sums (fixed order), running-stat update (momentum, unbiased var)
+__global__ void lite_bn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
+                                        float* __restrict__ run_mean, float* __restrict__ run_var, int nparts, int C,
+                                        long long count, float momentum, float eps, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (training) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+      s1 += part[((long long)i * C + c) * 2];
+      s2 += part[((long long)i * C + c) * 2 + 1];
+    }
+    const double m = s1 / (double)count;
+    double var = s2 / (double)count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+    const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+  } else {
+    mean[c] = run_mean[c];
+    rstd[c] = 1.f / sqrtf(run_var[c] + eps);
+  }
+}
+
+// y[b][c][p] = max_{a<2} lrelu(gamma*(z[2p+a]-mean)*rstd + beta)
+__global__ __launch_bounds__(256) void lite_bn_act_pool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ y,
+                                                                   long long total, int C, int T, float slope) {
+  const int Tp = T / 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % Tp);
+    const long long bc = i / Tp;
+    const int c = (int)(bc % C);
+    const float g = gamma[c] * rstd[c], sh = beta[c] - mean[c] * g;
+    const float a0 = lrelu(fmaf(z[bc * T + 2 * p], g, sh), slope);
+    const float a1 = lrelu(fmaf(z[bc * T + 2 * p + 1], g, sh), slope);
+    y[i] = a1 > a0 ? a1 : a0;
+  }
+}
+
+// backward of pool + lrelu: dbn[b][c][t] (gradient w.r.t. the BN output), and per-(b) partial sums
+// (sum dbn, sum dbn*xhat) per channel
+__global__ __launch_bounds__(256) void lite_bn_act_pool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ dbn, float* __restrict__ part, int C,
+                                                                   int T, float slope) {
+  __shared__ float r1[256], r2[256];
+  const int b = blockIdx.y, c = blockIdx.x;
+  const int Tp = T / 2;
+  const float g = gamma[c] * rstd[c], sh = beta[c] - mean[c] * g;
+  const long long base = ((long long)b * C + c) * T;
+  float s1 = 0.f, s2 = 0.f;
+  for (int p = threadIdx.x; p < (T + 1) / 2; p += blockDim.x) {
+    float d0 = 0.f, d1 = 0.f;
+    if (p < Tp) {
+      const float z0 = z[base + 2 * p], z1 = z[base + 2 * p + 1];
+      const float n0 = fmaf(z0, g, sh), n1 = fmaf(z1, g, sh);
+      const float a0 = lrelu(n0, slope), a1 = lrelu(n1, slope);
+      const float gy = dy[((long long)b * C + c) * Tp + p];
+      if (a1 > a0) d1 = gy * (n1 > 0.f ? 1.f : slope); else d0 = gy * (n0 > 0.f ? 1.f : slope);
+      dbn[base + 2 * p] = d0;
+      dbn[base + 2 * p + 1] = d1;
+      s1 += d0 + d1;
+      s2 += d0 * (z0 - mean[c]) * rstd[c] + d1 * (z1 - mean[c]) * rstd[c];
+    } else if (2 * p < T) {
+      dbn[base + 2 * p] = 0.f;          // odd T: the last sample is dropped by the pool
+    }
+  }
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      r1[threadIdx.x] += r1[threadIdx.x + off];
+      r2[threadIdx.x] += r2[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[((long long)b * C + c) * 2] = r1[0];
+    part[((long long)b * C + c) * 2 + 1] = r2[0];
+  }
+}
+
+// dgamma, dbeta and, in place, dz = gamma*rstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))  (train)
+//                                dz = gamma*rstd*dbn                                      (eval)
+__global__ void lite_bn_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      float* __restrict__ sums, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    s1 += part[((long long)b * C + c) * 2];
+    s2 += part[((long long)b * C + c) * 2 + 1];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  sums[c * 2] = (float)s1;
+  sums[c * 2 + 1] = (float)s2;
+}
+__global__ __launch_bounds__(256) void lite_bn_dz_kernel(float* __restrict__ dbn, const float* __restrict__ z,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                         long long total, int C, int T, long long count, int training) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / T) % C);
+    const float gr = gamma[c] * rstd[c];
+    float d = dbn[i];
+    if (training) {
+      const float xh = (z[i] - mean[c]) * rstd[c];
+      d = d - sums[c * 2] / (float)count - xh * sums[c * 2 + 1] / (float)count;
+    }
+    dbn[i] = gr * d;
+  }
+}
+
+// conv backward: dx[b][i][t] = sum_{o,j} dz[b][o][t - j + pad] w[o][i][j];  per-b weight-gradient partials
+__global__ __launch_bounds__(256) void lite_conv_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+                                                           float* __restrict__ dx, int Cin, int Cout, int T, int k, int pad) {
+  extern __shared__ __attribute__((aligned(16))) float ds[];      // [Cout][LT + k - 1]
+  const int b = blockIdx.y, t0 = blockIdx.x * LT;
+  const int W = LT + k - 1;
+  for (int i = threadIdx.x; i < Cout * W; i += blockDim.x) {
+    const int o = i / W, tt = t0 + (i % W) - (k - 1 - pad);
+    ds[i] = (tt >= 0 && tt < T) ? dz[((long long)b * Cout + o) * T + tt] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = t0 + lane;
+  for (int ci = wave; ci < Cin; ci += 4) {
+    float acc = 0.f;
+    for (int o = 0; o < Cout; ++o)
+      for (int j = 0; j < k; ++j)      // dz index t - j + pad = t0 + lane + (k-1-j) - (k-1-pad)
+        acc = fmaf(w[((long long)o * Cin + ci) * k + j], ds[o * W + lane + (k - 1 - j)], acc);
+    if (t < T) dx[((long long)b * Cin + ci) * T + t] = acc;
+  }
+}
+// dwpart[b][o][i][j] = sum_t dz[b][o][t] x[b][i][t + j - pad];  dbpart[b][o] = sum_t dz[b][o][t]
+__global__ __launch_bounds__(256) void lite_conv_dw_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                           float* __restrict__ dwpart, float* __restrict__ dbpart, int Cin,
+                                                           int Cout, int T, int k, int pad) {
+  const int b = blockIdx.x;
+  const int n = Cout * Cin * k;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const int j = e % k, ci = (e / k) % Cin, o = e / (k * Cin);
+    const float* dzr = dz + ((long long)b * Cout + o) * T;
+    const float* xr = x + ((long long)b * Cin + ci) * T;
+    float acc = 0.f;
+    const int lo = max(0, pad - j), hi = min(T, T + pad - j);
+    for (int t = lo; t < hi; ++t) acc = fmaf(dzr[t], xr[t + j - pad], acc);
+    dwpart[(long long)b * n + e] = acc;
+  }
+  for (int o = threadIdx.x; o < Cout; o += blockDim.x) {
+    const float* dzr = dz + ((long long)b * Cout + o) * T;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += dzr[t];
+    dbpart[(long long)b * Cout + o] = acc;
+  }
+}
+
+// ---- small LSTM, whole sequence per launch, one workgroup per batch row ---------------------
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void lite_lstm_fwd_kernel(const float* __restrict__ xl, const float* __restrict__ w_ih,
+                                                            const float* __restrict__ w_hh, const float* __restrict__ b_ih,
+                                                            const float* __restrict__ b_hh, float* __restrict__ act,
+                                                            float* __restrict__ cs, float* __restrict__ hs, int L, int H,
+                                                            int in_dim) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // h[H], c[H], gates[4H]
+  float* h = sm;
+  float* c = sm + H;
+  float* gt = sm + 2 * H;
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) h[i] = c[i] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < L; ++t) {
+    for (int r = threadIdx.x; r < 4 * H; r += blockDim.x) {
+      float acc = b_ih[r];
+      for (int d = 0; d < in_dim; ++d) acc = fmaf(xl[((long long)b * L + t) * in_dim + d], w_ih[r * in_dim + d], acc);
+      float hh = b_hh[r];
+      const float* wr = w_hh + (long long)r * H;
+      for (int q = 0; q < H; ++q) hh = fmaf(h[q], wr[q], hh);
+      const float pre = acc + hh;
+      gt[r] = (r >= 2 * H && r < 3 * H) ? tanhf(pre) : sigm(pre);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < H; q += blockDim.x) {
+      const float cn = gt[H + q] * c[q] + gt[q] * gt[2 * H + q];
+      c[q] = cn;
+      h[q] = gt[3 * H + q] * tanhf(cn);
+      cs[((long long)b * L + t) * H + q] = cn;
+      hs[((long long)b * L + t) * H + q] = h[q];
+    }
+    for (int r = threadIdx.x; r < 4 * H; r += blockDim.x) act[((long long)b * L + t) * 4 * H + r] = gt[r];
+    __syncthreads();
+  }
+}
+
+// BPTT: dh_last (B,H) -> dgates (B,L,4H) (pre-activation gradients)
+__global__ __launch_bounds__(256) void lite_lstm_bwd_kernel(const float* __restrict__ dh_last, const float* __restrict__ w_hh,
+                                                            const float* __restrict__ act, const float* __restrict__ cs,
+                                                            float* __restrict__ dgates, int L, int H, int ld_dh) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dh[H], dc[H], dg[4H]
+  float* dh = sm;
+  float* dc = sm + H;
+  float* dg = sm + 2 * H;
+  const int b = blockIdx.x;
+  for (int q = threadIdx.x; q < H; q += blockDim.x) {
+    dh[q] = dh_last[(long long)b * ld_dh + q];
+    dc[q] = 0.f;
+  }
+  __syncthreads();
+  for (int t = L - 1; t >= 0; --t) {
+    const float* a = act + ((long long)b * L + t) * 4 * H;
+    for (int q = threadIdx.x; q < H; q += blockDim.x) {
+      const float ig = a[q], fg = a[H + q], gg = a[2 * H + q], og = a[3 * H + q];
+      const float cn = cs[((long long)b * L + t) * H + q];
+      const float cp = t > 0 ? cs[((long long)b * L + t - 1) * H + q] : 0.f;
+      const float tc = tanhf(cn);
+      const float dcur = dc[q] + dh[q] * og * (1.f - tc * tc);
+      dg[q] = dcur * gg * ig * (1.f - ig);
+      dg[H + q] = dcur * cp * fg * (1.f - fg);
+      dg[2 * H + q] = dcur * ig * (1.f - gg * gg);
+      dg[3 * H + q] = dh[q] * tc * og * (1.f - og);
+      dc[q] = dcur * fg;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < 4 * H; r += blockDim.x) dgates[((long long)b * L + t) * 4 * H + r] = dg[r];
+    for (int q = threadIdx.x; q < H; q += blockDim.x) {
+      float acc = 0.f;
+      for (int r = 0; r < 4 * H; ++r) acc = fmaf(dg[r], w_hh[(long long)r * H + q], acc);
+      dh[q] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// feat[b][0:F] = y2[b][:] (flattened conv features), feat[b][F:F+H] = h_L[b]; dropout (fc.0) on all
+__global__ __launch_bounds__(256) void lite_cat_kernel(const float* __restrict__ y2, const float* __restrict__ hs,
+                                                       float* __restrict__ feat, int B, int F, int H, int L, int ldf,
+                                                       float p_drop, uint64_t seed) {
+  const long long total = (long long)B * ldf;
+  const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ldf), b = (int)(i / ldf);
+    float v = 0.f;
+    if (col < F) v = y2[(long long)b * F + col];
+    else if (col < F + H) v = hs[((long long)b * L + (L - 1)) * H + (col - F)];
+    if (p_drop > 0.f && col < F + H) {
+      uint64_t zz = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)(b * (long long)(F + H) + col) + 1);
+      zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+      zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+      zz ^= zz >> 31;
+      const float u = (float)(zz >> 40) * (1.0f / 16777216.0f);
+      v = u >= p_drop ? v * ks : 0.f;
+    }
+    feat[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void lite_uncat_kernel(const float* __restrict__ dfeat, float* __restrict__ dy2,
+                                                         float* __restrict__ dh, int B, int F, int H, int ldf, float p_drop,
+                                                         uint64_t seed) {
+  const long long total = (long long)B * (F + H);
+  const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (F + H)), b = (int)(i / (F + H));
+    float v = dfeat[(long long)b * ldf + col];
+    if (p_drop > 0.f) {
+      uint64_t zz = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)i + 1);
+      zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull;
+      zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull;
+      zz ^= zz >> 31;
+      const float u = (float)(zz >> 40) * (1.0f / 16777216.0f);
+      v = u >= p_drop ? v * ks : 0.f;
+    }
+    if (col < F) dy2[(long long)b * F + col] = v; else dh[(long long)b * H + (col - F)] = v;
+  }
+}
+
+static inline unsigned lgrid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return (unsigned)g;
+}
+
+}  // namespace tl
+using namespace tl;
+
+extern "C" int tl_lite_conv_fwd(const float* x, const float* w, const float* bias, float* z, float* part, int B, int Cin,
+                                int Cout, int T, int k, int pad, void* stream) {
+  TL_REQUIRE(x && w && bias && z, "lite_conv_fwd: null pointer");
+  TL_REQUIRE(B > 0 && B <= 65535 && Cin > 0 && Cout > 0 && T > 0 && k >= 1 && 2 * pad == k - 1, "lite_conv_fwd: bad sizes (needs 'same' padding)");
+  const size_t lds = (size_t)Cin * (LT + k - 1) * 4;
+  TL_REQUIRE(lds <= 64 * 1024, "lite_conv_fwd: Cin too large for the LDS tile");
+  dim3 grid((T + LT - 1) / LT, B);
+  hipLaunchKernelGGL(lite_conv_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, z, part, Cin, Cout, T, k, pad);
+  return check_launch("lite_conv_fwd");
+}
+extern "C" int tl_lite_bn_finalize(const float* part, float* mean, float* rstd, float* run_mean, float* run_var,
+                                   int nparts, int C, int64_t count, float momentum, float eps, int training, void* stream) {
+  TL_REQUIRE(mean && rstd && run_mean && run_var && C > 0 && (part || !training), "lite_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(lite_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, mean, rstd,
+                     run_mean, run_var, nparts, C, (long long)count, momentum, eps, training);
+  return check_launch("lite_bn_finalize");
+}
+extern "C" int tl_lite_bn_act_pool_fwd(const float* z, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, float* y, int B, int C, int T, float slope, void* stream) {
+  TL_REQUIRE(z && mean && rstd && gamma && beta && y && T >= 2, "lite_bn_act_pool_fwd: bad arguments");
+  const long long total = (long long)B * C * (T / 2);
+  hipLaunchKernelGGL(lite_bn_act_pool_fwd_kernel, dim3(lgrid(total)), dim3(256), 0, (hipStream_t)stream, z, mean, rstd,
+                     gamma, beta, y, total, C, T, slope);
+  return check_launch("lite_bn_act_pool_fwd");
+}
+extern "C" int tl_lite_bn_act_pool_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
+                                       float* work, int B, int C, int T, float slope, int training, void* stream) {
+  TL_REQUIRE(dy && z && mean && rstd && gamma && beta && dz && dgamma && dbeta && work, "lite_bn_act_pool_bwd: null pointer");
+  TL_REQUIRE(B > 0 && B <= 65535 && C > 0 && T >= 2, "lite_bn_act_pool_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = work;                         // [B][C][2]
+  float* sums = work + (size_t)B * C * 2;     // [C][2]
+  hipLaunchKernelGGL(lite_bn_act_pool_bwd_kernel, dim3(C, B), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, dz, part, C, T, slope);
+  hipLaunchKernelGGL(lite_bn_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, dgamma, dbeta, sums, B, C);
+  const long long total = (long long)B * C * T;
+  hipLaunchKernelGGL(lite_bn_dz_kernel, dim3(lgrid(total)), dim3(256), 0, st, dz, z, mean, rstd, gamma, sums, total, C, T,
+                     (long long)B * T, training);
+  return check_launch("lite_bn_act_pool_bwd");
+}
+extern "C" int tl_lite_conv_bwd(const float* dz, const float* x, const float* w, float* dx, float* dwpart, float* dbpart,
+                                int B, int Cin, int Cout, int T, int k, int pad, void* stream) {
+  TL_REQUIRE(dz && x && w && dwpart && dbpart, "lite_conv_bwd: null pointer");
+  TL_REQUIRE(B > 0 && B <= 65535 && 2 * pad == k - 1, "lite_conv_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    const size_t lds = (size_t)Cout * (LT + k - 1) * 4;
+    TL_REQUIRE(lds <= 64 * 1024, "lite_conv_bwd: Cout too large for the LDS tile");
+    hipLaunchKernelGGL(lite_conv_dx_kernel, dim3((T + LT - 1) / LT, B), dim3(256), lds, st, dz, w, dx, Cin, Cout, T, k, pad);
+  }
+  hipLaunchKernelGGL(lite_conv_dw_kernel, dim3(B), dim3(256), 0, st, dz, x, dwpart, dbpart, Cin, Cout, T, k, pad);
+  return check_launch("lite_conv_bwd");
+}
+extern "C" int tl_lite_lstm_fwd(const float* xl, const float* w_ih, const float* w_hh, const float* b_ih,
+                                const float* b_hh, float* act, float* cs, float* hs, int B, int L, int H, int in_dim,
+                                void* stream) {
+  TL_REQUIRE(xl && w_ih && w_hh && b_ih && b_hh && act && cs && hs && B > 0 && L > 0 && H > 0, "lite_lstm_fwd: bad arguments");
+  const size_t lds = (size_t)6 * H * 4;
+  TL_REQUIRE(lds <= 64 * 1024, "lite_lstm_fwd: hidden size too large");
+  hipLaunchKernelGGL(lite_lstm_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, xl, w_ih, w_hh, b_ih, b_hh, act, cs,
+                     hs, L, H, in_dim);
+  return check_launch("lite_lstm_fwd");
+}
+extern "C" int tl_lite_lstm_bwd(const float* dh_last, const float* w_hh, const float* act, const float* cs,
+                                float* dgates, int B, int L, int H, int ld_dh, void* stream) {
+  TL_REQUIRE(dh_last && w_hh && act && cs && dgates && B > 0 && L > 0 && H > 0, "lite_lstm_bwd: bad arguments");
+  const size_t lds = (size_t)6 * H * 4;
+  TL_REQUIRE(lds <= 64 * 1024, "lite_lstm_bwd: hidden size too large");
+  hipLaunchKernelGGL(lite_lstm_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dh_last, w_hh, act, cs, dgates, L,
+                     H, ld_dh);
+  return check_launch("lite_lstm_bwd");
+}
+extern "C" int tl_lite_cat(const float* y2, const float* hs, float* feat, int B, int F, int H, int L, int ldf,
+                           float p_drop, uint64_t seed, void* stream) {
+  TL_REQUIRE(y2 && hs && feat && ldf >= F + H && p_drop >= 0.f && p_drop < 1.f, "lite_cat: bad arguments");
+  hipLaunchKernelGGL(lite_cat_kernel, dim3(lgrid((long long)B * ldf)), dim3(256), 0, (hipStream_t)stream, y2, hs, feat, B, F,
+                     H, L, ldf, p_drop, seed);
+  return check_launch("lite_cat");
+}
+extern "C" int tl_lite_uncat(const float* dfeat, float* dy2, float* dh, int B, int F, int H, int ldf, float p_drop,
+                             uint64_t seed, void* stream) {
+  TL_REQUIRE(dfeat && dy2 && dh && ldf >= F + H && p_drop >= 0.f && p_drop < 1.f, "lite_uncat: bad arguments");
+  hipLaunchKernelGGL(lite_uncat_kernel, dim3(lgrid((long long)B * (F + H))), dim3(256), 0, (hipStream_t)stream, dfeat, dy2,
+                     dh, B, F, H, ldf, p_drop, seed);
+  return check_launch("lite_uncat");
+}

@@ -32,10 +32,13 @@ class SynthesisModel(nn.Module, ABC):
 
 
 class _CnnFunction(torch.autograd.Function):
+    """Shared by both models: ``model._engine`` does the work on detached tensors."""
+
     @staticmethod
     def forward(ctx, x, labels, model, need_grad, *params):
-        eng: CnnEngine = model._engine
+        eng = model._engine
         prm = dict(zip(model._pnames, (p.detach() for p in params)))
+        prm.update(model._engine_buffers())
         out = eng.forward(prm, x, labels, training=model.training, save=need_grad, seed=model._next_seed())
         ctx.model = model
         ctx.prm = prm
@@ -45,7 +48,7 @@ class _CnnFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         model = ctx.model
-        eng: CnnEngine = model._engine
+        eng = model._engine
         if ctx.generation != eng.generation:
             raise RuntimeError("SynthesisModelCNN: backward after a newer forward; intermediates were overwritten")
         dout = dout.contiguous().float()
@@ -53,7 +56,7 @@ class _CnnFunction(torch.autograd.Function):
             pad = torch.zeros(dout.shape[0], eng.ldd, dtype=dout.dtype, device=dout.device)
             pad[:, :eng.out_dim] = dout
             dout = pad
-        grads = {k: torch.empty_like(v) for k, v in ctx.prm.items()}
+        grads = {k: torch.empty_like(ctx.prm[k]) for k in model._pnames}
         eng.backward(ctx.prm, dout, grads)
         return (None, None, None, None) + tuple(grads[k] for k in model._pnames)
 
@@ -112,6 +115,9 @@ class SynthesisModelCNN(SynthesisModel):
         self._drop_calls += 1
         return (torch.initial_seed() * 0x9E3779B1 + self._drop_calls) & 0xFFFFFFFFFFFFFFFF
 
+    def _engine_buffers(self):
+        return {}
+
     def forward(self, inputs_ecog: torch.Tensor, inputs_labels: torch.Tensor) -> torch.Tensor:
         _lib.require_gpu(inputs_ecog, "SynthesisModelCNN.forward")
         params = [p for _, p in self.named_parameters()]
@@ -150,17 +156,24 @@ class SynthesisLite(SynthesisModel):
             nn.Dropout(dropout), nn.Linear(self.ecog_out_dim + lstm_hidden, 512), nn.LeakyReLU(negative_slope),
             nn.Linear(512, output_dim),
         )
-        self._cfg = dict(output_dim=output_dim, n_channels=n_channels, n_timepoints=n_timepoints,
-                         label_dim=label_dim, conv_channels=conv_channels, lstm_hidden=lstm_hidden,
-                         dropout=dropout, negative_slope=negative_slope)
-        self._engine = None
+        if lstm_hidden % 4 != 0:
+            raise ValueError("lstm_hidden must be a multiple of 4 on the MI355X path")
+        from .._lite_engine import LiteEngine
+        self._pnames: List[str] = [n for n, _ in self.named_parameters()]
+        self._engine = LiteEngine(output_dim, n_channels, n_timepoints, label_dim, conv_channels, lstm_hidden,
+                                  dropout, negative_slope)
         self._drop_calls = 0
 
     def _next_seed(self) -> int:
         self._drop_calls += 1
         return (torch.initial_seed() * 0x9E3779B1 + self._drop_calls) & 0xFFFFFFFFFFFFFFFF
 
+    def _engine_buffers(self):
+        return {k: v for k, v in self.named_buffers()}
+
     def forward(self, x_ecog: torch.Tensor, x_label: torch.Tensor) -> torch.Tensor:
         _lib.require_gpu(x_ecog, "SynthesisLite.forward")
-        from .._lite_engine import lite_apply
-        return lite_apply(self, x_ecog, x_label.to(x_ecog.device))
+        params = [p for _, p in self.named_parameters()]
+        _lib.require_gpu(params[0], "SynthesisLite parameters")
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _CnnFunction.apply(x_ecog, x_label.to(x_ecog.device), self, need_grad, *params)

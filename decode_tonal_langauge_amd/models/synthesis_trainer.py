@@ -124,6 +124,7 @@ class SynthesisTrainer:
         prm = {k: params[k].detach() for k in names}
         if self._grads is None:
             self._grads = {k: torch.empty_like(v) for k, v in prm.items()}
+        prm.update(model._engine_buffers())
         out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True, seed=model._next_seed())
         B, D = out.shape
         dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)

@@ -154,6 +154,37 @@ int tl_nadam(float* p, const float* g, float* m, float* v, int64_t n, float coef
 int tl_tone_dynamics(const int64_t* tone, const int64_t* syl, const float* table, float* labels,
                      int32_t* err, int B, int n_tones, int L, void* stream);
 
+/* ---- SynthesisLite blocks (models/synthesis_models.py:236-263,265-296) ----------------------
+ * x (B,Cin,T) channels-first like the reference's Conv1d; 'same' padding (2*pad == k-1).       */
+/* z = conv1d(x,w)+bias; part[(b*ntile+tile)][Cout][2] = per-tile (sum z, sum z^2), ntile=ceil(T/64) */
+int tl_lite_conv_fwd(const float* x, const float* w, const float* bias, float* z, float* part,
+                     int B, int Cin, int Cout, int T, int k, int pad, void* stream);
+/* BatchNorm1d statistics: training -> batch mean / rstd from `part` (+ running-stat update,
+ * unbiased variance); eval -> from the running buffers                                        */
+int tl_lite_bn_finalize(const float* part, float* mean, float* rstd, float* run_mean, float* run_var,
+                        int nparts, int C, int64_t count, float momentum, float eps, int training, void* stream);
+/* y (B,C,T/2) = MaxPool1d(2)(LeakyReLU(BN(z)))                                                 */
+int tl_lite_bn_act_pool_fwd(const float* z, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, float* y, int B, int C, int T, float slope, void* stream);
+/* backward of the same: dy (B,C,T/2) -> dz (B,C,T), dgamma, dbeta; work holds (B*C*2 + C*2) floats */
+int tl_lite_bn_act_pool_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, float* dz, float* dgamma, float* dbeta,
+                            float* work, int B, int C, int T, float slope, int training, void* stream);
+/* conv backward: dx (B,Cin,T) (may be null), dwpart (B,Cout*Cin*k), dbpart (B,Cout) per-sample partials */
+int tl_lite_conv_bwd(const float* dz, const float* x, const float* w, float* dx, float* dwpart, float* dbpart,
+                     int B, int Cin, int Cout, int T, int k, int pad, void* stream);
+/* label LSTM over the whole sequence: xl (B,L,in_dim) -> act (B,L,4H), cs, hs (B,L,H)          */
+int tl_lite_lstm_fwd(const float* xl, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                     float* act, float* cs, float* hs, int B, int L, int H, int in_dim, void* stream);
+/* BPTT from the gradient of the last hidden state: dgates (B,L,4H)                             */
+int tl_lite_lstm_bwd(const float* dh_last, const float* w_hh, const float* act, const float* cs, float* dgates,
+                     int B, int L, int H, int ld_dh, void* stream);
+/* feat (B,ldf) = Dropout([flatten(y2) | h_L]) and its backward split                           */
+int tl_lite_cat(const float* y2, const float* hs, float* feat, int B, int F, int H, int L, int ldf,
+                float p_drop, uint64_t seed, void* stream);
+int tl_lite_uncat(const float* dfeat, float* dy2, float* dh, int B, int F, int H, int ldf, float p_drop,
+                  uint64_t seed, void* stream);
+
 /* ---- preprocess/signal band extraction (preprocess/signal/frequency_filter.py) ------------ */
 /* Gaussian-bank analytic envelope, circular, exact DFT-domain taps supplied by the host:
  * taps (nb, ntap, 2) complex float64 kernels h_b[n], n = k - half for k in [0, ntap), ntap <= T
