@@ -75,31 +75,57 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
   f32x4 ra[A_F4];          // staged A (DIRECT) or G (UNPOOL)
   uint32_t rbits[A_F4];    // UNPOOL: raw 32-bit arg word (bit set -> odd row of the pair); the
                            // nibble is extracted at LDS-store time so the load stays in flight
-  f32x4 rb[4];
+  f32x4 rbP[4], rbQ[4];    // two B staging sets: B is prefetched TWO K-steps ahead (HBM/L2 latency
+                           // under full load exceeds one 64-MFMA step; measured in scripts/mfma_ablate.hip)
 
   const long long Abase = R0 + p.row_shift;        // first staged A row (even for UNPOOL)
 
+  // Per-thread row pointers and validity are loop-invariant (a thread stages the same rows of
+  // every K-chunk): hoist them, so a K-step issues its global loads with one 64-bit add each.
+  const float* aptr[A_F4];
+  const uint32_t* abptr[A_F4];
+  bool aok[A_F4];
+  (void)abptr;
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    const int idx = tid + i * 256;
+    const int r = idx >> 3, c4 = idx & 7;
+    if constexpr (LOADER == LOAD_DIRECT) {
+      const long long row = Abase + r;
+      aok[i] = r < arows_used && row >= 0 && row < p.A_rows;
+      aptr[i] = p.A + (aok[i] ? row : 0) * (long long)p.lda + c4 * 4;
+      abptr[i] = nullptr;
+    } else {
+      const long long prow = (Abase >> 1) + r;     // Abase is even
+      aok[i] = (r < (arows_used + 1) / 2) && prow >= 0 && prow < p.A_rows &&
+               (int)((2 * prow) % p.Tp) < p.Tvalid_in;
+      aptr[i] = p.A + (aok[i] ? prow : 0) * (long long)p.lda + c4 * 4;
+      abptr[i] = p.abits + (aok[i] ? prow : 0) * (long long)p.ld_abits;
+    }
+  }
+  const float* bptr[4];
+  bool bok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * 256;
+    const int r = idx >> 3, c4 = idx & 7;
+    bok[i] = (n0 + r) < p.N;
+    bptr[i] = p.Bw + (long long)(bok[i] ? n0 + r : 0) * p.ldb + c4 * 4;
+  }
+  const bool ktail = (p.K % BK) != 0;             // wave-uniform: the hot shapes have K % 32 == 0
+  const int kq = (tid & 7) * 4;
+  const long long tap_stride = (long long)p.N * p.ldb;
+
   auto load_a = [&](int chunk) {
     const int kc = (kc_begin + chunk) * BK;
+    const bool kok = !ktail || (kc + kq) < p.K;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const int idx = tid + i * 256;
-      const int r = idx >> 3, c4 = idx & 7;
-      const int k = kc + c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       uint32_t nib = 0;
-      if constexpr (LOADER == LOAD_DIRECT) {
-        const long long row = Abase + r;
-        if (r < arows_used && row >= 0 && row < p.A_rows && k < p.K)
-          v = *reinterpret_cast<const f32x4*>(p.A + row * (long long)p.lda + k);
-      } else {
-        const long long prow = (Abase >> 1) + r;   // Abase is even
-        const bool ok = (r < (arows_used + 1) / 2) && prow >= 0 && prow < p.A_rows && k < p.K &&
-                        (int)((2 * prow) % p.Tp) < p.Tvalid_in;
-        if (ok) {
-          v = *reinterpret_cast<const f32x4*>(p.A + prow * (long long)p.lda + k);
-          nib = p.abits[prow * (long long)p.ld_abits + (k >> 5)];
-        }
+      if (aok[i] && kok) {
+        v = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
+        if constexpr (LOADER == LOAD_UNPOOL) nib = abptr[i][kc >> 5];
       }
       ra[i] = v;
       rbits[i] = nib;
@@ -129,20 +155,18 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
       }
     }
   };
-  auto load_b = [&](int chunk, int j) {
+  auto load_b = [&](f32x4 (&rb)[4], int chunk, int j) {
     const int kc = (kc_begin + chunk) * BK;
+    const bool kok = !ktail || (kc + kq) < p.K;
+    const long long off = (long long)j * tap_stride + kc;     // wave-uniform
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 256;
-      const int r = idx >> 3, c4 = idx & 7;
-      const int n = n0 + r, k = kc + c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n < p.N && k < p.K)
-        v = *reinterpret_cast<const f32x4*>(p.Bw + ((long long)j * p.N + n) * (long long)p.ldb + k);
+      if (bok[i] && kok) v = *reinterpret_cast<const f32x4*>(bptr[i] + off);
       rb[i] = v;
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](const f32x4 (&rb)[4], int buf) {
     float* dst = Bs + buf * BN * LDS_LD;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -176,39 +200,55 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][q], fb[ni][q], acc[mi][ni], 0, 0, 0);
   };
 
-  if (nsteps > 0) {
-    load_a(0);
-    load_b(0, 0);
-    store_a(0);
-    store_b(0);
-  }
-  __syncthreads();
-
-  for (int s = 0; s < nsteps; ++s) {
-    const int chunk = s / J, j = s - chunk * J;
-    const int s1 = s + 1;
-    const int chunk1 = s1 / J, j1 = s1 - chunk1 * J;
-    const bool more = s1 < nsteps;
-    const bool newa = more && (j1 == 0);
-    const int abuf = chunk & 1, bbuf = s & 1;
-    load_frag(fa0, fb0, abuf, bbuf, j, 0);
-    if (more) {
-      load_b(chunk1, j1);
-      if (newa) load_a(chunk1);
+  // One K-step.  `rb_ld` receives B(s+2); `rb_st` holds B(s+1) (loaded one step ago) and is written
+  // to LDS mid-step.  A(chunk+1) is loaded at the first tap of a chunk and stored at its last tap.
+  // (chunk, tap) counters advanced without divisions
+  int c_cur = 0, j_cur = 0;          // step s
+  int c_ld = 0, j_ld = 0;            // step s + 2 (next B tile to load)
+  auto advance = [&](int& c, int& j) {
+    if (++j == J) {
+      j = 0;
+      ++c;
     }
+  };
+  auto kstep = [&](int s, f32x4 (&rb_ld)[4], const f32x4 (&rb_st)[4]) {
+    const int chunk = c_cur, j = j_cur;
+    const int abuf = chunk & 1, bbuf = s & 1;
+    const bool more = s + 1 < nsteps;
+    const bool has_next_chunk = chunk + 1 < nchunks;
+    load_frag(fa0, fb0, abuf, bbuf, j, 0);
+    if (s + 2 < nsteps) load_b(rb_ld, c_ld, j_ld);
+    if (j == 0 && has_next_chunk) load_a(chunk + 1);
     if (s > 0) mfma_group(fa1, fb1);             // k-group 3 of the previous step (registers)
     load_frag(fa1, fb1, abuf, bbuf, j, 1);
     mfma_group(fa0, fb0);
     load_frag(fa0, fb0, abuf, bbuf, j, 2);
     mfma_group(fa1, fb1);
-    if (more) {                                   // global loads issued at the top have landed
-      store_b(s1 & 1);
-      if (newa) store_a(chunk1 & 1);
-    }
+    if (more) store_b(rb_st, bbuf ^ 1);
+    if (j == J - 1 && has_next_chunk) store_a(abuf ^ 1);
     load_frag(fa1, fb1, abuf, bbuf, j, 3);
     mfma_group(fa0, fb0);
+    advance(c_cur, j_cur);
+    advance(c_ld, j_ld);
     __syncthreads();
+  };
+
+  if (nsteps > 0) {
+    load_a(0);
+    load_b(rbP, 0, 0);
+    store_a(0);
+    store_b(rbP, 0);
+    advance(c_ld, j_ld);
+    if (nsteps > 1) load_b(rbQ, c_ld, j_ld);
+    advance(c_ld, j_ld);
   }
+  __syncthreads();
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    kstep(s, rbP, rbQ);
+    kstep(s + 1, rbQ, rbP);
+  }
+  if (s < nsteps) kstep(s, rbP, rbQ);
   if (nsteps > 0) mfma_group(fa1, fb1);
 
   // ---------------------------------- epilogue ----------------------------------
@@ -313,14 +353,23 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
 
   const int ntm1 = (p.Mdim + 127) / 128;          // m tiles per tap
   const int ntn = (p.Ndim + 127) / 128;
-  // blockIdx.x -> (tap j, m tile, n tile): n fastest so that neighbours share the A panel
-  int bid = blockIdx.x;
-  const int tn = bid % ntn;
-  bid /= ntn;
-  const int tm = bid % ntm1;
-  const int j = bid / ntm1;
+  // Work item = (split z, tap j, m tile, n tile).  Every tile of one split reads the SAME rows of
+  // A and B, so all tiles of a split must share an L2: blocks b and b+8 sit on one XCD, hence the
+  // bijective remap that hands each XCD a contiguous run of work items (split-major).
+  const long long tiles = (long long)ntm1 * ntn * p.J;
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int z = (int)(bid / tiles);
+  int tid_tile = (int)(bid % tiles);
+  const int tn = tid_tile % ntn;
+  tid_tile /= ntn;
+  const int tm = tid_tile % ntm1;
+  const int j = tid_tile / ntm1;
   const int m0 = tm * 128, n0 = tn * 128;
-  const int z = blockIdx.y;
 
   const long long ksteps_all = (p.Krows + BK - 1) / BK;
   const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
@@ -337,54 +386,83 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  f32x4 ra[4], rb[4];
-  uint32_t rnib[2];
-  (void)rnib;
+  // two staging sets (P/Q): tiles are prefetched two K-steps ahead
+  f32x4 raP[4], rbP[4], raQ[4], rbQ[4];
+  uint32_t rnP[2], rnQ[2];
+  (void)rnP; (void)rnQ;
 
-  auto load_tiles = [&](long long step) {
-    const long long k0 = (ks_begin + step) * BK;
+  // Hoisted per-thread state: row pointers advance by a wave-uniform stride per K-step, column
+  // validity is loop-invariant, row validity ((row % Tp) < Tvalid) is tracked incrementally.
+  constexpr int NB = (LOADER == LOAD_DIRECT) ? 4 : 2;
+  const int krows = (int)p.Krows;                       // host guarantees < 2^31
+  const int a_lim = (int)(p.A_rows < p.Krows + j ? p.A_rows : p.Krows + j);
+  const int b_lim = (LOADER == LOAD_DIRECT) ? (int)(p.B_rows < p.Krows ? p.B_rows : p.Krows)
+                                            : (int)(2 * p.B_rows < p.Krows ? 2 * p.B_rows : p.Krows);
+  const int kbase = (int)(ks_begin * BK);
+  const float* aptr[4];
+  int arow[4];
+  const bool amok = (m0 + (tid & 31) * 4) < p.Mdim;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (tid + i * 256) >> 5;
+    arow[i] = kbase + r + j;
+    aptr[i] = p.A + (long long)arow[i] * p.lda + m0 + (tid & 31) * 4;
+  }
+  const float* bptr[NB];
+  const uint32_t* bbptr[NB];
+  int brow[NB], bt[NB];
+  (void)bbptr;
+  const int ncol = n0 + (tid & 31) * 4;
+  const bool bnok = ncol < p.Ndim;
+  const int dstep = BK % p.Tp;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = (tid + i * 256) >> 5;
+    if constexpr (LOADER == LOAD_DIRECT) {
+      brow[i] = kbase + r;                              // B row
+      bptr[i] = p.B + (long long)brow[i] * p.ldb + ncol;
+      bbptr[i] = nullptr;
+    } else {
+      brow[i] = kbase + 2 * r;                          // even conv row of the pooled pair
+      bptr[i] = p.B + (long long)(brow[i] >> 1) * p.ldb + ncol;
+      bbptr[i] = p.bbits + (long long)(brow[i] >> 1) * p.ld_bbits + (ncol >> 5);
+    }
+    bt[i] = brow[i] % p.Tp;
+  }
+  const long long a_step = (long long)BK * p.lda;
+  const long long b_step = (LOADER == LOAD_DIRECT) ? (long long)BK * p.ldb : (long long)(BK / 2) * p.ldb;
+  const long long bb_step = (long long)(BK / 2) * p.ld_bbits;
+
+  // loads the tiles of the NEXT not-yet-loaded step and advances the per-thread state
+  auto load_tiles = [&](f32x4 (&ra)[4], f32x4 (&rb)[4], uint32_t (&rnib)[2], long long /*step*/) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 256;
-      const int r = idx >> 5, c4 = idx & 31;
-      const long long row = k0 + r + j;
-      const int m = m0 + c4 * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < p.A_rows && (k0 + r) < p.Krows && m < p.Mdim)
-        v = *reinterpret_cast<const f32x4*>(p.A + row * (long long)p.lda + m);
+      if (amok && arow[i] < a_lim) v = *reinterpret_cast<const f32x4*>(aptr[i]);
       ra[i] = v;
+      aptr[i] += a_step;
+      arow[i] += BK;
     }
-    if constexpr (LOADER == LOAD_DIRECT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + i * 256;
-        const int r = idx >> 5, c4 = idx & 31;
-        const long long row = k0 + r;
-        const int n = n0 + c4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < p.Krows && row < p.B_rows && n < p.Ndim && (int)(row % p.Tp) < p.Tvalid)
-          v = *reinterpret_cast<const f32x4*>(p.B + row * (long long)p.ldb + n);
-        rb[i] = v;
+    for (int i = 0; i < NB; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      uint32_t nib = 0;
+      if (bnok && brow[i] < b_lim && bt[i] < p.Tvalid) {
+        v = *reinterpret_cast<const f32x4*>(bptr[i]);
+        if constexpr (LOADER == LOAD_UNPOOL) nib = *bbptr[i];
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * 256;
-        const int pr = idx >> 5, c4 = idx & 31;
-        const long long prow = (k0 >> 1) + pr;        // k0 is a multiple of BK (even)
-        const int n = n0 + c4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        uint32_t nib = 0;
-        if (2 * prow < p.Krows && prow < p.B_rows && n < p.Ndim && (int)((2 * prow) % p.Tp) < p.Tvalid) {
-          v = *reinterpret_cast<const f32x4*>(p.B + prow * (long long)p.ldb + n);
-          nib = p.bbits[prow * (long long)p.ld_bbits + (n >> 5)];     // raw word, nibble at store time
-        }
-        rb[i] = v;
+      rb[i] = v;
+      if constexpr (LOADER == LOAD_UNPOOL) {
         rnib[i] = nib;
+        bbptr[i] += bb_step;
       }
+      bptr[i] += b_step;
+      brow[i] += BK;
+      bt[i] += dstep;
+      if (bt[i] >= p.Tp) bt[i] -= p.Tp;
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](const f32x4 (&ra)[4], const f32x4 (&rb)[4], const uint32_t (&rnib)[2], int buf) {
     float* da = As + buf * BK * TN_LD;
     float* db = Bs + buf * BK * TN_LD;
 #pragma unroll
@@ -406,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
         const int idx = tid + i * 256;
         const int pr = idx >> 5, c4 = idx & 31;
         f32x4 e, o;
-        const uint32_t nibv = rnib[i] >> ((n0 + c4 * 4) & 31);
+        const uint32_t nibv = rnib[i] >> (ncol & 31);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const bool odd = (nibv >> q) & 1u;
@@ -443,26 +521,34 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][mi], fb[q][ni], acc[mi][ni], 0, 0, 0);
   };
 
-  if (nsteps > 0) {
-    load_tiles(0);
-    store_tiles(0);
-  }
-  __syncthreads();
-  for (long long s = 0; s < nsteps; ++s) {
-    const bool more = s + 1 < nsteps;
+  auto kstep = [&](long long s, f32x4 (&ra_ld)[4], f32x4 (&rb_ld)[4], uint32_t (&rn_ld)[2], const f32x4 (&ra_st)[4],
+                   const f32x4 (&rb_st)[4], const uint32_t (&rn_st)[2]) {
     const int buf = (int)(s & 1);
     load_frag(ta0, tb0, buf, 0);
-    if (more) load_tiles(s + 1);
+    if (s + 2 < nsteps) load_tiles(ra_ld, rb_ld, rn_ld, s + 2);
     if (s > 0) mfma_group(ta1, tb1);
     load_frag(ta1, tb1, buf, 1);
     mfma_group(ta0, tb0);
     load_frag(ta0, tb0, buf, 2);
     mfma_group(ta1, tb1);
-    if (more) store_tiles(buf ^ 1);
+    if (s + 1 < nsteps) store_tiles(ra_st, rb_st, rn_st, buf ^ 1);
     load_frag(ta1, tb1, buf, 3);
     mfma_group(ta0, tb0);
     __syncthreads();
+  };
+
+  if (nsteps > 0) {
+    load_tiles(raP, rbP, rnP, 0);
+    store_tiles(raP, rbP, rnP, 0);
+    if (nsteps > 1) load_tiles(raQ, rbQ, rnQ, 1);
   }
+  __syncthreads();
+  long long s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
+    kstep(s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
+  }
+  if (s < nsteps) kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
   if (nsteps > 0) mfma_group(ta1, tb1);
 
   float* out = p.slab + (long long)z * p.slab_stride;
@@ -622,6 +708,7 @@ extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
   if (p.splitk < 1) p.splitk = 1;
   TL_REQUIRE(p.A && p.B && p.slab, "tn_window: null A/B/slab");
   TL_REQUIRE(p.Krows > 0 && p.Mdim > 0 && p.Ndim > 0, "tn_window: bad sizes");
+  TL_REQUIRE(p.Krows + 64 < (1LL << 31), "tn_window: more than 2^31 reduction rows");
   TL_REQUIRE(p.Mdim % 4 == 0 && p.Ndim % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "tn_window: dims/ld must be multiples of 4");
   TL_REQUIRE(p.J >= 1 && p.J <= 3, "tn_window: J must be 1..3");
   TL_REQUIRE(p.Tp > 0, "tn_window: Tp must be positive");

@@ -96,6 +96,71 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ A, const f
   out[(long long)blockIdx.x * 256 + tid] = sum;
 }
 
+
+// prefetch distance 2: registers set P (even steps) / Q (odd steps); loads issued at step s are stored to LDS
+// at the end of step s+1 (a full extra K-step of latency tolerance)
+__global__ __launch_bounds__(256, 2) void kd2(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out,
+                                              int nsteps, int lda) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * AROWS * LDS_LD + 2 * 128 * LDS_LD];
+  float* As = lds;
+  float* Bs = lds + 2 * AROWS * LDS_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  for (int i = tid; i < 2 * AROWS * LDS_LD + 2 * 128 * LDS_LD; i += 256) lds[i] = (float)((i * 7 + blockIdx.x) & 15) * 0.01f;
+  __syncthreads();
+  f32x4 fa[2], fb[2];
+  f32x4 rbP[4], rbQ[4];
+  for (int i = 0; i < 4; ++i) rbP[i] = rbQ[i] = f32x4{0, 0, 0, 0};
+  auto loadB = [&](f32x4 (&rb)[4], int s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, r = idx >> 3, c4 = idx & 7;
+      rb[i] = *reinterpret_cast<const f32x4*>(B + (long long)r * 512 + ((s * 32) & 511) + c4 * 4);
+    }
+  };
+  auto storeB = [&](const f32x4 (&rb)[4], int s) {
+    float* db = Bs + ((s + 1) & 1) * 128 * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, r = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<f32x4*>(db + r * LDS_LD + c4 * 4) = rb[i];
+    }
+  };
+  auto compute = [&](int s) {
+    const float* a_s = As + (s & 1) * AROWS * LDS_LD + (wm * 64 + lr + (s % 3)) * LDS_LD + lh * 4;
+    const float* b_s = Bs + (s & 1) * 128 * LDS_LD + (wn * 64 + lr) * LDS_LD + lh * 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      fa[0] = *reinterpret_cast<const f32x4*>(a_s + kk * 8);
+      fa[1] = *reinterpret_cast<const f32x4*>(a_s + 32 * LDS_LD + kk * 8);
+      fb[0] = *reinterpret_cast<const f32x4*>(b_s + kk * 8);
+      fb[1] = *reinterpret_cast<const f32x4*>(b_s + 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][q], fb[ni][q], acc[mi][ni], 0, 0, 0);
+    }
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    loadB(rbP, s + 2);
+    compute(s);
+    storeB(rbQ, s);          // loaded one step ago
+    __syncthreads();
+    loadB(rbQ, s + 3);
+    compute(s + 1);
+    storeB(rbP, s + 1);
+    __syncthreads();
+  }
+  float sum = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+  out[(long long)blockIdx.x * 256 + tid] = sum;
+}
+
 template <int VAR, int LOADS = (VAR >= 3), int STORES = (VAR >= 3)>
 void run(const char* name, const float* A, const float* B, float* out, int nwg, int nsteps, int lda) {
   hipEvent_t e0, e1;
@@ -126,5 +191,14 @@ int main() {
   run<3>("V3 + global loads + LDS stores (full loop)", A, B, out, nwg, nsteps, lda);
   run<2, 1, 0>("V4 barrier + global loads only", A, B, out, nwg, nsteps, lda);
   run<2, 0, 1>("V5 barrier + LDS stores only", A, B, out, nwg, nsteps, lda);
+  {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kd2, dim3(nwg), dim3(256), 0, 0, A, B, out, nsteps, lda); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(kd2, dim3(nwg), dim3(256), 0, 0, A, B, out, nsteps, lda);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    printf("%-44s %8.3f ms  %7.2f TFLOP/s\n", "V6 B only: loads dist-2 + stores", ms, (double)nwg * 4 * nsteps * 64 * 4096.0 / ms / 1e9);
+  }
   return 0;
 }
