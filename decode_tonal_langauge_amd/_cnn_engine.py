@@ -237,7 +237,10 @@ class CnnEngine:
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
         nd = _r4(st.cout)
-        tiles = st.k * ((st.cin + 127) // 128) * ((nd + 127) // 128)
+        if st.k == 3:      # all-taps kernel: 128 x 64 tiles
+            tiles = ((st.cin + 127) // 128) * ((nd + 63) // 64)
+        else:
+            tiles = st.k * ((st.cin + 127) // 128) * ((nd + 127) // 128)
         sk = self._splitk(tiles, (rows_in + 31) // 32)
         slab = torch.empty(sk, st.k * st.cin, ldg, **f32)
         kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0],

@@ -568,6 +568,219 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
 
 
 // ------------------------------------------------------------------------------------------
+// TN, all three taps per workgroup (the conv weight gradient): one staged activation tile
+// (BK + 2 rows) and one staged dZ tile feed the accumulators of all 3 taps, so the staging work
+// per MFMA is half that of the one-tap kernel.  Block tile 128 (C_in) x 64 (C_out), wave tile
+// 64 x 32 x 3 taps = 96 accumulator registers, still 2 workgroups per CU.
+// ------------------------------------------------------------------------------------------
+constexpr int T3_BN = 64, T3_LDA = 128 + 4, T3_LDB = T3_BN + 4, T3_AR = BK + 2;
+
+template <int LOADER>
+__global__ __launch_bounds__(256, 2) void tn3_kernel(const tl_tn_params p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * T3_AR * T3_LDA + 2 * BK * T3_LDB];
+  float* As = lds;
+  float* Bs = lds + 2 * T3_AR * T3_LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int ntm = (p.Mdim + 127) / 128, ntn = (p.Ndim + T3_BN - 1) / T3_BN;
+  const long long tiles = (long long)ntm * ntn;
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int z = (int)(bid / tiles);
+  const int tt = (int)(bid % tiles);
+  const int m0 = (tt / ntn) * 128, n0 = (tt % ntn) * T3_BN;
+
+  const long long ksteps_all = (p.Krows + BK - 1) / BK;
+  const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const long long nsteps = ks_end > ks_begin ? ks_end - ks_begin : 0;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  constexpr int NB = (LOADER == LOAD_DIRECT) ? 2 : 1;
+  f32x4 raP[5], raQ[5], rbP[NB], rbQ[NB];
+  uint32_t rnP[NB], rnQ[NB];
+  (void)rnP; (void)rnQ;
+
+  const int krows = (int)p.Krows;
+  (void)krows;
+  const int a_lim = (int)(p.A_rows < p.Krows + 2 ? p.A_rows : p.Krows + 2);
+  const int b_lim = (LOADER == LOAD_DIRECT) ? (int)(p.B_rows < p.Krows ? p.B_rows : p.Krows)
+                                            : (int)(2 * p.B_rows < p.Krows ? 2 * p.B_rows : p.Krows);
+  const int kbase = (int)(ks_begin * BK);
+  const float* aptr[5];
+  int arow[5];
+  bool aact[5];
+  const bool amok = (m0 + (tid & 31) * 4) < p.Mdim;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = (tid + i * 256) >> 5;           // 0..39, rows >= 34 unused
+    aact[i] = r < T3_AR;
+    arow[i] = kbase + r;
+    aptr[i] = p.A + (long long)arow[i] * p.lda + m0 + (tid & 31) * 4;
+  }
+  const float* bptr[NB];
+  const uint32_t* bbptr[NB];
+  int brow[NB], bt[NB];
+  (void)bbptr;
+  const int ncol = n0 + (tid & 15) * 4;
+  const bool bnok = ncol < p.Ndim;
+  const int dstep = BK % p.Tp;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = (tid + i * 256) >> 4;           // 16 float4 per 64-column row
+    if constexpr (LOADER == LOAD_DIRECT) {
+      brow[i] = kbase + r;
+      bptr[i] = p.B + (long long)brow[i] * p.ldb + ncol;
+      bbptr[i] = nullptr;
+    } else {
+      brow[i] = kbase + 2 * r;
+      bptr[i] = p.B + (long long)(brow[i] >> 1) * p.ldb + ncol;
+      bbptr[i] = p.bbits + (long long)(brow[i] >> 1) * p.ld_bbits + (ncol >> 5);
+    }
+    bt[i] = brow[i] % p.Tp;
+  }
+  const long long a_step = (long long)BK * p.lda;
+  const long long b_step = (LOADER == LOAD_DIRECT) ? (long long)BK * p.ldb : (long long)(BK / 2) * p.ldb;
+  const long long bb_step = (long long)(BK / 2) * p.ld_bbits;
+
+  auto load_tiles = [&](f32x4 (&ra)[5], f32x4 (&rb)[NB], uint32_t (&rn)[NB]) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (aact[i] && amok && arow[i] < a_lim) v = *reinterpret_cast<const f32x4*>(aptr[i]);
+      ra[i] = v;
+      aptr[i] += a_step;
+      arow[i] += BK;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      uint32_t nib = 0;
+      if (bnok && brow[i] < b_lim && bt[i] < p.Tvalid) {
+        v = *reinterpret_cast<const f32x4*>(bptr[i]);
+        if constexpr (LOADER == LOAD_UNPOOL) nib = *bbptr[i];
+      }
+      rb[i] = v;
+      if constexpr (LOADER == LOAD_UNPOOL) {
+        rn[i] = nib;
+        bbptr[i] += bb_step;
+      }
+      bptr[i] += b_step;
+      brow[i] += BK;
+      bt[i] += dstep;
+      if (bt[i] >= p.Tp) bt[i] -= p.Tp;
+    }
+  };
+  auto store_tiles = [&](const f32x4 (&ra)[5], const f32x4 (&rb)[NB], const uint32_t (&rn)[NB], int buf) {
+    float* da = As + buf * T3_AR * T3_LDA;
+    float* db = Bs + buf * BK * T3_LDB;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 5, c4 = idx & 31;
+      if (r < T3_AR) *reinterpret_cast<f32x4*>(da + r * T3_LDA + c4 * 4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 4, c4 = idx & 15;
+      if constexpr (LOADER == LOAD_DIRECT) {
+        *reinterpret_cast<f32x4*>(db + r * T3_LDB + c4 * 4) = rb[i];
+      } else {
+        f32x4 e, o;
+        const uint32_t nibv = rn[i] >> (ncol & 31);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool odd = (nibv >> q) & 1u;
+          e[q] = odd ? 0.f : rb[i][q];
+          o[q] = odd ? rb[i][q] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(db + (2 * r) * T3_LDB + c4 * 4) = e;
+        *reinterpret_cast<f32x4*>(db + (2 * r + 1) * T3_LDB + c4 * 4) = o;
+      }
+    }
+  };
+
+  // fragments of one k-group (8 rows = 4 MFMA k-steps): A needs rows lh .. lh+8 (taps 0..2)
+  float fa0[10][2], fb0[4], fa1[10][2], fb1[4];
+  auto load_frag = [&](float (&fa)[10][2], float (&fb)[4], int buf, int g) {
+    const float* a_s = As + buf * T3_AR * T3_LDA + (g * 8 + lh) * T3_LDA + wm * 64 + lr;
+    const float* b_s = Bs + buf * BK * T3_LDB + (g * 8 + lh) * T3_LDB + wn * 32 + lr;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      fa[r][0] = a_s[r * T3_LDA];
+      fa[r][1] = a_s[r * T3_LDA + 32];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb[q] = b_s[q * 2 * T3_LDB];
+  };
+  auto mfma_group = [&](const float (&fa)[10][2], const float (&fb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2 * q + j][mi], fb[q], acc[j][mi], 0, 0, 0);
+  };
+  auto kstep = [&](long long s, f32x4 (&ra_ld)[5], f32x4 (&rb_ld)[NB], uint32_t (&rn_ld)[NB], const f32x4 (&ra_st)[5],
+                   const f32x4 (&rb_st)[NB], const uint32_t (&rn_st)[NB]) {
+    const int buf = (int)(s & 1);
+    load_frag(fa0, fb0, buf, 0);
+    if (s + 2 < nsteps) load_tiles(ra_ld, rb_ld, rn_ld);
+    if (s > 0) mfma_group(fa1, fb1);
+    load_frag(fa1, fb1, buf, 1);
+    mfma_group(fa0, fb0);
+    load_frag(fa0, fb0, buf, 2);
+    mfma_group(fa1, fb1);
+    if (s + 1 < nsteps) store_tiles(ra_st, rb_st, rn_st, buf ^ 1);
+    load_frag(fa1, fb1, buf, 3);
+    mfma_group(fa0, fb0);
+    __syncthreads();
+  };
+
+  if (nsteps > 0) {
+    load_tiles(raP, rbP, rnP);
+    store_tiles(raP, rbP, rnP, 0);
+    if (nsteps > 1) load_tiles(raQ, rbQ, rnQ);
+  }
+  __syncthreads();
+  long long s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
+    kstep(s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
+  }
+  if (s < nsteps) kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
+  if (nsteps > 0) mfma_group(fa1, fb1);
+
+  float* out = p.slab + (long long)z * p.slab_stride;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int col = n0 + wn * 32 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.Mdim && col < p.Ndim) out[((long long)j * p.Mdim + m) * (long long)p.ldc + col] = acc[j][mi][e];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN, skinny M (<= 32 rows of output): slab[z][m][n] = sum_k A[k][m] * B[k][n].  Used for
 // dh = dgates . W_hh on the few distinct label rows: B (5.4 GB) is streamed exactly once, so the
 // tile is 32 x 512 with a 16-deep K stage (33 KB in flight per workgroup, 2 workgroups per CU) and
@@ -723,6 +936,16 @@ extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
     dim3 grid((unsigned)((p.Ndim + SK_BN - 1) / SK_BN), (unsigned)p.splitk, 1);
     hipLaunchKernelGGL(tn_skinny_kernel, grid, dim3(256), 0, st, p);
     return check_launch("tn_skinny");
+  }
+  if (p.J == 3) {                                                    // all taps per workgroup
+    const long long t3 = (long long)((p.Mdim + 127) / 128) * ((p.Ndim + T3_BN - 1) / T3_BN);
+    TL_REQUIRE(t3 < (1LL << 31), "tn_window: grid too large");
+    dim3 grid((unsigned)t3, (unsigned)p.splitk, 1);
+    if (p.loader == LOAD_DIRECT)
+      hipLaunchKernelGGL((tn3_kernel<LOAD_DIRECT>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((tn3_kernel<LOAD_UNPOOL>), grid, dim3(256), 0, st, p);
+    return check_launch("tn3");
   }
   const long long ntm = (p.Mdim + 127) / 128, ntn = (p.Ndim + 127) / 128;
   const long long nwg = ntm * ntn * p.J;
