@@ -168,6 +168,8 @@ class CnnEngine:
         p.splitk, p.bm, p.J, p.Tp, p.slope = 1, 128, 1, 1, 0.0
         for k, v in kw.items():
             setattr(p, k, v)
+        # bm = 256 (8-wave workgroups) exists but measured slower than two independent 4-wave
+        # workgroups per CU (conv2 fwd 127 vs 129, dgrad 114 vs 124 TFLOP/s): not selected.
         ev = self._tick(tag)
         check(self.lib.tl_gemm_nt_window(C.byref(p), self._stream()), "tl_gemm_nt_window")
         if ev:

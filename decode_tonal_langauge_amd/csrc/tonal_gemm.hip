@@ -19,14 +19,25 @@ enum { EPI_STORE = 0, EPI_LRELU = 1, EPI_POOL = 2, EPI_MASK = 3 };
 // ------------------------------------------------------------------------------------------
 // NT window kernel
 // ------------------------------------------------------------------------------------------
+// BM = 256 runs 8 waves (512 threads, 4 x 2): the per-thread staging work per MFMA halves, which is
+// what limits the 128-row variant (scripts/mfma_ablate.hip); BM = 32 is the skinny-M streaming form.
+template <int BM>
+struct nt_cfg {
+  static constexpr int NTHR = (BM == 256) ? 512 : 256;
+  static constexpr int WM = (BM == 256) ? 4 : ((BM == 128) ? 2 : 1);   // waves along M
+  static constexpr int WN = (NTHR / 64) / WM;                            // waves along N
+};
+
 template <int BM, int LOADER, int EPI>
-__global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p) {
-  constexpr int WM = (BM == 128) ? 2 : 1;          // waves along M
-  constexpr int WN = 4 / WM;                       // waves along N
+__global__ __launch_bounds__(nt_cfg<BM>::NTHR, 2) void nt_window_kernel(const tl_nt_params p) {
+  constexpr int NTHR = nt_cfg<BM>::NTHR;
+  constexpr int WM = nt_cfg<BM>::WM;
+  constexpr int WN = nt_cfg<BM>::WN;
   constexpr int MI = BM / (32 * WM);               // 32x32 tiles per wave along M
   constexpr int NI = BN / (32 * WN);
   constexpr int AROWS = BM + 2;                    // staged rows incl. the tap window (J <= 3)
-  constexpr int A_F4 = (LOADER == LOAD_DIRECT) ? ((AROWS * 8 + 255) / 256) : ((AROWS / 2 * 8 + 255) / 256);
+  constexpr int A_F4 = (LOADER == LOAD_DIRECT) ? ((AROWS * 8 + NTHR - 1) / NTHR) : ((AROWS / 2 * 8 + NTHR - 1) / NTHR);
+  constexpr int B_F4 = BN * 8 / NTHR;
 
   __shared__ __attribute__((aligned(16))) float lds[2 * AROWS * LDS_LD + 2 * BN * LDS_LD];
   float* As = lds;                                 // [2][AROWS][LDS_LD]
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
   f32x4 ra[A_F4];          // staged A (DIRECT) or G (UNPOOL)
   uint32_t rbits[A_F4];    // UNPOOL: raw 32-bit arg word (bit set -> odd row of the pair); the
                            // nibble is extracted at LDS-store time so the load stays in flight
-  f32x4 rbP[4], rbQ[4];    // two B staging sets: B is prefetched TWO K-steps ahead (HBM/L2 latency
+  f32x4 rbP[B_F4], rbQ[B_F4];    // two B staging sets: B is prefetched TWO K-steps ahead (HBM/L2 latency
                            // under full load exceeds one 64-MFMA step; measured in scripts/mfma_ablate.hip)
 
   const long long Abase = R0 + p.row_shift;        // first staged A row (even for UNPOOL)
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
   (void)abptr;
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NTHR;
     const int r = idx >> 3, c4 = idx & 7;
     if constexpr (LOADER == LOAD_DIRECT) {
       const long long row = Abase + r;
@@ -103,11 +114,11 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
       abptr[i] = p.abits + (aok[i] ? prow : 0) * (long long)p.ld_abits;
     }
   }
-  const float* bptr[4];
-  bool bok[4];
+  const float* bptr[B_F4];
+  bool bok[B_F4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + i * 256;
+  for (int i = 0; i < B_F4; ++i) {
+    const int idx = tid + i * NTHR;
     const int r = idx >> 3, c4 = idx & 7;
     bok[i] = (n0 + r) < p.N;
     bptr[i] = p.Bw + (long long)(bok[i] ? n0 + r : 0) * p.ldb + c4 * 4;
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
     float* dst = As + buf * AROWS * LDS_LD;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NTHR;
       const int r = idx >> 3, c4 = idx & 7;
       if constexpr (LOADER == LOAD_DIRECT) {
         if (r < AROWS) *reinterpret_cast<f32x4*>(dst + r * LDS_LD + c4 * 4) = ra[i];
@@ -155,22 +166,22 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
       }
     }
   };
-  auto load_b = [&](f32x4 (&rb)[4], int chunk, int j) {
+  auto load_b = [&](f32x4 (&rb)[B_F4], int chunk, int j) {
     const int kc = (kc_begin + chunk) * BK;
     const bool kok = !ktail || (kc + kq) < p.K;
     const long long off = (long long)j * tap_stride + kc;     // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < B_F4; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (bok[i] && kok) v = *reinterpret_cast<const f32x4*>(bptr[i] + off);
       rb[i] = v;
     }
   };
-  auto store_b = [&](const f32x4 (&rb)[4], int buf) {
+  auto store_b = [&](const f32x4 (&rb)[B_F4], int buf) {
     float* dst = Bs + buf * BN * LDS_LD;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + i * 256;
+    for (int i = 0; i < B_F4; ++i) {
+      const int idx = tid + i * NTHR;
       const int r = idx >> 3, c4 = idx & 7;
       *reinterpret_cast<f32x4*>(dst + r * LDS_LD + c4 * 4) = rb[i];
     }
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void nt_window_kernel(const tl_nt_params p)
       ++c;
     }
   };
-  auto kstep = [&](int s, f32x4 (&rb_ld)[4], const f32x4 (&rb_st)[4]) {
+  auto kstep = [&](int s, f32x4 (&rb_ld)[B_F4], const f32x4 (&rb_st)[B_F4]) {
     const int chunk = c_cur, j = j_cur;
     const int abuf = chunk & 1, bbuf = s & 1;
     const bool more = s + 1 < nsteps;
@@ -311,12 +322,18 @@ static int launch_nt(const tl_nt_params& p, hipStream_t st) {
   if (nwg <= 0) return TL_OK;
   TL_REQUIRE(nwg < (1LL << 31), "nt_window: grid too large");
   dim3 grid((unsigned)nwg, (unsigned)p.splitk, 1);
-  hipLaunchKernelGGL((nt_window_kernel<BM, LOADER, EPI>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((nt_window_kernel<BM, LOADER, EPI>), grid, dim3(nt_cfg<BM>::NTHR), 0, st, p);
   return check_launch("nt_window");
 }
 
 template <int BM>
 static int dispatch_nt(const tl_nt_params& p, hipStream_t st) {
+  if constexpr (BM == 32) {
+    if (p.loader != LOAD_DIRECT) {
+      set_error("nt_window: bm = 32 supports the DIRECT loader only");
+      return TL_EINVAL;
+    }
+  }
   if (p.loader == LOAD_DIRECT) {
     switch (p.epilogue) {
       case EPI_STORE: return launch_nt<BM, LOAD_DIRECT, EPI_STORE>(p, st);
@@ -324,7 +341,7 @@ static int dispatch_nt(const tl_nt_params& p, hipStream_t st) {
       case EPI_POOL: return launch_nt<BM, LOAD_DIRECT, EPI_POOL>(p, st);
       case EPI_MASK: return launch_nt<BM, LOAD_DIRECT, EPI_MASK>(p, st);
     }
-  } else {
+  } else if constexpr (BM != 32) {
     switch (p.epilogue) {
       case EPI_STORE: return launch_nt<BM, LOAD_UNPOOL, EPI_STORE>(p, st);
       case EPI_MASK: return launch_nt<BM, LOAD_UNPOOL, EPI_MASK>(p, st);
@@ -894,7 +911,7 @@ extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
   TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K, "nt_window: lda/ldb smaller than K");
   TL_REQUIRE(p.J >= 1 && p.J <= 3, "nt_window: J must be 1..3");
   TL_REQUIRE(p.row_shift == 0 || p.row_shift == -(p.J - 1), "nt_window: row_shift must be 0 or -(J-1)");
-  TL_REQUIRE(p.bm == 128 || p.bm == 32, "nt_window: bm must be 128 or 32");
+  TL_REQUIRE(p.bm == 256 || p.bm == 128 || p.bm == 32, "nt_window: bm must be 256, 128 or 32");
   TL_REQUIRE(p.Tp > 0, "nt_window: Tp must be positive");
   TL_REQUIRE(p.splitk == 1 || p.epilogue == EPI_STORE, "nt_window: split-K needs the STORE epilogue");
   TL_REQUIRE(p.splitk <= 65535, "nt_window: splitk too large");
@@ -902,7 +919,7 @@ extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
     TL_REQUIRE(p.abits != nullptr, "nt_window: UNPOOL loader needs abits");
     TL_REQUIRE((p.row_shift % 2) == 0 && p.Tp % 2 == 0 && p.Tvalid_in % 2 == 0, "nt_window: UNPOOL needs even shift/Tp/Tvalid_in");
     TL_REQUIRE(p.K % 32 == 0 || p.ld_abits * 32 >= p.K, "nt_window: abits row too short");
-    TL_REQUIRE(p.bm == 128, "nt_window: UNPOOL loader needs bm = 128");
+    TL_REQUIRE(p.bm != 32, "nt_window: UNPOOL loader needs bm = 128 or 256");
   }
   if (p.epilogue == EPI_POOL) {
     TL_REQUIRE(p.obits != nullptr, "nt_window: POOL epilogue needs obits");
@@ -911,6 +928,7 @@ extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
   }
   if (p.epilogue == EPI_MASK) TL_REQUIRE(p.aux != nullptr, "nt_window: MASK epilogue needs aux");
   hipStream_t st = (hipStream_t)stream;
+  if (p.bm == 256) return dispatch_nt<256>(p, st);
   return p.bm == 128 ? dispatch_nt<128>(p, st) : dispatch_nt<32>(p, st);
 }
 

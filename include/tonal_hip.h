@@ -66,7 +66,7 @@ typedef struct {
   float slope;
   int loader, epilogue;
   int splitk; int64_t slab_stride;
-  int bm;             /* row-tile height: 128 (default) or 32 (skinny M)          */
+  int bm;             /* row-tile height: 256 (8 waves, large M), 128 (default) or 32 (skinny M) */
 } tl_nt_params;
 int tl_gemm_nt_window(const tl_nt_params* p, void* stream);
 
