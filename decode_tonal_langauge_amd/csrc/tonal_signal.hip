@@ -117,63 +117,93 @@ constexpr int MAX_TAPS = 17;
 
 template <typename TIN>
 __device__ __forceinline__ double ext_sample(const void* x, long long cbase, long long T, int edge, long long i) {
-#pragma clang fp contract(off)
-  // odd extension of scipy.signal.filtfilt (padtype='odd')
-  if (i < edge) return __dsub_rn(__dmul_rn(2.0, ld_as_f64<TIN>(x, cbase)), ld_as_f64<TIN>(x, cbase + (edge - i)));
-  if (i >= edge + T)
-    return __dsub_rn(__dmul_rn(2.0, ld_as_f64<TIN>(x, cbase + T - 1)), ld_as_f64<TIN>(x, cbase + T - 2 - (i - edge - T)));
+  // odd extension of scipy.signal.filtfilt (padtype='odd'); same roundings (2*x0 - x[k])
+  if (i < edge) return 2.0 * ld_as_f64<TIN>(x, cbase) - ld_as_f64<TIN>(x, cbase + (edge - i));
+  if (i >= edge + T) return 2.0 * ld_as_f64<TIN>(x, cbase + T - 1) - ld_as_f64<TIN>(x, cbase + T - 2 - (i - edge - T));
   return ld_as_f64<TIN>(x, cbase + (i - edge));
 }
 
+// filtfilt in three launches: (1) build the odd-extended signal TIME-MAJOR in `work` ([next][C]) so
+// that in the sequential pass the 64 lanes of a wave (= 64 channels) read one 512-B line per time
+// step; (2) forward and backward recurrences in place, one lane per channel, 8 samples of loads in
+// flight; (3) write the centre part back channel-major.
 template <typename TIN>
-__global__ __launch_bounds__(64) void filtfilt_kernel(const void* __restrict__ x, const double* __restrict__ b,
-                                                      const double* __restrict__ a, const double* __restrict__ zi,
-                                                      double* __restrict__ y, double* __restrict__ work, int C,
-                                                      long long T, int ntaps) {
-#pragma clang fp contract(off)   // HIP's __dadd_rn/__dmul_rn are plain + and *: keep them un-fused
+__global__ __launch_bounds__(256) void filtfilt_build_kernel(const void* __restrict__ x, double* __restrict__ work, int C,
+                                                             long long T, int edge) {
+  const long long next = T + 2LL * edge;
+  const long long total = next * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long ti = i / C;
+    work[i] = ext_sample<TIN>(x, (long long)c * T, T, edge, ti);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void filtfilt_iir_kernel(const double* __restrict__ b, const double* __restrict__ a,
+                                                          const double* __restrict__ zi, double* __restrict__ work, int C,
+                                                          long long next, int ntaps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const int edge = 3 * ntaps;
-  const long long next = T + 2LL * edge;
-  double bb[MAX_TAPS], aa[MAX_TAPS], z[MAX_TAPS];
+  double bb[NT], aa[NT], z[NT];
 #pragma unroll
-  for (int k = 0; k < MAX_TAPS; ++k) {
+  for (int k = 0; k < NT; ++k) {
     bb[k] = k < ntaps ? b[k] : 0.0;
     aa[k] = k < ntaps ? a[k] : 0.0;
   }
-  const long long cb = (long long)c * T;
-  double* w = work + (long long)c * next;
-  // forward pass over the odd-extended signal
-  {
-    const double x0 = ext_sample<TIN>(x, cb, T, edge, 0);
+  constexpr int U = 8;
+  // pass 0: work[0] (extended input) -> work[1]; pass 1: work[1] reversed -> work[0].
+  // Separate in/out buffers let the next chunk's loads fly while this chunk's recurrence runs.
+  for (int pass = 0; pass < 2; ++pass) {
+    const double* __restrict__ in = work + (long long)pass * next * C + c;
+    double* __restrict__ out = work + (long long)(1 - pass) * next * C + c;
+    const long long first = pass == 0 ? 0 : next - 1;
+    const long long dir = pass == 0 ? 1 : -1;
+    const double x0 = in[first * C];
 #pragma unroll
-    for (int k = 0; k < MAX_TAPS; ++k) z[k] = (k < ntaps - 1) ? __dmul_rn(zi[k], x0) : 0.0;
-    for (long long i = 0; i < next; ++i) {
-      const double xv = ext_sample<TIN>(x, cb, T, edge, i);
-      // same operation order and roundings as scipy's lfilter C loop (no FMA contraction):
-      // y = z0 + b0*x;  z_k = (z_{k+1} + x*b_{k+1}) - y*a_{k+1}
-      const double yv = __dadd_rn(z[0], __dmul_rn(bb[0], xv));
+    for (int k = 0; k < NT; ++k) z[k] = (k < ntaps - 1) ? zi[k] * x0 : 0.0;
+    double cur[U], nxt[U];
+    long long n = 0;
+    if (next >= U) {
 #pragma unroll
-      for (int k = 0; k < MAX_TAPS - 1; ++k)
-        z[k] = __dsub_rn(__dadd_rn(z[k + 1], __dmul_rn(xv, bb[k + 1])), __dmul_rn(yv, aa[k + 1]));
-      w[i] = yv;
+      for (int u = 0; u < U; ++u) cur[u] = in[(first + dir * u) * C];
+    }
+    for (; n + U <= next; n += U) {
+      const bool more = n + 2 * U <= next;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = in[(first + dir * (n + U + u)) * C];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // scipy lfilter order: y = z0 + b0*x;  z_k = (z_{k+1} + x*b_{k+1}) - y*a_{k+1}
+        const double yv = z[0] + bb[0] * cur[u];
+#pragma unroll
+        for (int k = 0; k < NT - 1; ++k) z[k] = (z[k + 1] + cur[u] * bb[k + 1]) - yv * aa[k + 1];
+        out[(first + dir * (n + u)) * C] = yv;
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+      }
+    }
+    for (; n < next; ++n) {
+      const double xs = in[(first + dir * n) * C];
+      const double yv = z[0] + bb[0] * xs;
+#pragma unroll
+      for (int k = 0; k < NT - 1; ++k) z[k] = (z[k + 1] + xs * bb[k + 1]) - yv * aa[k + 1];
+      out[(first + dir * n) * C] = yv;
     }
   }
-  // backward pass
-  {
-    const double x0 = w[next - 1];
-#pragma unroll
-    for (int k = 0; k < MAX_TAPS; ++k) z[k] = (k < ntaps - 1) ? __dmul_rn(zi[k], x0) : 0.0;
-    for (long long i = next - 1; i >= 0; --i) {
-      const double xv = w[i];
-      // same operation order and roundings as scipy's lfilter C loop (no FMA contraction):
-      // y = z0 + b0*x;  z_k = (z_{k+1} + x*b_{k+1}) - y*a_{k+1}
-      const double yv = __dadd_rn(z[0], __dmul_rn(bb[0], xv));
-#pragma unroll
-      for (int k = 0; k < MAX_TAPS - 1; ++k)
-        z[k] = __dsub_rn(__dadd_rn(z[k + 1], __dmul_rn(xv, bb[k + 1])), __dmul_rn(yv, aa[k + 1]));
-      if (i >= edge && i < edge + T) y[cb + (i - edge)] = yv;
-    }
+}
+
+__global__ __launch_bounds__(256) void filtfilt_out_kernel(const double* __restrict__ work, double* __restrict__ y, int C,
+                                                           long long T, int edge) {
+  const long long total = T * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long t = i % T;
+    const int c = (int)(i / T);
+    y[i] = work[(t + edge) * C + c];
   }
 }
 
@@ -275,12 +305,25 @@ extern "C" int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, con
   TL_REQUIRE(x && b && a && zi && y && work, "filtfilt: null pointer");
   TL_REQUIRE(ntaps >= 2 && ntaps <= MAX_TAPS, "filtfilt: ntaps must be 2..%d", MAX_TAPS);
   TL_REQUIRE(C > 0 && T > 3LL * ntaps, "filtfilt: the input must be longer than padlen = %d", 3 * ntaps);
-  dim3 grid((unsigned)((C + 63) / 64));
   hipStream_t st = (hipStream_t)stream;
+  const int edge = 3 * ntaps;
+  const long long next = T + 2LL * edge;
+  long long g = (next * C + 255) / 256;
+  if (g > 8192) g = 8192;
   if (x_is_f64)
-    hipLaunchKernelGGL((filtfilt_kernel<double>), grid, dim3(64), 0, st, x, b, a, zi, y, work, C, (long long)T, ntaps);
+    hipLaunchKernelGGL((filtfilt_build_kernel<double>), dim3((unsigned)g), dim3(256), 0, st, x, work, C, (long long)T, edge);
   else
-    hipLaunchKernelGGL((filtfilt_kernel<float>), grid, dim3(64), 0, st, x, b, a, zi, y, work, C, (long long)T, ntaps);
+    hipLaunchKernelGGL((filtfilt_build_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, x, work, C, (long long)T, edge);
+  dim3 grid((unsigned)((C + 63) / 64));
+  if (ntaps <= 5)
+    hipLaunchKernelGGL((filtfilt_iir_kernel<5>), grid, dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
+  else if (ntaps <= 9)
+    hipLaunchKernelGGL((filtfilt_iir_kernel<9>), grid, dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
+  else
+    hipLaunchKernelGGL((filtfilt_iir_kernel<MAX_TAPS>), grid, dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
+  long long g2 = ((long long)T * C + 255) / 256;
+  if (g2 > 8192) g2 = 8192;
+  hipLaunchKernelGGL(filtfilt_out_kernel, dim3((unsigned)g2), dim3(256), 0, st, work, y, C, (long long)T, edge);
   return check_launch("filtfilt");
 }
 

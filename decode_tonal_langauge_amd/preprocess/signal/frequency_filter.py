@@ -121,6 +121,23 @@ def analytic_taps(T: int, sampling_rate: float, cfs: np.ndarray, sds: np.ndarray
     return np.ascontiguousarray(ker[:, idx]), half
 
 
+_TAPS_CACHE = {}
+
+
+def _device_taps(T, sampling_rate, cfs, sds, dev):
+    """Device copy of the band kernels, cached per (length, rate, bank): the host-side inverse DFT
+    is coefficient generation and must not sit in front of every call."""
+    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev))
+    hit = _TAPS_CACHE.get(key)
+    if hit is None:
+        taps, half = analytic_taps(T, sampling_rate, cfs, sds)
+        tp = torch.from_numpy(np.ascontiguousarray(np.stack([taps.real, taps.imag], axis=-1))).to(dev)
+        if len(_TAPS_CACHE) > 32:
+            _TAPS_CACHE.clear()
+        hit = _TAPS_CACHE[key] = (tp, taps.shape[1], half)
+    return hit
+
+
 def hilbert_filter(data, sampling_rate: int, freq_ranges: Union[List[Tuple[float, float]], Tuple[float, float]],
                    f0: float = 0.018, octspace: float = 1 / 7, filterbank_bias: float = math.log10(0.39),
                    filterbank_slope: float = 0.5, envelope: bool = True):
@@ -131,12 +148,10 @@ def hilbert_filter(data, sampling_rate: int, freq_ranges: Union[List[Tuple[float
     if len(cfs) == 0:
         # the reference's mean over an empty band axis yields NaN
         return _ret(torch.full((C, T), float("nan"), dtype=torch.float64, device=x.device), was_np)
-    taps, half = analytic_taps(T, sampling_rate, cfs, sds)
-    ntap = taps.shape[1]
+    tp, ntap, half = _device_taps(T, sampling_rate, cfs, sds, x.device)
     if ntap > _MAX_TAPS_LDS:
         raise ValueError(f"hilbert_filter: the band kernels need {ntap} taps at this sampling rate; "
                          f"the MI355X kernel supports up to {_MAX_TAPS_LDS}")
-    tp = torch.from_numpy(np.ascontiguousarray(np.stack([taps.real, taps.imag], axis=-1))).to(x.device)
     y = torch.empty(C, T, dtype=torch.float64, device=x.device)
     check(_lib.load().tl_gauss_envelope(ptr(x), int(x.dtype == torch.float64), ptr(tp), ptr(y), C, T, len(cfs), ntap,
                                         half, int(bool(envelope)), _stream()), "tl_gauss_envelope")
@@ -174,7 +189,7 @@ def butter_filter(data, freqs: Union[Tuple[float, float], float], fs: float, ord
         zi = lfilter_zi(bb, aa)
         dev = x.device
         bd, ad, zd = (torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev) for v in (bb, aa, zi))
-        work = torch.empty(C, T + 2 * edge, dtype=torch.float64, device=dev)
+        work = torch.empty(2, T + 2 * edge, C, dtype=torch.float64, device=dev)
         check(lib.tl_filtfilt_f64(ptr(x), int(x.dtype == torch.float64), ptr(bd), ptr(ad), ptr(zd), ptr(y), ptr(work),
                                   C, T, ntaps, _stream()), "tl_filtfilt_f64")
     out = _ret(y, was_np)

@@ -192,7 +192,8 @@ int tl_lite_uncat(const float* dfeat, float* dy2, float* dh, int B, int F, int H
  * mean_b |sum_n h_b[n] x[(t-n) mod T]| (envelope != 0) or the mean of the real parts.        */
 int tl_gauss_envelope(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T,
                       int nb, int ntap, int half, int envelope, void* stream);
-/* zero-phase IIR (scipy filtfilt, odd padding, lfilter_zi), fp64 (frequency_filter.py:226-227) */
+/* zero-phase IIR (scipy filtfilt, odd padding, lfilter_zi), fp64 (frequency_filter.py:226-227);
+ * work holds 2*C*(T + 6*ntaps) doubles                                                        */
 int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, const double* a, const double* zi,
                     double* y, double* work, int C, int64_t T, int ntaps, void* stream);
 /* causal cascade of biquads (sosfilt), fp64 (frequency_filter.py:223-224)                     */

@@ -254,3 +254,50 @@ def test_trainer_history_matches_reference_golden(dev):
     assert abs(mcd - float(g9["eval_mcd"])) < 1e-3 * float(g9["eval_mcd"])
     assert recon.shape == g9["recon"].shape and rel(origin, g9["origin"]) < 1e-6
     assert rel(recon, g9["recon"]) < 2e-2
+
+
+def test_signal_full_size_properties(dev):
+    """BASELINE C5 shape (256 ch x 24 000 samples): size-independent properties of the filters."""
+    from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(256, 24000, device=dev, generator=g, dtype=torch.float32)
+    y = torch.randn(256, 24000, device=dev, generator=g, dtype=torch.float32)
+    lin = lambda f: float(((f(2.0 * x - 3.0 * y) - (2.0 * f(x) - 3.0 * f(y))).abs().max() / f(x).abs().max()))
+    # analytic band signal (real part), zero-phase IIR and FIR are linear maps
+    assert lin(lambda v: ff.hilbert_filter(v, 400, [70., 150.], envelope=False)) < 1e-6
+    assert lin(lambda v: ff.butter_filter(v, [0.3, 100], 400)) < 1e-5
+    assert lin(lambda v: ff.fir_bandpass_filter(v, 400, 390, [100.]).double()) < 1e-5
+    # envelope is positively homogeneous and non-negative; per-channel independence
+    env = ff.hilbert_filter(x, 400, [70., 150.])
+    assert env.dtype == torch.float64 and float(env.min()) >= 0.0
+    assert float((ff.hilbert_filter(-2.5 * x, 400, [70., 150.]) - 2.5 * env).abs().max() / env.max()) < 1e-6
+    sub = ff.hilbert_filter(x[100:104].contiguous(), 400, [70., 150.])
+    assert torch.equal(sub, env[100:104])
+    # FIR impulse response = taps (causal, zero initial state)
+    imp = torch.zeros(1, 1000, device=dev, dtype=torch.float64)
+    imp[0, 0] = 1.0
+    from scipy.signal import firwin
+    taps = firwin(65, [60 * 0.9 / 200, 60 * 1.1 / 200], pass_zero=False, fs=400)
+    h = ff.fir_bandpass_filter(imp, 400, 64, [60.])[0, :65].cpu().numpy()
+    assert np.max(np.abs(h - taps)) < 1e-15
+
+
+def test_cnn_full_size_batch_properties(dev):
+    """North-star shape (128 ch x 400, batch 256), small LSTM width to keep the test light:
+    eval-mode outputs are per-sample (permutation equivariance, sub-batch equality)."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    torch.manual_seed(0)
+    model = SynthesisModelCNN(80, 128, 400, lstm_channels=1, dropout=0.5).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(256, 128, 400, device=dev, generator=g)
+    tones = torch.randint(0, 4, (256,), generator=torch.Generator().manual_seed(1))
+    syls = torch.randint(0, 2, (256,), generator=torch.Generator().manual_seed(2))
+    lab = gi.tone_dynamics(tones, syls).to(dev)
+    with torch.no_grad():
+        out = model(x, lab)
+        perm = torch.randperm(256, generator=torch.Generator().manual_seed(3)).to(dev)
+        out_p = model(x[perm].contiguous(), lab[perm].contiguous())
+        out_s = model(x[:8].contiguous(), lab[:8].contiguous())
+    assert out.shape == (256, 80) and torch.isfinite(out).all()
+    assert float((out[perm] - out_p).abs().max() / out.abs().max()) < 1e-5
+    assert float((out[:8] - out_s).abs().max() / out.abs().max()) < 1e-5
