@@ -14,9 +14,11 @@ L1 on truncated targets, backward, (DP: gradient reduction), NAdam, loss + MCD a
 Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns 256 windows.
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel family of the step (conv2 = 53 % of the forward MACs):
-               algorithmic FLOPs per launch / mean launch time measured with HIP events on the
-               launch stream, against the dense fp32 MFMA peak (157.3 TFLOP/s).
+  roofline     the dominant kernel of the step (the rocprofv3 kernel name with the largest total
+               time; one name covers its conv2/conv3/conv4 launches): mean algorithmic FLOPs per
+               launch / mean launch time, measured with HIP events on the launch stream, against
+               the dense fp32 MFMA peak (157.3 TFLOP/s); `traffic` = HBM bytes per launch from the
+               committed rocprofv3 PMC passes (profiles/pmc_traffic.json).
   cpu_baseline the CPU oracle (oracle/synthesis_oracle.py, PyTorch-CPU fp32 restatement of the
                reference) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -157,22 +159,36 @@ def main():
     if rank == 0:
         roof = None
         if tsum:
-            fam = {}
-            for name, (n, ms) in tsum.items():
-                stage = int(name[4])
-                fam.setdefault(stage, []).append((name, n, ms))
-            # dominant family = the conv stage with the largest total time
-            stage = max(fam, key=lambda s: sum(n * ms for _, n, ms in fam[s]))
-            fl = conv_flops(eng, stage, B)
-            per = {name: {"launches": n, "ms": round(ms, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
-                   for name, n, ms in fam[stage]}
-            tot_ms = sum(ms for _, _, ms in fam[stage])
-            ach = len(fam[stage]) * fl / (tot_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": f"conv{stage} fwd+dgrad+wgrad (nt_window/tn_window, fp32 MFMA 32x32x2)",
-                    "flops_per_launch": fl, "per_kernel": per,
-                    "all_kernels_ms": {k: round(v[1], 3) for k, v in sorted(tsum.items())}}
+            # kernel families as rocprofv3 names them: one name covers the conv2/conv3/conv4 launches
+            fams = {"nt_window_kernel<128,UNPOOL,MASK> (conv input-gradient)": ["conv2_dgrad", "conv3_dgrad", "conv4_dgrad"],
+                    "nt_window_kernel<128,DIRECT,POOL> (conv forward)": ["conv2_fwd", "conv3_fwd", "conv4_fwd"],
+                    "tn3_kernel<UNPOOL> (conv weight-gradient)": ["conv2_wgrad", "conv3_wgrad"]}
+            stats = {}
+            for fam, tags in fams.items():
+                tags = [t for t in tags if t in tsum]
+                if not tags:
+                    continue
+                fl = [conv_flops(eng, int(t[4]), B) for t in tags]
+                ms = [tsum[t][1] for t in tags]
+                stats[fam] = {"ms_per_step": sum(ms), "launches_per_step": len(tags),
+                              "flops_per_launch": sum(fl) / len(tags), "avg_launch_ms": sum(ms) / len(tags),
+                              "tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12}
+            dom = max(stats, key=lambda k: stats[k]["ms_per_step"])
+            d = stats[dom]
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(dom)
+            roof = {"bound": "mfma", "achieved": round(d["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(d["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
+                    "flops_per_launch": d["flops_per_launch"], "avg_launch_ms": round(d["avg_launch_ms"], 3),
+                    "launches_per_step": d["launches_per_step"],
+                    "families": {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms_per_step"], 2)}
+                                 for k, v in stats.items()},
+                    "per_launch": {t: {"ms": round(tsum[t][1], 3),
+                                       "tflops": round(conv_flops(eng, int(t[4]), B) / (tsum[t][1] * 1e-3) / 1e12, 2)}
+                                   for t in sorted(tsum)}}
         cpu = None
         if not args.no_cpu_baseline:
             try:

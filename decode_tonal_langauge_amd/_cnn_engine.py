@@ -243,7 +243,7 @@ class CnnEngine:
             tiles = ((st.cin + 127) // 128) * ((nd + 63) // 64)
         else:
             tiles = st.k * ((st.cin + 127) // 128) * ((nd + 127) // 128)
-        sk = self._splitk(tiles, (rows_in + 31) // 32)
+        sk = self._splitk(tiles, (rows_in + 31) // 32, 1024)     # two rounds of 512 resident workgroups
         slab = torch.empty(sk, st.k * st.cin, ldg, **f32)
         kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0],
                   Mdim=st.cin, Ndim=nd, lda=st.cin, ldb=ldg, ldc=ldg, J=st.k, Tp=st.tp_in, splitk=sk,
@@ -253,9 +253,15 @@ class CnnEngine:
         else:
             kw.update(loader=LOAD_DIRECT, Tvalid=st.tout)
         self._tn(tag=f"conv{st.idx}_wgrad", **kw)
-        # slab[z][j][i][o] -> torch (O, I, J, 1)
-        self._permute(slab, gw, (1, st.cout, st.cin, st.k), (0, 1, ldg, st.cin * ldg), nz=sk,
-                      zs=st.k * st.cin * ldg)
+        # sum the split-K slabs with coalesced reads first ([j][i][o], o contiguous), then permute the
+        # small result to torch's (O, I, J, 1)
+        if sk > 1:
+            red = torch.empty(st.k * st.cin, ldg, **f32)
+            n = st.k * st.cin * ldg
+            self._permute(slab, red, (1, 1, 1, n), (0, 0, 0, 1), nz=sk, zs=n)
+        else:
+            red = slab
+        self._permute(red, gw, (1, st.cout, st.cin, st.k), (0, 1, ldg, st.cin * ldg))
         self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
 
     def stage_dgrad(self, st: _Stage, w: torch.Tensor) -> None:
