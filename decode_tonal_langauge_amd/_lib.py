@@ -82,6 +82,9 @@ SIGNATURES = {
     "tl_lite_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_lite_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, C.c_uint64, _P]),
     "tl_lite_uncat": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, C.c_uint64, _P]),
+    "tl_row_zscore": (_I, [_P, _I, _P, _P, _I, _L, _L, _L, _I, _P]),
+    "tl_car": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),
+    "tl_rolling_zscore": (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
     "tl_gauss_envelope": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_filtfilt_f64": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
     "tl_sosfilt_f64": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),

@@ -1,4 +1,5 @@
 from .classifier import ClassifierModel
+from .deep_classifiers import CNNClassifier, CNNRNNClassifier
 from .simple_classifiers import LogisticRegressionClassifier, ShallowNNClassifier
 from .synthesis_models import SynthesisModel, SynthesisModelCNN, SynthesisLite
 from .synthesis_trainer import SynthesisTrainer, compute_mcd

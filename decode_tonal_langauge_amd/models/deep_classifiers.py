@@ -1,0 +1,102 @@
+"""Deep tone / syllable classifiers (API mirror of reference models/deep_classifiers.py:17-343).
+
+They run forward-only inside every synthesis train step (reference models/synthesis_trainer.py:207-210).
+Their kernels are a "next" row of the hot-path scope: this module keeps the
+reference's constructor arguments, sub-module names (hence ``state_dict`` keys, so pre-trained
+``.pt`` files load) and forward semantics - including the raw ``view`` that re-interprets the
+(B, 256, t', w) feature map as (B, t', 256*w) in ``CNNRNNClassifier`` (:315) - and executes on stock
+PyTorch-ROCm until HIP versions exist.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .classifier import ClassifierModel
+
+
+def _temporal_length(layers, n: int) -> int:
+    for layer in layers:
+        if isinstance(layer, nn.Conv2d):
+            k, s, p = layer.kernel_size[0], layer.stride[0], layer.padding[0]
+        elif isinstance(layer, nn.MaxPool2d):
+            k = layer.kernel_size[0] if isinstance(layer.kernel_size, tuple) else layer.kernel_size
+            s = layer.stride[0] if isinstance(layer.stride, tuple) else (layer.stride or k)
+            p = layer.padding[0] if isinstance(layer.padding, tuple) else layer.padding
+        else:
+            continue
+        n = (n + 2 * p - k) // s + 1
+    return n
+
+
+class CNNClassifier(ClassifierModel):
+    """Six (3,1) convolutions over time shared across electrodes, five (2,1) max-pools, two Linear
+    layers and a sigmoid (reference :17-155)."""
+
+    def __init__(self, input_channels: int, input_length: int, n_classes: int, dropout_rate: float = 0.5,
+                 negative_slope: float = 0.01) -> None:
+        super().__init__(n_classes)
+        if input_channels <= 0:
+            raise ValueError("Input channels must be a positive integer.")
+        widths = [(1, 512, True), (512, 512, True), (512, 512, True), (512, 512, True), (512, 512, False),
+                  (512, 256, True)]
+        layers = []
+        for cin, cout, pool in widths:
+            layers += [nn.Conv2d(cin, cout, kernel_size=(3, 1)), nn.LeakyReLU(negative_slope=negative_slope)]
+            if pool:
+                layers.append(nn.MaxPool2d(kernel_size=(2, 1)))
+        layers.append(nn.Dropout(dropout_rate))
+        self.feature_extractor = nn.Sequential(*layers)
+        self.latent_length = _temporal_length(self.feature_extractor, input_length)
+        if self.latent_length <= 0:
+            raise ValueError("Input length is too small for the convolutional layers. "
+                             "Please increase the input length or adjust the model architecture.")
+        self.classifier = nn.Sequential(
+            nn.Flatten(), nn.Linear(256 * input_channels * self.latent_length, 1024),
+            nn.LeakyReLU(negative_slope=negative_slope), nn.Linear(1024, n_classes), nn.Sigmoid())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.unsqueeze(1).permute(0, 1, 3, 2)            # (B, 1, T, C)
+        return self.classifier(self.feature_extractor(x))
+
+
+class CNNRNNClassifier(ClassifierModel):
+    """LSTM over electrodes in parallel with a (7,1) conv, concatenation, two more convs and a
+    second LSTM (reference :158-343)."""
+
+    def __init__(self, input_channels: int, input_length: int, n_classes: int, lstm_dim: int = 800,
+                 dropout: float = 0.5, negative_slope: float = 0.01) -> None:
+        super().__init__(n_classes)
+        if lstm_dim % input_length != 0:
+            raise ValueError(f"lstm_dim ({lstm_dim}) must be divisible by input_length ({input_length}).")
+        self.input_channels = input_channels
+        self.input_length = input_length
+        self.lstm1 = nn.LSTM(input_size=input_channels, hidden_size=lstm_dim, batch_first=True)
+
+        def head():
+            return nn.Sequential(nn.Conv2d(1, 1024, kernel_size=(7, 1)), nn.LeakyReLU(negative_slope=negative_slope),
+                                 nn.MaxPool2d(kernel_size=(2, 1), stride=(2, 1)))
+        self.conv_pool_block1 = head()
+        self.conv_pool_block2 = head()
+        self.conv_block3 = nn.Sequential(
+            nn.Conv2d(1024, 512, kernel_size=(7, 1)), nn.LeakyReLU(negative_slope=negative_slope),
+            nn.Conv2d(512, 256, kernel_size=(7, 1)), nn.LeakyReLU(negative_slope=negative_slope),
+            nn.MaxPool2d(kernel_size=(3, 1), stride=(3, 1)), nn.Dropout(dropout))
+        w = (lstm_dim // input_length) + input_channels
+        self.lstm2 = nn.LSTM(input_size=256 * w, hidden_size=512, batch_first=True)
+        self.output = nn.Linear(512, n_classes)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, C, T = x.shape
+        if C != self.input_channels:
+            raise ValueError(f"Expected {self.input_channels} channels, got {C}.")
+        if T != self.input_length:
+            raise ValueError(f"Expected input length {self.input_length}, got {T}.")
+        xt = x.permute(0, 2, 1)                            # (B, T, C)
+        h1 = self.lstm1(xt)[0][:, -1, :]                   # (B, lstm_dim)
+        a = self.conv_pool_block1(xt.unsqueeze(1))         # (B, 1024, t, C)
+        b = self.conv_pool_block2(h1.reshape(B, 1, T, -1))  # (B, 1024, t, lstm_dim // T)
+        f = self.conv_block3(torch.cat((b, a), dim=3))     # (B, 256, t', w)
+        f = f.contiguous().view(B, f.shape[2], -1)         # raw re-interpretation, as the reference (:315)
+        h2 = self.lstm2(f)[0][:, -1, :]
+        return torch.sigmoid(self.output(h2))

@@ -29,6 +29,7 @@ from torch.utils.data import TensorDataset
 
 from .data_loading.dataloaders import split_dataset
 from .data_loading.utils import select_non_discriminative_channels
+from .models.deep_classifiers import CNNClassifier, CNNRNNClassifier
 from .models.simple_classifiers import LogisticRegressionClassifier, ShallowNNClassifier
 from .models.synthesis_models import SynthesisLite, SynthesisModelCNN
 from .models.synthesis_trainer import SynthesisTrainer
@@ -70,9 +71,10 @@ def _build_classifier(name: str, n_channels: int, seq_length: int, n_classes: in
         return ShallowNNClassifier(input_dim=n_channels * seq_length, n_classes=n_classes, **kwargs)
     if name == 'logistic':
         return LogisticRegressionClassifier(input_dim=n_channels * seq_length, n_classes=n_classes, **kwargs)
-    if name in ('CNN', 'CNNRNN'):
-        raise NotImplementedError(f"{role} model '{name}': the deep classifiers are a 'next' row of the hot-path "
-                                  "scope (SURVEY.md section 8f-2) and are not part of this build yet")
+    if name == 'CNN':
+        return CNNClassifier(input_channels=n_channels, input_length=seq_length, n_classes=n_classes, **kwargs)
+    if name == 'CNNRNN':
+        return CNNRNNClassifier(input_channels=n_channels, input_length=seq_length, n_classes=n_classes, **kwargs)
     raise ValueError(f"Unknown {role} model name: {name}. Supported models: CNN, ShallowNN, logistic, CNNRNN.")
 
 

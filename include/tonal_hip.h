@@ -203,6 +203,16 @@ int tl_sosfilt_f64(const void* x, int x_is_f64, const double* sos, double* y, in
 int tl_fir_bank(const void* x, int x_is_f64, const double* taps, void* y, int y_is_f64, int C, int64_t T,
                 int nb, int ntap, void* stream);
 
+/* ---- other preprocess/signal steps (same run(data, params) plugin ABI) --------------------------
+ * per-channel z-score with statistics over [t0, t1): channel_zscore.py:22-27 (t0=0, t1=T) and
+ * zscore_rereference.py:66-68 (baseline interval); y has the input dtype; stats (C,2) f64 workspace */
+int tl_row_zscore(const void* x, int is_f64, void* y, double* stats, int C, int64_t T, int64_t t0, int64_t t1,
+                  int zero_nans, void* stream);
+/* common-average re-reference over the channels with include[c] != 0 (car_rereference.py:34-39)   */
+int tl_car(const void* x, int is_f64, const int32_t* include, void* y, int C, int64_t T, int n_inc, void* stream);
+/* pandas rolling(window, min_periods=1) z-score, sample std (rolling_zscore.py:36-49); y float64   */
+int tl_rolling_zscore(const void* x, int is_f64, double* y, int C, int64_t T, int window, int zero_nans, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

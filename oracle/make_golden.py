@@ -238,6 +238,30 @@ def main():
     np.savez_compressed(os.path.join(args.out, "g6_signal.npz"), in_checksum=gi.checksum(x, x2), hilbert=hil, hilbert_real=hil_re,
                         butter=but, butter_causal=but_c, fir=fir, fir2=fir2, hilbert2=hil2, run=runout)
 
+    # ---- G7: the other preprocess/signal steps ----------------------------------------------
+    import preprocess.signal.channel_zscore as r_cz
+    import preprocess.signal.zscore_rereference as r_zr
+    import preprocess.signal.car_rereference as r_car
+    import preprocess.signal.rolling_zscore as r_rz
+    xs_ = np.random.default_rng(7).standard_normal((5, 900)) * 3.0 + 1.5
+    xs32 = xs_.astype(np.float32)
+    cz = r_cz.run(xs_, Namespace())
+    cz32 = r_cz.run(xs32, Namespace())
+    zr = r_zr.run(xs_, Namespace(rereference_interval=[0.25, 1.5], signal_freq=200))
+    car = r_car.run(xs_, Namespace(exclude_channels=[1, 3]))
+    rz = r_rz.run(xs_, Namespace(window_length=0.25, signal_freq=200))
+    xn = xs_.copy()
+    xn[2, 100:130] = np.nan
+    rzn = r_rz.run(xn, Namespace(window_length=0.25, signal_freq=200, preserve_nans=False))
+    report["g7_channel_zscore"] = maxrel(sg.channel_zscore(xs_), cz)
+    report["g7_zscore_rereference"] = maxrel(sg.zscore_rereference(xs_, 50, 300), zr)
+    report["g7_car"] = maxrel(sg.car_rereference(xs_, [1, 3]), car)
+    report["g7_rolling"] = maxrel(np.nan_to_num(sg.rolling_zscore(xs_, 50)), np.nan_to_num(rz))
+    report["g7_rolling_nan"] = maxrel(sg.rolling_zscore(xn, 50, preserve_nans=False), rzn)
+    assert np.array_equal(np.isnan(sg.rolling_zscore(xs_, 50)), np.isnan(rz))
+    np.savez_compressed(os.path.join(args.out, "g7_steps.npz"), in_checksum=gi.checksum(xs_), channel_zscore=cz,
+                        channel_zscore_f32=cz32, zscore_rereference=zr, car=car, rolling=rz, rolling_nan=rzn)
+
     # ---- G8: split_dataset order --------------------------------------------------------
     ds = torch.utils.data.TensorDataset(torch.arange(100).float())
     loaders = rdl.split_dataset(ds, [0.9, 0.1], [True, False], batch_size=8, seed=42)

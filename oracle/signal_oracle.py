@@ -233,3 +233,53 @@ def run(data: np.ndarray, params) -> np.ndarray:
                                       center_frequencies=mp["center_frequencies"])
         chans.append(sig)
     return np.concatenate(chans, axis=0)
+
+
+# ---------------------------------------------------------------------------
+# Other preprocess/signal steps (the plugin ABI's neighbours of the band extraction)
+# ---------------------------------------------------------------------------
+
+def channel_zscore(data: np.ndarray, preserve_nans: bool = True) -> np.ndarray:
+    """preprocess/signal/channel_zscore.py:22-27: population std over the whole recording."""
+    mean = np.mean(data, axis=1, keepdims=True)
+    std = np.std(data, axis=1, keepdims=True)
+    z = (data - mean) / std
+    if not preserve_nans:
+        z[np.isnan(z)] = 0
+    return z
+
+
+def zscore_rereference(data: np.ndarray, start: int, end: int) -> np.ndarray:
+    """preprocess/signal/zscore_rereference.py:60-70: statistics of data[:, start:end]."""
+    if start < 0 or end > data.shape[1]:
+        raise ValueError("Reference time indices are out of bounds.")
+    if start >= end:
+        raise ValueError("Start time must be less than end time.")
+    m = np.mean(data[:, start:end], axis=1, keepdims=True)
+    s = np.std(data[:, start:end], axis=1, keepdims=True)
+    return (data - m) / s
+
+
+def car_rereference(data: np.ndarray, exclude_channels=()) -> np.ndarray:
+    """preprocess/signal/car_rereference.py:34-39."""
+    mask = np.ones(data.shape[0], dtype=bool)
+    mask[list(exclude_channels)] = False
+    return data - np.mean(data[mask, :], axis=0, keepdims=True)
+
+
+def rolling_zscore(data: np.ndarray, window_size: int, preserve_nans: bool = True) -> np.ndarray:
+    """preprocess/signal/rolling_zscore.py:36-49 restated without pandas: trailing window of
+    ``window_size`` samples, min_periods=1, mean and *sample* std (ddof=1) of the non-NaN values."""
+    x = np.asarray(data, dtype=np.float64)
+    C, T = x.shape
+    out = np.full((C, T), np.nan)
+    for t in range(T):
+        w = x[:, max(0, t - window_size + 1):t + 1]
+        n = np.sum(~np.isnan(w), axis=1)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mean = np.nansum(w, axis=1) / n
+            var = np.nansum((w - mean[:, None]) ** 2, axis=1) / (n - 1)
+            out[:, t] = np.where(n >= 2, (x[:, t] - mean) / np.sqrt(var), np.nan)
+    if not preserve_nans:
+        out[np.isnan(out)] = 0
+    return out

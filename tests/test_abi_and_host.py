@@ -170,3 +170,24 @@ def test_tone_dynamics_host_mirror():
         prepare_tone_dynamics({"0": [1]}, np.array([0, 0]), np.array([0]))
     sel = {"active_channels": [5, 1, 2, 9], "tone_discriminative": [2], "syllable_discriminative": [9, 7]}
     assert select_non_discriminative_channels(sel, ["tone_discriminative", "syllable_discriminative"]) == [1, 5]
+
+
+def test_deep_classifier_mirrors_shapes_and_errors():
+    from decode_tonal_langauge_amd.models import CNNClassifier, CNNRNNClassifier
+    c = CNNClassifier(input_channels=2, input_length=150, n_classes=2)
+    assert c.latent_length == 1 and list(c.state_dict())[0] == "feature_extractor.0.weight"
+    assert "classifier.1.weight" in c.state_dict() and c.get_layer_nparams().keys() == {"feature_extractor", "classifier"}
+    with torch.no_grad():
+        assert c.eval()(torch.randn(3, 2, 150)).shape == (3, 2)
+    with pytest.raises(ValueError, match="too small"):
+        CNNClassifier(input_channels=2, input_length=60, n_classes=2)
+    r = CNNRNNClassifier(input_channels=3, input_length=100, n_classes=4, lstm_dim=200)
+    assert {"lstm1.weight_ih_l0", "conv_pool_block1.0.weight", "conv_block3.2.bias", "lstm2.weight_hh_l0",
+            "output.bias"} <= set(r.state_dict())
+    with torch.no_grad():
+        out = r.eval()(torch.randn(2, 3, 100))
+    assert out.shape == (2, 4) and float(out.min()) >= 0 and float(out.max()) <= 1
+    with pytest.raises(ValueError, match="divisible"):
+        CNNRNNClassifier(input_channels=3, input_length=100, n_classes=4, lstm_dim=250)
+    with pytest.raises(ValueError, match="Expected 3 channels"):
+        r(torch.randn(2, 4, 100))

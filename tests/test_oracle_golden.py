@@ -164,3 +164,17 @@ def test_g8_split_and_g9_trainer_history():
             nb += 1
         hist.append((el / nb, em / nb))
     assert rel(np.array(hist), g9["history"]) < 1e-4
+
+
+def test_g7_other_signal_steps():
+    g = np.load(os.path.join(GOLD, "g7_steps.npz"))
+    x = np.random.default_rng(7).standard_normal((5, 900)) * 3.0 + 1.5
+    assert abs(gi.checksum(x) - float(g["in_checksum"])) < 1e-9 * float(g["in_checksum"])
+    assert rel(sg.channel_zscore(x), g["channel_zscore"]) < 1e-12
+    assert rel(sg.zscore_rereference(x, 50, 300), g["zscore_rereference"]) < 1e-12
+    assert rel(sg.car_rereference(x, [1, 3]), g["car"]) < 1e-12
+    rz = sg.rolling_zscore(x, 50)
+    assert np.array_equal(np.isnan(rz), np.isnan(g["rolling"])) and rel(np.nan_to_num(rz), np.nan_to_num(g["rolling"])) < 1e-12
+    xn = x.copy()
+    xn[2, 100:130] = np.nan
+    assert rel(sg.rolling_zscore(xn, 50, preserve_nans=False), g["rolling_nan"]) < 1e-12
