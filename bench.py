@@ -113,6 +113,8 @@ def main():
     torch.cuda.set_device(dev)
     B, C, T, D = args.batch, args.channels, args.timepoints, 80
 
+    # every rank draws the same 1.38 G initial weights on the host: share the cores between ranks
+    torch.set_num_threads(max(1, host_threads() // max(world, 1)))
     torch.manual_seed(1234)
     model = SynthesisModelCNN(D, C, T, dropout=args.dropout)
     tone_m = LogisticRegressionClassifier(8 * T, 4)

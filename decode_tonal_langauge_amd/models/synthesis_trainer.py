@@ -187,7 +187,7 @@ class SynthesisTrainer:
                 nb += 1
             stats = self._stats.clone()
             if self.world > 1:
-                torch.distributed.all_reduce(stats)
+                parallel.all_reduce_(stats)
                 stats /= self.world
             s = stats.tolist()                                  # the one host sync of the epoch
             epoch_loss, mcd = s[0] / max(nb, 1), s[1] / max(nb, 1)

@@ -40,6 +40,34 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+def _staged() -> bool:
+    """True when the process group cannot move device tensors itself (gloo): collectives are then
+    staged through host memory.  Production runs use RCCL ("nccl"), which never takes this path;
+    it exists so the data-parallel trainer logic can be exercised by two processes on one GPU."""
+    return dist.get_backend() == "gloo"
+
+
+def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
+    """In-place all-reduce (sum by default) of a tensor on any device."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and _staged():
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def _all_gather_rows(out: torch.Tensor, t: torch.Tensor) -> None:
+    if t.is_cuda and _staged():
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, t.detach().cpu().contiguous())
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, t)
+
+
 def shard_rows(n: int, rank: int, nranks: int) -> slice:
     """Rows of a global batch owned by ``rank`` (equal shards; the remainder goes to the last ranks)."""
     base, rem = divmod(n, nranks)
@@ -61,10 +89,10 @@ def allreduce_bucketed(tensors: List[torch.Tensor], bucket_bytes: int = 64 << 20
         if not bucket:
             return
         if len(bucket) == 1:
-            dist.all_reduce(bucket[0])
+            all_reduce_(bucket[0])
         else:
             flat = torch.cat([t.reshape(-1) for t in bucket])
-            dist.all_reduce(flat)
+            all_reduce_(flat)
             ofs = 0
             for t in bucket:
                 n = t.numel()
@@ -76,7 +104,7 @@ def allreduce_bucketed(tensors: List[torch.Tensor], bucket_bytes: int = 64 << 20
         nbytes = t.numel() * t.element_size()
         if nbytes >= bucket_bytes:
             flush()
-            dist.all_reduce(t)
+            all_reduce_(t)
             continue
         if size + nbytes > bucket_bytes:
             flush()
@@ -91,7 +119,7 @@ def gather_lowrank(dg: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, tor
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return dg, h
     n = dist.get_world_size()
-    k = torch.tensor([dg.shape[0]], device=dg.device, dtype=torch.int64)
+    k = torch.tensor([dg.shape[0]], dtype=torch.int64, device="cpu" if _staged() else dg.device)
     dist.all_reduce(k, op=dist.ReduceOp.MAX)
     kmax = int(k.item())
 
@@ -104,6 +132,6 @@ def gather_lowrank(dg: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, tor
 
     dg_all = torch.empty(n * kmax, dg.shape[1], dtype=dg.dtype, device=dg.device)
     h_all = torch.empty(n * kmax, h.shape[1], dtype=h.dtype, device=h.device)
-    dist.all_gather_into_tensor(dg_all, pad(dg))
-    dist.all_gather_into_tensor(h_all, pad(h))
+    _all_gather_rows(dg_all, pad(dg))
+    _all_gather_rows(h_all, pad(h))
     return dg_all, h_all

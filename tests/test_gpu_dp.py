@@ -1,0 +1,78 @@
+"""GPU: data-parallel equivalence of the fused trainer step.  Two processes share the one GPU of
+the test box (gloo process group, collectives staged through host memory - RCCL refuses two ranks
+on one device); each takes its row shard of the same global batches.  After two steps their
+parameters must equal those of a single process that trained on the whole batches (dropout 0):
+this exercises the row sharding, the bucketed all-reduce, the low-rank W_hh factor gather and the
+1/N gradient scale exactly as the 8-GPU RCCL run uses them."""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dev):
+    from decode_tonal_langauge_amd.models import LogisticRegressionClassifier, SynthesisModelCNN, SynthesisTrainer
+    from tests import golden_inputs as gi
+    torch.manual_seed(0)
+    model = SynthesisModelCNN(80, 8, 100, dropout=0.0)
+    tone = LogisticRegressionClassifier(4 * 100, 4)
+    syl = LogisticRegressionClassifier(4 * 100, 2)
+    tr = SynthesisTrainer(model, tone, syl, gi.TONE_MAP, device=dev, verbose=False)
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(8, 8, 100, generator=g), torch.randn(8, 4, 100, generator=g),
+                torch.randn(8, 4, 100, generator=g), 10 * torch.randn(8, 80, generator=g)) for _ in range(2)]
+    return model, tr, batches
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    from decode_tonal_langauge_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    model, tr, batches = _build(dev)
+    assert tr.world == world
+    model.train()
+    for b in batches:
+        tr.train_step(*b)
+    torch.cuda.synchronize()
+    # numpy (pickled by value): torch tensors would be shared through fds that die with this process
+    q.put((rank, {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}, tr._stats.cpu().numpy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_training_equals_single_process():
+    dev = torch.device("cuda:0")
+    model, tr, batches = _build(dev)
+    model.train()
+    for b in batches:
+        tr.train_step(*b)
+    ref = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    ref_stats = tr._stats.cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    from decode_tonal_langauge_amd.models import SynthesisModelCNN
+    init = {k: v.detach().clone() for k, v in SynthesisModelCNN(80, 8, 100, dropout=0.0).named_parameters()}
+    for rank, params, stats in res:
+        for k in ref:
+            upd = (ref[k] - init[k]).double()
+            err = float((torch.from_numpy(params[k]).double() - ref[k].double()).norm() / max(float(upd.norm()), 1e-30))
+            assert err < 2e-2, (rank, k, err)          # relative to the size of the two-step update
+    # both ranks hold identical parameters
+    for k in ref:
+        assert (res[0][1][k] == res[1][1][k]).all(), k
+    # mean of the two local losses equals the global loss (equal shards)
+    loss_dp = 0.5 * (float(res[0][2][0]) + float(res[1][2][0]))
+    assert abs(loss_dp - float(ref_stats[0])) < 1e-3 * abs(float(ref_stats[0]))
