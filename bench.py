@@ -97,12 +97,15 @@ def main():
     ap.add_argument("--timepoints", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--dropout", type=float, default=None, help="default: the model's own default (0.5 / 0.3)")
+    ap.add_argument("--model", choices=["full", "lite"], default="full",
+                    help="full = SynthesisModelCNN (headline, C3); lite = SynthesisLite (use --channels 32 "
+                         "--timepoints 200 --batch 64 for BASELINE config C2)")
     args = ap.parse_args()
 
     from decode_tonal_langauge_amd import parallel
     from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
-    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisLite, SynthesisModelCNN
     from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
 
     rank, world, local = parallel.init_from_env()
@@ -116,7 +119,12 @@ def main():
     # every rank draws the same 1.38 G initial weights on the host: share the cores between ranks
     torch.set_num_threads(max(1, host_threads() // max(world, 1)))
     torch.manual_seed(1234)
-    model = SynthesisModelCNN(D, C, T, dropout=args.dropout)
+    if args.model == "lite":
+        args.no_cpu_baseline = True
+        model = SynthesisLite(D, C, T, **({} if args.dropout is None else {"dropout": args.dropout}))
+    else:
+        model = SynthesisModelCNN(D, C, T, **({} if args.dropout is None else {"dropout": args.dropout}))
+    drop = args.dropout if args.dropout is not None else (0.3 if args.model == "lite" else 0.5)
     tone_m = LogisticRegressionClassifier(8 * T, 4)
     syl_m = LogisticRegressionClassifier(8 * T, 2)
     trainer = SynthesisTrainer(model, tone_m, syl_m, TONE_MAP, device=dev, verbose=False)
@@ -141,7 +149,7 @@ def main():
 
     for i in range(args.warmup):
         trainer.train_step(*data[i % nb])
-    if not args.no_kernel_timers:
+    if not args.no_kernel_timers and args.model == "full":
         eng.enable_timers(True)
     sync()
     t0 = time.perf_counter()
@@ -149,8 +157,9 @@ def main():
         trainer.train_step(*data[(args.warmup + i) % nb])
     sync()
     dt = time.perf_counter() - t0
-    tsum = eng.timer_summary() if eng.timers is not None else {}
-    eng.enable_timers(False)
+    tsum = eng.timer_summary() if getattr(eng, "timers", None) is not None else {}
+    if hasattr(eng, "enable_timers"):
+        eng.enable_timers(False)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -198,12 +207,13 @@ def main():
             except Exception as e:      # noqa: BLE001 - the baseline leg must not kill the bench line
                 cpu = {"value": None, "error": repr(e)}
         line = {
-            "metric": "mel-frames/sec (train step) SynthesisModelCNN, 128ch x 400t batch256",
+            "metric": "mel-frames/sec (train step) SynthesisModelCNN, 128ch x 400t batch256" if args.model == "full"
+                      else "mel-frames/sec (train step) SynthesisLite",
             "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"SynthesisModelCNN {C}ch x {T}t -> {D} mel, 4 tones x 2 syllables, L=5, "
-                                   f"batch {B} per GPU (global {GB}), dropout {args.dropout}, NAdam, "
+            "config": {"workload": f"{type(model).__name__} {C}ch x {T}t -> {D} mel, 4 tones x 2 syllables, L=5, "
+                                   f"batch {B} per GPU (global {GB}), dropout {drop}, NAdam, "
                                    f"{model.get_nparams():,} params",
                        "per_gpu_batch": B, "global_batch": GB, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu,

@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtonal_hip.so")
+LIB_PATH = os.environ.get("TONAL_HIP_LIB", os.path.join(_HERE, "libtonal_hip.so"))   # env override: A/B builds
 
 # epilogue / loader codes of tl_gemm_nt_window (include/tonal_hip.h)
 LOAD_DIRECT, LOAD_UNPOOL = 0, 1

@@ -348,3 +348,54 @@ def test_trainer_with_deep_classifiers(dev):
     assert len(hist) == 2 and all(np.isfinite(v) for h in hist for v in h)
     mcd, recon, origin = tr.evaluate(torch.utils.data.DataLoader(ds, batch_size=6))
     assert np.isfinite(mcd) and recon.shape == (12, 80) and origin.shape == (12, 80)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (B, C, T, out_dim, lstm_channels, conv_channels, L)
+    (1, 4, 100, 80, 6, 64, 5),        # batch of one
+    (3, 2, 61, 12, 2, 8, 1),          # L = 1 (no recurrence), odd T, tiny widths
+    (5, 6, 77, 7, 2, 10, 4),          # output_dim and conv_channels not multiples of 4
+    (9, 3, 130, 33, 4, 20, 3),        # odd channel count, odd output_dim
+    (130, 1, 64, 8, 4, 4, 2),         # one ECoG channel, batch > one row tile
+])
+def test_cnn_edge_shapes_against_oracle(dev, cfg):
+    """Ragged / minimal shapes: forward and every parameter gradient against the CPU oracle."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    from oracle import synthesis_oracle as so
+    B, C, T, D, lc, cc, L = cfg
+    torch.manual_seed(B * 1000 + T)
+    model = SynthesisModelCNN(D, C, T, lstm_channels=lc, conv_channels=cc, dropout=0.0)
+    params = {k: v.detach().clone() for k, v in model.named_parameters()}
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(B, C, T, generator=g)
+    lab = torch.randint(0, 4, (B, 2, L), generator=g).float()
+    tgt = torch.randn(B, D, generator=g)
+    model.to(dev).train()
+    out = model(x.to(dev), lab.to(dev))
+    ((out - tgt.to(dev)) ** 2).mean().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    # oracle with the model's widths (its helper assumes the reference's names/shapes only)
+    ref = so.cnn_forward(leaves, x, lab)
+    ref_grads = dict(zip(leaves, torch.autograd.grad(((ref - tgt) ** 2).mean(), list(leaves.values()))))
+    assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    for k, p in model.named_parameters():
+        gref = ref_grads[k].numpy()
+        if np.abs(gref).max() < 1e-12:
+            assert float(p.grad.abs().max()) < 1e-9, k
+        else:
+            assert rel_l2(p.grad.cpu().numpy(), gref) < 5e-3, k
+
+
+def test_cnn_rejects_bad_inputs(dev):
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    model = SynthesisModelCNN(80, 4, 100).to(dev)
+    with pytest.raises(ValueError, match="expected ECoG input"):
+        model(torch.randn(2, 5, 100, device=dev), torch.randn(2, 2, 5, device=dev))
+    with pytest.raises(ValueError, match="expected labels"):
+        model(torch.randn(2, 4, 100, device=dev), torch.randn(2, 3, 5, device=dev))
+    with pytest.raises((ValueError, RuntimeError)):
+        SynthesisModelCNN(80, 4, 20)           # the conv stack consumes more samples than there are
+    with pytest.raises(ValueError, match="multiple of 4"):
+        SynthesisModelCNN(80, 3, 100, lstm_channels=1)
+    with pytest.raises(ValueError, match="negative_slope"):
+        SynthesisModelCNN(80, 4, 100, negative_slope=-0.1)
