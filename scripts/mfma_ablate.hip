@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ A, const f
   f32x16 acc[2][2];
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // fill LDS once
-  for (int i = tid; i < 2 * AROWS * LDS_LD + 2 * 128 * LDS_LD; i += 256) lds[i] = (float)((i * 7 + blockIdx.x) & 15) * 0.01f;
+  for (int i = tid; i < 2 * AROWS * LDS_LD + 2 * 128 * LDS_LD; i += 256) lds[i] = A[(long long)blockIdx.x * 4096 + (i & 4095)];
   __syncthreads();
   f32x4 fa[2], fb[2];
   fa[0] = fa[1] = fb[0] = fb[1] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void kd2(const float* __restrict__ A, const
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
   f32x16 acc[2][2];
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  for (int i = tid; i < 2 * AROWS * LDS_LD + 2 * 128 * LDS_LD; i += 256) lds[i] = (float)((i * 7 + blockIdx.x) & 15) * 0.01f;
+  for (int i = tid; i < 2 * AROWS * LDS_LD + 2 * 128 * LDS_LD; i += 256) lds[i] = A[(long long)blockIdx.x * 4096 + (i & 4095)];
   __syncthreads();
   f32x4 fa[2], fb[2];
   f32x4 rbP[4], rbQ[4];
@@ -183,8 +183,16 @@ int main() {
   hipMalloc(&A, arows * lda * sizeof(float));
   hipMalloc(&B, 512 * 512 * 3 * sizeof(float));
   hipMalloc(&out, (size_t)nwg * 256 * sizeof(float));
-  hipMemset(A, 0, arows * lda * sizeof(float));
-  hipMemset(B, 0, 512 * 512 * 3 * sizeof(float));
+  {  // random (not zero) operands: zero data inflates MFMA clocks (DVFS), cdna guide rule 25
+    std::vector<float> h(1 << 24);
+    unsigned x = 12345u;
+    for (auto& v : h) { x = x * 1664525u + 1013904223u; v = ((int)(x >> 9) - (1 << 22)) * (1.0f / (1 << 22)); }
+    for (long long off = 0; off < arows * lda; off += (1 << 24)) {
+      long long n = arows * lda - off; if (n > (1 << 24)) n = 1 << 24;
+      hipMemcpy(A + off, h.data(), n * sizeof(float), hipMemcpyHostToDevice);
+    }
+    hipMemcpy(B, h.data(), 512 * 512 * 3 * sizeof(float), hipMemcpyHostToDevice);
+  }
   run<0>("V0 MFMA only (operands in registers)", A, B, out, nwg, nsteps, lda);
   run<1>("V1 + ds_read_b128 fragments", A, B, out, nwg, nsteps, lda);
   run<2>("V2 + barrier per K-step", A, B, out, nwg, nsteps, lda);

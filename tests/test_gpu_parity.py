@@ -399,3 +399,21 @@ def test_cnn_rejects_bad_inputs(dev):
         SynthesisModelCNN(80, 3, 100, lstm_channels=1)
     with pytest.raises(ValueError, match="negative_slope"):
         SynthesisModelCNN(80, 4, 100, negative_slope=-0.1)
+
+
+def test_glds_variant_matches_default_kernel(dev, monkeypatch):
+    """The opt-in direct-to-LDS NT kernel (TONAL_GLDS=1) gives the same forward and gradients."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    xs, _t, _s, labs, tg = gi.train_batches(1, 6, 8, 200, seed=5)
+    outs, grads = [], []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("TONAL_GLDS", flag)
+        torch.manual_seed(1)
+        model = SynthesisModelCNN(80, 8, 200, dropout=0.0).to(dev).train()
+        out = model(xs[0].to(dev), labs[0].to(dev))
+        (out - tg[0].to(dev)).abs().mean().backward()
+        outs.append(out.detach().cpu().numpy())
+        grads.append({k: p.grad.cpu().numpy() for k, p in model.named_parameters()})
+    assert rel(outs[1], outs[0]) < 1e-5
+    for k in grads[0]:
+        assert rel_l2(grads[1][k], grads[0][k]) < 5e-3, k
