@@ -164,6 +164,32 @@ __global__ __launch_bounds__(256) void permute_reduce_kernel(const float* __rest
   }
 }
 
+// same, for few outputs and many slabs: one wave per output element, lanes stride over the slabs,
+// fixed-shape shuffle tree (deterministic)
+__global__ __launch_bounds__(256) void permute_reduce_zpar_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                  const float* __restrict__ bias_last, perm_args a,
+                                                                  long long total) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long i = wave; i < total; i += nwaves) {
+    long long r = i;
+    const long long i3 = r % a.d[3]; r /= a.d[3];
+    const long long i2 = r % a.d[2]; r /= a.d[2];
+    const long long i1 = r % a.d[1]; r /= a.d[1];
+    const long long i0 = r;
+    float acc = 0.f;
+    const bool ok = i0 < a.lim[0] && i1 < a.lim[1] && i2 < a.lim[2] && i3 < a.lim[3];
+    if (ok) {
+      const long long off = i0 * a.s[0] + i1 * a.s[1] + i2 * a.s[2] + i3 * a.s[3];
+      for (int z = lane; z < a.nz; z += 64) acc += src[off + z * a.zs];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) dst[i] = ok ? acc + (bias_last ? bias_last[i3] : 0.f) : 0.f;
+  }
+}
+
 // masked column sums (bias gradients): partial[blk][ncols].  float4 per thread along the
 // columns, 256/(ncols/4) rows per pass, 4 independent row loads in flight per thread, LDS
 // reduction over the row lanes (fixed order -> deterministic).
@@ -530,8 +556,12 @@ extern "C" int tl_permute_reduce(const float* src, float* dst, const int64_t dim
   }
   a.zs = zs;
   a.nz = nz;
-  hipLaunchKernelGGL(permute_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst,
-                     bias_last, a, total);
+  if (nz >= 64 && total <= 16384)
+    hipLaunchKernelGGL(permute_reduce_zpar_kernel, dim3(grid_for(total * 64)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, bias_last, a, total);
+  else
+    hipLaunchKernelGGL(permute_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       bias_last, a, total);
   return check_launch("permute_reduce");
 }
 
