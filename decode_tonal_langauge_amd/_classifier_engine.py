@@ -1,0 +1,117 @@
+"""Forward-only HIP path of ``CNNClassifier`` (reference models/deep_classifiers.py:62-99,115-119).
+
+The feature extractor is the same shared-weight (3,1) conv + LeakyReLU (+ (2,1) max-pool) pattern as
+the synthesis model's ECoG block, so it runs on the same kernels (``tl_conv1_fwd`` and the fp32-MFMA
+``tl_gemm_nt_window``) in the same channels-last, sequence-major layout; the two Linear layers are NT
+GEMMs on re-packed weights.  Used when the classifier is called without autograd on CUDA tensors -
+which is how the synthesis trainer uses it (reference models/synthesis_trainer.py:207-210: the
+outputs are arg-maxed and the classifiers are never updated)."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+from ._cnn_engine import CnnEngine, _r4
+from ._lib import EPI_LRELU, EPI_STORE, LOAD_DIRECT, check, ptr
+
+
+class CnnClassifierEngine(CnnEngine):
+    def __init__(self, n_electrodes: int, n_timepoints: int, stage_defs, hidden: int, n_classes: int,
+                 negative_slope: float):
+        # reuse the conv-stack geometry / buffers of the synthesis engine (no LSTM / concat part)
+        super().__init__(n_classes, n_electrodes, n_timepoints, 0, stage_defs[-1][0], 0.0, negative_slope,
+                         stage_defs, [4])
+        self.hidden = hidden
+        self.n_classes = n_classes
+        last = self.stages[-1]
+        self.c_last = last.cout
+        self.tp_last = last.tp_out
+        self.ld_last = last.cout if last.pool else self.ld5
+        self.kflat_cls = n_electrodes * self.tp_last * self.ld_last
+        self._packed: Dict[str, Tuple[int, torch.Tensor]] = {}
+
+    def _alloc(self, B: int, dev):
+        if self._B == B and getattr(self, "_dev", None) == dev:
+            return
+        self._B, self._dev = B, dev
+        S = B * self.C
+        self.S = S
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        self.P = {1: z(S * self.tp1, self.c1)}
+        self.bits = {1: zi(S * self.tp1, self.c1 // 32)}
+        for st in self.stages:
+            rows = S * st.tp_out
+            self.P[st.idx] = z(rows, st.cout if st.pool else _r4(st.cout))
+            if st.pool:
+                self.bits[st.idx] = zi(rows, st.cout // 32)
+
+    def _cached(self, key: str, param: torch.Tensor, build):
+        """Packed copies of the (usually frozen) classifier weights, rebuilt when the parameter changes."""
+        ver = (param._version, param.data_ptr())
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            hit = self._packed[key] = (ver, build())
+        return hit[1]
+
+    def forward_scores(self, convs: List[Tuple[torch.Tensor, torch.Tensor]], fc1, fc2, x: torch.Tensor) -> torch.Tensor:
+        B, Cn, T = x.shape
+        if Cn != self.C or T != self.T:
+            raise ValueError(f"expected input (B, {self.C}, {self.T}), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        dev = x.device
+        self._alloc(B, dev)
+        lib, st_ = self.lib, self._stream()
+        S = self.S
+        w1, b1 = convs[0]
+        check(lib.tl_conv1_fwd(ptr(x), ptr(w1.reshape(self.c1, self.k1).contiguous()), ptr(b1), ptr(self.P[1]),
+                               ptr(self.bits[1]), S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_),
+              "tl_conv1_fwd")
+        for st, (w, b) in zip(self.stages, convs[1:]):
+            wp = self._cached(f"conv{st.idx}", w, lambda w=w, st=st: self._pack_conv(w, st.cin, False))
+            src, dst = self.P[st.idx - 1], self.P[st.idx]
+            kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(b), out=ptr(dst), M=S * st.tp_in, A_rows=src.shape[0],
+                      N=st.cout, K=st.cin, lda=src.shape[1], ldb=st.cin, ldo=dst.shape[1], J=st.k, row_shift=0,
+                      Tp=st.tp_in, slope=self.slope, loader=LOAD_DIRECT)
+            if st.pool:
+                from ._lib import EPI_POOL
+                kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
+            else:
+                kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
+            self._nt(**kw)
+        feat = self.P[self.stages[-1].idx]                       # [S*tp_last][ld_last] == [B][kflat_cls]
+        w_fc1, b_fc1 = fc1
+        lat, latC = self.lat, self.lat * self.C
+
+        def pack_fc1():
+            dst = torch.empty(self.hidden, self.kflat_cls, dtype=torch.float32, device=dev)
+            # torch flatten of (B, ch, t, c): index ch*lat*C + t*C + c  ->  ours (c*Tp + t)*ld + ch
+            self._permute(w_fc1, dst, (self.hidden, self.C, self.tp_last, self.ld_last),
+                          (self.c_last * latC, 1, self.C, latC), (self.hidden, self.C, lat, self.c_last))
+            return dst
+        wp1 = self._cached("fc1", w_fc1, pack_fc1)
+        f32 = dict(dtype=torch.float32, device=dev)
+        nkc = (self.kflat_cls + 31) // 32
+        tiles = ((B + 127) // 128) * ((self.hidden + 127) // 128)
+        sk = self._splitk(tiles, nkc, 1024)
+        if sk > 1:
+            slab = torch.empty(sk, B, self.hidden, **f32)
+            self._nt(A=ptr(feat), Bw=ptr(wp1), out=ptr(slab), M=B, A_rows=B, N=self.hidden, K=self.kflat_cls,
+                     lda=self.kflat_cls, ldb=self.kflat_cls, ldo=self.hidden, loader=LOAD_DIRECT, epilogue=EPI_STORE,
+                     splitk=sk, slab_stride=B * self.hidden)
+            pre = torch.empty(B, self.hidden, **f32)
+            self._permute(slab, pre, (1, 1, B, self.hidden), (0, 0, self.hidden, 1), nz=sk, zs=B * self.hidden,
+                          bias=b_fc1)
+            a1 = torch.nn.functional.leaky_relu(pre, self.slope)
+        else:
+            a1 = torch.empty(B, self.hidden, **f32)
+            self._nt(A=ptr(feat), Bw=ptr(wp1), bias=ptr(b_fc1), out=ptr(a1), M=B, A_rows=B, N=self.hidden,
+                     K=self.kflat_cls, lda=self.kflat_cls, ldb=self.kflat_cls, ldo=self.hidden, loader=LOAD_DIRECT,
+                     epilogue=EPI_LRELU, slope=self.slope)
+        w_fc2, b_fc2 = fc2
+        out = torch.empty(B, self.n_classes, **f32)
+        self._nt(A=ptr(a1), Bw=ptr(w_fc2.contiguous()), bias=ptr(b_fc2), out=ptr(out), M=B, A_rows=B,
+                 N=self.n_classes, K=self.hidden, lda=self.hidden, ldb=self.hidden, ldo=self.n_classes,
+                 loader=LOAD_DIRECT, epilogue=EPI_STORE)
+        return torch.sigmoid(out)

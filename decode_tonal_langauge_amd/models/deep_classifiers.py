@@ -55,7 +55,34 @@ class CNNClassifier(ClassifierModel):
             nn.Flatten(), nn.Linear(256 * input_channels * self.latent_length, 1024),
             nn.LeakyReLU(negative_slope=negative_slope), nn.Linear(1024, n_classes), nn.Sigmoid())
 
+        self._hip = None
+        self._hip_cfg = (input_channels, input_length, negative_slope)
+
+    def _hip_engine(self):
+        if self._hip is None:
+            from .._classifier_engine import CnnClassifierEngine
+            stage_defs, convs = [], [m for m in self.feature_extractor if isinstance(m, nn.Conv2d)]
+            for m in self.feature_extractor:
+                if isinstance(m, nn.Conv2d):
+                    stage_defs.append([m.out_channels, m.kernel_size[0], False])
+                elif isinstance(m, nn.MaxPool2d):
+                    stage_defs[-1][2] = True
+            self._hip = CnnClassifierEngine(self._hip_cfg[0], self._hip_cfg[1], [tuple(s) for s in stage_defs],
+                                            self.classifier[1].out_features, self.n_classes, self._hip_cfg[2])
+            assert self._hip.lat == self.latent_length and len(convs) == len(stage_defs)
+        return self._hip
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # Inference on the GPU (how the synthesis trainer calls it): hand-written HIP path.  Anything
+        # that needs autograd through the classifier (its own training is outside the hot-path
+        # scope) uses the module graph on stock PyTorch-ROCm.
+        needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        dropout_active = self.training and self.feature_extractor[-1].p > 0
+        if x.is_cuda and not needs_graph and not dropout_active and self._hip_cfg[2] >= 0:
+            convs = [(m.weight.detach(), m.bias.detach()) for m in self.feature_extractor if isinstance(m, nn.Conv2d)]
+            fc1, fc2 = self.classifier[1], self.classifier[3]
+            return self._hip_engine().forward_scores(convs, (fc1.weight.detach(), fc1.bias.detach()),
+                                                     (fc2.weight.detach(), fc2.bias.detach()), x)
         x = x.unsqueeze(1).permute(0, 1, 3, 2)            # (B, 1, T, C)
         return self.classifier(self.feature_extractor(x))
 

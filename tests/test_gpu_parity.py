@@ -417,3 +417,18 @@ def test_glds_variant_matches_default_kernel(dev, monkeypatch):
     assert rel(outs[1], outs[0]) < 1e-5
     for k in grads[0]:
         assert rel_l2(grads[1][k], grads[0][k]) < 5e-3, k
+
+
+def test_cnn_classifier_hip_forward_matches_module_graph(dev):
+    """CNNClassifier inference on the HIP conv kernels vs the same module's stock PyTorch graph."""
+    from decode_tonal_langauge_amd.models import CNNClassifier
+    torch.manual_seed(0)
+    for (C, T, B) in ((4, 160, 5), (3, 233, 9)):
+        clf = CNNClassifier(input_channels=C, input_length=T, n_classes=3).to(dev).eval()
+        x = torch.randn(B, C, T, device=dev)
+        with torch.no_grad():
+            hip = clf(x)
+        assert clf._hip is not None, "HIP path was not taken"
+        ref = clf.classifier(clf.feature_extractor(x.unsqueeze(1).permute(0, 1, 3, 2)))
+        assert hip.shape == ref.shape == (B, 3)
+        assert float((hip - ref.detach()).abs().max()) < 1e-5
