@@ -162,7 +162,7 @@ def main():
         eng.enable_timers(False)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        parallel.all_reduce_(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     value = GB * args.steps / dt
