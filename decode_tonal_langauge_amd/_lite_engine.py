@@ -135,10 +135,17 @@ class LiteEngine:
             w1p = torch.empty(self.hid, self.ldf, **f32)
             self._permute(w1, w1p, (1, 1, self.hid, self.ldf), (0, 0, fh, 1), (1, 1, self.hid, fh))
             w1 = w1p
-        self.a1 = torch.empty(B, self.hid, **f32)
-        self._nt(A=ptr(self.feat), Bw=ptr(w1), bias=ptr(t["fc.1.bias"]), out=ptr(self.a1), M=B, A_rows=B, N=self.hid,
-                 K=self.ldf, lda=self.ldf, ldb=self.ldf, ldo=self.hid, loader=LOAD_DIRECT, epilogue=EPI_LRELU,
-                 slope=self.slope)
+        # fc.1: M = B is small, so the grid comes from split-K (32-row tiles x 4 column tiles x splits)
+        bm = 32 if B <= 64 else 128
+        tiles = ((B + bm - 1) // bm) * ((self.hid + 127) // 128)
+        sk = int(max(1, min((self.ldf + 31) // 32, 256 // tiles)))
+        slab = torch.empty(sk, B, self.hid, **f32)
+        self._nt(A=ptr(self.feat), Bw=ptr(w1), out=ptr(slab), M=B, A_rows=B, N=self.hid, K=self.ldf, lda=self.ldf,
+                 ldb=self.ldf, ldo=self.hid, loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm, splitk=sk,
+                 slab_stride=B * self.hid)
+        pre = torch.empty(B, self.hid, **f32)
+        self._permute(slab, pre, (1, 1, B, self.hid), (0, 0, self.hid, 1), nz=sk, zs=B * self.hid, bias=t["fc.1.bias"])
+        self.a1 = torch.nn.functional.leaky_relu(pre, self.slope)
         out = torch.empty(B, self.out_dim, **f32)
         self._nt(A=ptr(self.a1), Bw=ptr(t["fc.3.weight"]), bias=ptr(t["fc.3.bias"]), out=ptr(out), M=B, A_rows=B,
                  N=self.out_dim, K=self.hid, lda=self.hid, ldb=self.hid, ldo=self.out_dim, loader=LOAD_DIRECT,

@@ -632,7 +632,6 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
   // Hoisted per-thread state: row pointers advance by a wave-uniform stride per K-step, column
   // validity is loop-invariant, row validity ((row % Tp) < Tvalid) is tracked incrementally.
   constexpr int NB = (LOADER == LOAD_DIRECT) ? 4 : 2;
-  const int krows = (int)p.Krows;                       // host guarantees < 2^31
   const int a_lim = (int)(p.A_rows < p.Krows + j ? p.A_rows : p.Krows + j);
   const int b_lim = (LOADER == LOAD_DIRECT) ? (int)(p.B_rows < p.Krows ? p.B_rows : p.Krows)
                                             : (int)(2 * p.B_rows < p.Krows ? 2 * p.B_rows : p.Krows);
@@ -852,8 +851,6 @@ __global__ __launch_bounds__(256, 2) void tn3_kernel(const tl_tn_params p) {
   uint32_t rnP[NB], rnQ[NB];
   (void)rnP; (void)rnQ;
 
-  const int krows = (int)p.Krows;
-  (void)krows;
   const int a_lim = (int)(p.A_rows < p.Krows + 2 ? p.A_rows : p.Krows + 2);
   const int b_lim = (LOADER == LOAD_DIRECT) ? (int)(p.B_rows < p.Krows ? p.B_rows : p.Krows)
                                             : (int)(2 * p.B_rows < p.Krows ? 2 * p.B_rows : p.Krows);

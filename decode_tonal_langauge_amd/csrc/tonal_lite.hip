@@ -48,26 +48,34 @@ __global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restr
 }
 
 // mean / rstd from the partial sums (fixed order), running-stat update (momentum, unbiased var)
-__global__ void lite_bn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
-                                        float* __restrict__ run_mean, float* __restrict__ run_var, int nparts, int C,
-                                        long long count, float momentum, float eps, int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void lite_bn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                                              float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                              float* __restrict__ run_var, int nparts, int C, long long count,
+                                                              float momentum, float eps, int training) {
+  const int c = blockIdx.x;                      // one wave per channel, lanes stride over the partials
+  const int lane = threadIdx.x;
   if (training) {
     double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nparts; ++i) {
+    for (int i = lane; i < nparts; i += 64) {
       s1 += part[((long long)i * C + c) * 2];
       s2 += part[((long long)i * C + c) * 2 + 1];
     }
-    const double m = s1 / (double)count;
-    double var = s2 / (double)count - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
-    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
-    const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
-  } else {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_down(s1, o);
+      s2 += __shfl_down(s2, o);
+    }
+    if (lane == 0) {
+      const double m = s1 / (double)count;
+      double var = s2 / (double)count - m * m;
+      if (var < 0.0) var = 0.0;
+      mean[c] = (float)m;
+      rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+      const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+  } else if (lane == 0) {
     mean[c] = run_mean[c];
     rstd[c] = 1.f / sqrtf(run_var[c] + eps);
   }
@@ -137,19 +145,25 @@ __global__ __launch_bounds__(256) void lite_bn_act_pool_bwd_kernel(const float* 
 
 // dgamma, dbeta and, in place, dz = gamma*rstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))  (train)
 //                                dz = gamma*rstd*dbn                                      (eval)
-__global__ void lite_bn_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                      float* __restrict__ sums, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void lite_bn_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ sums, int B, int C) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b) {
+  for (int b = lane; b < B; b += 64) {
     s1 += part[((long long)b * C + c) * 2];
     s2 += part[((long long)b * C + c) * 2 + 1];
   }
-  dbeta[c] = (float)s1;
-  dgamma[c] = (float)s2;
-  sums[c * 2] = (float)s1;
-  sums[c * 2 + 1] = (float)s2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_down(s1, o);
+    s2 += __shfl_down(s2, o);
+  }
+  if (lane == 0) {
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    sums[c * 2] = (float)s1;
+    sums[c * 2 + 1] = (float)s2;
+  }
 }
 __global__ __launch_bounds__(256) void lite_bn_dz_kernel(float* __restrict__ dbn, const float* __restrict__ z,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -194,20 +208,30 @@ __global__ __launch_bounds__(256) void lite_conv_dw_kernel(const float* __restri
                                                            int Cout, int T, int k, int pad) {
   const int b = blockIdx.x;
   const int n = Cout * Cin * k;
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;       // one weight element per thread
+  if (e < n) {
     const int j = e % k, ci = (e / k) % Cin, o = e / (k * Cin);
     const float* dzr = dz + ((long long)b * Cout + o) * T;
     const float* xr = x + ((long long)b * Cin + ci) * T;
-    float acc = 0.f;
     const int lo = max(0, pad - j), hi = min(T, T + pad - j);
-    for (int t = lo; t < hi; ++t) acc = fmaf(dzr[t], xr[t + j - pad], acc);
-    dwpart[(long long)b * n + e] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int t = lo;
+    for (; t + 4 <= hi; t += 4) {
+      a0 = fmaf(dzr[t], xr[t + j - pad], a0);
+      a1 = fmaf(dzr[t + 1], xr[t + 1 + j - pad], a1);
+      a2 = fmaf(dzr[t + 2], xr[t + 2 + j - pad], a2);
+      a3 = fmaf(dzr[t + 3], xr[t + 3 + j - pad], a3);
+    }
+    for (; t < hi; ++t) a0 = fmaf(dzr[t], xr[t + j - pad], a0);
+    dwpart[(long long)b * n + e] = (a0 + a1) + (a2 + a3);
   }
-  for (int o = threadIdx.x; o < Cout; o += blockDim.x) {
-    const float* dzr = dz + ((long long)b * Cout + o) * T;
-    float acc = 0.f;
-    for (int t = 0; t < T; ++t) acc += dzr[t];
-    dbpart[(long long)b * Cout + o] = acc;
+  if (blockIdx.y == 0) {
+    for (int o = threadIdx.x; o < Cout; o += blockDim.x) {
+      const float* dzr = dz + ((long long)b * Cout + o) * T;
+      float acc = 0.f;
+      for (int t = 0; t < T; ++t) acc += dzr[t];
+      dbpart[(long long)b * Cout + o] = acc;
+    }
   }
 }
 
@@ -353,7 +377,7 @@ extern "C" int tl_lite_conv_fwd(const float* x, const float* w, const float* bia
 extern "C" int tl_lite_bn_finalize(const float* part, float* mean, float* rstd, float* run_mean, float* run_var,
                                    int nparts, int C, int64_t count, float momentum, float eps, int training, void* stream) {
   TL_REQUIRE(mean && rstd && run_mean && run_var && C > 0 && (part || !training), "lite_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(lite_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, mean, rstd,
+  hipLaunchKernelGGL(lite_bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, part, mean, rstd,
                      run_mean, run_var, nparts, C, (long long)count, momentum, eps, training);
   return check_launch("lite_bn_finalize");
 }
@@ -374,7 +398,7 @@ extern "C" int tl_lite_bn_act_pool_bwd(const float* dy, const float* z, const fl
   float* part = work;                         // [B][C][2]
   float* sums = work + (size_t)B * C * 2;     // [C][2]
   hipLaunchKernelGGL(lite_bn_act_pool_bwd_kernel, dim3(C, B), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, dz, part, C, T, slope);
-  hipLaunchKernelGGL(lite_bn_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, dgamma, dbeta, sums, B, C);
+  hipLaunchKernelGGL(lite_bn_reduce_kernel, dim3(C), dim3(64), 0, st, part, dgamma, dbeta, sums, B, C);
   const long long total = (long long)B * C * T;
   hipLaunchKernelGGL(lite_bn_dz_kernel, dim3(lgrid(total)), dim3(256), 0, st, dz, z, mean, rstd, gamma, sums, total, C, T,
                      (long long)B * T, training);
@@ -390,7 +414,8 @@ extern "C" int tl_lite_conv_bwd(const float* dz, const float* x, const float* w,
     TL_REQUIRE(lds <= 64 * 1024, "lite_conv_bwd: Cout too large for the LDS tile");
     hipLaunchKernelGGL(lite_conv_dx_kernel, dim3((T + LT - 1) / LT, B), dim3(256), lds, st, dz, w, dx, Cin, Cout, T, k, pad);
   }
-  hipLaunchKernelGGL(lite_conv_dw_kernel, dim3(B), dim3(256), 0, st, dz, x, dwpart, dbpart, Cin, Cout, T, k, pad);
+  hipLaunchKernelGGL(lite_conv_dw_kernel, dim3(B, (Cout * Cin * k + 255) / 256), dim3(256), 0, st, dz, x, dwpart, dbpart, Cin,
+                     Cout, T, k, pad);
   return check_launch("lite_conv_bwd");
 }
 extern "C" int tl_lite_lstm_fwd(const float* xl, const float* w_ih, const float* w_hh, const float* b_ih,

@@ -330,6 +330,37 @@ __global__ __launch_bounds__(256) void lstm_ih_grad_kernel(const float* __restri
   db[r] = accb;
 }
 
+// few gate rows (SynthesisLite: 4H = 256): one wave per row, lanes stride over the (t,u) pairs
+__global__ __launch_bounds__(64) void lstm_ih_grad_wave_kernel(const float* __restrict__ dgates, const float* __restrict__ x,
+                                                               float* __restrict__ dw_ih, float* __restrict__ db, int LU,
+                                                               int H, int in_dim) {
+  const long long r = blockIdx.x;
+  const int lane = threadIdx.x;
+  float accw[MAXKT];
+#pragma unroll
+  for (int d = 0; d < MAXKT; ++d) accw[d] = 0.f;
+  float accb = 0.f;
+  for (int tu = lane; tu < LU; tu += 64) {
+    const float g = dgates[(long long)tu * 4 * H + r];
+    accb += g;
+#pragma unroll
+    for (int d = 0; d < MAXKT; ++d)
+      if (d < in_dim) accw[d] = fmaf(g, x[tu * in_dim + d], accw[d]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    accb += __shfl_down(accb, o);
+#pragma unroll
+    for (int d = 0; d < MAXKT; ++d) accw[d] += __shfl_down(accw[d], o);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < MAXKT; ++d)
+      if (d < in_dim) dw_ih[r * in_dim + d] = accw[d];
+    db[r] = accb;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // concat + dropout glue
 // ------------------------------------------------------------------------------------------
@@ -601,8 +632,12 @@ extern "C" int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih
   TL_REQUIRE(dgates && x && dw_ih && db, "lstm_ih_grad: null pointer");
   TL_REQUIRE(in_dim >= 1 && in_dim <= MAXKT, "lstm_ih_grad: in_dim must be 1..%d", MAXKT);
   const long long total = 4LL * H;
-  hipLaunchKernelGGL(lstm_ih_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     dgates, x, dw_ih, db, L, U, H, in_dim);
+  if (total <= 8192 && (long long)L * U >= 64)
+    hipLaunchKernelGGL(lstm_ih_grad_wave_kernel, dim3((unsigned)total), dim3(64), 0, (hipStream_t)stream, dgates, x, dw_ih,
+                       db, L * U, H, in_dim);
+  else
+    hipLaunchKernelGGL(lstm_ih_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dgates, x, dw_ih, db, L, U, H, in_dim);
   return check_launch("lstm_ih_grad");
 }
 
