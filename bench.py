@@ -201,7 +201,7 @@ def main():
                                        "tflops": round(conv_flops(eng, int(t[4]), B) / (tsum[t][1] * 1e-3) / 1e12, 2)}
                                    for t in sorted(tsum)}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the 1-GPU run only
             try:
                 cpu = cpu_baseline(model, 2, C, T, D)
             except Exception as e:      # noqa: BLE001 - the baseline leg must not kill the bench line
