@@ -85,6 +85,7 @@ SIGNATURES = {
     "tl_row_zscore": (_I, [_P, _I, _P, _P, _I, _L, _L, _L, _I, _P]),
     "tl_car": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),
     "tl_rolling_zscore": (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),
+    "tl_fft_resample": (_I, [_P, _I, _P, _I, _L, _L, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
     "tl_gauss_envelope": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_filtfilt_f64": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
     "tl_sosfilt_f64": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),

@@ -108,6 +108,103 @@ __global__ __launch_bounds__(256) void rolling_zscore_kernel(const void* __restr
   y[(long long)c * Tn + t] = out;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// FFT resampling (scipy.signal.resample as used by preprocess/signal/downsample.py:21-27): the DFT of
+// an arbitrary length n is evaluated with Bluestein's chirp-z identity on a power-of-two Stockham
+// FFT (fp64, complex interleaved, batched over channels).  Chirps, their spectra and the twiddle
+// table are coefficient data prepared by the host.
+// ------------------------------------------------------------------------------------------
+struct c64 { double re, im; };
+__device__ __forceinline__ c64 cmul(c64 a, c64 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ c64 cconj(c64 a) { return {a.re, -a.im}; }
+
+// one radix-2 Stockham pass: out[j0] = a + w b, out[j0 + ns] = a - w b
+__global__ __launch_bounds__(256) void fft_pass_kernel(const c64* __restrict__ in, c64* __restrict__ out,
+                                                       const c64* __restrict__ tw, long long total_half, int m2, int ns,
+                                                       int inverse) {
+  const int half = m2 >> 1;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total_half; i += (long long)gridDim.x * blockDim.x) {
+    const long long c = i / half;
+    const int j = (int)(i % half);
+    const int k = j & (ns - 1);
+    c64 w = tw[(long long)k * (half / ns)];                 // exp(-2 pi i k / (2 ns))
+    if (inverse) w.im = -w.im;
+    const c64 a = in[c * m2 + j];
+    const c64 b = cmul(in[c * m2 + j + half], w);
+    const int j0 = ((j - k) << 1) + k;
+    out[c * m2 + j0] = {a.re + b.re, a.im + b.im};
+    out[c * m2 + j0 + ns] = {a.re - b.re, a.im - b.im};
+  }
+}
+
+// a[c][j] = x[c][j] * conj(w[j]) for j < n, 0 up to m2
+template <typename T>
+__global__ __launch_bounds__(256) void rs_prep_kernel(const void* __restrict__ x, const c64* __restrict__ w, c64* __restrict__ a,
+                                                      long long total, int n, int m2) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % m2);
+    const long long c = i / m2;
+    c64 v = {0.0, 0.0};
+    if (j < n) {
+      const double xv = ldd<T>(x, c * n + j);
+      v = {xv * w[j].re, -xv * w[j].im};
+    }
+    a[i] = v;
+  }
+}
+// A[c][m] *= Bf[m]
+__global__ __launch_bounds__(256) void rs_cmul_kernel(c64* __restrict__ A, const c64* __restrict__ Bf, long long total, int m2) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    A[i] = cmul(A[i], Bf[i % m2]);
+}
+// Spectrum hand-over.  c1 (c, m2a) holds the chirp-convolved forward transform (un-normalised inverse
+// FFT, scale 1/m2a folded in here): X[k] = conj(w1[k]) c1[k] / m2a, k < nx.  Build the half-spectrum Y
+// of scipy.signal.resample (copy up to the smaller Nyquist; double / halve the shared Nyquist bin),
+// extend it Hermitian-ly as irfft does, and emit a2[k] = conj(Yc[k]) conj(w2[k]) padded to m2b.
+__global__ __launch_bounds__(256) void rs_spec_kernel(const c64* __restrict__ c1, const c64* __restrict__ w1,
+                                                      const c64* __restrict__ w2, c64* __restrict__ a2, long long total,
+                                                      int nx, int num, int m2a, int m2b) {
+  const int N = nx < num ? nx : num;
+  const int nyq = N / 2 + 1;
+  const double inv = 1.0 / (double)m2a;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % m2b);
+    const long long c = i / m2b;
+    c64 v = {0.0, 0.0};
+    if (k < num) {
+      const int kk = (k <= num / 2) ? k : num - k;          // index into the half spectrum Y
+      c64 y = {0.0, 0.0};
+      if (kk < nyq) {
+        const c64 cx = c1[c * m2a + kk];
+        y = cmul(cconj(w1[kk]), cx);
+        y.re *= inv;
+        y.im *= inv;
+        if (N % 2 == 0 && kk == N / 2) {
+          const double f = (num < nx) ? 2.0 : ((nx < num) ? 0.5 : 1.0);
+          y.re *= f;
+          y.im *= f;
+        }
+      }
+      if (kk == 0 || (num % 2 == 0 && kk == num / 2)) y.im = 0.0;      // C2R ignores these imaginary parts
+      const c64 yc = (k <= num / 2) ? y : cconj(y);
+      v = cmul(cconj(yc), cconj(w2[k]));
+    }
+    a2[i] = v;
+  }
+}
+// y[c][m] = Re(conj(w2[m]) c2[m]) / (m2b * nx)      (ifft = conj(DFT(conj .))/num, times num/nx)
+template <typename T>
+__global__ __launch_bounds__(256) void rs_out_kernel(const c64* __restrict__ c2, const c64* __restrict__ w2, T* __restrict__ y,
+                                                     long long total, int num, int m2b, double scale) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i % num);
+    const long long c = i / num;
+    const c64 d = cmul(cconj(w2[m]), c2[c * m2b + m]);
+    y[i] = (T)(d.re * scale);
+  }
+}
+
 static inline unsigned sgrid(long long total) {
   long long g = (total + 255) / 256;
   if (g < 1) g = 1;
@@ -156,4 +253,60 @@ extern "C" int tl_rolling_zscore(const void* x, int is_f64, double* y, int C, in
   else
     hipLaunchKernelGGL((rolling_zscore_kernel<float>), grid, dim3(256), lds, st, x, y, (long long)T, window, zero_nans);
   return check_launch("rolling_zscore");
+}
+
+// in-place power-of-two FFT of `buf` (C, m2) complex128 with scratch `tmp`; result ends in `buf`
+static int fft_pow2(tl::c64* buf, tl::c64* tmp, const tl::c64* tw, int C, int m2, int inverse, hipStream_t st) {
+  tl::c64* in = buf;
+  tl::c64* out = tmp;
+  const long long total_half = (long long)C * (m2 / 2);
+  for (int ns = 1; ns < m2; ns <<= 1) {
+    hipLaunchKernelGGL(tl::fft_pass_kernel, dim3(sgrid(total_half)), dim3(256), 0, st, in, out, tw, total_half, m2, ns, inverse);
+    tl::c64* t = in; in = out; out = t;
+  }
+  if (in != buf && hipMemcpyAsync(buf, in, sizeof(tl::c64) * (size_t)C * m2, hipMemcpyDeviceToDevice, st) != hipSuccess)
+  {
+    tl::set_error("fft_pow2: device copy failed");
+    return -1;
+  }
+  return check_launch("fft_pow2");
+}
+
+extern "C" int tl_fft_resample(const void* x, int is_f64, void* y, int C, int64_t nx, int64_t num, const double* w1,
+                               const double* bf1, const double* tw1, int m2a, const double* w2, const double* bf2,
+                               const double* tw2, int m2b, double* work, void* stream) {
+  TL_REQUIRE(x && y && w1 && bf1 && tw1 && w2 && bf2 && tw2 && work, "fft_resample: null pointer");
+  TL_REQUIRE(C > 0 && nx > 1 && num > 0, "fft_resample: bad sizes");
+  TL_REQUIRE(m2a >= 2 * nx - 1 && (m2a & (m2a - 1)) == 0 && m2b >= 2 * num - 1 && (m2b & (m2b - 1)) == 0,
+             "fft_resample: m2a/m2b must be powers of two >= 2n-1");
+  hipStream_t st = (hipStream_t)stream;
+  const int mmax = m2a > m2b ? m2a : m2b;
+  tl::c64* A = reinterpret_cast<tl::c64*>(work);                 // (C, mmax)
+  tl::c64* T = A + (size_t)C * mmax;                              // scratch (C, mmax)
+  tl::c64* A2 = T + (size_t)C * mmax;                             // (C, m2b)
+  const tl::c64* W1 = reinterpret_cast<const tl::c64*>(w1);
+  const tl::c64* W2 = reinterpret_cast<const tl::c64*>(w2);
+  const long long ta = (long long)C * m2a, tb = (long long)C * m2b;
+  if (is_f64)
+    hipLaunchKernelGGL((tl::rs_prep_kernel<double>), dim3(sgrid(ta)), dim3(256), 0, st, x, W1, A, ta, (int)nx, m2a);
+  else
+    hipLaunchKernelGGL((tl::rs_prep_kernel<float>), dim3(sgrid(ta)), dim3(256), 0, st, x, W1, A, ta, (int)nx, m2a);
+  int rc = fft_pow2(A, T, reinterpret_cast<const tl::c64*>(tw1), C, m2a, 0, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(tl::rs_cmul_kernel, dim3(sgrid(ta)), dim3(256), 0, st, A, reinterpret_cast<const tl::c64*>(bf1), ta, m2a);
+  rc = fft_pow2(A, T, reinterpret_cast<const tl::c64*>(tw1), C, m2a, 1, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(tl::rs_spec_kernel, dim3(sgrid(tb)), dim3(256), 0, st, A, W1, W2, A2, tb, (int)nx, (int)num, m2a, m2b);
+  rc = fft_pow2(A2, T, reinterpret_cast<const tl::c64*>(tw2), C, m2b, 0, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(tl::rs_cmul_kernel, dim3(sgrid(tb)), dim3(256), 0, st, A2, reinterpret_cast<const tl::c64*>(bf2), tb, m2b);
+  rc = fft_pow2(A2, T, reinterpret_cast<const tl::c64*>(tw2), C, m2b, 1, st);
+  if (rc) return rc;
+  const long long to = (long long)C * num;
+  const double scale = 1.0 / ((double)m2b * (double)nx);
+  if (is_f64)
+    hipLaunchKernelGGL((tl::rs_out_kernel<double>), dim3(sgrid(to)), dim3(256), 0, st, A2, W2, (double*)y, to, (int)num, m2b, scale);
+  else
+    hipLaunchKernelGGL((tl::rs_out_kernel<float>), dim3(sgrid(to)), dim3(256), 0, st, A2, W2, (float*)y, to, (int)num, m2b, scale);
+  return check_launch("fft_resample");
 }

@@ -213,6 +213,14 @@ int tl_car(const void* x, int is_f64, const int32_t* include, void* y, int C, in
 /* pandas rolling(window, min_periods=1) z-score, sample std (rolling_zscore.py:36-49); y float64   */
 int tl_rolling_zscore(const void* x, int is_f64, double* y, int C, int64_t T, int window, int zero_nans, void* stream);
 
+/* FFT resampling = scipy.signal.resample(x, num, axis=1) (downsample.py:21-27): Bluestein chirp-z on
+ * power-of-two FFTs.  Host-prepared coefficient arrays (complex128 interleaved): w1 (nx) / w2 (num)
+ * chirps exp(i pi m^2 / n); bf1 (m2a) / bf2 (m2b) spectra of the chirp filters; tw1 (m2a/2) / tw2
+ * (m2b/2) twiddles exp(-2 pi i k / m2).  work: C * (2*max(m2a,m2b) + m2b) complex128.  y has x's dtype. */
+int tl_fft_resample(const void* x, int is_f64, void* y, int C, int64_t nx, int64_t num, const double* w1,
+                    const double* bf1, const double* tw1, int m2a, const double* w2, const double* bf2,
+                    const double* tw2, int m2b, double* work, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,3 +283,31 @@ def rolling_zscore(data: np.ndarray, window_size: int, preserve_nans: bool = Tru
     if not preserve_nans:
         out[np.isnan(out)] = 0
     return out
+
+
+def resample_fft(x: np.ndarray, num: int) -> np.ndarray:
+    """``scipy.signal.resample(x, num, axis=1)`` for real input, restated with numpy.fft: rfft, copy
+    the bins up to the smaller Nyquist (doubling / halving a shared even-length Nyquist bin), irfft,
+    scale by num/N.  (preprocess/signal/downsample.py:25 calls it.)  Like scipy.fft, float32 input
+    is transformed in single precision."""
+    x = np.asarray(x)
+    nx = x.shape[1]
+    dt = np.complex64 if x.dtype == np.float32 else np.complex128
+    X = np.fft.rfft(x.astype(np.float64), axis=1)
+    Y = np.zeros((x.shape[0], num // 2 + 1), dtype=np.complex128)
+    N = min(num, nx)
+    nyq = N // 2 + 1
+    Y[:, :nyq] = X[:, :nyq]
+    if N % 2 == 0:
+        if num < nx:
+            Y[:, N // 2] *= 2.0
+        elif nx < num:
+            Y[:, N // 2] *= 0.5
+    y = np.fft.irfft(Y, num, axis=1) * (float(num) / float(nx))
+    return y.astype(np.float32) if dt == np.complex64 else y
+
+
+def downsample(data: np.ndarray, signal_freq: float, downsample_freq: float = 400):
+    """preprocess/signal/downsample.py:21-27: returns (resampled data, new signal_freq)."""
+    n_samples = int(data.shape[1] * (downsample_freq / signal_freq))
+    return resample_fft(data, n_samples), downsample_freq

@@ -432,3 +432,23 @@ def test_cnn_classifier_hip_forward_matches_module_graph(dev):
         ref = clf.classifier(clf.feature_extractor(x.unsqueeze(1).permute(0, 1, 3, 2)))
         assert hip.shape == ref.shape == (B, 3)
         assert float((hip - ref.detach()).abs().max()) < 1e-5
+
+
+def test_downsample_matches_reference_golden(dev):
+    from decode_tonal_langauge_amd.preprocess.signal import downsample
+    g = np.load(os.path.join(GOLD, "g7_steps.npz"))
+    x = np.random.default_rng(7).standard_normal((5, 900)) * 3.0 + 1.5
+    prm = Namespace(signal_freq=1000, downsample_freq=400)
+    out = downsample.run(x, prm)
+    assert prm.signal_freq == 400 and out.shape == (5, 360) and out.dtype == np.float64
+    assert rel(out, g["downsample"]) < 1e-11
+    o32 = downsample.run(x.astype(np.float32), Namespace(signal_freq=1000))
+    assert o32.dtype == np.float32 and rel(o32, g["downsample_f32"]) < 1e-5
+    up = downsample.run(x[:, :601], Namespace(signal_freq=300, downsample_freq=400))
+    assert up.shape == g["downsample_up"].shape and rel(up, g["downsample_up"]) < 1e-11
+    # a long recording with an awkward (prime) length, device resident: the resampled band-limited
+    # signal interpolates the original (round trip up then down returns the input)
+    t = torch.randn(3, 10007, device=dev, dtype=torch.float64)
+    up2 = downsample.resample(t, 20014)
+    back = downsample.resample(up2, 10007)
+    assert float((back - t).abs().max()) < 1e-9

@@ -178,3 +178,7 @@ def test_g7_other_signal_steps():
     xn = x.copy()
     xn[2, 100:130] = np.nan
     assert rel(sg.rolling_zscore(xn, 50, preserve_nans=False), g["rolling_nan"]) < 1e-12
+    ds, fs = sg.downsample(x, 1000, 400)
+    assert fs == 400 and rel(ds, g["downsample"]) < 1e-12
+    assert rel(sg.downsample(x.astype(np.float32), 1000)[0], g["downsample_f32"]) < 1e-5
+    assert rel(sg.downsample(x[:, :601], 300, 400)[0], g["downsample_up"]) < 1e-12
