@@ -143,7 +143,7 @@ def main():
     model.train()
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,7 +160,7 @@ def main():
     tsum = eng.timer_summary() if getattr(eng, "timers", None) is not None else {}
     if hasattr(eng, "enable_timers"):
         eng.enable_timers(False)
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         parallel.all_reduce_(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -219,7 +219,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -91,6 +91,7 @@ class SynthesisTrainer:
         self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._grads = None
         self.rank, self.world = parallel.world()
+        self.dp = parallel.active()
 
     # ------------------------------------------------------------------ helpers
     def _labels(self, inputs_tone, inputs_syllable) -> torch.Tensor:
@@ -130,10 +131,10 @@ class SynthesisTrainer:
         dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)
         check(self.lib.tl_l1_mcd(ptr(out), ptr(targets), ptr(dout), ptr(self._stats), B, D, eng.ldd, 1, 1.0,
                                  torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
-        gather = parallel.gather_lowrank if self.world > 1 else None
+        gather = parallel.gather_lowrank if self.dp else None
         eng.backward(prm, dout, self._grads, gather_whh=gather)
         scale = 1.0
-        if self.world > 1:
+        if self.dp:
             skip = getattr(eng, "lowrank_param", None)
             parallel.allreduce_bucketed([g for k, g in self._grads.items() if k != skip])
             scale = 1.0 / self.world
@@ -147,7 +148,7 @@ class SynthesisTrainer:
         loss = self.criterion(outputs, tgt)
         loss.backward()
         scale = 1.0
-        if self.world > 1:
+        if self.dp:
             parallel.allreduce_bucketed([p.grad for p in self.model.parameters() if p.grad is not None])
             scale = 1.0 / self.world
         self.optimizer.step(grad_scale=scale)
@@ -186,7 +187,7 @@ class SynthesisTrainer:
                 self.train_step(inputs_non, inputs_syllable, inputs_tone, targets)
                 nb += 1
             stats = self._stats.clone()
-            if self.world > 1:
+            if self.dp:
                 parallel.all_reduce_(stats)
                 stats /= self.world
             s = stats.tolist()                                  # the one host sync of the epoch

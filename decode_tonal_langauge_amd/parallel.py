@@ -23,7 +23,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    forced = os.environ.get("TONAL_DP_FORCE") == "1"       # single-rank rehearsal of the exchange step
+    if (world > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -38,6 +39,14 @@ def world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def active() -> bool:
+    """True when the gradient exchange must run: a process group with more than one rank, or a
+    single-rank group under ``TONAL_DP_FORCE=1`` (drives the real RCCL calls on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("TONAL_DP_FORCE") == "1"
 
 
 def _staged() -> bool:
@@ -79,7 +88,7 @@ def shard_rows(n: int, rank: int, nranks: int) -> slice:
 def allreduce_bucketed(tensors: List[torch.Tensor], bucket_bytes: int = 64 << 20) -> None:
     """Sum-all-reduce ``tensors`` in place, coalesced into flat buckets (few, large messages:
     xGMI rings are per-link bound)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not active():
         return
     bucket: List[torch.Tensor] = []
     size = 0
@@ -116,7 +125,7 @@ def allreduce_bucketed(tensors: List[torch.Tensor], bucket_bytes: int = 64 << 20
 def gather_lowrank(dg: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather the factors of the W_hh gradient: dg (k, 4H), h (k, H) with a per-rank k.
     Ranks pad to the common maximum with zero rows (which add nothing to dg^T . h)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not active():
         return dg, h
     n = dist.get_world_size()
     k = torch.tensor([dg.shape[0]], dtype=torch.int64, device="cpu" if _staged() else dg.device)

@@ -76,3 +76,50 @@ def test_two_rank_training_equals_single_process():
     # mean of the two local losses equals the global loss (equal shards)
     loss_dp = 0.5 * (float(res[0][2][0]) + float(res[1][2][0]))
     assert abs(loss_dp - float(ref_stats[0])) < 1e-3 * abs(float(ref_stats[0]))
+
+
+def _rccl_worker(port, q):
+    """One rank on the RCCL ("nccl") backend with the exchange step forced on: the same
+    all_reduce / all_gather_into_tensor / barrier calls the multi-GPU run issues, on device tensors."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      TONAL_DP_FORCE="1")
+    from decode_tonal_langauge_amd import parallel
+    import torch.distributed as dist
+    os.environ["WORLD_SIZE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    assert parallel.active() and not parallel._staged()
+    dev = torch.device("cuda:0")
+    model, tr, batches = _build(dev)
+    assert tr.dp and tr.world == 1
+    model.train()
+    for b in batches:
+        tr.train_step(*b)
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put(({k: v.detach().cpu().numpy() for k, v in model.named_parameters()}, tr._stats.cpu().numpy()))
+    dist.destroy_process_group()
+
+
+def test_exchange_step_over_rccl_single_rank():
+    dev = torch.device("cuda:0")
+    model, tr, batches = _build(dev)
+    model.train()
+    for b in batches:
+        tr.train_step(*b)
+    ref = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(30500 + (os.getpid() % 1000), q))
+    p.start()
+    params, stats = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    torch.manual_seed(0)
+    from decode_tonal_langauge_amd.models import SynthesisModelCNN
+    init = {k: v.detach().clone() for k, v in SynthesisModelCNN(80, 8, 100, dropout=0.0).named_parameters()}
+    for k in ref:
+        upd = (ref[k] - init[k]).double()
+        err = float((torch.from_numpy(params[k]).double() - ref[k].double()).norm() / max(float(upd.norm()), 1e-30))
+        assert err < 2e-2, (k, err)
+    assert abs(float(stats[0]) - float(tr._stats[0])) < 1e-3 * abs(float(tr._stats[0]))
