@@ -15,6 +15,7 @@ activation matrix - no im2col copy exists anywhere.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, List, Optional
 
@@ -88,6 +89,9 @@ class CnnEngine:
         self.ldd = _r4(output_dim)
         self.lowrank_param = "label_lstm.weight_hh_l0"   # reduced via gathered factors under DP
         self.timers = None
+        # Winograd F(2,3) kernels for the pooled 3-tap stages (2/3 of the MFMA work of the direct
+        # form); TONAL_WINO=0 selects the direct kernels (kept for A/B runs and as the parity partner)
+        self.wino = os.environ.get("TONAL_WINO", "1") != "0"
         self._B = None
         self.generation = 0
         self._saved_generation = -1
@@ -163,7 +167,7 @@ class CnnEngine:
         check(self.lib.tl_permute_reduce(src.data_ptr() + 4 * src_off, dst.data_ptr(), d, s, l, nz, zs, ptr(bias),
                                          self._stream()), "tl_permute_reduce")
 
-    def _nt(self, tag=None, **kw):
+    def _nt(self, tag=None, fn="tl_gemm_nt_window", **kw):
         p = NtParams()
         p.splitk, p.bm, p.J, p.Tp, p.slope = 1, 128, 1, 1, 0.0
         for k, v in kw.items():
@@ -171,17 +175,17 @@ class CnnEngine:
         # bm = 256 (8-wave workgroups) exists but measured slower than two independent 4-wave
         # workgroups per CU (conv2 fwd 127 vs 129, dgrad 114 vs 124 TFLOP/s): not selected.
         ev = self._tick(tag)
-        check(self.lib.tl_gemm_nt_window(C.byref(p), self._stream()), "tl_gemm_nt_window")
+        check(getattr(self.lib, fn)(C.byref(p), self._stream()), fn)
         if ev:
             ev[1].record()
 
-    def _tn(self, tag=None, **kw):
+    def _tn(self, tag=None, fn="tl_gemm_tn_window", **kw):
         p = TnParams()
         p.splitk, p.J, p.Tp, p.Tvalid = 1, 1, 1, 1
         for k, v in kw.items():
             setattr(p, k, v)
         ev = self._tick(tag)
-        check(self.lib.tl_gemm_tn_window(C.byref(p), self._stream()), "tl_gemm_tn_window")
+        check(getattr(self.lib, fn)(C.byref(p), self._stream()), fn)
         if ev:
             ev[1].record()
 
@@ -204,13 +208,27 @@ class CnnEngine:
         return dst
 
 
+    def _use_wino(self, st) -> bool:
+        return (self.wino and st.k == 3 and st.pool and st.cin % 32 == 0 and st.cout % 32 == 0
+                and st.tp_in % 2 == 0)
+
+    def _pack_wino(self, w, forward: bool):
+        """torch (O, I, 3, 1) -> the 4 Winograd taps: forward [4][O][I] or input-gradient [4][I][O]."""
+        O, I = w.shape[0], w.shape[1]
+        dst = torch.empty(4, O, I, dtype=torch.float32, device=w.device) if forward else \
+            torch.empty(4, I, O, dtype=torch.float32, device=w.device)
+        check(self.lib.tl_wino_weights(ptr(w), ptr(dst) if forward else None, None if forward else ptr(dst),
+                                       O, I, I, O, self._stream()), "tl_wino_weights")
+        return dst
+
     # ------------------------------------------------------------------ one ecog stage (2..5)
     STAGE_NAMES = {2: "ecog_conv_block.3", 3: "ecog_conv_block.6", 4: "ecog_conv_block.9", 5: "ecog_conv_block.12"}
 
     def stage_forward(self, st: _Stage, w: torch.Tensor, bia: torch.Tensor) -> None:
         """conv (k,1) + bias + LeakyReLU (+ max-pool, arg-max bits): P[idx-1] -> P[idx]."""
         S = self.S
-        wp = self._pack_conv(w, st.cin, False)
+        wino = self._use_wino(st)
+        wp = self._pack_wino(w, True) if wino else self._pack_conv(w, st.cin, False)
         src = self.P[st.idx - 1]
         kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(self.P[st.idx]), M=S * st.tp_in,
                   A_rows=src.shape[0], N=st.cout, K=st.cin, lda=src.shape[1], ldb=st.cin,
@@ -220,7 +238,7 @@ class CnnEngine:
             kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
         else:
             kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
-        self._nt(tag=f"conv{st.idx}_fwd", **kw)
+        self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino_nt" if wino else "tl_gemm_nt_window", **kw)
 
     def _colsum(self, Gm, rows, ncols, ld, Tp, Tvalid, dst):
         nc4 = _r4(ncols)                       # pad columns of G are zero by construction
@@ -239,6 +257,24 @@ class CnnEngine:
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
         nd = _r4(st.cout)
+        if self._use_wino(st):
+            tiles = ((st.cin + 127) // 128) * ((nd + 63) // 64)
+            sk = self._splitk(tiles, (rows_in + 31) // 32, 1024)
+            slab = torch.empty(sk, 4 * st.cin, ldg, **f32)
+            self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino_tn", A=ptr(Xin), B=ptr(Gs), slab=ptr(slab),
+                     Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=st.cin,
+                     ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk, slab_stride=4 * st.cin * ldg,
+                     loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
+            if sk > 1:
+                red = torch.empty(4 * st.cin, ldg, **f32)
+                n = 4 * st.cin * ldg
+                self._permute(slab, red, (1, 1, 1, n), (0, 0, 0, 1), nz=sk, zs=n)
+            else:
+                red = slab
+            check(self.lib.tl_wino_wgrad_finalize(ptr(red), ptr(gw), st.cout, st.cin, ldg, self._stream()),
+                  "tl_wino_wgrad_finalize")
+            self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
+            return
         if st.k == 3:      # all-taps kernel: 128 x 64 tiles
             tiles = ((st.cin + 127) // 128) * ((nd + 63) // 64)
         else:
@@ -271,7 +307,8 @@ class CnnEngine:
         Gs = self.G[st.idx]
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
-        wd = self._pack_conv(w, st.cin, True)           # [J][cin][r4(cout)]
+        wino = self._use_wino(st)
+        wd = self._pack_wino(w, False) if wino else self._pack_conv(w, st.cin, True)   # [J or 4][cin][r4(cout)]
         kd = wd.shape[2]
         kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=ptr(self.G[st.idx - 1]), M=rows_in, A_rows=Gs.shape[0],
                   N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k, row_shift=-(st.k - 1),
@@ -281,7 +318,7 @@ class CnnEngine:
                       Tvalid_in=2 * st.tout)
         else:
             kw.update(loader=LOAD_DIRECT)
-        self._nt(tag=f"conv{st.idx}_dgrad", **kw)
+        self._nt(tag=f"conv{st.idx}_dgrad", fn="tl_conv3_wino_nt" if wino else "tl_gemm_nt_window", **kw)
 
     # ------------------------------------------------------------------ forward
     def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,

@@ -1,0 +1,601 @@
+// Winograd F(2,3) forms of the 3-tap (k,1) convolutions (conv2 / conv3 of the ECoG stack,
+// models/synthesis_models.py:91-97) on the fp32 matrix pipe of gfx950.
+//
+// The max-pool (2,1) that follows each of these convolutions groups the conv rows in pairs
+// (2P, 2P+1); a pair needs the four input rows d0..d3 = 2P .. 2P+3 and
+//     y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3,   m_i = (B^T d)_i . (G g)_i
+//     B^T d = [d0 - d2, d1 + d2, d2 - d1, d1 - d3],  G g = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2]
+// i.e. 4 channel contractions per pair instead of 6: 2/3 of the MFMA work of the direct form for
+// the forward pass, the input gradient (same algorithm on dZ with flipped, transposed taps) and -
+// by the transposition principle - the weight gradient:
+//     dg = G^T [ (A dy) (x) (B^T d) ],   A dy = [dy0, dy0 + dy1, dy0 - dy1, -dy1]
+// All transform constants are 0, +-1, 1/2: exact in fp32; only the summation order differs from
+// the direct convolution.
+//
+// Layout is that of tonal_gemm.hip (rows = (sequence, time), channels last).  LDS keeps the staged
+// input rows in two planes (even rows E, odd rows O, 144-byte row stride), so the four rows of a
+// pair are E[p], O[p], E[p+1], O[p+1] and a fragment of B^T d is two conflict-free ds_read_b128
+// plus one vector add.
+#include "tonal_common.h"
+#include <type_traits>
+
+namespace tl {
+
+enum { W_LOAD_DIRECT = 0, W_LOAD_UNPOOL = 1 };
+enum { W_EPI_POOL = 2, W_EPI_MASK = 3 };        // numbering of tl_nt_params.epilogue
+
+constexpr int W_BP = 128;            // output pairs per workgroup (256 conv rows)
+constexpr int W_BN = 128;            // output columns per workgroup
+constexpr int W_BK = 32;             // K depth of one stage
+constexpr int W_LD = W_BK + 4;       // 36 floats: conflict-free ds_read_b128
+constexpr int W_PR = W_BP + 1;       // staged pairs per plane
+constexpr int W_NTHR = 512;          // 8 waves: 4 (pairs) x 2 (columns), wave tile 32 pairs x 64 columns
+
+// ------------------------------------------------------------------------------------------
+// weights: torch (O, I, 3, 1) -> forward taps [4][O][ld_f] and input-gradient taps [4][I][ld_d]
+// (flipped and transposed: V_j' = W_{2-j'}^T)
+// ------------------------------------------------------------------------------------------
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ dgr,
+                                    int O, int I, int ld_f, int ld_d) {
+  const long long n_f = (long long)O * ld_f, n_d = (long long)I * ld_d;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (fwd != nullptr && idx < n_f) {
+    const int o = (int)(idx / ld_f), i = (int)(idx % ld_f);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (i < I) {
+      const float* s = w + ((long long)o * I + i) * 3;
+      g0 = s[0], g1 = s[1], g2 = s[2];
+    }
+    fwd[idx] = g0;
+    fwd[n_f + idx] = 0.5f * ((g0 + g2) + g1);
+    fwd[2 * n_f + idx] = 0.5f * ((g0 + g2) - g1);
+    fwd[3 * n_f + idx] = g2;
+  }
+  if (dgr != nullptr && idx < n_d) {
+    const int i = (int)(idx / ld_d), o = (int)(idx % ld_d);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (o < O) {
+      const float* s = w + ((long long)o * I + i) * 3;
+      g0 = s[2], g1 = s[1], g2 = s[0];          // flipped taps
+    }
+    dgr[idx] = g0;
+    dgr[n_d + idx] = 0.5f * ((g0 + g2) + g1);
+    dgr[2 * n_d + idx] = 0.5f * ((g0 + g2) - g1);
+    dgr[3 * n_d + idx] = g2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT form: forward (DIRECT loader, POOL epilogue) and input gradient (UNPOOL loader, MASK epilogue)
+// A K-step is (32-deep channel chunk, transform index i); step i accumulates into m_i.
+// Software pipeline as in nt_window_kernel: register-staged global loads (B two steps ahead, the
+// A chunk one chunk ahead), LDS double buffering, fragment sets F0/F1 with the last k-group of a
+// step carried across the barrier.
+// ------------------------------------------------------------------------------------------
+template <int LOADER, int EPI>
+__global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p) {
+  constexpr int PLANE = W_PR * W_LD;
+  constexpr int A_F4 = (LOADER == W_LOAD_DIRECT) ? ((2 * W_PR * 8 + W_NTHR - 1) / W_NTHR)
+                                                 : ((W_PR * 8 + W_NTHR - 1) / W_NTHR);
+  constexpr int B_F4 = W_BN * 8 / W_NTHR;      // 2
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * PLANE + 2 * W_BN * W_LD];
+  float* As = lds;                               // [2 buffers][2 planes][W_PR][W_LD]
+  float* Bs = lds + 2 * 2 * PLANE;               // [2][W_BN][W_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int ntn = (p.N + W_BN - 1) / W_BN;
+  const long long ntm = (p.M + 2 * W_BP - 1) / (2 * W_BP);
+  const long long nwg = ntm * ntn;
+  long long bid = blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const long long tm = bid / ntn;
+  const int tn = (int)(bid % ntn);
+  const long long R0 = tm * (2 * W_BP);          // first conv row of the tile (even)
+  const int n0 = tn * W_BN;
+  const int nchunks = p.K / W_BK;                // host-checked: K % 32 == 0
+  const int nsteps = nchunks * 4;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 ra[A_F4];
+  uint32_t rbits[A_F4];
+  f32x4 rbP[B_F4], rbQ[B_F4];
+  (void)rbits;
+
+  const long long Abase = R0 + p.row_shift;      // first staged input row (even)
+  const float* aptr[A_F4];
+  const uint32_t* abptr[A_F4];
+  bool aok[A_F4];
+  (void)abptr;
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    const int idx = tid + i * W_NTHR;
+    const int r = idx >> 3, c4 = idx & 7;
+    if constexpr (LOADER == W_LOAD_DIRECT) {
+      const long long row = Abase + r;
+      aok[i] = r < 2 * W_PR && row >= 0 && row < p.A_rows;
+      aptr[i] = p.A + (aok[i] ? row : 0) * (long long)p.lda + c4 * 4;
+      abptr[i] = nullptr;
+    } else {
+      const long long prow = (Abase >> 1) + r;
+      aok[i] = r < W_PR && prow >= 0 && prow < p.A_rows && (int)((2 * prow) % p.Tp) < p.Tvalid_in;
+      aptr[i] = p.A + (aok[i] ? prow : 0) * (long long)p.lda + c4 * 4;
+      abptr[i] = p.abits + (aok[i] ? prow : 0) * (long long)p.ld_abits;
+    }
+  }
+  const float* bptr[B_F4];
+  bool bok[B_F4];
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) {
+    const int idx = tid + i * W_NTHR;
+    const int r = idx >> 3, c4 = idx & 7;
+    bok[i] = (n0 + r) < p.N;
+    bptr[i] = p.Bw + (long long)(bok[i] ? n0 + r : 0) * p.ldb + c4 * 4;
+  }
+  const long long tap_stride = (long long)p.N * p.ldb;
+
+  auto load_a = [&](int chunk) {
+    const int kc = chunk * W_BK;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      uint32_t nib = 0;
+      if (aok[i]) {
+        v = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
+        if constexpr (LOADER == W_LOAD_UNPOOL) nib = abptr[i][kc >> 5];
+      }
+      ra[i] = v;
+      if constexpr (LOADER == W_LOAD_UNPOOL) rbits[i] = nib;
+    }
+  };
+  auto store_a = [&](int buf) {
+    float* dst = As + buf * 2 * PLANE;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + i * W_NTHR;
+      const int r = idx >> 3, c4 = idx & 7;
+      if constexpr (LOADER == W_LOAD_DIRECT) {
+        if (r < 2 * W_PR) *reinterpret_cast<f32x4*>(dst + (r & 1) * PLANE + (r >> 1) * W_LD + c4 * 4) = ra[i];
+      } else {
+        if (r < W_PR) {
+          f32x4 e, o;
+          const uint32_t nibv = rbits[i] >> ((c4 * 4) & 31);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool odd = (nibv >> q) & 1u;
+            e[q] = odd ? 0.f : ra[i][q];
+            o[q] = odd ? ra[i][q] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(dst + r * W_LD + c4 * 4) = e;
+          *reinterpret_cast<f32x4*>(dst + PLANE + r * W_LD + c4 * 4) = o;
+        }
+      }
+    }
+  };
+  auto load_b = [&](f32x4 (&rb)[B_F4], int step) {
+    const long long off = (long long)(step & 3) * tap_stride + (step >> 2) * W_BK;
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (bok[i]) v = *reinterpret_cast<const f32x4*>(bptr[i] + off);
+      rb[i] = v;
+    }
+  };
+  auto store_b = [&](const f32x4 (&rb)[B_F4], int buf) {
+    float* dst = Bs + buf * W_BN * W_LD;
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int idx = tid + i * W_NTHR;
+      const int r = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<f32x4*>(dst + r * W_LD + c4 * 4) = rb[i];
+    }
+  };
+
+  // fragment sets: x, y are the two staged rows whose sum / difference is (B^T d)_i
+  f32x4 fx0, fy0, fb0[2], fx1, fy1, fb1[2];
+  const int a_lane = (wm * 32 + lr) * W_LD + lh * 4;
+  const int b_lane = (wn * 64 + lr) * W_LD + lh * 4;
+  auto load_frag = [&](auto I, f32x4& fx, f32x4& fy, f32x4 (&fb)[2], int abuf, int bbuf, int kk) {
+    constexpr int i = decltype(I)::value;
+    // i = 0: E[p] - E[p+1]   i = 1: O[p] + E[p+1]   i = 2: E[p+1] - O[p]   i = 3: O[p] - O[p+1]
+    constexpr int xo = (i == 0) ? 0 : ((i == 2) ? W_LD : PLANE);
+    constexpr int yo = (i == 0 || i == 1) ? W_LD : ((i == 2) ? PLANE : PLANE + W_LD);
+    const float* a_s = As + abuf * 2 * PLANE + a_lane + kk * 8;
+    const float* b_s = Bs + bbuf * W_BN * W_LD + b_lane + kk * 8;
+    fx = *reinterpret_cast<const f32x4*>(a_s + xo);
+    fy = *reinterpret_cast<const f32x4*>(a_s + yo);
+    fb[0] = *reinterpret_cast<const f32x4*>(b_s);
+    fb[1] = *reinterpret_cast<const f32x4*>(b_s + 32 * W_LD);
+  };
+  auto mfma_group = [&](auto I, const f32x4& fx, const f32x4& fy, const f32x4 (&fb)[2]) {
+    constexpr int i = decltype(I)::value;
+    const f32x4 a = (i == 1) ? (fx + fy) : (fx - fy);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], fb[0][q], acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], fb[1][q], acc[i][1], 0, 0, 0);
+    }
+  };
+
+  auto kstep = [&](auto I, int s, f32x4 (&rb_ld)[B_F4], const f32x4 (&rb_st)[B_F4]) {
+    constexpr int i = decltype(I)::value;
+    using Prev = std::integral_constant<int, (i + 3) & 3>;
+    const int chunk = s >> 2;
+    const int abuf = chunk & 1, bbuf = s & 1;
+    const bool more = s + 1 < nsteps;
+    const bool has_next_chunk = chunk + 1 < nchunks;
+    load_frag(I, fx0, fy0, fb0, abuf, bbuf, 0);
+    if (s + 2 < nsteps) load_b(rb_ld, s + 2);
+    if (i == 0 && has_next_chunk) load_a(chunk + 1);
+    if (s > 0) mfma_group(Prev{}, fx1, fy1, fb1);       // k-group 3 of the previous step (registers)
+    load_frag(I, fx1, fy1, fb1, abuf, bbuf, 1);
+    mfma_group(I, fx0, fy0, fb0);
+    load_frag(I, fx0, fy0, fb0, abuf, bbuf, 2);
+    mfma_group(I, fx1, fy1, fb1);
+    if (more) store_b(rb_st, bbuf ^ 1);
+    if (i == 3 && has_next_chunk) store_a(abuf ^ 1);
+    load_frag(I, fx1, fy1, fb1, abuf, bbuf, 3);
+    mfma_group(I, fx0, fy0, fb0);
+    __syncthreads();
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  if (nsteps > 0) {
+    load_a(0);
+    load_b(rbP, 0);
+    store_a(0);
+    store_b(rbP, 0);
+    load_b(rbQ, 1);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += 4) {
+    kstep(I0{}, s, rbP, rbQ);
+    kstep(I1{}, s + 1, rbQ, rbP);
+    kstep(I2{}, s + 2, rbP, rbQ);
+    kstep(I3{}, s + 3, rbQ, rbP);
+  }
+  if (nsteps > 0) mfma_group(I3{}, fx1, fy1, fb1);
+
+  // ---- epilogue: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3 per (pair, column) ----
+  const long long P0 = (R0 >> 1) + wm * 32 + 4 * lh;       // pair of accumulator element e = 0
+  const int t0 = (int)((2 * P0) % p.Tp);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int colbase = n0 + wn * 64 + ni * 32;
+    const int col = colbase + lr;
+    const bool colok = col < p.N;
+    if constexpr (EPI == W_EPI_POOL) {
+      const float bv = (colok && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int po = (e & 3) + 8 * (e >> 2);
+        const long long P = P0 + po;
+        const float m1 = acc[1][ni][e], m2 = acc[2][ni][e];
+        const float y0 = lrelu((acc[0][ni][e] + m1) + m2 + bv, p.slope);
+        const float y1 = lrelu((m1 - m2) - acc[3][ni][e] + bv, p.slope);
+        const bool rowok = 2 * P < p.M;
+        const bool valid = rowok && ((t0 + 2 * po) % p.Tp) < p.Tvalid;
+        const bool sel = valid && colok && (y1 > y0);
+        const float o = valid ? (sel ? y1 : y0) : 0.f;
+        if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
+        const unsigned long long m = __ballot(sel);
+        if (lr == 0 && rowok && colbase < p.N)
+          p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(m >> (32 * lh));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int po = (e & 3) + 8 * (e >> 2);
+        const long long R = 2 * (P0 + po);
+        const float m1 = acc[1][ni][e], m2 = acc[2][ni][e];
+        float v0 = (acc[0][ni][e] + m1) + m2;
+        float v1 = (m1 - m2) - acc[3][ni][e];
+        if (R < p.M && colok) {                            // M is even: the pair shares validity
+          const float a0 = p.aux[R * (long long)p.ldaux + col];
+          const float a1 = p.aux[(R + 1) * (long long)p.ldaux + col];
+          v0 = a0 > 0.f ? v0 : v0 * p.slope;
+          v1 = a1 > 0.f ? v1 : v1 * p.slope;
+          p.out[R * (long long)p.ldo + col] = v0;
+          p.out[(R + 1) * (long long)p.ldo + col] = v1;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN form (weight gradient): slab[z][i][m][n] = sum_{pairs in split z} (B^T d)_i[m] * (A dy)_i[n]
+// with d = the activation rows 2P..2P+3 (A operand, C_in) and dy = the un-pooled dZ rows 2P, 2P+1
+// (B operand, C_out): dy0 = G (bit clear), dy1 = G (bit set).  Stored transforms: i = 3 uses +dy1
+// (the finalize step flips its sign).  Tile 128 (C_in) x 64 (C_out), wave tile 64 x 32 x 4
+// transforms = 128 accumulator registers, 2 workgroups per CU; a K-step is 32 rows = 16 pairs.
+// ------------------------------------------------------------------------------------------
+constexpr int WT_BN = 64, WT_LDA = 128 + 4, WT_LDB = WT_BN + 4, WT_AR = W_BK + 2;
+
+__global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * WT_AR * WT_LDA + 2 * W_BK * WT_LDB];
+  float* As = lds;                                 // [2][34 rows][132]
+  float* Bs = lds + 2 * WT_AR * WT_LDA;            // [2][32 rows (pair r -> rows 2r: dy0, 2r+1: dy1)][68]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int ntm = (p.Mdim + 127) / 128, ntn = (p.Ndim + WT_BN - 1) / WT_BN;
+  const long long tiles = (long long)ntm * ntn;
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int z = (int)(bid / tiles);
+  const int tt = (int)(bid % tiles);
+  const int m0 = (tt / ntn) * 128, n0 = (tt % ntn) * WT_BN;
+
+  const long long ksteps_all = (p.Krows + W_BK - 1) / W_BK;
+  const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const long long nsteps = ks_end > ks_begin ? ks_end - ks_begin : 0;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  f32x4 raP[5], raQ[5], rbP, rbQ;
+  uint32_t rnP, rnQ;
+
+  const int a_lim = (int)(p.A_rows < p.Krows + 2 ? p.A_rows : p.Krows + 2);
+  const int b_lim = (int)(2 * p.B_rows < p.Krows ? 2 * p.B_rows : p.Krows);
+  const int kbase = (int)(ks_begin * W_BK);
+  // activation tile: thread t stages rows (t >> 5) + 8 i, i < 5 (row 32, 33 for i = 4): one 32-bit
+  // per-thread offset on a wave-uniform base that advances by 32 rows per K-step
+  const bool amok = (m0 + (tid & 31) * 4) < p.Mdim;
+  const int a_toff = (tid >> 5) * p.lda + (tid & 31) * 4;
+  const int a_r = tid >> 5;
+  long long a_row0 = kbase;
+  const int ncol = n0 + (tid & 15) * 4;
+  const bool bnok = ncol < p.Ndim;
+  const int dstep = W_BK % p.Tp;
+  int brow = kbase + 2 * (tid >> 4);               // conv row of this thread's pair (even)
+  const float* bptr = p.B + (long long)(brow >> 1) * p.ldb + ncol;
+  const uint32_t* bbptr = p.bbits + (long long)(brow >> 1) * p.ld_bbits + (ncol >> 5);
+  int bt = brow % p.Tp;
+  const long long b_step = (long long)(W_BK / 2) * p.ldb;
+  const long long bb_step = (long long)(W_BK / 2) * p.ld_bbits;
+
+  auto load_tiles = [&](f32x4 (&ra)[5], f32x4& rb, uint32_t& rn) {
+    const float* au = p.A + a_row0 * (long long)p.lda + m0;       // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const bool act = (i < 4) || a_r < 2;
+      if (act && amok && a_row0 + a_r + 8 * i < a_lim)
+        v = *reinterpret_cast<const f32x4*>(au + (long long)(8 * i) * p.lda + a_toff);
+      ra[i] = v;
+    }
+    a_row0 += W_BK;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    uint32_t nib = 0;
+    if (bnok && brow < b_lim && bt < p.Tvalid) {
+      v = *reinterpret_cast<const f32x4*>(bptr);
+      nib = *bbptr;
+    }
+    rb = v;
+    rn = nib;
+    bbptr += bb_step;
+    bptr += b_step;
+    brow += W_BK;
+    bt += dstep;
+    if (bt >= p.Tp) bt -= p.Tp;
+  };
+  auto store_tiles = [&](const f32x4 (&ra)[5], const f32x4& rb, const uint32_t& rn, int buf) {
+    float* da = As + buf * WT_AR * WT_LDA;
+    float* db = Bs + buf * W_BK * WT_LDB;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 5, c4 = idx & 31;
+      if (r < WT_AR) *reinterpret_cast<f32x4*>(da + r * WT_LDA + c4 * 4) = ra[i];
+    }
+    const int r = tid >> 4, c4 = tid & 15;
+    f32x4 e, o;
+    const uint32_t nibv = rn >> (ncol & 31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool odd = (nibv >> q) & 1u;
+      e[q] = odd ? 0.f : rb[q];
+      o[q] = odd ? rb[q] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(db + (2 * r) * WT_LDB + c4 * 4) = e;
+    *reinterpret_cast<f32x4*>(db + (2 * r + 1) * WT_LDB + c4 * 4) = o;
+  };
+
+  // fragments of one MFMA k-step (2 pairs): lane (lr, lh) of k-step q works on pair 2q + lh of the
+  // chunk: activation rows 4q + 2lh .. + 3, dZ rows 4q + 2lh (dy0) and + 1 (dy1).
+  float fa0[4][2], fb0[2], fa1[4][2], fb1[2];
+  auto load_frag = [&](float (&fa)[4][2], float (&fb)[2], int buf, int q) {
+    const float* a_s = As + buf * WT_AR * WT_LDA + (q * 4 + 2 * lh) * WT_LDA + wm * 64 + lr;
+    const float* b_s = Bs + buf * W_BK * WT_LDB + (q * 4 + 2 * lh) * WT_LDB + wn * 32 + lr;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      fa[d][0] = a_s[d * WT_LDA];
+      fa[d][1] = a_s[d * WT_LDA + 32];
+    }
+    fb[0] = b_s[0];
+    fb[1] = b_s[WT_LDB];
+  };
+  auto mfma_group = [&](const float (&fa)[4][2], const float (&fb)[2]) {
+    const float e = fb[0], o = fb[1];
+    const float b1 = e + o, b2 = e - o;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const float d0 = fa[0][mi], d1 = fa[1][mi], d2 = fa[2][mi], d3 = fa[3][mi];
+      acc[0][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0 - d2, e, acc[0][mi], 0, 0, 0);
+      acc[1][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 + d2, b1, acc[1][mi], 0, 0, 0);
+      acc[2][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2 - d1, b2, acc[2][mi], 0, 0, 0);
+      acc[3][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 - d3, o, acc[3][mi], 0, 0, 0);
+    }
+  };
+  auto kstep = [&](long long s, f32x4 (&ra_ld)[5], f32x4& rb_ld, uint32_t& rn_ld, const f32x4 (&ra_st)[5],
+                   const f32x4& rb_st, const uint32_t& rn_st) {
+    const int buf = (int)(s & 1);
+    load_frag(fa0, fb0, buf, 0);
+    if (s + 2 < nsteps) load_tiles(ra_ld, rb_ld, rn_ld);
+    if (s > 0) mfma_group(fa1, fb1);
+    load_frag(fa1, fb1, buf, 1);
+    mfma_group(fa0, fb0);
+    load_frag(fa0, fb0, buf, 2);
+    mfma_group(fa1, fb1);
+    load_frag(fa1, fb1, buf, 3);
+    mfma_group(fa0, fb0);
+    load_frag(fa0, fb0, buf, 4);
+    mfma_group(fa1, fb1);
+    if (s + 1 < nsteps) store_tiles(ra_st, rb_st, rn_st, buf ^ 1);
+    load_frag(fa1, fb1, buf, 5);
+    mfma_group(fa0, fb0);
+    load_frag(fa0, fb0, buf, 6);
+    mfma_group(fa1, fb1);
+    load_frag(fa1, fb1, buf, 7);
+    mfma_group(fa0, fb0);
+    __syncthreads();
+  };
+
+  if (nsteps > 0) {
+    load_tiles(raP, rbP, rnP);
+    store_tiles(raP, rbP, rnP, 0);
+    if (nsteps > 1) load_tiles(raQ, rbQ, rnQ);
+  }
+  __syncthreads();
+  long long s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
+    kstep(s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
+  }
+  if (s < nsteps) kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
+  if (nsteps > 0) mfma_group(fa1, fb1);
+
+  float* out = p.slab + (long long)z * p.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int col = n0 + wn * 32 + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.Mdim && col < p.Ndim) out[((long long)i * p.Mdim + m) * (long long)p.ldc + col] = acc[i][mi][e];
+      }
+    }
+}
+
+// dW (O, I, 3) = G^T M from the reduced transforms red[4][I][ld] (M_3 stored with flipped sign)
+__global__ void wino_wgrad_finalize_kernel(const float* __restrict__ red, float* __restrict__ gw, int O, int I, int ld) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)O * I) return;
+  const int i = (int)(idx / O), o = (int)(idx % O);
+  const long long plane = (long long)I * ld;
+  const float* s = red + (long long)i * ld + o;
+  const float m0 = s[0], m1 = s[plane], m2 = s[2 * plane], m3 = -s[3 * plane];
+  float* d = gw + ((long long)o * I + i) * 3;
+  const float h = 0.5f * (m1 + m2);
+  d[0] = m0 + h;
+  d[1] = 0.5f * (m1 - m2);
+  d[2] = h + m3;
+}
+
+}  // namespace tl
+
+extern "C" int tl_wino_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(w != nullptr && (fwd != nullptr || dgr != nullptr), "wino_weights: null pointer");
+  TL_REQUIRE(O > 0 && I > 0, "wino_weights: bad sizes");
+  TL_REQUIRE((fwd == nullptr || ld_f >= I) && (dgr == nullptr || ld_d >= O), "wino_weights: leading dimension too small");
+  const long long nf = fwd ? (long long)O * ld_f : 0, nd = dgr ? (long long)I * ld_d : 0;
+  const long long n = nf > nd ? nf : nd;
+  hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, fwd,
+                     dgr, O, I, ld_f, ld_d);
+  return check_launch("wino_weights");
+}
+
+extern "C" int tl_conv3_wino_nt(const tl_nt_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "wino_nt: null params");
+  const tl_nt_params& p = *pp;
+  TL_REQUIRE(p.A && p.Bw && p.out, "wino_nt: null A/Bw/out");
+  TL_REQUIRE(p.J == 3, "wino_nt: the Winograd form is for 3-tap convolutions");
+  TL_REQUIRE(p.M >= 0 && p.M % 2 == 0 && p.N > 0 && p.K > 0, "wino_nt: bad M/N/K %lld/%d/%d", (long long)p.M, p.N, p.K);
+  TL_REQUIRE(p.K % W_BK == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino_nt: K %% 32, lda %% 4, ldb %% 4 must be 0");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K, "wino_nt: lda/ldb smaller than K");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 2 == 0, "wino_nt: Tp must be positive and even");
+  TL_REQUIRE(p.splitk <= 1, "wino_nt: no split-K");
+  const long long nwg = ((p.M + 2 * W_BP - 1) / (2 * W_BP)) * ((p.N + W_BN - 1) / W_BN);
+  if (nwg <= 0) return TL_OK;
+  TL_REQUIRE(nwg < (1LL << 31), "wino_nt: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (p.loader == W_LOAD_DIRECT && p.epilogue == W_EPI_POOL) {
+    TL_REQUIRE(p.row_shift == 0, "wino_nt: forward needs row_shift 0");
+    TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0, "wino_nt: POOL needs obits and an even Tvalid");
+    TL_REQUIRE(p.N % 32 == 0 && p.ld_obits * 32 >= p.N, "wino_nt: POOL needs N %% 32 == 0");
+    hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_DIRECT, W_EPI_POOL>), dim3((unsigned)nwg), dim3(W_NTHR), 0, st, p);
+  } else if (p.loader == W_LOAD_UNPOOL && p.epilogue == W_EPI_MASK) {
+    TL_REQUIRE(p.row_shift == -2, "wino_nt: input gradient needs row_shift -2");
+    TL_REQUIRE(p.abits != nullptr && p.aux != nullptr, "wino_nt: UNPOOL/MASK need abits and aux");
+    TL_REQUIRE(p.Tvalid_in % 2 == 0, "wino_nt: UNPOOL needs an even Tvalid_in");
+    hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_UNPOOL, W_EPI_MASK>), dim3((unsigned)nwg), dim3(W_NTHR), 0, st, p);
+  } else {
+    set_error("wino_nt: unsupported loader/epilogue combination %d/%d", p.loader, p.epilogue);
+    return TL_EINVAL;
+  }
+  return check_launch("wino_nt");
+}
+
+extern "C" int tl_conv3_wino_tn(const tl_tn_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "wino_tn: null params");
+  tl_tn_params p = *pp;
+  if (p.splitk < 1) p.splitk = 1;
+  TL_REQUIRE(p.A && p.B && p.slab && p.bbits, "wino_tn: null A/B/bbits/slab");
+  TL_REQUIRE(p.J == 3 && p.loader == W_LOAD_UNPOOL, "wino_tn: 3 taps, UNPOOL loader only");
+  TL_REQUIRE(p.Krows > 0 && p.Krows % 2 == 0 && p.Mdim > 0 && p.Ndim > 0, "wino_tn: bad sizes");
+  TL_REQUIRE(p.Krows + 64 < (1LL << 31), "wino_tn: more than 2^31 reduction rows");
+  TL_REQUIRE(p.Mdim % 4 == 0 && p.Ndim % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino_tn: dims/ld must be multiples of 4");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 2 == 0 && p.Tvalid % 2 == 0, "wino_tn: even Tp/Tvalid needed");
+  TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim, "wino_tn: bbits row too short");
+  TL_REQUIRE(p.splitk <= 65535, "wino_tn: splitk too large");
+  const long long t = (long long)((p.Mdim + 127) / 128) * ((p.Ndim + WT_BN - 1) / WT_BN);
+  TL_REQUIRE(t < (1LL << 31), "wino_tn: grid too large");
+  hipLaunchKernelGGL(wino_tn_kernel, dim3((unsigned)t, (unsigned)p.splitk, 1), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("wino_tn");
+}
+
+extern "C" int tl_wino_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(red && gw && O > 0 && I > 0 && ld >= O, "wino_wgrad_finalize: bad arguments");
+  const long long n = (long long)O * I;
+  hipLaunchKernelGGL(wino_wgrad_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, red,
+                     gw, O, I, ld);
+  return check_launch("wino_wgrad_finalize");
+}

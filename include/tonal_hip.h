@@ -89,6 +89,25 @@ typedef struct {
   int splitk; int64_t slab_stride;
 } tl_tn_params;
 int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Winograd F(2,3) forms of the 3-tap convolutions that are followed by MaxPool (2,1)
+ * (conv2, conv3: models/synthesis_models.py:91-97; their backward in loss.backward(),
+ * models/synthesis_trainer.py:226).  Same data contracts as the two windowed GEMMs above with
+ * J = 3, but 4 channel contractions per output row pair instead of 6.
+ *   tl_wino_weights        w (O, I, 3, 1) -> forward taps fwd [4][O][ld_f] and input-gradient taps
+ *                          dgr [4][I][ld_d] (either may be null)
+ *   tl_conv3_wino_nt       tl_gemm_nt_window with Bw = the 4 transformed taps; loader/epilogue
+ *                          DIRECT/POOL (forward, row_shift 0) or UNPOOL/MASK (input gradient,
+ *                          row_shift -2); K % 32 == 0, M even
+ *   tl_conv3_wino_tn       tl_gemm_tn_window (UNPOOL) writing the 4 transform accumulators
+ *                          slab[z][4][Mdim][ldc] (slab_stride >= 4*Mdim*ldc)
+ *   tl_wino_wgrad_finalize red [4][I][ld] (slabs summed by the caller) -> dW (O, I, 3, 1)
+ * ------------------------------------------------------------------------------------------ */
+int tl_wino_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
+int tl_conv3_wino_nt(const tl_nt_params* p, void* stream);
+int tl_conv3_wino_tn(const tl_tn_params* p, void* stream);
+int tl_wino_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
 int tl_sizeof_nt_params(void);
 int tl_sizeof_tn_params(void);
