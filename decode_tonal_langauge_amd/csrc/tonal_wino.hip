@@ -19,6 +19,14 @@
 #include "tonal_common.h"
 #include <type_traits>
 
+// The LLVM scheduler sinks the ds_reads of the next fragment set towards their first use; pinning the
+// hand-written order with scheduling fences (-DWINO_FENCE) measured 3 % slower, so it is off.
+#ifdef WINO_FENCE
+#define W_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define W_SCHED_FENCE() ((void)0)
+#endif
+
 namespace tl {
 
 enum { W_LOAD_DIRECT = 0, W_LOAD_UNPOOL = 1 };
@@ -29,7 +37,10 @@ constexpr int W_BN = 128;            // output columns per workgroup
 constexpr int W_BK = 32;             // K depth of one stage
 constexpr int W_LD = W_BK + 4;       // 36 floats: conflict-free ds_read_b128
 constexpr int W_PR = W_BP + 1;       // staged pairs per plane
-constexpr int W_NTHR = 512;          // 8 waves: 4 (pairs) x 2 (columns), wave tile 32 pairs x 64 columns
+#ifndef WINO_MI
+#define WINO_MI 1
+#endif
+constexpr int W_MI = WINO_MI;       // 32-pair MFMA tiles per wave along M (1: 8 waves, 2: 4 waves per workgroup)
 
 // ------------------------------------------------------------------------------------------
 // weights: torch (O, I, 3, 1) -> forward taps [4][O][ld_f] and input-gradient taps [4][I][ld_d]
@@ -72,12 +83,14 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
 // A chunk one chunk ahead), LDS double buffering, fragment sets F0/F1 with the last k-group of a
 // step carried across the barrier.
 // ------------------------------------------------------------------------------------------
-template <int LOADER, int EPI>
-__global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p) {
+template <int LOADER, int EPI, int MI>
+__global__ __launch_bounds__(512 / MI, 2 / MI) void wino_nt_kernel(const tl_nt_params p) {
+  // MI = 1: 8 waves, 4 (pairs) x 2 (columns), wave tile 32 pairs x 64 columns, 2 waves per SIMD
+  // MI = 2: 4 waves, 2 x 2, wave tile 64 pairs x 64 columns (256 accumulator registers), 1 wave per SIMD
+  constexpr int NTHR = 512 / MI;
   constexpr int PLANE = W_PR * W_LD;
-  constexpr int A_F4 = (LOADER == W_LOAD_DIRECT) ? ((2 * W_PR * 8 + W_NTHR - 1) / W_NTHR)
-                                                 : ((W_PR * 8 + W_NTHR - 1) / W_NTHR);
-  constexpr int B_F4 = W_BN * 8 / W_NTHR;      // 2
+  constexpr int A_F4 = (LOADER == W_LOAD_DIRECT) ? ((2 * W_PR * 8 + NTHR - 1) / NTHR) : ((W_PR * 8 + NTHR - 1) / NTHR);
+  constexpr int B_F4 = W_BN * 8 / NTHR;
 
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * PLANE + 2 * W_BN * W_LD];
   float* As = lds;                               // [2 buffers][2 planes][W_PR][W_LD]
@@ -104,13 +117,15 @@ __global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p
   const int nchunks = p.K / W_BK;                // host-checked: K % 32 == 0
   const int nsteps = nchunks * 4;
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][MI][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int m = 0; m < MI; ++m)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][m][j][e] = 0.f;
 
   f32x4 ra[A_F4];
   uint32_t rbits[A_F4];
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p
   (void)abptr;
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
-    const int idx = tid + i * W_NTHR;
+    const int idx = tid + i * NTHR;
     const int r = idx >> 3, c4 = idx & 7;
     if constexpr (LOADER == W_LOAD_DIRECT) {
       const long long row = Abase + r;
@@ -139,13 +154,11 @@ __global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p
     }
   }
   const float* bptr[B_F4];
-  bool bok[B_F4];
 #pragma unroll
   for (int i = 0; i < B_F4; ++i) {
-    const int idx = tid + i * W_NTHR;
+    const int idx = tid + i * NTHR;
     const int r = idx >> 3, c4 = idx & 7;
-    bok[i] = (n0 + r) < p.N;
-    bptr[i] = p.Bw + (long long)(bok[i] ? n0 + r : 0) * p.ldb + c4 * 4;
+    bptr[i] = p.Bw + (long long)((n0 + r) < p.N ? n0 + r : 0) * p.ldb + c4 * 4;
   }
   const long long tap_stride = (long long)p.N * p.ldb;
 
@@ -153,21 +166,17 @@ __global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p
     const int kc = chunk * W_BK;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      uint32_t nib = 0;
-      if (aok[i]) {
-        v = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
-        if constexpr (LOADER == W_LOAD_UNPOOL) nib = abptr[i][kc >> 5];
-      }
-      ra[i] = v;
-      if constexpr (LOADER == W_LOAD_UNPOOL) rbits[i] = nib;
+      // unconditional (branch-free) loads from clamped addresses.  DIRECT: a row outside the matrix
+      // only feeds pairs the epilogue zeroes; UNPOOL: masked at LDS-store time.
+      ra[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
+      if constexpr (LOADER == W_LOAD_UNPOOL) rbits[i] = abptr[i][kc >> 5];
     }
   };
   auto store_a = [&](int buf) {
     float* dst = As + buf * 2 * PLANE;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-      const int idx = tid + i * W_NTHR;
+      const int idx = tid + i * NTHR;
       const int r = idx >> 3, c4 = idx & 7;
       if constexpr (LOADER == W_LOAD_DIRECT) {
         if (r < 2 * W_PR) *reinterpret_cast<f32x4*>(dst + (r & 1) * PLANE + (r >> 1) * W_LD + c4 * 4) = ra[i];
@@ -178,8 +187,9 @@ __global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const bool odd = (nibv >> q) & 1u;
-            e[q] = odd ? 0.f : ra[i][q];
-            o[q] = odd ? ra[i][q] : 0.f;
+            const float g = aok[i] ? ra[i][q] : 0.f;
+            e[q] = odd ? 0.f : g;
+            o[q] = odd ? g : 0.f;
           }
           *reinterpret_cast<f32x4*>(dst + r * W_LD + c4 * 4) = e;
           *reinterpret_cast<f32x4*>(dst + PLANE + r * W_LD + c4 * 4) = o;
@@ -190,66 +200,75 @@ __global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p
   auto load_b = [&](f32x4 (&rb)[B_F4], int step) {
     const long long off = (long long)(step & 3) * tap_stride + (step >> 2) * W_BK;
 #pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (bok[i]) v = *reinterpret_cast<const f32x4*>(bptr[i] + off);
-      rb[i] = v;
-    }
+    for (int i = 0; i < B_F4; ++i)          // rows past N are clamped: they only feed columns never stored
+      rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + off);
   };
   auto store_b = [&](const f32x4 (&rb)[B_F4], int buf) {
     float* dst = Bs + buf * W_BN * W_LD;
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) {
-      const int idx = tid + i * W_NTHR;
+      const int idx = tid + i * NTHR;
       const int r = idx >> 3, c4 = idx & 7;
       *reinterpret_cast<f32x4*>(dst + r * W_LD + c4 * 4) = rb[i];
     }
   };
 
   // fragment sets: x, y are the two staged rows whose sum / difference is (B^T d)_i
-  f32x4 fx0, fy0, fb0[2], fx1, fy1, fb1[2];
-  const int a_lane = (wm * 32 + lr) * W_LD + lh * 4;
+  f32x4 fx0[MI], fy0[MI], fb0[2], fx1[MI], fy1[MI], fb1[2];
+  const int a_lane = (wm * (32 * MI) + lr) * W_LD + lh * 4;
   const int b_lane = (wn * 64 + lr) * W_LD + lh * 4;
-  auto load_frag = [&](auto I, f32x4& fx, f32x4& fy, f32x4 (&fb)[2], int abuf, int bbuf, int kk) {
+  auto load_frag = [&](auto I, f32x4 (&fx)[MI], f32x4 (&fy)[MI], f32x4 (&fb)[2], int abuf, int bbuf, int kk) {
     constexpr int i = decltype(I)::value;
     // i = 0: E[p] - E[p+1]   i = 1: O[p] + E[p+1]   i = 2: E[p+1] - O[p]   i = 3: O[p] - O[p+1]
     constexpr int xo = (i == 0) ? 0 : ((i == 2) ? W_LD : PLANE);
     constexpr int yo = (i == 0 || i == 1) ? W_LD : ((i == 2) ? PLANE : PLANE + W_LD);
     const float* a_s = As + abuf * 2 * PLANE + a_lane + kk * 8;
     const float* b_s = Bs + bbuf * W_BN * W_LD + b_lane + kk * 8;
-    fx = *reinterpret_cast<const f32x4*>(a_s + xo);
-    fy = *reinterpret_cast<const f32x4*>(a_s + yo);
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+      fx[m] = *reinterpret_cast<const f32x4*>(a_s + m * 32 * W_LD + xo);
+      fy[m] = *reinterpret_cast<const f32x4*>(a_s + m * 32 * W_LD + yo);
+    }
     fb[0] = *reinterpret_cast<const f32x4*>(b_s);
     fb[1] = *reinterpret_cast<const f32x4*>(b_s + 32 * W_LD);
   };
-  auto mfma_group = [&](auto I, const f32x4& fx, const f32x4& fy, const f32x4 (&fb)[2]) {
+  auto mfma_group = [&](auto I, const f32x4 (&fx)[MI], const f32x4 (&fy)[MI], const f32x4 (&fb)[2]) {
     constexpr int i = decltype(I)::value;
-    const f32x4 a = (i == 1) ? (fx + fy) : (fx - fy);
+    f32x4 a[MI];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], fb[0][q], acc[i][0], 0, 0, 0);
-      acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], fb[1][q], acc[i][1], 0, 0, 0);
-    }
+    for (int m = 0; m < MI; ++m) a[m] = (i == 1) ? (fx[m] + fy[m]) : (fx[m] - fy[m]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int m = 0; m < MI; ++m) {
+        acc[i][m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], fb[0][q], acc[i][m][0], 0, 0, 0);
+        acc[i][m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], fb[1][q], acc[i][m][1], 0, 0, 0);
+      }
   };
 
-  auto kstep = [&](auto I, int s, f32x4 (&rb_ld)[B_F4], const f32x4 (&rb_st)[B_F4]) {
+  // One K-step (transform i of one chunk).  LAST = the final chunk: no further A chunk, B loads /
+  // stores only while steps remain - resolved at compile time, so the loop body has no branches.
+  auto kstep = [&](auto I, auto LAST, int s, f32x4 (&rb_ld)[B_F4], const f32x4 (&rb_st)[B_F4]) {
     constexpr int i = decltype(I)::value;
+    constexpr bool last = decltype(LAST)::value;
     using Prev = std::integral_constant<int, (i + 3) & 3>;
     const int chunk = s >> 2;
     const int abuf = chunk & 1, bbuf = s & 1;
-    const bool more = s + 1 < nsteps;
-    const bool has_next_chunk = chunk + 1 < nchunks;
     load_frag(I, fx0, fy0, fb0, abuf, bbuf, 0);
-    if (s + 2 < nsteps) load_b(rb_ld, s + 2);
-    if (i == 0 && has_next_chunk) load_a(chunk + 1);
-    if (s > 0) mfma_group(Prev{}, fx1, fy1, fb1);       // k-group 3 of the previous step (registers)
+    if constexpr (!last || i < 2) load_b(rb_ld, s + 2);
+    if constexpr (!last && i == 0) load_a(chunk + 1);
+    W_SCHED_FENCE();
+    mfma_group(Prev{}, fx1, fy1, fb1);                   // k-group 3 of the previous step (registers)
     load_frag(I, fx1, fy1, fb1, abuf, bbuf, 1);
+    W_SCHED_FENCE();
     mfma_group(I, fx0, fy0, fb0);
     load_frag(I, fx0, fy0, fb0, abuf, bbuf, 2);
+    W_SCHED_FENCE();
     mfma_group(I, fx1, fy1, fb1);
-    if (more) store_b(rb_st, bbuf ^ 1);
-    if (i == 3 && has_next_chunk) store_a(abuf ^ 1);
+    if constexpr (!last || i < 3) store_b(rb_st, bbuf ^ 1);
+    if constexpr (!last && i == 3) store_a(abuf ^ 1);
     load_frag(I, fx1, fy1, fb1, abuf, bbuf, 3);
+    W_SCHED_FENCE();
     mfma_group(I, fx0, fy0, fb0);
     __syncthreads();
   };
@@ -258,64 +277,77 @@ __global__ __launch_bounds__(W_NTHR, 2) void wino_nt_kernel(const tl_nt_params p
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
+  using Mid = std::false_type;
+  using Last = std::true_type;
 
-  if (nsteps > 0) {
-    load_a(0);
-    load_b(rbP, 0);
-    store_a(0);
-    store_b(rbP, 0);
-    load_b(rbQ, 1);
-  }
+  // the carried group of the (non-existent) step -1: zero operands, adds nothing
+#pragma unroll
+  for (int m = 0; m < MI; ++m) fx1[m] = fy1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fb1[0] = fb1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_a(0);
+  load_b(rbP, 0);
+  store_a(0);
+  store_b(rbP, 0);
+  load_b(rbQ, 1);
   __syncthreads();
-  for (int s = 0; s < nsteps; s += 4) {
-    kstep(I0{}, s, rbP, rbQ);
-    kstep(I1{}, s + 1, rbQ, rbP);
-    kstep(I2{}, s + 2, rbP, rbQ);
-    kstep(I3{}, s + 3, rbQ, rbP);
+  int s = 0;
+  for (; s + 4 < nsteps; s += 4) {
+    kstep(I0{}, Mid{}, s, rbP, rbQ);
+    kstep(I1{}, Mid{}, s + 1, rbQ, rbP);
+    kstep(I2{}, Mid{}, s + 2, rbP, rbQ);
+    kstep(I3{}, Mid{}, s + 3, rbQ, rbP);
   }
-  if (nsteps > 0) mfma_group(I3{}, fx1, fy1, fb1);
+  kstep(I0{}, Last{}, s, rbP, rbQ);
+  kstep(I1{}, Last{}, s + 1, rbQ, rbP);
+  kstep(I2{}, Last{}, s + 2, rbP, rbQ);
+  kstep(I3{}, Last{}, s + 3, rbQ, rbP);
+  mfma_group(I3{}, fx1, fy1, fb1);
 
   // ---- epilogue: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3 per (pair, column) ----
-  const long long P0 = (R0 >> 1) + wm * 32 + 4 * lh;       // pair of accumulator element e = 0
-  const int t0 = (int)((2 * P0) % p.Tp);
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int colbase = n0 + wn * 64 + ni * 32;
-    const int col = colbase + lr;
-    const bool colok = col < p.N;
-    if constexpr (EPI == W_EPI_POOL) {
-      const float bv = (colok && p.bias) ? p.bias[col] : 0.f;
+  for (int mi = 0; mi < MI; ++mi) {
+    const long long P0 = (R0 >> 1) + wm * (32 * MI) + mi * 32 + 4 * lh;       // pair of accumulator element e = 0
+    const int t0 = (int)((2 * P0) % p.Tp);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int po = (e & 3) + 8 * (e >> 2);
-        const long long P = P0 + po;
-        const float m1 = acc[1][ni][e], m2 = acc[2][ni][e];
-        const float y0 = lrelu((acc[0][ni][e] + m1) + m2 + bv, p.slope);
-        const float y1 = lrelu((m1 - m2) - acc[3][ni][e] + bv, p.slope);
-        const bool rowok = 2 * P < p.M;
-        const bool valid = rowok && ((t0 + 2 * po) % p.Tp) < p.Tvalid;
-        const bool sel = valid && colok && (y1 > y0);
-        const float o = valid ? (sel ? y1 : y0) : 0.f;
-        if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
-        const unsigned long long m = __ballot(sel);
-        if (lr == 0 && rowok && colbase < p.N)
-          p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(m >> (32 * lh));
-      }
-    } else {
+    for (int ni = 0; ni < 2; ++ni) {
+      const int colbase = n0 + wn * 64 + ni * 32;
+      const int col = colbase + lr;
+      const bool colok = col < p.N;
+      if constexpr (EPI == W_EPI_POOL) {
+        const float bv = (colok && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int po = (e & 3) + 8 * (e >> 2);
-        const long long R = 2 * (P0 + po);
-        const float m1 = acc[1][ni][e], m2 = acc[2][ni][e];
-        float v0 = (acc[0][ni][e] + m1) + m2;
-        float v1 = (m1 - m2) - acc[3][ni][e];
-        if (R < p.M && colok) {                            // M is even: the pair shares validity
-          const float a0 = p.aux[R * (long long)p.ldaux + col];
-          const float a1 = p.aux[(R + 1) * (long long)p.ldaux + col];
-          v0 = a0 > 0.f ? v0 : v0 * p.slope;
-          v1 = a1 > 0.f ? v1 : v1 * p.slope;
-          p.out[R * (long long)p.ldo + col] = v0;
-          p.out[(R + 1) * (long long)p.ldo + col] = v1;
+        for (int e = 0; e < 16; ++e) {
+          const int po = (e & 3) + 8 * (e >> 2);
+          const long long P = P0 + po;
+          const float m1 = acc[1][mi][ni][e], m2 = acc[2][mi][ni][e];
+          const float y0 = lrelu((acc[0][mi][ni][e] + m1) + m2 + bv, p.slope);
+          const float y1 = lrelu((m1 - m2) - acc[3][mi][ni][e] + bv, p.slope);
+          const bool rowok = 2 * P < p.M;
+          const bool valid = rowok && ((t0 + 2 * po) % p.Tp) < p.Tvalid;
+          const bool sel = valid && colok && (y1 > y0);
+          const float o = valid ? (sel ? y1 : y0) : 0.f;
+          if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
+          const unsigned long long m = __ballot(sel);
+          if (lr == 0 && rowok && colbase < p.N)
+            p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(m >> (32 * lh));
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int po = (e & 3) + 8 * (e >> 2);
+          const long long R = 2 * (P0 + po);
+          const float m1 = acc[1][mi][ni][e], m2 = acc[2][mi][ni][e];
+          float v0 = (acc[0][mi][ni][e] + m1) + m2;
+          float v1 = (m1 - m2) - acc[3][mi][ni][e];
+          if (R < p.M && colok) {                            // M is even: the pair shares validity
+            const float a0 = p.aux[R * (long long)p.ldaux + col];
+            const float a1 = p.aux[(R + 1) * (long long)p.ldaux + col];
+            v0 = a0 > 0.f ? v0 : v0 * p.slope;
+            v1 = a1 > 0.f ? v1 : v1 * p.slope;
+            p.out[R * (long long)p.ldo + col] = v0;
+            p.out[(R + 1) * (long long)p.ldo + col] = v1;
+          }
         }
       }
     }
@@ -367,46 +399,34 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
   f32x4 raP[5], raQ[5], rbP, rbQ;
   uint32_t rnP, rnQ;
 
-  const int a_lim = (int)(p.A_rows < p.Krows + 2 ? p.A_rows : p.Krows + 2);
+  // Global loads are unconditional (no divergent branches in the K loop): row / column indices are
+  // clamped into the matrices.  A clamped activation row only ever meets a zero dZ pair (rows past
+  // the end belong to invalid time steps); an invalid dZ pair is zeroed when it is written to LDS.
+  const int a_last = (int)(p.A_rows < p.Krows + 2 ? p.A_rows : p.Krows + 2) - 1;
   const int b_lim = (int)(2 * p.B_rows < p.Krows ? 2 * p.B_rows : p.Krows);
   const int kbase = (int)(ks_begin * W_BK);
-  // activation tile: thread t stages rows (t >> 5) + 8 i, i < 5 (row 32, 33 for i = 4): one 32-bit
-  // per-thread offset on a wave-uniform base that advances by 32 rows per K-step
-  const bool amok = (m0 + (tid & 31) * 4) < p.Mdim;
-  const int a_toff = (tid >> 5) * p.lda + (tid & 31) * 4;
-  const int a_r = tid >> 5;
-  long long a_row0 = kbase;
+  const int acol = m0 + (((m0 + (tid & 31) * 4) < p.Mdim) ? (tid & 31) * 4 : 0);
+  int a_row = kbase + (tid >> 5);                  // thread t stages rows (t >> 5) + 8 i, i < 5
   const int ncol = n0 + (tid & 15) * 4;
   const bool bnok = ncol < p.Ndim;
+  const int ncolc = bnok ? ncol : n0;
   const int dstep = W_BK % p.Tp;
   int brow = kbase + 2 * (tid >> 4);               // conv row of this thread's pair (even)
-  const float* bptr = p.B + (long long)(brow >> 1) * p.ldb + ncol;
-  const uint32_t* bbptr = p.bbits + (long long)(brow >> 1) * p.ld_bbits + (ncol >> 5);
   int bt = brow % p.Tp;
-  const long long b_step = (long long)(W_BK / 2) * p.ldb;
-  const long long bb_step = (long long)(W_BK / 2) * p.ld_bbits;
+  const int b_last = (int)p.B_rows - 1;
 
   auto load_tiles = [&](f32x4 (&ra)[5], f32x4& rb, uint32_t& rn) {
-    const float* au = p.A + a_row0 * (long long)p.lda + m0;       // wave-uniform
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const bool act = (i < 4) || a_r < 2;
-      if (act && amok && a_row0 + a_r + 8 * i < a_lim)
-        v = *reinterpret_cast<const f32x4*>(au + (long long)(8 * i) * p.lda + a_toff);
-      ra[i] = v;
+      const int row = min(a_row + 8 * i, a_last);
+      ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long long)row * p.lda + acol);
     }
-    a_row0 += W_BK;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    uint32_t nib = 0;
-    if (bnok && brow < b_lim && bt < p.Tvalid) {
-      v = *reinterpret_cast<const f32x4*>(bptr);
-      nib = *bbptr;
-    }
-    rb = v;
-    rn = nib;
-    bbptr += bb_step;
-    bptr += b_step;
+    a_row += W_BK;
+    const int pr = min(brow >> 1, b_last);
+    rb = *reinterpret_cast<const f32x4*>(p.B + (long long)pr * p.ldb + ncolc);
+    // arg-max nibble of the 4 columns in bits 0..3, "pair is valid" in bit 4
+    rn = ((p.bbits[(long long)pr * p.ld_bbits + (ncolc >> 5)] >> (ncolc & 31)) & 0xFu) |
+         ((bnok && brow < b_lim && bt < p.Tvalid) ? 0x10u : 0u);
     brow += W_BK;
     bt += dstep;
     if (bt >= p.Tp) bt -= p.Tp;
@@ -422,12 +442,13 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
     }
     const int r = tid >> 4, c4 = tid & 15;
     f32x4 e, o;
-    const uint32_t nibv = rn >> (ncol & 31);
+    const bool rv = (rn & 0x10u) != 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const bool odd = (nibv >> q) & 1u;
-      e[q] = odd ? 0.f : rb[q];
-      o[q] = odd ? rb[q] : 0.f;
+      const bool odd = (rn >> q) & 1u;
+      const float g = rv ? rb[q] : 0.f;
+      e[q] = odd ? 0.f : g;
+      o[q] = odd ? g : 0.f;
     }
     *reinterpret_cast<f32x4*>(db + (2 * r) * WT_LDB + c4 * 4) = e;
     *reinterpret_cast<f32x4*>(db + (2 * r + 1) * WT_LDB + c4 * 4) = o;
@@ -459,12 +480,15 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
       acc[3][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 - d3, o, acc[3][mi], 0, 0, 0);
     }
   };
-  auto kstep = [&](long long s, f32x4 (&ra_ld)[5], f32x4& rb_ld, uint32_t& rn_ld, const f32x4 (&ra_st)[5],
-                   const f32x4& rb_st, const uint32_t& rn_st) {
+  // TAIL = false: steady state, the step prefetches the tiles of step s + 2 and writes those of
+  // s + 1 to LDS unconditionally (no branch in the loop body); TAIL = true: the last <= 3 steps.
+  auto kstep = [&](auto TAIL, long long s, f32x4 (&ra_ld)[5], f32x4& rb_ld, uint32_t& rn_ld,
+                   const f32x4 (&ra_st)[5], const f32x4& rb_st, const uint32_t& rn_st) {
+    constexpr bool tail = decltype(TAIL)::value;
     const int buf = (int)(s & 1);
     load_frag(fa0, fb0, buf, 0);
-    if (s + 2 < nsteps) load_tiles(ra_ld, rb_ld, rn_ld);
-    if (s > 0) mfma_group(fa1, fb1);
+    if (!tail || s + 2 < nsteps) load_tiles(ra_ld, rb_ld, rn_ld);
+    mfma_group(fa1, fb1);                          // last k-step of the previous step (registers)
     load_frag(fa1, fb1, buf, 1);
     mfma_group(fa0, fb0);
     load_frag(fa0, fb0, buf, 2);
@@ -473,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
     mfma_group(fa0, fb0);
     load_frag(fa0, fb0, buf, 4);
     mfma_group(fa1, fb1);
-    if (s + 1 < nsteps) store_tiles(ra_st, rb_st, rn_st, buf ^ 1);
+    if (!tail || s + 1 < nsteps) store_tiles(ra_st, rb_st, rn_st, buf ^ 1);
     load_frag(fa1, fb1, buf, 5);
     mfma_group(fa0, fb0);
     load_frag(fa0, fb0, buf, 6);
@@ -482,6 +506,12 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
     mfma_group(fa0, fb0);
     __syncthreads();
   };
+  using Y = std::true_type;
+  using N = std::false_type;
+
+#pragma unroll
+  for (int d = 0; d < 4; ++d) fa1[d][0] = fa1[d][1] = 0.f;       // carried group of step -1: adds nothing
+  fb1[0] = fb1[1] = 0.f;
 
   if (nsteps > 0) {
     load_tiles(raP, rbP, rnP);
@@ -490,12 +520,15 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
   }
   __syncthreads();
   long long s = 0;
-  for (; s + 1 < nsteps; s += 2) {
-    kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
-    kstep(s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
+  for (; s + 3 < nsteps; s += 2) {
+    kstep(N{}, s, raP, rbP, rnP, raQ, rbQ, rnQ);
+    kstep(N{}, s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
   }
-  if (s < nsteps) kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
-  if (nsteps > 0) mfma_group(fa1, fb1);
+  for (; s < nsteps; s += 2) {
+    kstep(Y{}, s, raP, rbP, rnP, raQ, rbQ, rnQ);
+    if (s + 1 < nsteps) kstep(Y{}, s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
+  }
+  mfma_group(fa1, fb1);
 
   float* out = p.slab + (long long)z * p.slab_stride;
 #pragma unroll
@@ -559,12 +592,12 @@ extern "C" int tl_conv3_wino_nt(const tl_nt_params* pp, void* stream) {
     TL_REQUIRE(p.row_shift == 0, "wino_nt: forward needs row_shift 0");
     TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0, "wino_nt: POOL needs obits and an even Tvalid");
     TL_REQUIRE(p.N % 32 == 0 && p.ld_obits * 32 >= p.N, "wino_nt: POOL needs N %% 32 == 0");
-    hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_DIRECT, W_EPI_POOL>), dim3((unsigned)nwg), dim3(W_NTHR), 0, st, p);
+    hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_DIRECT, W_EPI_POOL, W_MI>), dim3((unsigned)nwg), dim3(512 / W_MI), 0, st, p);
   } else if (p.loader == W_LOAD_UNPOOL && p.epilogue == W_EPI_MASK) {
     TL_REQUIRE(p.row_shift == -2, "wino_nt: input gradient needs row_shift -2");
     TL_REQUIRE(p.abits != nullptr && p.aux != nullptr, "wino_nt: UNPOOL/MASK need abits and aux");
     TL_REQUIRE(p.Tvalid_in % 2 == 0, "wino_nt: UNPOOL needs an even Tvalid_in");
-    hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_UNPOOL, W_EPI_MASK>), dim3((unsigned)nwg), dim3(W_NTHR), 0, st, p);
+    hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_UNPOOL, W_EPI_MASK, W_MI>), dim3((unsigned)nwg), dim3(512 / W_MI), 0, st, p);
   } else {
     set_error("wino_nt: unsupported loader/epilogue combination %d/%d", p.loader, p.epilogue);
     return TL_EINVAL;

@@ -12,6 +12,7 @@ ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--channels", type=int, default=16)
 ap.add_argument("--timepoints", type=int, default=400)
 ap.add_argument("--iters", type=int, default=0)
+ap.add_argument("--only-wino", action="store_true", help="timing of the Winograd kernels only")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
@@ -36,7 +37,7 @@ def rel(a, b):
 
 
 fill()
-for si in (2, 3):
+for si in (() if args.only_wino else (2, 3)):
     st = eng.stages[si - 2]
     w = torch.randn(st.cout, st.cin, st.k, 1, device=dev, generator=g) * 0.02
     b = torch.randn(st.cout, device=dev, generator=g) * 0.1
@@ -59,13 +60,13 @@ for si in (2, 3):
           f"  dgrad rel {rel(wn[2], d[2]):.3e}  wgrad rel {rel(wn[3], d[3]):.3e}  bias {rel(wn[4], d[4]):.3e}", flush=True)
 
 if args.iters:
-    for si in (2, 3):
+    for si in ((2,) if args.only_wino else (2, 3)):
         st = eng.stages[si - 2]
         w = torch.randn(st.cout, st.cin, st.k, 1, device=dev, generator=g) * 0.02
         b = torch.randn(st.cout, device=dev, generator=g) * 0.1
         gw, gb = torch.empty_like(w), torch.empty_like(b)
         fl = 2.0 * B * eng.C * st.tc * st.k * st.cin * st.cout
-        for mode in (False, True):
+        for mode in ((True,) if args.only_wino else (False, True)):
             eng.wino = mode
             for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("dgrad", lambda: eng.stage_dgrad(st, w)),
                              ("wgrad", lambda: eng.stage_wgrad(st, gw, gb))):
