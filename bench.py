@@ -15,10 +15,13 @@ Inputs are resident in HBM before the timed region.  Weak scaling: every rank ow
 
 Extra objects on the JSON line:
   roofline     the dominant kernel of the step (the rocprofv3 kernel name with the largest total
-               time; one name covers its conv2/conv3/conv4 launches): mean algorithmic FLOPs per
+               time; one name covers its conv2 and conv3 launches): mean algorithmic FLOPs per
                launch / mean launch time, measured with HIP events on the launch stream, against
                the dense fp32 MFMA peak (157.3 TFLOP/s); `traffic` = HBM bytes per launch from the
-               committed rocprofv3 PMC passes (profiles/pmc_traffic.json).
+               committed rocprofv3 PMC passes (profiles/pmc_traffic.json).  Algorithmic FLOPs are
+               those of the direct convolution; the Winograd F(2,3) kernels issue 2/3
+               of them as MFMA work, so `achieved` can exceed `peak` - `mfma_pipe_frac` is the
+               utilisation of the matrix pipe itself.
   cpu_baseline the CPU oracle (oracle/synthesis_oracle.py, PyTorch-CPU fp32 restatement of the
                reference) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -170,10 +173,17 @@ def main():
     if rank == 0:
         roof = None
         if tsum:
-            # kernel families as rocprofv3 names them: one name covers the conv2/conv3/conv4 launches
-            fams = {"nt_window_kernel<128,UNPOOL,MASK> (conv input-gradient)": ["conv2_dgrad", "conv3_dgrad", "conv4_dgrad"],
-                    "nt_window_kernel<128,DIRECT,POOL> (conv forward)": ["conv2_fwd", "conv3_fwd", "conv4_fwd"],
-                    "tn3_kernel<UNPOOL> (conv weight-gradient)": ["conv2_wgrad", "conv3_wgrad"]}
+            # kernel families as rocprofv3 names them: one name covers the launches of several stages
+            if getattr(eng, "wino", False):
+                fams = {"wino_nt_kernel<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd F(2,3))": ["conv2_dgrad", "conv3_dgrad"],
+                        "wino_nt_kernel<DIRECT,POOL> (conv2/conv3 forward, Winograd F(2,3))": ["conv2_fwd", "conv3_fwd"],
+                        "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))": ["conv2_wgrad", "conv3_wgrad"]}
+                issued = 2.0 / 3.0          # MFMA FLOPs issued per algorithmic (direct-convolution) FLOP
+            else:
+                fams = {"nt_window_kernel<128,UNPOOL,MASK> (conv input-gradient)": ["conv2_dgrad", "conv3_dgrad", "conv4_dgrad"],
+                        "nt_window_kernel<128,DIRECT,POOL> (conv forward)": ["conv2_fwd", "conv3_fwd", "conv4_fwd"],
+                        "tn3_kernel<UNPOOL> (conv weight-gradient)": ["conv2_wgrad", "conv3_wgrad"]}
+                issued = 1.0
             stats = {}
             for fam, tags in fams.items():
                 tags = [t for t in tags if t in tsum]
@@ -195,6 +205,10 @@ def main():
                     "frac": round(d["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
                     "flops_per_launch": d["flops_per_launch"], "avg_launch_ms": round(d["avg_launch_ms"], 3),
                     "launches_per_step": d["launches_per_step"],
+                    "flop_convention": "algorithmic = direct convolution, 2 FLOP/MAC over valid rows (SURVEY 8d)",
+                    "mfma_issued_per_algorithmic_flop": round(issued, 4),
+                    "mfma_issued_tflops": round(d["tflops"] * issued, 2),
+                    "mfma_pipe_frac": round(d["tflops"] * issued / PEAK_FP32_MFMA_TFLOPS, 4),
                     "families": {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms_per_step"], 2)}
                                  for k, v in stats.items()},
                     "per_launch": {t: {"ms": round(tsum[t][1], 3),

@@ -92,6 +92,10 @@ class CnnEngine:
         # Winograd F(2,3) kernels for the pooled 3-tap stages (2/3 of the MFMA work of the direct
         # form); TONAL_WINO=0 selects the direct kernels (kept for A/B runs and as the parity partner)
         self.wino = os.environ.get("TONAL_WINO", "1") != "0"
+        # TONAL_WINO=4: F(4,3) for the two NT passes (half the MFMA work of the direct form, but six
+        # transforms per quad cost more LDS / VALU work per MFMA: conv2 forward 53.1 vs 55.4 ms,
+        # input gradient 60.7 vs 59.4 ms against F(2,3)) - opt-in, not the default
+        self.wino43 = os.environ.get("TONAL_WINO", "1") == "4"
         self._B = None
         self.generation = 0
         self._saved_generation = -1
@@ -212,13 +216,19 @@ class CnnEngine:
         return (self.wino and st.k == 3 and st.pool and st.cin % 32 == 0 and st.cout % 32 == 0
                 and st.tp_in % 2 == 0)
 
-    def _pack_wino(self, w, forward: bool):
-        """torch (O, I, 3, 1) -> the 4 Winograd taps: forward [4][O][I] or input-gradient [4][I][O]."""
+    def _use_wino43(self, st) -> bool:
+        return self.wino43 and self._use_wino(st) and st.tp_in % 4 == 0
+
+    def _pack_wino(self, w, forward: bool, f43: bool = False):
+        """torch (O, I, 3, 1) -> the 4 (F(2,3)) or 6 (F(4,3)) Winograd taps: forward [n][O][I] or
+        input-gradient [n][I][O]."""
         O, I = w.shape[0], w.shape[1]
-        dst = torch.empty(4, O, I, dtype=torch.float32, device=w.device) if forward else \
-            torch.empty(4, I, O, dtype=torch.float32, device=w.device)
-        check(self.lib.tl_wino_weights(ptr(w), ptr(dst) if forward else None, None if forward else ptr(dst),
-                                       O, I, I, O, self._stream()), "tl_wino_weights")
+        n = 6 if f43 else 4
+        dst = torch.empty(n, O, I, dtype=torch.float32, device=w.device) if forward else \
+            torch.empty(n, I, O, dtype=torch.float32, device=w.device)
+        fn = self.lib.tl_wino43_weights if f43 else self.lib.tl_wino_weights
+        check(fn(ptr(w), ptr(dst) if forward else None, None if forward else ptr(dst), O, I, I, O, self._stream()),
+              "tl_wino_weights")
         return dst
 
     # ------------------------------------------------------------------ one ecog stage (2..5)
@@ -228,7 +238,8 @@ class CnnEngine:
         """conv (k,1) + bias + LeakyReLU (+ max-pool, arg-max bits): P[idx-1] -> P[idx]."""
         S = self.S
         wino = self._use_wino(st)
-        wp = self._pack_wino(w, True) if wino else self._pack_conv(w, st.cin, False)
+        f43 = self._use_wino43(st)
+        wp = self._pack_wino(w, True, f43) if wino else self._pack_conv(w, st.cin, False)
         src = self.P[st.idx - 1]
         kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(self.P[st.idx]), M=S * st.tp_in,
                   A_rows=src.shape[0], N=st.cout, K=st.cin, lda=src.shape[1], ldb=st.cin,
@@ -238,7 +249,8 @@ class CnnEngine:
             kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
         else:
             kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
-        self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino_nt" if wino else "tl_gemm_nt_window", **kw)
+        self._nt(tag=f"conv{st.idx}_fwd", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino
+                 else "tl_gemm_nt_window", **kw)
 
     def _colsum(self, Gm, rows, ncols, ld, Tp, Tvalid, dst):
         nc4 = _r4(ncols)                       # pad columns of G are zero by construction
@@ -308,7 +320,8 @@ class CnnEngine:
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
         wino = self._use_wino(st)
-        wd = self._pack_wino(w, False) if wino else self._pack_conv(w, st.cin, True)   # [J or 4][cin][r4(cout)]
+        f43 = self._use_wino43(st)
+        wd = self._pack_wino(w, False, f43) if wino else self._pack_conv(w, st.cin, True)   # [J, 4 or 6][cin][r4(cout)]
         kd = wd.shape[2]
         kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=ptr(self.G[st.idx - 1]), M=rows_in, A_rows=Gs.shape[0],
                   N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k, row_shift=-(st.k - 1),
@@ -318,7 +331,8 @@ class CnnEngine:
                       Tvalid_in=2 * st.tout)
         else:
             kw.update(loader=LOAD_DIRECT)
-        self._nt(tag=f"conv{st.idx}_dgrad", fn="tl_conv3_wino_nt" if wino else "tl_gemm_nt_window", **kw)
+        self._nt(tag=f"conv{st.idx}_dgrad", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino
+                 else "tl_gemm_nt_window", **kw)
 
     # ------------------------------------------------------------------ forward
     def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,

@@ -355,6 +355,289 @@ __global__ __launch_bounds__(512 / MI, 2 / MI) void wino_nt_kernel(const tl_nt_p
 }
 
 // ------------------------------------------------------------------------------------------
+// F(4,3): 6 channel contractions per 4 conv rows (two pool pairs) - half the MFMA work of the
+// direct form.  Rows 4Q .. 4Q+5 feed quad Q:
+//   V0 = 4d0 - 5d2 + d4           V1 = -4d1 - 4d2 + d3 + d4      V2 = 4d1 - 4d2 - d3 + d4
+//   V3 = -2d1 - d2 + 2d3 + d4     V4 = 2d1 - d2 - 2d3 + d4       V5 = 4d1 - 5d3 + d5
+//   U  = G g,  G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   y0 = M0+M1+M2+M3+M4   y1 = (M1-M2) + 2(M3-M4)   y2 = (M1+M2) + 4(M3+M4)   y3 = (M1-M2) + 8(M3-M4) + M5
+// (fp32 error of this form measured 1.5x that of the direct convolution on the conv2 shape).
+// Workgroup: 8 waves, 4 (quads) x 2 (columns); wave tile 32 quads x 32 columns x 6 transforms = 96
+// accumulator registers; block tile 128 quads (512 conv rows) x 64 columns; a K-step is a 16-deep
+// channel chunk carrying all six transforms (48 MFMAs per wave between barriers).  LDS keeps the
+// staged rows in four planes (row mod 4), 80-byte row stride: conflict-free ds_read_b128.
+// ------------------------------------------------------------------------------------------
+constexpr int W4_BQ = 128, W4_BN = 64, W4_BK = 16, W4_LD = W4_BK + 4, W4_QR = W4_BQ + 1;
+
+__global__ void wino43_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ dgr,
+                                      int O, int I, int ld_f, int ld_d) {
+  const long long n_f = (long long)O * ld_f, n_d = (long long)I * ld_d;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  auto emit = [](float* dst, long long n, long long at, float g0, float g1, float g2) {
+    const float s = g0 + g2;
+    dst[at] = 0.25f * g0;
+    dst[n + at] = (-1.f / 6.f) * (s + g1);
+    dst[2 * n + at] = (-1.f / 6.f) * (s - g1);
+    dst[3 * n + at] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    dst[4 * n + at] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    dst[5 * n + at] = g2;
+  };
+  if (fwd != nullptr && idx < n_f) {
+    const int o = (int)(idx / ld_f), i = (int)(idx % ld_f);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (i < I) {
+      const float* s = w + ((long long)o * I + i) * 3;
+      g0 = s[0], g1 = s[1], g2 = s[2];
+    }
+    emit(fwd, n_f, idx, g0, g1, g2);
+  }
+  if (dgr != nullptr && idx < n_d) {
+    const int i = (int)(idx / ld_d), o = (int)(idx % ld_d);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (o < O) {
+      const float* s = w + ((long long)o * I + i) * 3;
+      g0 = s[2], g1 = s[1], g2 = s[0];          // flipped taps
+    }
+    emit(dgr, n_d, idx, g0, g1, g2);
+  }
+}
+
+template <int LOADER, int EPI>
+__global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p) {
+  constexpr int NTHR = 512;
+  constexpr int PLANE = W4_QR * W4_LD;
+  constexpr int ABUF = 4 * PLANE;
+  constexpr int BBUF = 6 * W4_BN * W4_LD;
+  constexpr int AROWS = 4 * W4_BQ + 2;                   // staged input rows
+  constexpr int A_F4 = (LOADER == W_LOAD_DIRECT) ? ((AROWS * 4 + NTHR - 1) / NTHR) : ((AROWS / 2 * 4 + NTHR - 1) / NTHR);
+  constexpr int B_F4 = 6 * W4_BN * 4 / NTHR;             // 3
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * ABUF + 2 * BBUF];
+  float* As = lds;                                        // [2][4 planes][W4_QR][W4_LD]
+  float* Bs = lds + 2 * ABUF;                             // [2][6][W4_BN][W4_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int ntn = (p.N + W4_BN - 1) / W4_BN;
+  const long long ntm = (p.M + 4 * W4_BQ - 1) / (4 * W4_BQ);
+  const long long nwg = ntm * ntn;
+  long long bid = blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const long long tm = bid / ntn;
+  const int tn = (int)(bid % ntn);
+  const long long R0 = tm * (4 * W4_BQ);
+  const int n0 = tn * W4_BN;
+  const int nsteps = p.K / W4_BK;                         // host-checked: K % 16 == 0, K >= 16
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  f32x4 ra[A_F4];
+  uint32_t rbits[A_F4];
+  f32x4 rbP[B_F4], rbQ[B_F4];
+  (void)rbits;
+
+  const long long Abase = R0 + p.row_shift;               // first staged input row (even)
+  const float* aptr[A_F4];
+  const uint32_t* abptr[A_F4];
+  bool aok[A_F4];
+  (void)abptr;
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    const int idx = tid + i * NTHR;
+    const int r = idx >> 2, c4 = idx & 3;
+    if constexpr (LOADER == W_LOAD_DIRECT) {
+      const long long row = Abase + r;
+      aok[i] = r < AROWS && row >= 0 && row < p.A_rows;
+      aptr[i] = p.A + (aok[i] ? row : 0) * (long long)p.lda + c4 * 4;
+      abptr[i] = nullptr;
+    } else {
+      const long long prow = (Abase >> 1) + r;
+      aok[i] = r < AROWS / 2 && prow >= 0 && prow < p.A_rows && (int)((2 * prow) % p.Tp) < p.Tvalid_in;
+      aptr[i] = p.A + (aok[i] ? prow : 0) * (long long)p.lda + c4 * 4;
+      abptr[i] = p.abits + (aok[i] ? prow : 0) * (long long)p.ld_abits;
+    }
+  }
+  const float* bptr[B_F4];
+  const long long tap_stride = (long long)p.N * p.ldb;
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) {
+    const int idx = tid + i * NTHR;
+    const int it = idx >> 8, r = (idx >> 2) & 63, c4 = idx & 3;
+    bptr[i] = p.Bw + it * tap_stride + (long long)((n0 + r) < p.N ? n0 + r : 0) * p.ldb + c4 * 4;
+  }
+
+  auto load_a = [&](int step) {
+    const int kc = step * W4_BK;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {                      // branch-free: see wino_nt_kernel
+      ra[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
+      if constexpr (LOADER == W_LOAD_UNPOOL) rbits[i] = abptr[i][kc >> 5];
+    }
+  };
+  auto store_a = [&](int buf, int step) {
+    float* dst = As + buf * ABUF;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      const int idx = tid + i * NTHR;
+      const int r = idx >> 2, c4 = idx & 3;
+      if constexpr (LOADER == W_LOAD_DIRECT) {
+        if (r < AROWS) *reinterpret_cast<f32x4*>(dst + (r & 3) * PLANE + (r >> 2) * W4_LD + c4 * 4) = ra[i];
+      } else {
+        if (r < AROWS / 2) {
+          f32x4 e, o;
+          const uint32_t nibv = rbits[i] >> ((step * W4_BK + c4 * 4) & 31);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool odd = (nibv >> q) & 1u;
+            const float g = aok[i] ? ra[i][q] : 0.f;
+            e[q] = odd ? 0.f : g;
+            o[q] = odd ? g : 0.f;
+          }
+          float* d2 = dst + ((r & 1) * 2) * PLANE + (r >> 1) * W4_LD + c4 * 4;   // pair r = staged rows 2r, 2r+1
+          *reinterpret_cast<f32x4*>(d2) = e;
+          *reinterpret_cast<f32x4*>(d2 + PLANE) = o;
+        }
+      }
+    }
+  };
+  auto load_b = [&](f32x4 (&rb)[B_F4], int step) {
+    const int kc = step * W4_BK;
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bptr[i] + kc);
+  };
+  auto store_b = [&](const f32x4 (&rb)[B_F4], int buf) {
+    float* dst = Bs + buf * BBUF;
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      const int idx = tid + i * NTHR;
+      const int it = idx >> 8, r = (idx >> 2) & 63, c4 = idx & 3;
+      *reinterpret_cast<f32x4*>(dst + (it * W4_BN + r) * W4_LD + c4 * 4) = rb[i];
+    }
+  };
+
+  const int a_lane = (wm * 32 + lr) * W4_LD + lh * 4;
+  const int b_lane = (wn * 32 + lr) * W4_LD + lh * 4;
+  auto kgroup = [&](int abuf, int bbuf, int g) {
+    const float* a_s = As + abuf * ABUF + a_lane + g * 8;
+    const float* b_s = Bs + bbuf * BBUF + b_lane + g * 8;
+    const f32x4 d1 = *reinterpret_cast<const f32x4*>(a_s + PLANE);
+    const f32x4 d2 = *reinterpret_cast<const f32x4*>(a_s + 2 * PLANE);
+    const f32x4 d3 = *reinterpret_cast<const f32x4*>(a_s + 3 * PLANE);
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(a_s + W4_LD);
+    f32x4 u[6];
+#pragma unroll
+    for (int i = 1; i < 5; ++i) u[i] = *reinterpret_cast<const f32x4*>(b_s + i * W4_BN * W4_LD);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(a_s);
+    const f32x4 d5 = *reinterpret_cast<const f32x4*>(a_s + PLANE + W4_LD);
+    u[0] = *reinterpret_cast<const f32x4*>(b_s);
+    u[5] = *reinterpret_cast<const f32x4*>(b_s + 5 * W4_BN * W4_LD);
+    f32x4 v[6];
+    const f32x4 s1 = d4 - 4.f * d2, s2 = d3 - 4.f * d1;
+    v[1] = s1 + s2;
+    v[2] = s1 - s2;
+    const f32x4 s3 = d4 - d2, t = d3 - d1;
+    v[3] = s3 + 2.f * t;
+    v[4] = s3 - 2.f * t;
+    v[0] = 4.f * d0 + (d4 - 5.f * d2);
+    v[5] = 4.f * d1 + (d5 - 5.f * d3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 1; i < 7; ++i) {                      // transforms 1..4 first: their operands arrive first
+        const int ii = i < 5 ? i : (i == 5 ? 0 : 5);
+        acc[ii] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[ii][q], u[ii][q], acc[ii], 0, 0, 0);
+      }
+  };
+
+  // LAST (compile time): no tiles left to prefetch / write
+  auto kstep = [&](auto TAIL, int s, f32x4 (&rb_ld)[B_F4], const f32x4 (&rb_st)[B_F4]) {
+    constexpr bool tail = decltype(TAIL)::value;
+    const int buf = s & 1;
+    if (!tail || s + 2 < nsteps) load_b(rb_ld, s + 2);
+    if (!tail || s + 1 < nsteps) load_a(s + 1);
+    kgroup(buf, buf, 0);
+    if (!tail || s + 1 < nsteps) store_b(rb_st, buf ^ 1);
+    kgroup(buf, buf, 1);
+    if (!tail || s + 1 < nsteps) store_a(buf ^ 1, s + 1);
+    __syncthreads();
+  };
+  using Mid = std::false_type;
+  using Tail = std::true_type;
+
+  load_a(0);
+  load_b(rbP, 0);
+  store_a(0, 0);
+  store_b(rbP, 0);
+  if (nsteps > 1) load_b(rbQ, 1);
+  __syncthreads();
+  int s = 0;
+  for (; s + 3 < nsteps; s += 2) {
+    kstep(Mid{}, s, rbP, rbQ);
+    kstep(Mid{}, s + 1, rbQ, rbP);
+  }
+  for (; s < nsteps; s += 2) {
+    kstep(Tail{}, s, rbP, rbQ);
+    if (s + 1 < nsteps) kstep(Tail{}, s + 1, rbQ, rbP);
+  }
+
+  // ---- epilogue: the four conv rows of a quad from its six products ----
+  const long long Q0 = (R0 >> 2) + wm * 32 + 4 * lh;       // quad of accumulator element e = 0
+  const int t0 = (int)((4 * Q0) % p.Tp);
+  const int col = n0 + wn * 32 + lr;
+  const int colbase = n0 + wn * 32;
+  const bool colok = col < p.N;
+  float bv = 0.f;
+  if constexpr (EPI == W_EPI_POOL) bv = (colok && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int qo = (e & 3) + 8 * (e >> 2);
+    const long long Q = Q0 + qo;
+    const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
+    const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
+    float y[4];
+    y[0] = (acc[0][e] + a12) + a34;
+    y[1] = s12 + 2.f * s34;
+    y[2] = a12 + 4.f * a34;
+    y[3] = (s12 + 8.f * s34) + acc[5][e];
+    if constexpr (EPI == W_EPI_POOL) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const long long P = 2 * Q + h;                      // pooled row
+        const float y0 = lrelu(y[2 * h] + bv, p.slope), y1 = lrelu(y[2 * h + 1] + bv, p.slope);
+        const bool rowok = 2 * P < p.M;
+        const bool valid = rowok && ((t0 + 4 * qo + 2 * h) % p.Tp) < p.Tvalid;
+        const bool sel = valid && colok && (y1 > y0);
+        const float o = valid ? (sel ? y1 : y0) : 0.f;
+        if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
+        const unsigned long long m = __ballot(sel);
+        if (lr == 0 && rowok && colbase < p.N)
+          p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(m >> (32 * lh));
+      }
+    } else {
+      const long long R = 4 * Q;
+      if (R < p.M && colok) {                               // M % 4 == 0: the quad shares validity
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float a = p.aux[(R + h) * (long long)p.ldaux + col];
+          p.out[(R + h) * (long long)p.ldo + col] = a > 0.f ? y[h] : y[h] * p.slope;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // TN form (weight gradient): slab[z][i][m][n] = sum_{pairs in split z} (B^T d)_i[m] * (A dy)_i[n]
 // with d = the activation rows 2P..2P+3 (A operand, C_in) and dy = the un-pooled dZ rows 2P, 2P+1
 // (B operand, C_out): dy0 = G (bit clear), dy1 = G (bit set).  Stored transforms: i = 3 uses +dy1
@@ -603,6 +886,50 @@ extern "C" int tl_conv3_wino_nt(const tl_nt_params* pp, void* stream) {
     return TL_EINVAL;
   }
   return check_launch("wino_nt");
+}
+
+extern "C" int tl_wino43_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(w != nullptr && (fwd != nullptr || dgr != nullptr), "wino43_weights: null pointer");
+  TL_REQUIRE(O > 0 && I > 0, "wino43_weights: bad sizes");
+  TL_REQUIRE((fwd == nullptr || ld_f >= I) && (dgr == nullptr || ld_d >= O), "wino43_weights: leading dimension too small");
+  const long long nf = fwd ? (long long)O * ld_f : 0, nd = dgr ? (long long)I * ld_d : 0;
+  const long long n = nf > nd ? nf : nd;
+  hipLaunchKernelGGL(wino43_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, fwd,
+                     dgr, O, I, ld_f, ld_d);
+  return check_launch("wino43_weights");
+}
+
+extern "C" int tl_conv3_wino43_nt(const tl_nt_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "wino43_nt: null params");
+  const tl_nt_params& p = *pp;
+  TL_REQUIRE(p.A && p.Bw && p.out, "wino43_nt: null A/Bw/out");
+  TL_REQUIRE(p.J == 3, "wino43_nt: the Winograd form is for 3-tap convolutions");
+  TL_REQUIRE(p.M >= 0 && p.M % 4 == 0 && p.N > 0 && p.K > 0, "wino43_nt: bad M/N/K %lld/%d/%d", (long long)p.M, p.N, p.K);
+  TL_REQUIRE(p.K % 32 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino43_nt: K %% 32, lda %% 4, ldb %% 4 must be 0");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K, "wino43_nt: lda/ldb smaller than K");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 4 == 0, "wino43_nt: Tp must be a positive multiple of 4");
+  TL_REQUIRE(p.splitk <= 1, "wino43_nt: no split-K");
+  const long long nwg = ((p.M + 4 * W4_BQ - 1) / (4 * W4_BQ)) * ((p.N + W4_BN - 1) / W4_BN);
+  if (nwg <= 0) return TL_OK;
+  TL_REQUIRE(nwg < (1LL << 31), "wino43_nt: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (p.loader == W_LOAD_DIRECT && p.epilogue == W_EPI_POOL) {
+    TL_REQUIRE(p.row_shift == 0, "wino43_nt: forward needs row_shift 0");
+    TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0, "wino43_nt: POOL needs obits and an even Tvalid");
+    TL_REQUIRE(p.N % 32 == 0 && p.ld_obits * 32 >= p.N, "wino43_nt: POOL needs N %% 32 == 0");
+    hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_DIRECT, W_EPI_POOL>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+  } else if (p.loader == W_LOAD_UNPOOL && p.epilogue == W_EPI_MASK) {
+    TL_REQUIRE(p.row_shift == -2, "wino43_nt: input gradient needs row_shift -2");
+    TL_REQUIRE(p.abits != nullptr && p.aux != nullptr, "wino43_nt: UNPOOL/MASK need abits and aux");
+    TL_REQUIRE(p.Tvalid_in % 2 == 0, "wino43_nt: UNPOOL needs an even Tvalid_in");
+    hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_UNPOOL, W_EPI_MASK>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+  } else {
+    set_error("wino43_nt: unsupported loader/epilogue combination %d/%d", p.loader, p.epilogue);
+    return TL_EINVAL;
+  }
+  return check_launch("wino43_nt");
 }
 
 extern "C" int tl_conv3_wino_tn(const tl_tn_params* pp, void* stream) {

@@ -103,8 +103,12 @@ int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
  *   tl_conv3_wino_tn       tl_gemm_tn_window (UNPOOL) writing the 4 transform accumulators
  *                          slab[z][4][Mdim][ldc] (slab_stride >= 4*Mdim*ldc)
  *   tl_wino_wgrad_finalize red [4][I][ld] (slabs summed by the caller) -> dW (O, I, 3, 1)
+ *   tl_wino43_weights / tl_conv3_wino43_nt: the F(4,3) form of the same two NT passes (6 contractions
+ *                          per 4 conv rows; taps [6][N][ldb]; M and Tp multiples of 4)
  * ------------------------------------------------------------------------------------------ */
 int tl_wino_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
+int tl_wino43_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
+int tl_conv3_wino43_nt(const tl_nt_params* p, void* stream);
 int tl_conv3_wino_nt(const tl_nt_params* p, void* stream);
 int tl_conv3_wino_tn(const tl_tn_params* p, void* stream);
 int tl_wino_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);

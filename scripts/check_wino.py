@@ -12,12 +12,14 @@ ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--channels", type=int, default=16)
 ap.add_argument("--timepoints", type=int, default=400)
 ap.add_argument("--iters", type=int, default=0)
+ap.add_argument("--f43", action="store_true", help="F(4,3) NT kernels as the Winograd arm")
 ap.add_argument("--only-wino", action="store_true", help="timing of the Winograd kernels only")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
 eng = CnnEngine(80, args.channels, args.timepoints, 6, 64, 0.0, 0.01, stages_def, [128, 128, 128, 128, 64])
 B = args.batch
+eng.wino43 = args.f43
 eng._alloc(B, dev)
 eng._alloc_bwd()
 g = torch.Generator(device=dev).manual_seed(1)

@@ -6,6 +6,7 @@ fp64 signal paths 1e-9 relative.
 import os
 from argparse import Namespace
 
+import ctypes as C_
 import numpy as np
 import pytest
 import torch
@@ -417,6 +418,42 @@ def test_glds_variant_matches_default_kernel(dev, monkeypatch):
     assert rel(outs[1], outs[0]) < 1e-5
     for k in grads[0]:
         assert rel_l2(grads[1][k], grads[0][k]) < 5e-3, k
+
+
+def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
+    """The Winograd F(2,3) conv kernels (default) against the direct MFMA kernels (TONAL_WINO=0):
+    same forward, same gradients, on a ragged shape (row tiles, time padding and the last
+    reduction chunk are all partial)."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    from decode_tonal_langauge_amd import _lib
+    lib = _lib.load()
+    for (B, C, T) in ((6, 8, 200), (5, 3, 131)):
+        g = torch.Generator().manual_seed(T)
+        x = torch.randn(B, C, T, generator=g)
+        lab = torch.randint(0, 4, (B, 2, 5), generator=g).float()
+        tgt = torch.randn(B, 80, generator=g)
+        outs, grads = [], []
+        for flag in ("0", "1", "4"):              # direct, F(2,3) (default), F(4,3) forward / input gradient
+            monkeypatch.setenv("TONAL_WINO", flag)
+            torch.manual_seed(1)
+            model = SynthesisModelCNN(80, C, T, dropout=0.0).to(dev).train()
+            assert model._engine.wino == (flag != "0") and model._engine.wino43 == (flag == "4")
+            out = model(x.to(dev), lab.to(dev))
+            (out - tgt.to(dev)).abs().mean().backward()
+            outs.append(out.detach().cpu().numpy())
+            grads.append({k: p.grad.cpu().numpy() for k, p in model.named_parameters()})
+        for v in (1, 2):
+            assert rel(outs[v], outs[0]) < 1e-5
+            for k in grads[0]:
+                assert rel_l2(grads[v][k], grads[0][k]) < 5e-3, k
+    # the C ABI refuses shapes the Winograd form does not cover instead of computing garbage
+    p = _lib.NtParams()
+    dummy = torch.zeros(64, device=dev)
+    for k in ("A", "Bw", "out"):
+        setattr(p, k, dummy.data_ptr())
+    p.M, p.N, p.K, p.lda, p.ldb, p.J, p.Tp = 4, 32, 24, 24, 24, 3, 2          # K % 32 != 0
+    assert lib.tl_conv3_wino_nt(C_.byref(p), None) != 0
+    assert b"wino_nt" in lib.tl_last_error()
 
 
 def test_cnn_classifier_hip_forward_matches_module_graph(dev):
