@@ -1,0 +1,47 @@
+"""Reduce the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of `bench.py` into
+profiles/pmc_traffic.json: HBM bytes per launch of the three dominant conv kernel families.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o f -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o w -- python3 bench.py ...
+    python scripts/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w
+
+Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are
+in KiB; FETCH_SIZE tallies the 128-B requests of 16-B/lane streaming reads at 64 B, so it is doubled.
+"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+FAMILIES = {
+    "wino_nt_kernel<1, 3, 1>": "wino_nt_kernel<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd F(2,3))",
+    "wino_nt_kernel<0, 2, 1>": "wino_nt_kernel<DIRECT,POOL> (conv2/conv3 forward, Winograd F(2,3))",
+    "wino_tn_kernel": "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))",
+}
+
+
+def collect(d, counter):
+    tot, n = defaultdict(float), defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            for key, fam in FAMILIES.items():
+                if key in r["Kernel_Name"]:
+                    tot[fam] += float(r["Counter_Value"])
+                    n[fam].add(r["Dispatch_Id"])
+    return tot, {k: len(v) for k, v in n.items()}
+
+
+fetch, nf = collect(sys.argv[1], "FETCH_SIZE")
+write, nw = collect(sys.argv[2], "WRITE_SIZE")
+out = {}
+for fam in FAMILIES.values():
+    if fam not in fetch or fam not in write:
+        continue
+    rd = fetch[fam] / nf[fam] * 1024 * 2
+    wr = write[fam] / nw[fam] * 1024
+    out[fam] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_averaged": nf[fam],
+                "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 tallies 128-B requests at 64 B for 16-B/lane streaming "
+                              "reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE KiB x1024"}
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
