@@ -175,15 +175,17 @@ def main():
         if tsum:
             # kernel families as rocprofv3 names them: one name covers the launches of several stages
             if getattr(eng, "wino", False):
-                fams = {"wino_nt_kernel<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd F(2,3))": ["conv2_dgrad", "conv3_dgrad"],
-                        "wino_nt_kernel<DIRECT,POOL> (conv2/conv3 forward, Winograd F(2,3))": ["conv2_fwd", "conv3_fwd"],
+                nt, nt_frac = ("wino43_nt_kernel", "F(4,3)") if getattr(eng, "wino43", False) else ("wino_nt_kernel", "F(2,3)")
+                fams = {f"{nt}<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd {nt_frac})": ["conv2_dgrad", "conv3_dgrad"],
+                        f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {nt_frac})": ["conv2_fwd", "conv3_fwd"],
                         "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))": ["conv2_wgrad", "conv3_wgrad"]}
-                issued = 2.0 / 3.0          # MFMA FLOPs issued per algorithmic (direct-convolution) FLOP
+                # MFMA FLOPs issued per algorithmic (direct-convolution) FLOP of each family
+                issued_of = {k: (0.5 if "F(4,3)" in k else 2.0 / 3.0) for k in fams}
             else:
                 fams = {"nt_window_kernel<128,UNPOOL,MASK> (conv input-gradient)": ["conv2_dgrad", "conv3_dgrad", "conv4_dgrad"],
                         "nt_window_kernel<128,DIRECT,POOL> (conv forward)": ["conv2_fwd", "conv3_fwd", "conv4_fwd"],
                         "tn3_kernel<UNPOOL> (conv weight-gradient)": ["conv2_wgrad", "conv3_wgrad"]}
-                issued = 1.0
+                issued_of = {k: 1.0 for k in fams}
             stats = {}
             for fam, tags in fams.items():
                 tags = [t for t in tags if t in tsum]
@@ -196,6 +198,7 @@ def main():
                               "tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12}
             dom = max(stats, key=lambda k: stats[k]["ms_per_step"])
             d = stats[dom]
+            issued = issued_of[dom]
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):

@@ -442,10 +442,10 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-  f32x4 ra[A_F4];
-  uint32_t rbits[A_F4];
-  f32x4 rbP[B_F4], rbQ[B_F4];
-  (void)rbits;
+  f32x4 raP[A_F4], raQ[A_F4];   // the A chunk streams from HBM: prefetched two K-steps ahead
+  uint32_t rbitsP[A_F4], rbitsQ[A_F4];
+  f32x4 rb[B_F4];               // the weight tile comes from L2 / Infinity Cache: one K-step of prefetch
+  (void)rbitsP; (void)rbitsQ;
 
   const long long Abase = R0 + p.row_shift;               // first staged input row (even)
   const float* aptr[A_F4];
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
     bptr[i] = p.Bw + it * tap_stride + (long long)((n0 + r) < p.N ? n0 + r : 0) * p.ldb + c4 * 4;
   }
 
-  auto load_a = [&](int step) {
+  auto load_a = [&](f32x4 (&ra)[A_F4], uint32_t (&rbits)[A_F4], int step) {
     const int kc = step * W4_BK;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {                      // branch-free: see wino_nt_kernel
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
       if constexpr (LOADER == W_LOAD_UNPOOL) rbits[i] = abptr[i][kc >> 5];
     }
   };
-  auto store_a = [&](int buf, int step) {
+  auto store_a = [&](const f32x4 (&ra)[A_F4], const uint32_t (&rbits)[A_F4], int buf, int step) {
     float* dst = As + buf * ABUF;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
@@ -528,68 +528,89 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
 
   const int a_lane = (wm * 32 + lr) * W4_LD + lh * 4;
   const int b_lane = (wn * 32 + lr) * W4_LD + lh * 4;
-  auto kgroup = [&](int abuf, int bbuf, int g) {
-    const float* a_s = As + abuf * ABUF + a_lane + g * 8;
-    const float* b_s = Bs + bbuf * BBUF + b_lane + g * 8;
-    const f32x4 d1 = *reinterpret_cast<const f32x4*>(a_s + PLANE);
-    const f32x4 d2 = *reinterpret_cast<const f32x4*>(a_s + 2 * PLANE);
-    const f32x4 d3 = *reinterpret_cast<const f32x4*>(a_s + 3 * PLANE);
-    const f32x4 d4 = *reinterpret_cast<const f32x4*>(a_s + W4_LD);
-    f32x4 u[6];
-#pragma unroll
-    for (int i = 1; i < 5; ++i) u[i] = *reinterpret_cast<const f32x4*>(b_s + i * W4_BN * W4_LD);
-    const f32x4 d0 = *reinterpret_cast<const f32x4*>(a_s);
-    const f32x4 d5 = *reinterpret_cast<const f32x4*>(a_s + PLANE + W4_LD);
-    u[0] = *reinterpret_cast<const f32x4*>(b_s);
-    u[5] = *reinterpret_cast<const f32x4*>(b_s + 5 * W4_BN * W4_LD);
-    f32x4 v[6];
-    const f32x4 s1 = d4 - 4.f * d2, s2 = d3 - 4.f * d1;
-    v[1] = s1 + s2;
-    v[2] = s1 - s2;
-    const f32x4 s3 = d4 - d2, t = d3 - d1;
-    v[3] = s3 + 2.f * t;
-    v[4] = s3 - 2.f * t;
-    v[0] = 4.f * d0 + (d4 - 5.f * d2);
-    v[5] = 4.f * d1 + (d5 - 5.f * d3);
+  // Software pipeline of one K-step (two 8-deep k-groups g0, g1; transforms split in alpha = {1..4},
+  // whose operands are rows d1..d4, and beta = {0, 5}): the beta MFMAs of g1 are carried in registers
+  // across the barrier and run while the alpha fragments of the next step are read from LDS.
+  f32x4 cv0 = {0.f, 0.f, 0.f, 0.f}, cv5 = cv0, cu0 = cv0, cu5 = cv0;
+  auto rd = [&](const float* ptr) { return *reinterpret_cast<const f32x4*>(ptr); };
+  auto alpha_mfma = [&](const f32x4 (&v)[4], const f32x4 (&u)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int i = 1; i < 7; ++i) {                      // transforms 1..4 first: their operands arrive first
-        const int ii = i < 5 ? i : (i == 5 ? 0 : 5);
-        acc[ii] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[ii][q], u[ii][q], acc[ii], 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i) acc[i + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i][q], u[i][q], acc[i + 1], 0, 0, 0);
   };
-
-  // LAST (compile time): no tiles left to prefetch / write
-  auto kstep = [&](auto TAIL, int s, f32x4 (&rb_ld)[B_F4], const f32x4 (&rb_st)[B_F4]) {
+  auto beta_mfma = [&](const f32x4& v0, const f32x4& u0, const f32x4& v5, const f32x4& u5) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[q], u0[q], acc[0], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(v5[q], u5[q], acc[5], 0, 0, 0);
+    }
+  };
+  auto kstep = [&](auto TAIL, int s, f32x4 (&ra_ld)[A_F4], uint32_t (&rbits_ld)[A_F4], const f32x4 (&ra_st)[A_F4],
+                   const uint32_t (&rbits_st)[A_F4]) {
     constexpr bool tail = decltype(TAIL)::value;
     const int buf = s & 1;
-    if (!tail || s + 2 < nsteps) load_b(rb_ld, s + 2);
-    if (!tail || s + 1 < nsteps) load_a(s + 1);
-    kgroup(buf, buf, 0);
-    if (!tail || s + 1 < nsteps) store_b(rb_st, buf ^ 1);
-    kgroup(buf, buf, 1);
-    if (!tail || s + 1 < nsteps) store_a(buf ^ 1, s + 1);
+    const float* a_s = As + buf * ABUF + a_lane;
+    const float* b_s = Bs + buf * BBUF + b_lane;
+    constexpr int US = W4_BN * W4_LD;
+    // alpha(g0) reads
+    f32x4 d1 = rd(a_s + PLANE), d2 = rd(a_s + 2 * PLANE), d3 = rd(a_s + 3 * PLANE), d4 = rd(a_s + W4_LD);
+    f32x4 u[4] = {rd(b_s + US), rd(b_s + 2 * US), rd(b_s + 3 * US), rd(b_s + 4 * US)};
+    if (!tail || s + 1 < nsteps) load_b(rb, s + 1);
+    if (!tail || s + 2 < nsteps) load_a(ra_ld, rbits_ld, s + 2);
+    beta_mfma(cv0, cu0, cv5, cu5);                        // carried from the previous step
+    // beta(g0) reads
+    f32x4 d0 = rd(a_s), d5 = rd(a_s + PLANE + W4_LD), u0 = rd(b_s), u5 = rd(b_s + 5 * US);
+    f32x4 v[4];
+    {
+      const f32x4 s1 = d4 - 4.f * d2, s2 = d3 - 4.f * d1, s3 = d4 - d2, t = d3 - d1;
+      v[0] = s1 + s2;
+      v[1] = s1 - s2;
+      v[2] = s3 + 2.f * t;
+      v[3] = s3 - 2.f * t;
+    }
+    f32x4 t0 = d4 - 5.f * d2, t5 = 4.f * d1 - 5.f * d3;
+    alpha_mfma(v, u);
+    f32x4 v0 = 4.f * d0 + t0, v5 = t5 + d5;
+    // alpha(g1) reads
+    d1 = rd(a_s + PLANE + 8), d2 = rd(a_s + 2 * PLANE + 8), d3 = rd(a_s + 3 * PLANE + 8), d4 = rd(a_s + W4_LD + 8);
+    f32x4 w[4] = {rd(b_s + US + 8), rd(b_s + 2 * US + 8), rd(b_s + 3 * US + 8), rd(b_s + 4 * US + 8)};
+    beta_mfma(v0, u0, v5, u5);
+    if (!tail || s + 1 < nsteps) store_b(rb, buf ^ 1);
+    // beta(g1) reads
+    d0 = rd(a_s + 8), d5 = rd(a_s + PLANE + W4_LD + 8), cu0 = rd(b_s + 8), cu5 = rd(b_s + 5 * US + 8);
+    {
+      const f32x4 s1 = d4 - 4.f * d2, s2 = d3 - 4.f * d1, s3 = d4 - d2, t = d3 - d1;
+      v[0] = s1 + s2;
+      v[1] = s1 - s2;
+      v[2] = s3 + 2.f * t;
+      v[3] = s3 - 2.f * t;
+    }
+    t0 = d4 - 5.f * d2, t5 = 4.f * d1 - 5.f * d3;
+    alpha_mfma(v, w);
+    cv0 = 4.f * d0 + t0, cv5 = t5 + d5;
+    if (!tail || s + 1 < nsteps) store_a(ra_st, rbits_st, buf ^ 1, s + 1);
     __syncthreads();
   };
   using Mid = std::false_type;
   using Tail = std::true_type;
 
-  load_a(0);
-  load_b(rbP, 0);
-  store_a(0, 0);
-  store_b(rbP, 0);
-  if (nsteps > 1) load_b(rbQ, 1);
+  load_a(raP, rbitsP, 0);
+  load_b(rb, 0);
+  store_a(raP, rbitsP, 0, 0);
+  store_b(rb, 0);
+  if (nsteps > 1) load_a(raQ, rbitsQ, 1);
   __syncthreads();
   int s = 0;
   for (; s + 3 < nsteps; s += 2) {
-    kstep(Mid{}, s, rbP, rbQ);
-    kstep(Mid{}, s + 1, rbQ, rbP);
+    kstep(Mid{}, s, raP, rbitsP, raQ, rbitsQ);
+    kstep(Mid{}, s + 1, raQ, rbitsQ, raP, rbitsP);
   }
   for (; s < nsteps; s += 2) {
-    kstep(Tail{}, s, rbP, rbQ);
-    if (s + 1 < nsteps) kstep(Tail{}, s + 1, rbQ, rbP);
+    kstep(Tail{}, s, raP, rbitsP, raQ, rbitsQ);
+    if (s + 1 < nsteps) kstep(Tail{}, s + 1, raQ, rbitsQ, raP, rbitsP);
   }
+  beta_mfma(cv0, cu0, cv5, cu5);
 
   // ---- epilogue: the four conv rows of a quad from its six products ----
   const long long Q0 = (R0 >> 2) + wm * 32 + 4 * lh;       // quad of accumulator element e = 0
