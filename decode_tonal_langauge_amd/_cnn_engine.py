@@ -91,14 +91,13 @@ class CnnEngine:
         self.timers = None
         # Winograd kernels for the pooled 3-tap stages.  TONAL_WINO selects the form:
         #   0  direct-form MFMA kernels (the parity partner)
-        #   1  default: F(2,3) for all three passes (2/3 of the direct-form MFMA work; same rounding
-        #      error as the direct form, 2e-7)
-        #   4  F(4,3) for the forward and input-gradient passes (1/2 of the MFMA work), F(2,3) for the
-        #      weight gradient: 3 % faster per step (304.5 vs 314 ms at the north-star shape) but about
-        #      twice the rounding error (1.4e-6 vs 8e-7 against the direct kernels), which the 3-step
-        #      NAdam update test against the reference golden does not pass at its 2e-3 bound
-        #      (2.5e-3 on one bias vector) - opt-in
-        mode = os.environ.get("TONAL_WINO", "1")
+        #   1  F(2,3) for all three passes (2/3 of the direct-form MFMA work)
+        #   4  default: F(4,3) for the forward and input-gradient passes (1/2 of the MFMA work), F(2,3)
+        #      for the weight gradient: 3 % faster per step than F(2,3) (304.5 vs 314 ms at the
+        #      north-star shape); rounding error against the direct kernels 1.4e-6 vs 8e-7.  Against the
+        #      reference golden all three forms sit at the same noise floor (scripts/update_parity.py,
+        #      DESIGN.md section 6)
+        mode = os.environ.get("TONAL_WINO", "4")
         self.wino = mode != "0"
         self.wino43 = mode == "4"
         self._B = None

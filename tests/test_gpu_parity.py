@@ -104,7 +104,11 @@ def test_cnn_train_steps_match_reference_golden(dev):
     assert rel(mcds, g["mcds"]) < 1e-4
     for k, p in model.named_parameters():
         fin = p.detach().cpu().numpy()
-        tol = 5e-2 if k.startswith("ecog_conv_block") else 2e-3
+        # NAdam divides by sqrt(v): after 3 steps the update of a bias whose gradient is tiny carries the
+        # rounding noise of any independent fp32 summation order at the 2-3e-3 level (direct MFMA form
+        # 1.8e-3 / 3.2e-3, F(2,3) 1.8e-3 / 3.2e-3, F(4,3) 2.5e-3 / 1.0e-3 on concat_conv_block.4.bias /
+        # ecog_conv_block.9.bias; scripts/update_parity.py) - bound at 2x that floor
+        tol = 5e-2 if k.startswith("ecog_conv_block") else 5e-3
         if "final." + k in g:
             assert gi.update_rel_l2(fin, g["final." + k], init[k]) < tol, k
         else:
@@ -421,7 +425,7 @@ def test_glds_variant_matches_default_kernel(dev, monkeypatch):
 
 
 def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
-    """The Winograd conv kernels (default F(2,3); opt-in F(4,3)) against the direct MFMA kernels (TONAL_WINO=0):
+    """The Winograd conv kernels (F(2,3); default F(4,3) + F(2,3)) against the direct MFMA kernels (TONAL_WINO=0):
     same forward, same gradients, on a ragged shape (row tiles, time padding and the last
     reduction chunk are all partial)."""
     from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
@@ -433,7 +437,7 @@ def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
         lab = torch.randint(0, 4, (B, 2, 5), generator=g).float()
         tgt = torch.randn(B, 80, generator=g)
         outs, grads = [], []
-        for flag in ("0", "1", "4"):              # direct, F(2,3) (default), F(4,3) forward / input gradient
+        for flag in ("0", "1", "4"):              # direct, F(2,3), default (F(4,3) forward / input gradient)
             monkeypatch.setenv("TONAL_WINO", flag)
             torch.manual_seed(1)
             model = SynthesisModelCNN(80, C, T, dropout=0.0).to(dev).train()
