@@ -66,7 +66,7 @@ class CnnClassifierEngine(CnnEngine):
         S = self.S
         w1, b1 = convs[0]
         check(lib.tl_conv1_fwd(ptr(x), ptr(w1.reshape(self.c1, self.k1).contiguous()), ptr(b1), ptr(self.P[1]),
-                               ptr(self.bits[1]), S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_),
+                               ptr(self.bits[1]), None, S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_),
               "tl_conv1_fwd")
         for st, (w, b) in zip(self.stages, convs[1:]):
             wp = self._cached(f"conv{st.idx}", w, lambda w=w, st=st: self._pack_conv(w, st.cin, False))

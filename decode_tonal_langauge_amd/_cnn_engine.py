@@ -116,12 +116,14 @@ class CnnEngine:
         zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
         self.P = {1: z(S * self.tp1, self.c1)}
         self.bits = {1: zi(S * self.tp1, self.c1 // 32)}
+        self.sbits = {1: zi(S * self.tp1, self.c1 // 32)}      # "pooled output > 0": the LeakyReLU' mask of backward
         for st in self.stages:
             rows = S * st.tp_out
             ld = st.cout if st.pool else self.ld5
             self.P[st.idx] = z(rows, ld)
             if st.pool:
                 self.bits[st.idx] = zi(rows, st.cout // 32)
+                self.sbits[st.idx] = zi(rows, st.cout // 32)
         rows5 = S * self.tp5
         self.rows5 = rows5
         self.Xc = z(rows5, self.ldx)
@@ -250,7 +252,8 @@ class CnnEngine:
                   ldo=self.P[st.idx].shape[1], J=st.k, row_shift=0, Tp=st.tp_in, slope=self.slope,
                   loader=LOAD_DIRECT)
         if st.pool:
-            kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
+            kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), osign=ptr(self.sbits[st.idx]),
+                      ld_obits=st.cout // 32, Tvalid=2 * st.tout)
         else:
             kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
         self._nt(tag=f"conv{st.idx}_fwd", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino
@@ -330,6 +333,8 @@ class CnnEngine:
         kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=ptr(self.G[st.idx - 1]), M=rows_in, A_rows=Gs.shape[0],
                   N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k, row_shift=-(st.k - 1),
                   Tp=st.tp_in, epilogue=EPI_MASK, slope=self.slope)
+        if (st.idx - 1) in self.sbits:            # the input of this stage came out of a pooling epilogue
+            kw.update(auxbits=ptr(self.sbits[st.idx - 1]), ld_auxbits=self.sbits[st.idx - 1].shape[1])
         if st.pool:
             kw.update(loader=LOAD_UNPOOL, abits=ptr(self.bits[st.idx]), ld_abits=st.cout // 32,
                       Tvalid_in=2 * st.tout)
@@ -359,7 +364,7 @@ class CnnEngine:
         # ---- stage 1 (C_in = 1) ----
         w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
         check(lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]), ptr(self.P[1]), ptr(self.bits[1]),
-                               S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd")
+                               ptr(self.sbits[1]), S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd")
         # ---- stages 2..5: windowed implicit GEMM on fp32 MFMA ----
         for st in self.stages:
             self.stage_forward(st, prm[self.STAGE_NAMES[st.idx] + ".weight"], prm[self.STAGE_NAMES[st.idx] + ".bias"])

@@ -32,6 +32,7 @@ class NtParams(C.Structure):
         ("loader", C.c_int), ("epilogue", C.c_int),
         ("splitk", C.c_int), ("slab_stride", C.c_int64),
         ("bm", C.c_int),
+        ("osign", C.c_void_p), ("auxbits", C.c_void_p), ("ld_auxbits", C.c_int),
     ]
 
 
@@ -66,7 +67,7 @@ SIGNATURES = {
     "tl_wino_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_sizeof_nt_params": (_I, []),
     "tl_sizeof_tn_params": (_I, []),
-    "tl_conv1_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
+    "tl_conv1_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
     "tl_conv1_wgrad": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P]),
     "tl_permute_reduce": (_I, [_P, _P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _L, _P, _P]),
     "tl_colsum": (_I, [_P, _P, _I, _L, _I, _I, _I, _I, _P]),

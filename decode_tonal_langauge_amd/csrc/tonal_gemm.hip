@@ -50,9 +50,12 @@ __device__ __forceinline__ void nt_epilogue(const tl_nt_params& p, f32x16 (&acc)
             const long long prow = (Rq >> 1) + e;
             if (rowok && colok) p.out[prow * (long long)p.ldo + col] = o;
             const unsigned long long m = __ballot(sel);
-            if (lr == 0 && rowok && (n0 + wn * (NI * 32) + ni * 32) < p.N)
-              p.obits[prow * (long long)p.ld_obits + ((n0 + wn * (NI * 32) + ni * 32) >> 5)] =
-                  (uint32_t)(m >> (32 * lh));
+            const unsigned long long ms = __ballot(o > 0.f);
+            if (lr == 0 && rowok && (n0 + wn * (NI * 32) + ni * 32) < p.N) {
+              const long long at = prow * (long long)p.ld_obits + ((n0 + wn * (NI * 32) + ni * 32) >> 5);
+              p.obits[at] = (uint32_t)(m >> (32 * lh));
+              if (p.osign != nullptr) p.osign[at] = (uint32_t)(ms >> (32 * lh));
+            }
           }
         }
       } else {
@@ -66,8 +69,12 @@ __device__ __forceinline__ void nt_epilogue(const tl_nt_params& p, f32x16 (&acc)
             float v = acc[mi][ni][e] + bv;
             if constexpr (EPI == EPI_LRELU) v = lrelu(v, p.slope);
             if constexpr (EPI == EPI_MASK) {
-              const float a = p.aux[R * (long long)p.ldaux + col];
-              v = a > 0.f ? v : v * p.slope;
+              bool pos;
+              if (p.auxbits != nullptr)
+                pos = (p.auxbits[R * (long long)p.ld_auxbits + (col >> 5)] >> (col & 31)) & 1u;
+              else
+                pos = p.aux[R * (long long)p.ldaux + col] > 0.f;
+              v = pos ? v : v * p.slope;
             }
             outp[R * (long long)p.ldo + col] = v;
           }
@@ -1144,7 +1151,7 @@ extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
     TL_REQUIRE(p.Tp % 2 == 0 && p.Tvalid % 2 == 0, "nt_window: POOL needs even Tp/Tvalid");
     TL_REQUIRE(p.N % 32 == 0 && p.ld_obits * 32 >= p.N, "nt_window: POOL needs N %% 32 == 0");
   }
-  if (p.epilogue == EPI_MASK) TL_REQUIRE(p.aux != nullptr, "nt_window: MASK epilogue needs aux");
+  if (p.epilogue == EPI_MASK) TL_REQUIRE(p.aux != nullptr || p.auxbits != nullptr, "nt_window: MASK epilogue needs aux or auxbits");
   hipStream_t st = (hipStream_t)stream;
   // Direct-to-LDS staging variant: measured equal to the register-staged kernel (conv2 fwd 129.6 vs
   // 128.6 TFLOP/s, whole step 416 vs 418 ms), so the simpler kernel stays the default; TONAL_GLDS=1

@@ -31,8 +31,9 @@ constexpr int MAXKT = 8;
 
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ P,
-                                                        uint32_t* __restrict__ bits, long long S, int T, int kt,
-                                                        int C1, int Tp, int Tout, float slope) {
+                                                        uint32_t* __restrict__ bits, uint32_t* __restrict__ sign,
+                                                        long long S, int T, int kt, int C1, int Tp, int Tout,
+                                                        float slope) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const long long seq = blockIdx.x;
   for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
@@ -61,9 +62,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       const long long row = seq * Tp + p;
       P[row * C1 + o] = out;
       const unsigned long long m = __ballot(sel);
+      const unsigned long long ms = __ballot(out > 0.f);
       if (lane == 0) {
         bits[row * (C1 >> 5) + (o >> 5)] = (uint32_t)m;
         bits[row * (C1 >> 5) + (o >> 5) + 1] = (uint32_t)(m >> 32);
+        if (sign != nullptr) {
+          sign[row * (C1 >> 5) + (o >> 5)] = (uint32_t)ms;
+          sign[row * (C1 >> 5) + (o >> 5) + 1] = (uint32_t)(ms >> 32);
+        }
       }
     }
   }
@@ -546,8 +552,8 @@ extern "C" int tl_device_count(void) {
   return n;
 }
 
-extern "C" int tl_conv1_fwd(const float* x, const float* w, const float* b, float* P, uint32_t* bits, int64_t S,
-                            int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream) {
+extern "C" int tl_conv1_fwd(const float* x, const float* w, const float* b, float* P, uint32_t* bits, uint32_t* sign,
+                            int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream) {
   TL_REQUIRE(x && w && b && P && bits, "conv1_fwd: null pointer");
   TL_REQUIRE(S > 0 && S < (1LL << 31), "conv1_fwd: bad S");
   TL_REQUIRE(ktaps >= 1 && ktaps <= MAXKT, "conv1_fwd: ktaps must be 1..%d", MAXKT);
@@ -555,7 +561,7 @@ extern "C" int tl_conv1_fwd(const float* x, const float* w, const float* b, floa
   TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_fwd: Tout/Tp/T inconsistent (%d,%d,%d)", Tout, Tp, T);
   TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_fwd: T too large for the LDS window");
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,
-                     bits, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+                     bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
   return check_launch("conv1_fwd");
 }
 

@@ -329,8 +329,11 @@ __global__ __launch_bounds__(512 / MI, 2 / MI) void wino_nt_kernel(const tl_nt_p
           const float o = valid ? (sel ? y1 : y0) : 0.f;
           if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
           const unsigned long long m = __ballot(sel);
-          if (lr == 0 && rowok && colbase < p.N)
+          const unsigned long long ms = __ballot(o > 0.f);
+          if (lr == 0 && rowok && colbase < p.N) {
             p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(m >> (32 * lh));
+            if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(ms >> (32 * lh));
+          }
         }
       } else {
 #pragma unroll
@@ -341,10 +344,16 @@ __global__ __launch_bounds__(512 / MI, 2 / MI) void wino_nt_kernel(const tl_nt_p
           float v0 = (acc[0][mi][ni][e] + m1) + m2;
           float v1 = (m1 - m2) - acc[3][mi][ni][e];
           if (R < p.M && colok) {                            // M is even: the pair shares validity
-            const float a0 = p.aux[R * (long long)p.ldaux + col];
-            const float a1 = p.aux[(R + 1) * (long long)p.ldaux + col];
-            v0 = a0 > 0.f ? v0 : v0 * p.slope;
-            v1 = a1 > 0.f ? v1 : v1 * p.slope;
+            bool pos0, pos1;
+            if (p.auxbits != nullptr) {
+              pos0 = (p.auxbits[R * (long long)p.ld_auxbits + (colbase >> 5)] >> lr) & 1u;
+              pos1 = (p.auxbits[(R + 1) * (long long)p.ld_auxbits + (colbase >> 5)] >> lr) & 1u;
+            } else {
+              pos0 = p.aux[R * (long long)p.ldaux + col] > 0.f;
+              pos1 = p.aux[(R + 1) * (long long)p.ldaux + col] > 0.f;
+            }
+            v0 = pos0 ? v0 : v0 * p.slope;
+            v1 = pos1 ? v1 : v1 * p.slope;
             p.out[R * (long long)p.ldo + col] = v0;
             p.out[(R + 1) * (long long)p.ldo + col] = v1;
           }
@@ -642,16 +651,23 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
         const float o = valid ? (sel ? y1 : y0) : 0.f;
         if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
         const unsigned long long m = __ballot(sel);
-        if (lr == 0 && rowok && colbase < p.N)
+        const unsigned long long ms = __ballot(o > 0.f);
+        if (lr == 0 && rowok && colbase < p.N) {
           p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(m >> (32 * lh));
+          if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(ms >> (32 * lh));
+        }
       }
     } else {
       const long long R = 4 * Q;
       if (R < p.M && colok) {                               // M % 4 == 0: the quad shares validity
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          const float a = p.aux[(R + h) * (long long)p.ldaux + col];
-          p.out[(R + h) * (long long)p.ldo + col] = a > 0.f ? y[h] : y[h] * p.slope;
+          bool pos;
+          if (p.auxbits != nullptr)
+            pos = (p.auxbits[(R + h) * (long long)p.ld_auxbits + (colbase >> 5)] >> lr) & 1u;
+          else
+            pos = p.aux[(R + h) * (long long)p.ldaux + col] > 0.f;
+          p.out[(R + h) * (long long)p.ldo + col] = pos ? y[h] : y[h] * p.slope;
         }
       }
     }
@@ -899,7 +915,7 @@ extern "C" int tl_conv3_wino_nt(const tl_nt_params* pp, void* stream) {
     hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_DIRECT, W_EPI_POOL, W_MI>), dim3((unsigned)nwg), dim3(512 / W_MI), 0, st, p);
   } else if (p.loader == W_LOAD_UNPOOL && p.epilogue == W_EPI_MASK) {
     TL_REQUIRE(p.row_shift == -2, "wino_nt: input gradient needs row_shift -2");
-    TL_REQUIRE(p.abits != nullptr && p.aux != nullptr, "wino_nt: UNPOOL/MASK need abits and aux");
+    TL_REQUIRE(p.abits != nullptr && (p.aux != nullptr || p.auxbits != nullptr), "wino_nt: UNPOOL/MASK need abits and aux or auxbits");
     TL_REQUIRE(p.Tvalid_in % 2 == 0, "wino_nt: UNPOOL needs an even Tvalid_in");
     hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_UNPOOL, W_EPI_MASK, W_MI>), dim3((unsigned)nwg), dim3(512 / W_MI), 0, st, p);
   } else {
@@ -943,7 +959,7 @@ extern "C" int tl_conv3_wino43_nt(const tl_nt_params* pp, void* stream) {
     hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_DIRECT, W_EPI_POOL>), dim3((unsigned)nwg), dim3(512), 0, st, p);
   } else if (p.loader == W_LOAD_UNPOOL && p.epilogue == W_EPI_MASK) {
     TL_REQUIRE(p.row_shift == -2, "wino43_nt: input gradient needs row_shift -2");
-    TL_REQUIRE(p.abits != nullptr && p.aux != nullptr, "wino43_nt: UNPOOL/MASK need abits and aux");
+    TL_REQUIRE(p.abits != nullptr && (p.aux != nullptr || p.auxbits != nullptr), "wino43_nt: UNPOOL/MASK need abits and aux or auxbits");
     TL_REQUIRE(p.Tvalid_in % 2 == 0, "wino43_nt: UNPOOL needs an even Tvalid_in");
     hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_UNPOOL, W_EPI_MASK>), dim3((unsigned)nwg), dim3(512), 0, st, p);
   } else {

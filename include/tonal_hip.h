@@ -67,6 +67,11 @@ typedef struct {
   int loader, epilogue;
   int splitk; int64_t slab_stride;
   int bm;             /* row-tile height: 256 (8 waves, large M), 128 (default) or 32 (skinny M) */
+  /* 1 bit per element, rows x ceil(cols/32) words like abits/obits: the POOL epilogue also writes
+   * "pooled output > 0" to osign (leading dimension ld_obits, may be null); the MASK epilogue reads
+   * its LeakyReLU' mask from auxbits (leading dimension ld_auxbits) instead of the floats in aux
+   * when auxbits is not null - 1/32 of the bytes                                                   */
+  uint32_t* osign; const uint32_t* auxbits; int ld_auxbits;
 } tl_nt_params;
 int tl_gemm_nt_window(const tl_nt_params* p, void* stream);
 
@@ -117,8 +122,8 @@ int tl_sizeof_nt_params(void);
 int tl_sizeof_tn_params(void);
 
 /* ---- first conv stage, C_in = 1 (models/synthesis_models.py:87-89) ----------------------
- * x (S, T) -> P1 rows (S*Tp, C1) + arg-max bits; w (C1,3) b (C1).                          */
-int tl_conv1_fwd(const float* x, const float* w, const float* b, float* P, uint32_t* bits,
+ * x (S, T) -> P1 rows (S*Tp, C1) + arg-max bits (+ sign bits "P1 > 0", may be null); w (C1,3) b (C1). */
+int tl_conv1_fwd(const float* x, const float* w, const float* b, float* P, uint32_t* bits, uint32_t* sign,
                  int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream);
 /* its weight/bias gradient from G1 = dL/dZ at the arg-max: partial[nblk][(ktaps+1)*C1]      */
 int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial,
