@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_LRELU, EPI_MASK, EPI_POOL, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, NtParams, TnParams,
+from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_POOL, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, NtParams, TnParams,
                    check, ptr)
 
 
@@ -100,6 +100,8 @@ class CnnEngine:
         mode = os.environ.get("TONAL_WINO", "4")
         self.wino = mode != "0"
         self.wino43 = mode == "4"
+        # fold the first stage's weight gradient into the stage-2 input-gradient epilogue (Winograd kernels)
+        self.fuse_c1 = os.environ.get("TONAL_FUSE_C1", "1") != "0"
         self._B = None
         self.generation = 0
         self._saved_generation = -1
@@ -138,7 +140,9 @@ class CnnEngine:
         f32 = dict(dtype=torch.float32, device=dev)
         z = lambda *s: torch.zeros(*s, **f32)
         S = self.S
-        self.G = {1: z(S * self.tp1, self.c1)}
+        self.G = {}
+        if not (self.fuse_c1 and self._c1_fusable() and self._use_wino(self.stages[0])):
+            self.G[1] = z(S * self.tp1, self.c1)      # otherwise G1 never leaves the stage-2 epilogue
         for st in self.stages:
             self.G[st.idx] = z(S * st.tp_out, st.cout if st.pool else self.ld5)
         self.GY = [z(self.rows5, d[3]) for d in self.concat_dims]
@@ -221,6 +225,10 @@ class CnnEngine:
     def _use_wino(self, st) -> bool:
         return (self.wino and st.k == 3 and st.pool and st.cin % 32 == 0 and st.cout % 32 == 0
                 and st.tp_in % 2 == 0)
+
+    def _c1_fusable(self) -> bool:
+        # the epilogue reads x[2t + a + j] for j < 3 unconditionally (4 floats from 2t)
+        return self.k1 <= 3 and self.T >= 2 * self.tout1 + 2
 
     def _use_wino43(self, st) -> bool:
         return self.wino43 and self._use_wino(st) and st.tp_in % 4 == 0
@@ -319,8 +327,12 @@ class CnnEngine:
         self._permute(red, gw, (1, st.cout, st.cin, st.k), (0, 1, ldg, st.cin * ldg))
         self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
 
-    def stage_dgrad(self, st: _Stage, w: torch.Tensor) -> None:
-        """G[idx-1] = (dZ[idx] (*) flipped W) * LeakyReLU'(P[idx-1])."""
+    def stage_dgrad(self, st: _Stage, w: torch.Tensor):
+        """G[idx-1] = (dZ[idx] (*) flipped W) * LeakyReLU'(P[idx-1]).
+
+        For stage 2 on the Winograd kernels G[1] is not stored: the epilogue contracts it with the raw
+        signal into per-row-tile partial sums of the first stage's weight / bias gradient, which are
+        returned (shape (tiles, (k1 + 1) * c1), layout of ``tl_conv1_wgrad``'s partials)."""
         S = self.S
         Xin = self.P[st.idx - 1]
         Gs = self.G[st.idx]
@@ -330,9 +342,10 @@ class CnnEngine:
         f43 = self._use_wino43(st)
         wd = self._pack_wino(w, False, f43) if wino else self._pack_conv(w, st.cin, True)   # [J, 4 or 6][cin][r4(cout)]
         kd = wd.shape[2]
-        kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=ptr(self.G[st.idx - 1]), M=rows_in, A_rows=Gs.shape[0],
-                  N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k, row_shift=-(st.k - 1),
-                  Tp=st.tp_in, epilogue=EPI_MASK, slope=self.slope)
+        fuse = st.idx == 2 and wino and self.fuse_c1 and self._c1_fusable()
+        kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=None if fuse else ptr(self.G[st.idx - 1]), M=rows_in,
+                  A_rows=Gs.shape[0], N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k,
+                  row_shift=-(st.k - 1), Tp=st.tp_in, epilogue=EPI_MASK, slope=self.slope)
         if (st.idx - 1) in self.sbits:            # the input of this stage came out of a pooling epilogue
             kw.update(auxbits=ptr(self.sbits[st.idx - 1]), ld_auxbits=self.sbits[st.idx - 1].shape[1])
         if st.pool:
@@ -340,8 +353,16 @@ class CnnEngine:
                       Tvalid_in=2 * st.tout)
         else:
             kw.update(loader=LOAD_DIRECT)
+        part = None
+        if fuse:
+            tile_rows = 512 if f43 else 256
+            ntm = (rows_in + tile_rows - 1) // tile_rows
+            part = torch.empty(ntm, (self.k1 + 1) * self.c1, dtype=torch.float32, device=self._dev)
+            kw.update(epilogue=EPI_C1WGRAD, out=None, c1x=ptr(self._x), c1bits=ptr(self.bits[1]), c1partial=ptr(part),
+                      c1T=self.T, c1kt=self.k1, Tvalid=self.tout1)
         self._nt(tag=f"conv{st.idx}_dgrad", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino
                  else "tl_gemm_nt_window", **kw)
+        return part
 
     # ------------------------------------------------------------------ forward
     def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,
@@ -541,12 +562,14 @@ class CnnEngine:
         for st in reversed(self.stages):
             name = self.STAGE_NAMES[st.idx]
             self.stage_wgrad(st, grads[name + ".weight"], grads[name + ".bias"])
-            self.stage_dgrad(st, prm[name + ".weight"])
-        # ---- stage 1 weight / bias gradient ----
-        nblk = int(min(2048, S))
-        part = torch.empty(nblk, (self.k1 + 1) * self.c1, **f32)
-        check(lib.tl_conv1_wgrad(ptr(self._x), ptr(self.G[1]), ptr(self.bits[1]), ptr(part), nblk, S, self.T, self.k1,
-                                 self.c1, self.tp1, self.tout1, st_), "tl_conv1_wgrad")
+            part = self.stage_dgrad(st, prm[name + ".weight"])
+        # ---- stage 1 weight / bias gradient (partials come out of the stage-2 epilogue when fused) ----
+        if part is None:
+            nblk = int(min(2048, S))
+            part = torch.empty(nblk, (self.k1 + 1) * self.c1, **f32)
+            check(lib.tl_conv1_wgrad(ptr(self._x), ptr(self.G[1]), ptr(self.bits[1]), ptr(part), nblk, S, self.T, self.k1,
+                                     self.c1, self.tp1, self.tout1, st_), "tl_conv1_wgrad")
+        nblk = part.shape[0]
         zs = (self.k1 + 1) * self.c1
         self._permute(part, grads["ecog_conv_block.0.weight"], (1, 1, self.c1, self.k1), (0, 0, 1, self.c1), nz=nblk,
                       zs=zs)

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("TONAL_HIP_LIB", os.path.join(_HERE, "libtonal_hip.so"
 
 # epilogue / loader codes of tl_gemm_nt_window (include/tonal_hip.h)
 LOAD_DIRECT, LOAD_UNPOOL = 0, 1
-EPI_STORE, EPI_LRELU, EPI_POOL, EPI_MASK = 0, 1, 2, 3
+EPI_STORE, EPI_LRELU, EPI_POOL, EPI_MASK, EPI_C1WGRAD = 0, 1, 2, 3, 4
 
 
 class NtParams(C.Structure):
@@ -33,6 +33,7 @@ class NtParams(C.Structure):
         ("splitk", C.c_int), ("slab_stride", C.c_int64),
         ("bm", C.c_int),
         ("osign", C.c_void_p), ("auxbits", C.c_void_p), ("ld_auxbits", C.c_int),
+        ("c1x", C.c_void_p), ("c1bits", C.c_void_p), ("c1partial", C.c_void_p), ("c1T", C.c_int), ("c1kt", C.c_int),
     ]
 
 

@@ -30,7 +30,7 @@
 namespace tl {
 
 enum { W_LOAD_DIRECT = 0, W_LOAD_UNPOOL = 1 };
-enum { W_EPI_POOL = 2, W_EPI_MASK = 3 };        // numbering of tl_nt_params.epilogue
+enum { W_EPI_POOL = 2, W_EPI_MASK = 3, W_EPI_C1W = 4 };        // numbering of tl_nt_params.epilogue
 
 constexpr int W_BP = 128;            // output pairs per workgroup (256 conv rows)
 constexpr int W_BN = 128;            // output columns per workgroup
@@ -74,6 +74,79 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
     dgr[2 * n_d + idx] = 0.5f * ((g0 + g2) - g1);
     dgr[3 * n_d + idx] = g2;
   }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Fused first-stage weight gradient (epilogue 4).  The input gradient of conv2 is G1 = dL/dZ of conv1
+// at its arg-max; conv1 has one input channel, so its weight gradient is a contraction of G1 with the
+// raw signal: dW1[o][j] = sum_rows G1[row][o] * x[seq][2t + a + j].  Doing it on the accumulators
+// removes the 13.4 GB store of G1 and the kernel that re-read it.
+// ------------------------------------------------------------------------------------------
+struct c1w_acc {
+  float s[3], b;
+  __device__ __forceinline__ void clear() { s[0] = s[1] = s[2] = b = 0.f; }
+};
+// Walks the rows of one lane's accumulator elements without divisions: row R of the P1 row space is
+// (sequence, t) with R = seq * Tp + t; `wofs` indexes the two bit arrays, `xo` the raw signal.
+struct c1w_cursor {
+  long long wofs, xo;
+  int t;
+  __device__ __forceinline__ void init(const tl_nt_params& p, long long R, int colbase) {
+    const long long seq = R / p.Tp;
+    t = (int)(R - seq * p.Tp);
+    wofs = R * (long long)p.ld_auxbits + (colbase >> 5);
+    xo = seq * (long long)p.c1T + 2 * t;
+  }
+  __device__ __forceinline__ void advance(const tl_nt_params& p, int rows) {
+    t += rows;
+    wofs += (long long)rows * p.ld_auxbits;
+    xo += 2 * rows;
+    while (t >= p.Tp) {
+      t -= p.Tp;
+      xo += p.c1T - 2 * p.Tp;
+    }
+  }
+};
+// one row at offset h from the cursor: G1 = y * LeakyReLU'(sign bit), contracted with x[2t + a + j]
+__device__ __forceinline__ void c1w_row(c1w_acc& a, const tl_nt_params& p, const c1w_cursor& c, int h, float y, int lr) {
+  const long long w = c.wofs + (long long)h * p.ld_auxbits;
+  const bool pos = (p.auxbits[w] >> lr) & 1u;
+  const bool am = (p.c1bits[w] >> lr) & 1u;
+  const float* xp = p.c1x + c.xo + 2 * h;                 // wave-uniform address: broadcast loads
+  const float x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+  const float dz = pos ? y : y * p.slope;
+  a.s[0] = fmaf(dz, am ? x1 : x0, a.s[0]);
+  if (p.c1kt > 1) a.s[1] = fmaf(dz, am ? x2 : x1, a.s[1]);
+  if (p.c1kt > 2) a.s[2] = fmaf(dz, am ? x3 : x2, a.s[2]);
+  a.b += dz;
+}
+// block reduction over the row dimension: lanes lr / lr + 32 and the NWM waves that share a column;
+// red: LDS [NWM][NCOL][5].  Writes c1partial[tile][j][col] for the block's NCOL columns.
+template <int NWM, int NCOL>
+__device__ __forceinline__ void c1w_reduce_store(const tl_nt_params& p, float* red, const c1w_acc& a, int wm, int cl,
+                                                 int lh, long long tile, int col, bool colok) {
+  float v[4] = {a.s[0], a.s[1], a.s[2], a.b};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], 32);
+  if (lh == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(wm * NCOL + cl) * 4 + j] = v[j];
+  }
+  __syncthreads();
+  if (wm == 0 && lh == 0 && colok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWM; ++w) t += red[(w * NCOL + cl) * 4 + j];
+      v[j] = t;
+    }
+    float* dst = p.c1partial + tile * (long long)(p.c1kt + 1) * p.N;
+    for (int j = 0; j < p.c1kt; ++j) dst[(long long)j * p.N + col] = v[j];
+    dst[(long long)p.c1kt * p.N + col] = v[3];
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -335,6 +408,26 @@ __global__ __launch_bounds__(512 / MI, 2 / MI) void wino_nt_kernel(const tl_nt_p
             if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(ms >> (32 * lh));
           }
         }
+      } else if constexpr (EPI == W_EPI_C1W) {
+        c1w_acc ca;
+        ca.clear();
+        c1w_cursor cur;
+        cur.init(p, 2 * P0, colbase);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int po = (e & 3) + 8 * (e >> 2);
+          if (e > 0) cur.advance(p, (e & 3) ? 2 : 10);       // pair offsets 0,1,2,3, 8,.. -> row steps 2,2,2,10
+          const long long R = 2 * (P0 + po);
+          const float m1 = acc[1][mi][ni][e], m2 = acc[2][mi][ni][e];
+          const float v0 = (acc[0][mi][ni][e] + m1) + m2;
+          const float v1 = (m1 - m2) - acc[3][mi][ni][e];
+          if (R < p.M && colok) {                            // Tp is even: the pair stays inside one sequence
+            if (cur.t < p.Tvalid) c1w_row(ca, p, cur, 0, v0, lr);
+            if (cur.t + 1 < p.Tvalid) c1w_row(ca, p, cur, 1, v1, lr);
+          }
+        }
+        static_assert(EPI != W_EPI_C1W || MI == 1, "the fused conv1 weight gradient assumes one row tile per wave");
+        c1w_reduce_store<4, 128>(p, lds, ca, wm, wn * 64 + ni * 32 + lr, lh, tm, col, colok);
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -629,6 +722,10 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
   const bool colok = col < p.N;
   float bv = 0.f;
   if constexpr (EPI == W_EPI_POOL) bv = (colok && p.bias) ? p.bias[col] : 0.f;
+  c1w_acc ca;
+  ca.clear();
+  c1w_cursor cur;
+  if constexpr (EPI == W_EPI_C1W) cur.init(p, 4 * Q0, colbase);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int qo = (e & 3) + 8 * (e >> 2);
@@ -657,6 +754,13 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
           if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(ms >> (32 * lh));
         }
       }
+    } else if constexpr (EPI == W_EPI_C1W) {
+      if (e > 0) cur.advance(p, (e & 3) ? 4 : 20);           // quad offsets 0,1,2,3, 8,.. -> row steps 4,4,4,20
+      if (4 * Q < p.M && colok) {                            // Tp % 4 == 0: the quad stays inside one sequence
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (cur.t + h < p.Tvalid) c1w_row(ca, p, cur, h, y[h], lr);
+      }
     } else {
       const long long R = 4 * Q;
       if (R < p.M && colok) {                               // M % 4 == 0: the quad shares validity
@@ -672,6 +776,7 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
       }
     }
   }
+  if constexpr (EPI == W_EPI_C1W) c1w_reduce_store<4, 64>(p, lds, ca, wm, wn * 32 + lr, lh, tm, col, colok);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -897,7 +1002,7 @@ extern "C" int tl_conv3_wino_nt(const tl_nt_params* pp, void* stream) {
   using namespace tl;
   TL_REQUIRE(pp != nullptr, "wino_nt: null params");
   const tl_nt_params& p = *pp;
-  TL_REQUIRE(p.A && p.Bw && p.out, "wino_nt: null A/Bw/out");
+  TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W), "wino_nt: null A/Bw/out");
   TL_REQUIRE(p.J == 3, "wino_nt: the Winograd form is for 3-tap convolutions");
   TL_REQUIRE(p.M >= 0 && p.M % 2 == 0 && p.N > 0 && p.K > 0, "wino_nt: bad M/N/K %lld/%d/%d", (long long)p.M, p.N, p.K);
   TL_REQUIRE(p.K % W_BK == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino_nt: K %% 32, lda %% 4, ldb %% 4 must be 0");
@@ -918,6 +1023,11 @@ extern "C" int tl_conv3_wino_nt(const tl_nt_params* pp, void* stream) {
     TL_REQUIRE(p.abits != nullptr && (p.aux != nullptr || p.auxbits != nullptr), "wino_nt: UNPOOL/MASK need abits and aux or auxbits");
     TL_REQUIRE(p.Tvalid_in % 2 == 0, "wino_nt: UNPOOL needs an even Tvalid_in");
     hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_UNPOOL, W_EPI_MASK, W_MI>), dim3((unsigned)nwg), dim3(512 / W_MI), 0, st, p);
+  } else if (p.loader == W_LOAD_UNPOOL && p.epilogue == W_EPI_C1W) {
+    TL_REQUIRE(p.row_shift == -2 && p.abits != nullptr && p.Tvalid_in % 2 == 0, "wino_nt: input gradient needs row_shift -2, abits, even Tvalid_in");
+    TL_REQUIRE(p.auxbits && p.c1x && p.c1bits && p.c1partial, "wino_nt: epilogue 4 needs auxbits, c1x, c1bits, c1partial");
+    TL_REQUIRE(p.c1kt >= 1 && p.c1kt <= 3 && p.c1T >= 2 * p.Tvalid + 2, "wino_nt: epilogue 4: 1..3 taps, c1T >= 2*Tvalid + 2");
+    hipLaunchKernelGGL((wino_nt_kernel<W_LOAD_UNPOOL, W_EPI_C1W, 1>), dim3((unsigned)nwg), dim3(512), 0, st, p);
   } else {
     set_error("wino_nt: unsupported loader/epilogue combination %d/%d", p.loader, p.epilogue);
     return TL_EINVAL;
@@ -941,7 +1051,7 @@ extern "C" int tl_conv3_wino43_nt(const tl_nt_params* pp, void* stream) {
   using namespace tl;
   TL_REQUIRE(pp != nullptr, "wino43_nt: null params");
   const tl_nt_params& p = *pp;
-  TL_REQUIRE(p.A && p.Bw && p.out, "wino43_nt: null A/Bw/out");
+  TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W), "wino43_nt: null A/Bw/out");
   TL_REQUIRE(p.J == 3, "wino43_nt: the Winograd form is for 3-tap convolutions");
   TL_REQUIRE(p.M >= 0 && p.M % 4 == 0 && p.N > 0 && p.K > 0, "wino43_nt: bad M/N/K %lld/%d/%d", (long long)p.M, p.N, p.K);
   TL_REQUIRE(p.K % 32 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino43_nt: K %% 32, lda %% 4, ldb %% 4 must be 0");
@@ -962,6 +1072,11 @@ extern "C" int tl_conv3_wino43_nt(const tl_nt_params* pp, void* stream) {
     TL_REQUIRE(p.abits != nullptr && (p.aux != nullptr || p.auxbits != nullptr), "wino43_nt: UNPOOL/MASK need abits and aux or auxbits");
     TL_REQUIRE(p.Tvalid_in % 2 == 0, "wino43_nt: UNPOOL needs an even Tvalid_in");
     hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_UNPOOL, W_EPI_MASK>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+  } else if (p.loader == W_LOAD_UNPOOL && p.epilogue == W_EPI_C1W) {
+    TL_REQUIRE(p.row_shift == -2 && p.abits != nullptr && p.Tvalid_in % 2 == 0, "wino43_nt: input gradient needs row_shift -2, abits, even Tvalid_in");
+    TL_REQUIRE(p.auxbits && p.c1x && p.c1bits && p.c1partial, "wino43_nt: epilogue 4 needs auxbits, c1x, c1bits, c1partial");
+    TL_REQUIRE(p.c1kt >= 1 && p.c1kt <= 3 && p.c1T >= 2 * p.Tvalid + 2, "wino43_nt: epilogue 4: 1..3 taps, c1T >= 2*Tvalid + 2");
+    hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_UNPOOL, W_EPI_C1W>), dim3((unsigned)nwg), dim3(512), 0, st, p);
   } else {
     set_error("wino43_nt: unsupported loader/epilogue combination %d/%d", p.loader, p.epilogue);
     return TL_EINVAL;

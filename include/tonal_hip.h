@@ -72,6 +72,12 @@ typedef struct {
    * its LeakyReLU' mask from auxbits (leading dimension ld_auxbits) instead of the floats in aux
    * when auxbits is not null - 1/32 of the bytes                                                   */
   uint32_t* osign; const uint32_t* auxbits; int ld_auxbits;
+  /* epilogue 4 (Winograd input-gradient kernels only): the masked result is G1 = dL/dZ of the first
+   * conv stage (C_in = 1, models/synthesis_models.py:87-89) at its arg-max; instead of storing it
+   * the epilogue contracts it with the raw signal: c1partial[row tile][j][col] = sum_rows G1[row][col]
+   * * x[seq][2t + a + j] (j < c1kt taps) and [c1kt][col] = sum_rows G1 (bias), with a = arg-max bit
+   * in c1bits (leading dimension ld_auxbits), x = c1x (S, c1T), rows valid for t < Tvalid.          */
+  const float* c1x; const uint32_t* c1bits; float* c1partial; int c1T, c1kt;
 } tl_nt_params;
 int tl_gemm_nt_window(const tl_nt_params* p, void* stream);
 

@@ -17,6 +17,7 @@ dev = torch.device("cuda:0")
 stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
 eng = CnnEngine(80, 128, 400, 6, 64, 0.0, 0.01, stages_def, [128, 128, 128, 128, 64])
 B = args.batch
+eng.fuse_c1 = False          # stage kernels in isolation: keep G1 as a tensor
 eng._alloc(B, dev)
 eng._alloc_bwd()
 g = torch.Generator(device=dev).manual_seed(1)

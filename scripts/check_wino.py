@@ -20,6 +20,7 @@ stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (6
 eng = CnnEngine(80, args.channels, args.timepoints, 6, 64, 0.0, 0.01, stages_def, [128, 128, 128, 128, 64])
 B = args.batch
 eng.wino43 = args.f43
+eng.fuse_c1 = False          # stage kernels in isolation: keep G1 as a tensor
 eng._alloc(B, dev)
 eng._alloc_bwd()
 g = torch.Generator(device=dev).manual_seed(1)
