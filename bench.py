@@ -176,9 +176,14 @@ def main():
             # kernel families as rocprofv3 names them: one name covers the launches of several stages
             if getattr(eng, "wino", False):
                 nt, nt_frac = ("wino43_nt_kernel", "F(4,3)") if getattr(eng, "wino43", False) else ("wino_nt_kernel", "F(2,3)")
-                fams = {f"{nt}<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd {nt_frac})": ["conv2_dgrad", "conv3_dgrad"],
-                        f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {nt_frac})": ["conv2_fwd", "conv3_fwd"],
+                fused = getattr(eng, "fuse_c1", False) and eng._c1_fusable()
+                fams = {f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {nt_frac})": ["conv2_fwd", "conv3_fwd"],
                         "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))": ["conv2_wgrad", "conv3_wgrad"]}
+                if fused:       # the stage-2 launch carries the fused conv1 weight-gradient epilogue: its own kernel name
+                    fams[f"{nt}<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd {nt_frac})"] = ["conv2_dgrad"]
+                    fams[f"{nt}<UNPOOL,MASK> (conv3 input gradient, Winograd {nt_frac})"] = ["conv3_dgrad"]
+                else:
+                    fams[f"{nt}<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd {nt_frac})"] = ["conv2_dgrad", "conv3_dgrad"]
                 # MFMA FLOPs issued per algorithmic (direct-convolution) FLOP of each family
                 issued_of = {k: (0.5 if "F(4,3)" in k else 2.0 / 3.0) for k in fams}
             else:
