@@ -469,6 +469,10 @@ __global__ __launch_bounds__(512 / MI, 2 / MI) void wino_nt_kernel(const tl_nt_p
 // channel chunk carrying all six transforms (48 MFMAs per wave between barriers).  LDS keeps the
 // staged rows in four planes (row mod 4), 80-byte row stride: conflict-free ds_read_b128.
 // ------------------------------------------------------------------------------------------
+#ifndef W4_PIN
+#define W4_PIN 1          // 1: pin the weight-tile loads at the top of a K-step (conv2 fwd 51.5 -> 47.9 ms);
+                          // 2: the A loads too (spills); 0: leave both to the scheduler
+#endif
 constexpr int W4_BQ = 128, W4_BN = 64, W4_BK = 16, W4_LD = W4_BK + 4, W4_QR = W4_BQ + 1;
 
 __global__ void wino43_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ dgr,
@@ -659,7 +663,15 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
     f32x4 d1 = rd(a_s + PLANE), d2 = rd(a_s + 2 * PLANE), d3 = rd(a_s + 3 * PLANE), d4 = rd(a_s + W4_LD);
     f32x4 u[4] = {rd(b_s + US), rd(b_s + 2 * US), rd(b_s + 3 * US), rd(b_s + 4 * US)};
     if (!tail || s + 1 < nsteps) load_b(rb, s + 1);
+#if W4_PIN == 1
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (!tail || s + 2 < nsteps) load_a(ra_ld, rbits_ld, s + 2);
+    // keep the global loads here: left alone, the scheduler sinks them next to the LDS stores that
+    // consume them (shorter live ranges), which turns the prefetch into an exposed L2 round trip
+#if W4_PIN == 2
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     beta_mfma(cv0, cu0, cv5, cu5);                        // carried from the previous step
     // beta(g0) reads
     f32x4 d0 = rd(a_s), d5 = rd(a_s + PLANE + W4_LD), u0 = rd(b_s), u5 = rd(b_s + 5 * US);
