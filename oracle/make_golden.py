@@ -304,6 +304,46 @@ def main():
                         cls_checksum=gi.checksum(tone_model.linear.weight, syl_model.linear.weight))
     report["g9_trainer"] = 0.0
 
+    # ---- G10: classifier-training plumbing (BASELINE config C1): metrics, sample loading, factory ----
+    import json
+    import tempfile
+    import utils.metrics as rmet
+    import data_loading.sample_loading as rsl
+    import models.classifier_factory as rcf
+    rng = np.random.default_rng(5)
+    t_tone, p_tone = rng.integers(0, 4, 300), rng.integers(0, 4, 300)
+    t_syl, p_syl = rng.integers(0, 2, 300), rng.integers(0, 2, 300)
+    p_tone[:150] = t_tone[:150]
+    names = ["accuracy", "f1_score", "precision", "recall", "cohen_kappa", "confusion_matrix", "balanced_accuracy_score"]
+    single = rmet.compute_classification_metrics(t_tone, p_tone, names)
+    joint = rmet.compute_classification_metrics_joint({"syllable": t_syl, "tone": t_tone}, {"syllable": p_syl, "tone": p_tone}, names)
+    subj = gi.c1_subject()
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "subject_1.npz"), **subj)
+        with open(os.path.join(td, "subject_1.json"), "w") as f:
+            json.dump({"active_channels": list(range(16)), "tone_discriminative": [3, 1, 9, 12],
+                       "syllable_discriminative": [1, 2, 14]}, f)
+        prm = Namespace(sample_path=os.path.join(td, "subject_1.npz"), channel_file=os.path.join(td, "subject_1.json"),
+                        targets=["syllable", "tone"], features="ecog", class_labels={"tone": None, "syllable": ["i", "a"]})
+        h = rsl.ClassificationSampleHandler(prm)
+        data = h.load_data()
+        joint_names = list(h.prepare_class_labels(data["n_classes_dict"]))
+        h1 = rsl.ClassificationSampleHandler(Namespace(sample_path=prm.sample_path, targets="tone", features="ecog",
+                                                       class_labels={"tone": None}))
+        data1 = h1.load_data()
+        names1 = list(h1.prepare_class_labels(data1["n_classes_dict"]))
+    lr = rcf.get_classifier_by_name("models.simple_classifiers.LogisticRegressionClassifier", "cpu", 4, 16, 100)
+    sh = rcf.get_classifier_by_name("models.simple_classifiers.ShallowNNClassifier", "cpu", 4, 16, 100,
+                                    classifier_kwargs={"hidden_dim": 32})
+    np.savez_compressed(os.path.join(args.out, "g10_classifier_plumbing.npz"),
+                        **{"single." + k: np.asarray(v) for k, v in single.items()},
+                        **{"joint." + k: np.asarray(v) for k, v in joint.items()},
+                        labels=data["labels"], channels=data["selected_channels"], feat_sum=float(data["features"].sum()),
+                        joint_names=np.array(joint_names), labels1=data1["labels"], channels1=data1["selected_channels"],
+                        names1=np.array(names1), lr_nparams=lr.get_nparams(), shallow_nparams=sh.get_nparams(),
+                        in_checksum=gi.checksum(subj["ecog"], subj["tone"], subj["syllable"]))
+    report["g10_classifier_plumbing"] = 0.0
+
     for k, v in report.items():
         print(f"{k:28s} oracle-vs-reference max rel dev = {v:.3e}")
     bad = {k: v for k, v in report.items() if v > (2e-3 if 'update_l2' in k else 2e-5)}   # f32 resample: 3e-7

@@ -73,3 +73,17 @@ def update_rel_l2(final_a, final_b, init) -> float:
     da = (np.asarray(final_a, dtype=np.float64) - np.asarray(init, dtype=np.float64)).ravel()
     db = (np.asarray(final_b, dtype=np.float64) - np.asarray(init, dtype=np.float64)).ravel()
     return float(np.linalg.norm(da - db) / max(np.linalg.norm(db), 1e-30))
+
+
+def c1_subject(N: int = 400, C: int = 16, T: int = 100, seed: int = 2024):
+    """BASELINE config C1: synthetic ``subject_<id>.npz`` content - N(0,1) ECoG plus a class pattern,
+    4 tones x 2 syllables.  Returns a dict of arrays with the reference's sample-file keys."""
+    rng = np.random.default_rng(seed)
+    tone = rng.integers(0, 4, N)
+    syllable = rng.integers(0, 2, N)
+    ecog = rng.standard_normal((N, C, T)).astype(np.float32)
+    for k in range(4):                       # tone k lifts channels 4k..4k+3, syllable 1 adds a slow ramp
+        ecog[tone == k, 4 * k:4 * k + 4, :] += 0.5
+    ecog[syllable == 1] += np.linspace(-0.4, 0.4, T, dtype=np.float32)
+    return {"ecog": ecog, "ecog_sf": np.array(100), "tone": tone, "syllable": syllable,
+            "ecog_rest": rng.standard_normal((N, C, T)).astype(np.float32)}
