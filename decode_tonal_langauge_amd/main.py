@@ -33,7 +33,18 @@ def update_stage_cfg_io(stage_outputs: dict, stage: str, stage_cfg: dict):
 
 
 def _resolve(module_name: str, func_name: str):
-    module = importlib.import_module(module_name)
+    # reference configs name the stage modules bare ("train_classifier", "train_synthesizer"): those
+    # resolve to this package's modules of the same name
+    pkg = __name__.rsplit(".", 1)[0] if "." in __name__ else None
+    module = None
+    if pkg and "." not in module_name:
+        try:
+            module = importlib.import_module(f"{pkg}.{module_name}")
+        except ModuleNotFoundError as e:
+            if e.name != f"{pkg}.{module_name}":
+                raise
+    if module is None:
+        module = importlib.import_module(module_name)
     if not hasattr(module, func_name):
         raise ImportError(f"Module '{module_name}' does not have a function '{func_name}'"
                           f"Available functions: {', '.join(dir(module))}")
