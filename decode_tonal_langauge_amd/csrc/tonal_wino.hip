@@ -852,18 +852,37 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
   int bt = brow % p.Tp;
   const int b_last = (int)p.B_rows - 1;
 
-  auto load_tiles = [&](f32x4 (&ra)[5], f32x4& rb, uint32_t& rn) {
+  // FAST (compile time): every row of the chunk is inside both matrices, so the addresses are a
+  // wave-uniform base (SGPRs, advanced per step) plus a per-thread 32-bit offset fixed for the whole
+  // kernel - no per-load clamping or 64-bit VALU arithmetic.  The last three chunks of a split and any
+  // launch whose matrices are shorter than the reduction take the clamped path.
+  long long ld_row0 = kbase;                       // first row of the chunk the next load_tiles fetches
+  const unsigned a_toff = (unsigned)((tid >> 5) * p.lda + (acol - m0));
+  const unsigned b_toff = (unsigned)((tid >> 4) * p.ldb + (ncolc - n0));
+  const unsigned bb_toff = (unsigned)((tid >> 4) * p.ld_bbits + (ncolc >> 5));
+  auto load_tiles = [&](auto FAST, f32x4 (&ra)[5], f32x4& rb, uint32_t& rn) {
+    if constexpr (decltype(FAST)::value) {
+      const float* au = p.A + ld_row0 * (long long)p.lda + m0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int row = min(a_row + 8 * i, a_last);
-      ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long long)row * p.lda + acol);
+      for (int i = 0; i < 5; ++i) ra[i] = *reinterpret_cast<const f32x4*>(au + (long long)(8 * i) * p.lda + a_toff);
+      const long long pr0 = ld_row0 >> 1;
+      rb = *reinterpret_cast<const f32x4*>(p.B + pr0 * (long long)p.ldb + n0 + b_toff);
+      rn = ((p.bbits[pr0 * (long long)p.ld_bbits + bb_toff] >> (ncolc & 31)) & 0xFu) |
+           ((bnok && bt < p.Tvalid) ? 0x10u : 0u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int row = min(a_row + 8 * i, a_last);
+        ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long long)row * p.lda + acol);
+      }
+      const int pr = min(brow >> 1, b_last);
+      rb = *reinterpret_cast<const f32x4*>(p.B + (long long)pr * p.ldb + ncolc);
+      // arg-max nibble of the 4 columns in bits 0..3, "pair is valid" in bit 4
+      rn = ((p.bbits[(long long)pr * p.ld_bbits + (ncolc >> 5)] >> (ncolc & 31)) & 0xFu) |
+           ((bnok && brow < b_lim && bt < p.Tvalid) ? 0x10u : 0u);
     }
+    ld_row0 += W_BK;
     a_row += W_BK;
-    const int pr = min(brow >> 1, b_last);
-    rb = *reinterpret_cast<const f32x4*>(p.B + (long long)pr * p.ldb + ncolc);
-    // arg-max nibble of the 4 columns in bits 0..3, "pair is valid" in bit 4
-    rn = ((p.bbits[(long long)pr * p.ld_bbits + (ncolc >> 5)] >> (ncolc & 31)) & 0xFu) |
-         ((bnok && brow < b_lim && bt < p.Tvalid) ? 0x10u : 0u);
     brow += W_BK;
     bt += dstep;
     if (bt >= p.Tp) bt -= p.Tp;
@@ -924,7 +943,8 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
     constexpr bool tail = decltype(TAIL)::value;
     const int buf = (int)(s & 1);
     load_frag(fa0, fb0, buf, 0);
-    if (!tail || s + 2 < nsteps) load_tiles(ra_ld, rb_ld, rn_ld);
+    if constexpr (!tail) load_tiles(std::true_type{}, ra_ld, rb_ld, rn_ld);
+    else if (s + 2 < nsteps) load_tiles(std::false_type{}, ra_ld, rb_ld, rn_ld);
     mfma_group(fa1, fb1);                          // last k-step of the previous step (registers)
     load_frag(fa1, fb1, buf, 1);
     mfma_group(fa0, fb0);
@@ -951,16 +971,19 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
   fb1[0] = fb1[1] = 0.f;
 
   if (nsteps > 0) {
-    load_tiles(raP, rbP, rnP);
+    load_tiles(N{}, raP, rbP, rnP);
     store_tiles(raP, rbP, rnP, 0);
-    if (nsteps > 1) load_tiles(raQ, rbQ, rnQ);
+    if (nsteps > 1) load_tiles(N{}, raQ, rbQ, rnQ);
   }
   __syncthreads();
   long long s = 0;
-  for (; s + 3 < nsteps; s += 2) {
-    kstep(N{}, s, raP, rbP, rnP, raQ, rbQ, rnQ);
-    kstep(N{}, s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
-  }
+  // steady state: the chunk fetched at step s is s + 2 <= nsteps - 4, at least 96 rows before the end
+  const bool whole = p.A_rows >= p.Krows && 2 * p.B_rows >= p.Krows;
+  if (whole)
+    for (; s + 5 < nsteps; s += 2) {
+      kstep(N{}, s, raP, rbP, rnP, raQ, rbQ, rnQ);
+      kstep(N{}, s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
+    }
   for (; s < nsteps; s += 2) {
     kstep(Y{}, s, raP, rbP, rnP, raQ, rbQ, rnQ);
     if (s + 1 < nsteps) kstep(Y{}, s + 1, raQ, rbQ, rnQ, raP, rbP, rnP);
