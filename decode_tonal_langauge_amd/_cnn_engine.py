@@ -546,7 +546,10 @@ class CnnEngine:
             kr = (L - 1) * U
             fa, fb = dg[1:].reshape(kr, 4 * H), self._h[:L - 1].reshape(kr, H)
             if gather_whh is not None:
-                fa, fb = gather_whh(fa, fb)
+                # key of row (t, u): the step and the label sequence h_t was unrolled from
+                steps = torch.arange(L - 1, device=dev, dtype=torch.float32).repeat_interleave(U).unsqueeze(1)
+                keys = torch.cat([steps, self._xu.permute(1, 0, 2).reshape(U, 2 * L).repeat(L - 1, 1)], dim=1)
+                fa, fb = gather_whh(fa, fb, keys)
                 kr = fa.shape[0]
             self._tn(A=ptr(fa), B=ptr(fb), slab=ptr(gwhh), Krows=kr, A_rows=kr, B_rows=kr, Mdim=4 * H, Ndim=H,
                      lda=4 * H, ldb=H, ldc=H, loader=LOAD_DIRECT)

@@ -122,9 +122,16 @@ def allreduce_bucketed(tensors: List[torch.Tensor], bucket_bytes: int = 64 << 20
     flush()
 
 
-def gather_lowrank(dg: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def gather_lowrank(dg: torch.Tensor, h: torch.Tensor, keys: Optional[torch.Tensor] = None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather the factors of the W_hh gradient: dg (k, 4H), h (k, H) with a per-rank k.
-    Ranks pad to the common maximum with zero rows (which add nothing to dg^T . h)."""
+    Ranks pad to the common maximum with zero rows (which add nothing to dg^T . h).
+
+    ``keys`` (k, m) identifies what each row's ``h`` was computed from (time step + label sequence):
+    rows of different ranks with equal keys have bit-identical ``h`` (same weights, same kernel, rows
+    are independent), so their ``dg`` rows are summed after the gather.  The reduction length of the
+    gradient GEMM then stays at the number of distinct (step, label) pairs of the GLOBAL batch instead
+    of growing with the number of ranks."""
     if not active():
         return dg, h
     n = dist.get_world_size()
@@ -132,10 +139,10 @@ def gather_lowrank(dg: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, tor
     dist.all_reduce(k, op=dist.ReduceOp.MAX)
     kmax = int(k.item())
 
-    def pad(t):
+    def pad(t, fill=0.0):
         if t.shape[0] == kmax:
             return t.contiguous()
-        out = torch.zeros(kmax, t.shape[1], dtype=t.dtype, device=t.device)
+        out = torch.full((kmax, t.shape[1]), fill, dtype=t.dtype, device=t.device)
         out[:t.shape[0]] = t
         return out
 
@@ -143,4 +150,14 @@ def gather_lowrank(dg: torch.Tensor, h: torch.Tensor) -> Tuple[torch.Tensor, tor
     h_all = torch.empty(n * kmax, h.shape[1], dtype=h.dtype, device=h.device)
     _all_gather_rows(dg_all, pad(dg))
     _all_gather_rows(h_all, pad(h))
-    return dg_all, h_all
+    if keys is None:
+        return dg_all, h_all
+    keys_all = torch.empty(n * kmax, keys.shape[1], dtype=keys.dtype, device=keys.device)
+    _all_gather_rows(keys_all, pad(keys.contiguous(), fill=float("-inf")))       # pad rows share one key, dg = 0
+    _, inverse = torch.unique(keys_all, dim=0, return_inverse=True)
+    groups = int(inverse.max().item()) + 1
+    dg_sum = torch.zeros(groups, dg.shape[1], dtype=dg.dtype, device=dg.device).index_add_(0, inverse, dg_all)
+    # any member of a group carries the group's h: scatter (last writer wins, all writers are equal)
+    h_rep = torch.zeros(groups, h.shape[1], dtype=h.dtype, device=h.device)
+    h_rep[inverse] = h_all
+    return dg_sum, h_rep

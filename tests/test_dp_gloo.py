@@ -26,6 +26,15 @@ def _worker(rank, world, port, q):
     local = dg.t() @ h
     dist.all_reduce(local)
     ok = ok and torch.allclose(dga.t() @ ha, local, rtol=1e-5, atol=1e-5)
+    # keyed gather: rows with equal keys (same h on every rank) are merged, the product is unchanged
+    torch.manual_seed(3)
+    h_pool, key_pool = torch.randn(5, 6), torch.arange(5, dtype=torch.float32).unsqueeze(1) * torch.ones(1, 3)
+    pick = torch.tensor([0, 2, 4] if rank == 0 else [2, 3, 4, 1])
+    dgk = torch.randn(len(pick), 8)
+    dgm, hm = parallel.gather_lowrank(dgk, h_pool[pick], key_pool[pick])
+    localk = dgk.t() @ h_pool[pick]
+    dist.all_reduce(localk)
+    ok = ok and dgm.shape[0] == 6 and torch.allclose(dgm.t() @ hm, localk, rtol=1e-5, atol=1e-5)   # 5 keys + the pad key
     sl = parallel.shard_rows(10, rank, world)
     ok = ok and (sl.stop - sl.start == 5)
     q.put((rank, bool(ok)))
