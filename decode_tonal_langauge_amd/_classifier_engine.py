@@ -115,3 +115,90 @@ class CnnClassifierEngine(CnnEngine):
                  N=self.n_classes, K=self.hidden, lda=self.hidden, ldb=self.hidden, ldo=self.n_classes,
                  loader=LOAD_DIRECT, epilogue=EPI_STORE)
         return torch.sigmoid(out)
+
+
+class CnnRnnConvEngine:
+    """Convolutional trunk of ``CNNRNNClassifier`` (reference models/deep_classifiers.py:230-259, 294-312)
+    on the HIP kernels, forward only: the two (7,1) conv + LeakyReLU + (2,1) max-pool branches
+    (``tl_conv1_fwd``, C_in = 1), the width-wise concatenation, the two 7-tap convolutions
+    1024 -> 512 -> 256 with LeakyReLU (``tl_gemm_nt_window``, J = 7) and the (3,1) max-pool.  The two
+    LSTMs and the output layer stay library calls of the owning module.
+
+    Layout as everywhere else: one *sequence* per (batch element, width column), rows = time,
+    channels last; the LSTM branch comes first in the width order, as ``torch.cat((x1, x), dim=3)``."""
+
+    K = 7
+
+    def __init__(self, input_channels: int, input_length: int, lstm_dim: int, negative_slope: float):
+        from . import _lib
+        self.lib = _lib.load()
+        self.C, self.T = input_channels, input_length
+        self.w1 = lstm_dim // input_length
+        self.W = self.w1 + input_channels
+        self.slope = float(negative_slope)
+        self.t1 = (input_length - self.K + 1) // 2           # after conv (7,1) + pool (2,1)
+        self.ta = self.t1 - self.K + 1                        # after the 1024 -> 512 convolution
+        self.tb = self.ta - self.K + 1                        # after the 512 -> 256 convolution
+        self.tq = self.tb // 3                                # after pool (3,1)
+        if self.tq < 1:
+            raise ValueError("input_length too small for the CNN-RNN convolution stack")
+        self.Tp = (self.t1 + 1) // 2 * 2
+        self._packed: Dict[str, Tuple[tuple, torch.Tensor]] = {}
+        self._B = None
+
+    def _cached(self, key: str, param: torch.Tensor, build):
+        ver = (param._version, param.data_ptr())
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            hit = self._packed[key] = (ver, build())
+        return hit[1]
+
+    def _alloc(self, B: int, dev):
+        if self._B == B and self._dev == dev:
+            return
+        self._B, self._dev = B, dev
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        self.Pa, self.bits_a = z(B * self.C * self.Tp, 1024), zi(B * self.C * self.Tp, 32)
+        self.Pb, self.bits_b = z(B * self.w1 * self.Tp, 1024), zi(B * self.w1 * self.Tp, 32)
+        rows = B * self.W * self.Tp
+        self.Y1, self.Y2 = z(rows, 512), z(rows, 256)
+
+    def _conv7(self, src, w, b, dst, cin, cout, key):
+        def pack():
+            return w.detach().reshape(cout, cin, self.K).permute(2, 0, 1).contiguous()       # [J][O][I]
+        wp = self._cached(key, w, pack)
+        from ._lib import NtParams
+        import ctypes as C
+        p = NtParams()
+        p.A, p.Bw, p.bias, p.out = ptr(src), ptr(wp), ptr(b.detach()), ptr(dst)
+        p.M = p.A_rows = src.shape[0]
+        p.N, p.K, p.lda, p.ldb, p.ldo = cout, cin, cin, cin, cout
+        p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = self.K, 0, self.Tp, self.Tp, self.slope
+        p.loader, p.epilogue, p.splitk, p.bm = LOAD_DIRECT, EPI_LRELU, 1, 128
+        check(self.lib.tl_gemm_nt_window(C.byref(p), torch.cuda.current_stream().cuda_stream), "tl_gemm_nt_window")
+
+    @torch.no_grad()
+    def features(self, x: torch.Tensor, h1: torch.Tensor, block1, block2, conv3a, conv3b) -> torch.Tensor:
+        """x (B, C, T), h1 (B, lstm_dim); blockN / conv3x = (weight, bias).  Returns the tensor the
+        reference feeds to its second LSTM: (B, t', 256 * W) - a raw view of the contiguous
+        (B, 256, t', W) activation (reference :315)."""
+        B = x.shape[0]
+        dev = x.device
+        self._alloc(B, dev)
+        lib, st_ = self.lib, torch.cuda.current_stream().cuda_stream
+        xa = x.contiguous().float()                                                   # (B*C, T) sequences
+        xb = h1.float().reshape(B, self.T, self.w1).permute(0, 2, 1).contiguous()     # column j: h1[b, t*w1 + j]
+        for seqs, n, (w, b), P, bits in ((xa, B * self.C, block1, self.Pa, self.bits_a),
+                                         (xb, B * self.w1, block2, self.Pb, self.bits_b)):
+            check(lib.tl_conv1_fwd(ptr(seqs), ptr(w.detach().reshape(1024, self.K).contiguous()), ptr(b.detach()), ptr(P),
+                                   ptr(bits), None, n, self.T, self.K, 1024, self.Tp, self.t1, self.slope, st_),
+                  "tl_conv1_fwd")
+        row = self.Tp * 1024
+        P = torch.cat((self.Pb.view(B, self.w1, row), self.Pa.view(B, self.C, row)), dim=1).view(B * self.W * self.Tp, 1024)
+        self._conv7(P, conv3a[0], conv3a[1], self.Y1, 1024, 512, "conv3a")
+        self._conv7(self.Y1, conv3b[0], conv3b[1], self.Y2, 512, 256, "conv3b")
+        y = self.Y2.view(B, self.W, self.Tp, 256)[:, :, :3 * self.tq]
+        y = y.reshape(B, self.W, self.tq, 3, 256).amax(dim=3)                          # MaxPool (3,1)
+        f = y.permute(0, 3, 2, 1).contiguous()                                         # (B, 256, t', W)
+        return f.view(B, self.tq, -1)

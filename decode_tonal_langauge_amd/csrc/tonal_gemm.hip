@@ -100,7 +100,7 @@ __global__ __launch_bounds__(nt_cfg<BM>::NTHR, 2) void nt_window_kernel(const tl
   constexpr int WN = nt_cfg<BM>::WN;
   constexpr int MI = BM / (32 * WM);               // 32x32 tiles per wave along M
   constexpr int NI = BN / (32 * WN);
-  constexpr int AROWS = BM + 2;                    // staged rows incl. the tap window (J <= 3)
+  constexpr int AROWS = BM + 6;                    // staged rows incl. the tap window (J <= 7)
   constexpr int A_F4 = (LOADER == LOAD_DIRECT) ? ((AROWS * 8 + NTHR - 1) / NTHR) : ((AROWS / 2 * 8 + NTHR - 1) / NTHR);
   constexpr int B_F4 = BN * 8 / NTHR;
 
@@ -1134,7 +1134,7 @@ extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
   TL_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0, "nt_window: bad M/N/K %lld/%d/%d", (long long)p.M, p.N, p.K);
   TL_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "nt_window: K, lda, ldb must be multiples of 4");
   TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K, "nt_window: lda/ldb smaller than K");
-  TL_REQUIRE(p.J >= 1 && p.J <= 3, "nt_window: J must be 1..3");
+  TL_REQUIRE(p.J >= 1 && p.J <= 7, "nt_window: J must be 1..7");
   TL_REQUIRE(p.row_shift == 0 || p.row_shift == -(p.J - 1), "nt_window: row_shift must be 0 or -(J-1)");
   TL_REQUIRE(p.bm == 256 || p.bm == 128 || p.bm == 32, "nt_window: bm must be 256, 128 or 32");
   TL_REQUIRE(p.Tp > 0, "nt_window: Tp must be positive");
@@ -1158,7 +1158,7 @@ extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
   // selects this one (kept for A/B runs, covered by tests/test_gpu_parity.py).
   const char* genv = getenv("TONAL_GLDS");
   const bool glds_on = genv != nullptr && genv[0] == '1';
-  if (glds_on && p.bm == 128 && p.loader == LOAD_DIRECT && p.row_shift == 0 && (p.K % GK) == 0 && p.A_rows > 0) {
+  if (glds_on && p.J <= 3 && p.bm == 128 && p.loader == LOAD_DIRECT && p.row_shift == 0 && (p.K % GK) == 0 && p.A_rows > 0) {
     switch (p.epilogue) {
       case EPI_STORE: return launch_glds<EPI_STORE>(p, st);
       case EPI_LRELU: return launch_glds<EPI_LRELU>(p, st);

@@ -112,6 +112,7 @@ class CNNRNNClassifier(ClassifierModel):
         w = (lstm_dim // input_length) + input_channels
         self.lstm2 = nn.LSTM(input_size=256 * w, hidden_size=512, batch_first=True)
         self.output = nn.Linear(512, n_classes)
+        self._hip = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, C, T = x.shape
@@ -121,6 +122,19 @@ class CNNRNNClassifier(ClassifierModel):
             raise ValueError(f"Expected input length {self.input_length}, got {T}.")
         xt = x.permute(0, 2, 1)                            # (B, T, C)
         h1 = self.lstm1(xt)[0][:, -1, :]                   # (B, lstm_dim)
+        needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        slope = self.conv_pool_block1[1].negative_slope
+        if x.is_cuda and not needs_graph and not (self.training and self.conv_block3[5].p > 0) and slope >= 0:
+            # inference on CUDA (how the synthesis trainer calls the classifiers): the convolutional trunk
+            # runs on the HIP kernels, the two LSTMs and the output layer stay library calls
+            if self._hip is None:
+                from .._classifier_engine import CnnRnnConvEngine
+                self._hip = CnnRnnConvEngine(C, T, self.lstm1.hidden_size, slope)
+            wb = lambda m: (m.weight.detach(), m.bias.detach())
+            f = self._hip.features(x, h1, wb(self.conv_pool_block1[0]), wb(self.conv_pool_block2[0]),
+                                   wb(self.conv_block3[0]), wb(self.conv_block3[2]))
+            h2 = self.lstm2(f)[0][:, -1, :]
+            return torch.sigmoid(self.output(h2))
         a = self.conv_pool_block1(xt.unsqueeze(1))         # (B, 1024, t, C)
         b = self.conv_pool_block2(h1.reshape(B, 1, T, -1))  # (B, 1024, t, lstm_dim // T)
         f = self.conv_block3(torch.cat((b, a), dim=3))     # (B, 256, t', w)

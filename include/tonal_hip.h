@@ -60,7 +60,7 @@ typedef struct {
   int64_t A_rows;     /* rows addressable in A (G rows for UNPOOL)                */
   int N, K;           /* output columns, reduction length per tap (K % 4 == 0)    */
   int lda, ldb, ldo, ldaux, ld_abits, ld_obits;
-  int J;              /* taps (1..3); Bw is [J][N][ldb]                           */
+  int J;              /* taps (1..7); Bw is [J][N][ldb]                           */
   int row_shift;      /* 0 forward, -(J-1) input-gradient                         */
   int Tp, Tvalid, Tvalid_in;
   float slope;

@@ -34,7 +34,7 @@ def test_abi_argument_validation_without_gpu():
     p.A = p.Bw = p.out = 16
     p.M, p.N, p.K, p.lda, p.ldb, p.J, p.Tp = 128, 128, 30, 32, 32, 1, 1
     assert lib.tl_gemm_nt_window(C.byref(p), None) == -1 and b"multiples of 4" in lib.tl_last_error()
-    p.K, p.J = 32, 4
+    p.K, p.J = 32, 8
     assert lib.tl_gemm_nt_window(C.byref(p), None) == -1 and b"J must be" in lib.tl_last_error()
     t = _lib.TnParams()
     assert lib.tl_gemm_tn_window(C.byref(t), None) == -1

@@ -493,3 +493,30 @@ def test_downsample_matches_reference_golden(dev):
     up2 = downsample.resample(t, 20014)
     back = downsample.resample(up2, 10007)
     assert float((back - t).abs().max()) < 1e-9
+
+
+def test_cnnrnn_classifier_hip_trunk_matches_module_graph(dev):
+    """CNNRNNClassifier inference: convolutional trunk on the HIP kernels (7-tap convolutions) vs the same
+    module's stock PyTorch graph."""
+    from decode_tonal_langauge_amd.models import CNNRNNClassifier
+    torch.manual_seed(0)
+    for (C, T, B, lstm_dim) in ((4, 100, 3, 200), (3, 131, 5, 131)):
+        clf = CNNRNNClassifier(input_channels=C, input_length=T, n_classes=4, lstm_dim=lstm_dim).to(dev).eval()
+        x = torch.randn(B, C, T, device=dev)
+        with torch.no_grad():
+            hip = clf(x)
+        assert clf._hip is not None, "HIP path was not taken"
+        xt = x.permute(0, 2, 1)
+        h1 = clf.lstm1(xt)[0][:, -1, :]
+        a = clf.conv_pool_block1(xt.unsqueeze(1))
+        b = clf.conv_pool_block2(h1.reshape(B, 1, T, -1))
+        f = clf.conv_block3(torch.cat((b, a), dim=3))
+        with torch.no_grad():
+            feat = clf._hip.features(x, h1.detach(), *[(m.weight, m.bias) for m in (clf.conv_pool_block1[0],
+                                     clf.conv_pool_block2[0], clf.conv_block3[0], clf.conv_block3[2])])
+        fr = f.detach().contiguous().view(B, f.shape[2], -1)
+        assert feat.shape == fr.shape
+        assert float((feat - fr).abs().max()) < 1e-4 * max(1.0, float(fr.abs().max()))
+        ref = torch.sigmoid(clf.output(clf.lstm2(fr)[0][:, -1, :]))
+        assert hip.shape == ref.shape == (B, 4)
+        assert float((hip - ref.detach()).abs().max()) < 1e-4
