@@ -520,3 +520,50 @@ def test_cnnrnn_classifier_hip_trunk_matches_module_graph(dev):
         ref = torch.sigmoid(clf.output(clf.lstm2(fr)[0][:, -1, :]))
         assert hip.shape == ref.shape == (B, 4)
         assert float((hip - ref.detach()).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("widths", [(64, 96, 32), (32, 160, 64), (96, 32, 96)])
+def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
+    """Stage kernels at the C-ABI level on channel counts that are not multiples of the column tiles
+    (tile tails in N, one- and two-chunk K loops): all three Winograd forms against the direct kernels."""
+    from decode_tonal_langauge_amd._cnn_engine import CnnEngine
+    c1, c2, c3 = widths
+    defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
+    B, C, T = 3, 5, 236
+    g = torch.Generator(device=dev).manual_seed(sum(widths))
+    res = {}
+    for mode in ("0", "1", "4"):
+        eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
+        eng.wino, eng.wino43, eng.fuse_c1 = mode != "0", mode == "4", False
+        eng._alloc(B, dev)
+        eng._alloc_bwd()
+        g.manual_seed(sum(widths))
+        for k in sorted(eng.P):
+            eng.P[k].normal_(generator=g)
+        for k in sorted(eng.G):
+            eng.G[k].normal_(generator=g)
+        for k in sorted(eng.bits):
+            eng.bits[k].random_(-2**31, 2**31 - 1, generator=g)
+            eng.sbits[k].random_(-2**31, 2**31 - 1, generator=g)
+        out = []
+        for si in (2, 3):
+            st = eng.stages[si - 2]
+            w = torch.randn(st.cout, st.cin, 3, 1, device=dev, generator=g) * 0.05
+            b = torch.randn(st.cout, device=dev, generator=g) * 0.1
+            gw, gb = torch.zeros_like(w), torch.zeros_like(b)
+            keep = (eng.P[si].clone(), eng.bits[si].clone(), eng.sbits[si].clone())
+            eng.stage_dgrad(st, w)
+            eng.stage_wgrad(st, gw, gb)
+            dg = eng.G[si - 1].clone()
+            eng.stage_forward(st, w, b)
+            out.append((eng.P[si].clone(), eng.bits[si].clone(), dg, gw, gb))
+            eng.P[si].copy_(keep[0]); eng.bits[si].copy_(keep[1]); eng.sbits[si].copy_(keep[2])
+        res[mode] = out
+    for mode in ("1", "4"):
+        for (p0, b0, d0, w0, g0), (p1, b1, d1, w1, g1) in zip(res["0"], res[mode]):
+            assert rel(p1.cpu().numpy(), p0.cpu().numpy()) < 2e-5
+            flips = (b0 ^ b1)
+            assert int((flips != 0).sum()) <= 2                       # arg-max ties only
+            assert rel_l2(d1.cpu().numpy(), d0.cpu().numpy()) < 1e-5
+            assert rel_l2(w1.cpu().numpy(), w0.cpu().numpy()) < 1e-5
+            assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-6
