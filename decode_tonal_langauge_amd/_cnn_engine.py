@@ -452,11 +452,15 @@ class CnnEngine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, prm: Dict[str, torch.Tensor], dout: torch.Tensor, grads: Dict[str, torch.Tensor],
-                 gather_whh=None) -> None:
+                 gather_whh=None, whh_factors: bool = False) -> None:
         """dout: (B, ldd) gradient of the loss w.r.t. the output (pad columns zero).
         Fills ``grads[name]`` (torch layouts) for every parameter.  ``gather_whh(dg, h)`` may
         return the low-rank factors of every data-parallel rank (parallel.gather_lowrank): the
-        W_hh gradient written is then already the sum over ranks."""
+        W_hh gradient written is then already the sum over ranks.  With ``whh_factors`` the W_hh
+        gradient is not written at all: ``self.whh_factors = (fa, fb)`` (gradient = fa^T . fb) is left for
+        ``FusedNAdam.step(lowrank=...)``; ``None`` afterwards means the dense gradient was written instead
+        (rank above 64)."""
+        self.whh_factors = None
         if self._saved_generation != self.generation:
             raise RuntimeError("SynthesisModelCNN backward: the forward intermediates were overwritten by a later "
                                "forward pass (one forward/backward pair at a time per model)")
@@ -541,7 +545,10 @@ class CnnEngine:
                 self._tn(A=ptr(dgt), B=ptr(w_hh), slab=ptr(slab_h), Krows=4 * H, A_rows=4 * H, B_rows=4 * H, Mdim=ldt,
                          Ndim=H, lda=ldt, ldb=H, ldc=H, loader=LOAD_DIRECT, splitk=sk_h, slab_stride=ldt * H)
                 self._permute(slab_h, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=sk_h, zs=ldt * H)
-        gwhh = grads["label_lstm.weight_hh_l0"]
+        def dense_whh():                       # allocated on demand: the trainer path never needs it
+            if "label_lstm.weight_hh_l0" not in grads:
+                grads["label_lstm.weight_hh_l0"] = torch.empty(4 * H, H, **f32)
+            return grads["label_lstm.weight_hh_l0"]
         if L > 1:
             kr = (L - 1) * U
             fa, fb = dg[1:].reshape(kr, 4 * H), self._h[:L - 1].reshape(kr, H)
@@ -551,11 +558,17 @@ class CnnEngine:
                 keys = torch.cat([steps, self._xu.permute(1, 0, 2).reshape(U, 2 * L).repeat(L - 1, 1)], dim=1)
                 fa, fb = gather_whh(fa, fb, keys)
                 kr = fa.shape[0]
-            self._tn(A=ptr(fa), B=ptr(fb), slab=ptr(gwhh), Krows=kr, A_rows=kr, B_rows=kr, Mdim=4 * H, Ndim=H,
-                     lda=4 * H, ldb=H, ldc=H, loader=LOAD_DIRECT)
+            if whh_factors and kr <= 64:
+                # hand the factors to the optimiser (tl_nadam_lowrank): the 5.4 GB gradient is never formed
+                self.whh_factors = (fa.contiguous(), fb.contiguous())
+            else:
+                self._tn(A=ptr(fa), B=ptr(fb), slab=ptr(dense_whh()), Krows=kr, A_rows=kr, B_rows=kr, Mdim=4 * H,
+                         Ndim=H, lda=4 * H, ldb=H, ldc=H, loader=LOAD_DIRECT)
             del fa, fb
+        elif whh_factors:
+            self.whh_factors = (None, None)
         else:
-            gwhh.zero_()
+            dense_whh().zero_()
         gb = grads["label_lstm.bias_ih_l0"]
         check(lib.tl_lstm_ih_grad(ptr(dg), ptr(self._xu), ptr(grads["label_lstm.weight_ih_l0"]), ptr(gb), L, U, H, 2,
                                   st_), "tl_lstm_ih_grad")

@@ -80,6 +80,7 @@ SIGNATURES = {
                                   C.c_uint64, _P]),
     "tl_l1_mcd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "tl_nadam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "tl_nadam_lowrank": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_tone_dynamics": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "tl_lite_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tl_lite_bn_finalize": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _P]),

@@ -513,6 +513,68 @@ __global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ p, const
     nadam_one(p[i], g[i], m[i], v[i], cg, cm, b1, b2, bc2, eps, wd, gscale);
 }
 
+// NAdam on a parameter whose gradient is low rank: g = fa^T . fb (fa: kr x rows, fb: kr x cols),
+// formed in registers and never written to HBM.  Used for label_lstm.weight_hh_l0 (98.7 % of the
+// parameters): kr <= (L-1) * U = 32 distinct (step, label) rows, so the 5.4 GB gradient tensor and
+// its write + read disappear from the step.  Block tile 32 rows x 256 columns; a thread owns 8 rows
+// x 4 columns; the factor tiles sit in LDS ([k][32] and [k][256]).
+constexpr int LR_TR = 32, LR_TC = 256, LR_MAXK = 64;
+__global__ __launch_bounds__(256) void nadam_lowrank_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                            float* __restrict__ v, const float* __restrict__ fa,
+                                                            const float* __restrict__ fb, int kr, int rows, int cols,
+                                                            int ldfa, int ldfb, float cg, float cm, float b1, float b2,
+                                                            float bc2, float eps, float wd, float gscale) {
+  extern __shared__ __attribute__((aligned(16))) float lr_lds[];
+  float* sa = lr_lds;                        // [kr][LR_TR]
+  float* sb = lr_lds + kr * LR_TR;           // [kr][LR_TC]
+  const int r0 = blockIdx.x * LR_TR, c0 = blockIdx.y * LR_TC;
+  for (int i = threadIdx.x; i < kr * LR_TR; i += 256) {
+    const int k = i / LR_TR, r = i % LR_TR;
+    sa[i] = (r0 + r) < rows ? fa[(long long)k * ldfa + r0 + r] : 0.f;
+  }
+  for (int i = threadIdx.x; i < kr * (LR_TC / 4); i += 256) {
+    const int k = i / (LR_TC / 4), c4 = (i % (LR_TC / 4)) * 4;
+    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + c4 < cols) val = *reinterpret_cast<const f32x4*>(fb + (long long)k * ldfb + c0 + c4);
+    *reinterpret_cast<f32x4*>(sb + k * LR_TC + c4) = val;
+  }
+  __syncthreads();
+  const int cg4 = (threadIdx.x & 63) * 4, rg = (threadIdx.x >> 6) * 8;
+  f32x4 g[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) g[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < kr; ++k) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + k * LR_TC + cg4);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + k * LR_TR + rg);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + k * LR_TR + rg + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      g[r] += a0[r] * bv;
+      g[r + 4] += a1[r] * bv;
+    }
+  }
+  const int col = c0 + cg4;
+  if (col >= cols) return;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = r0 + rg + r;
+    if (row >= rows) break;
+    const long long at = ((long long)row * cols + col) >> 2;
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[at], mv = reinterpret_cast<f32x4*>(m)[at], vv = reinterpret_cast<f32x4*>(v)[at];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float pq = pv[q], mq = mv[q], vq = vv[q];
+      nadam_one(pq, g[r][q], mq, vq, cg, cm, b1, b2, bc2, eps, wd, gscale);
+      pv[q] = pq;
+      mv[q] = mq;
+      vv[q] = vq;
+    }
+    reinterpret_cast<f32x4*>(p)[at] = pv;
+    reinterpret_cast<f32x4*>(m)[at] = mv;
+    reinterpret_cast<f32x4*>(v)[at] = vv;
+  }
+}
+
 __global__ void tone_dynamics_kernel(const long long* __restrict__ tone, const long long* __restrict__ syl,
                                      const float* __restrict__ table, float* __restrict__ labels, int32_t* err, int B,
                                      int n_tones, int L) {
@@ -690,6 +752,21 @@ extern "C" int tl_nadam(float* p, const float* g, float* m, float* v, int64_t n,
   hipLaunchKernelGGL(nadam_kernel, dim3(grid_for(n / 4 + 1, 256, 256LL * 8)), dim3(256), 0, (hipStream_t)stream, p, g,
                      m, v, (long long)n, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps, weight_decay, grad_scale);
   return check_launch("nadam");
+}
+
+extern "C" int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
+                                int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
+                                float bias_corr2, float eps, float weight_decay, float grad_scale, void* stream) {
+  TL_REQUIRE(p && m && v && rows > 0 && cols > 0, "nadam_lowrank: bad arguments");
+  TL_REQUIRE(kr >= 0 && kr <= LR_MAXK && (kr == 0 || (fa && fb)), "nadam_lowrank: rank must be 0..%d with both factors", LR_MAXK);
+  TL_REQUIRE(cols % 4 == 0 && ldfb % 4 == 0 && ldfa >= rows && ldfb >= cols, "nadam_lowrank: cols / ldfb must be multiples of 4, ld >= extent");
+  TL_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)fb) & 15) == 0, "nadam_lowrank: pointers must be 16-byte aligned");
+  const unsigned gx = (unsigned)((rows + LR_TR - 1) / LR_TR), gy = (unsigned)((cols + LR_TC - 1) / LR_TC);
+  TL_REQUIRE(gy <= 65535u, "nadam_lowrank: more than 16.7 M columns");
+  hipLaunchKernelGGL(nadam_lowrank_kernel, dim3(gx, gy), dim3(256), (size_t)kr * (LR_TR + LR_TC) * 4, (hipStream_t)stream, p,
+                     m, v, fa, fb, kr, rows, cols, ldfa, ldfb, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps,
+                     weight_decay, grad_scale);
+  return check_launch("nadam_lowrank");
 }
 
 extern "C" int tl_tone_dynamics(const int64_t* tone, const int64_t* syl, const float* table, float* labels,

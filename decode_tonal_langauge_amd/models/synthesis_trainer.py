@@ -123,8 +123,11 @@ class SynthesisTrainer:
         names = model._pnames
         params = dict(model.named_parameters())
         prm = {k: params[k].detach() for k in names}
+        skip = getattr(eng, "lowrank_param", None)
         if self._grads is None:
-            self._grads = {k: torch.empty_like(v) for k, v in prm.items()}
+            # the low-rank parameter's gradient (5.4 GB at the north-star shape) is only materialised
+            # if its rank exceeds what the fused optimiser kernel takes (the engine then allocates it)
+            self._grads = {k: torch.empty_like(v) for k, v in prm.items() if k != skip}
         prm.update(model._engine_buffers())
         out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True, seed=model._next_seed())
         B, D = out.shape
@@ -132,13 +135,17 @@ class SynthesisTrainer:
         check(self.lib.tl_l1_mcd(ptr(out), ptr(targets), ptr(dout), ptr(self._stats), B, D, eng.ldd, 1, 1.0,
                                  torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
         gather = parallel.gather_lowrank if self.dp else None
-        eng.backward(prm, dout, self._grads, gather_whh=gather)
+        eng.backward(prm, dout, self._grads, gather_whh=gather, whh_factors=skip is not None)
         scale = 1.0
         if self.dp:
-            skip = getattr(eng, "lowrank_param", None)
             parallel.allreduce_bucketed([g for k, g in self._grads.items() if k != skip])
             scale = 1.0 / self.world
-        self.optimizer.step(grads={params[k]: self._grads[k] for k in names}, grad_scale=scale)
+        factors = getattr(eng, "whh_factors", None)
+        if factors is not None:          # the optimiser forms that gradient from its factors on the fly
+            self.optimizer.step(grads={params[k]: self._grads[k] for k in names if k != skip}, grad_scale=scale,
+                                lowrank={params[skip]: factors})
+        else:
+            self.optimizer.step(grads={params[k]: self._grads[k] for k in names}, grad_scale=scale)
 
     def _generic_step(self, inputs_non, inputs_label, targets) -> None:
         """Any other ``SynthesisModel`` subclass: torch autograd for the model, fused NAdam."""

@@ -45,15 +45,39 @@ class FusedNAdam(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    LOWRANK_MAX = 64          # largest factor rank tl_nadam_lowrank takes
+
     @torch.no_grad()
     def step(self, closure=None, grads: Optional[Dict[torch.nn.Parameter, torch.Tensor]] = None,
-             grad_scale: float = 1.0):
-        """``grads`` optionally maps parameter -> gradient tensor (fused trainer path, no ``.grad``)."""
+             grad_scale: float = 1.0, lowrank: Optional[Dict[torch.nn.Parameter, tuple]] = None):
+        """``grads`` optionally maps parameter -> gradient tensor (fused trainer path, no ``.grad``).
+        ``lowrank`` maps a 2-D parameter (rows, cols) to factors ``(fa (k, rows), fb (k, cols))`` of its
+        gradient ``fa^T . fb``, k <= LOWRANK_MAX (or ``(None, None)`` for a zero gradient): the update is
+        applied without materialising the gradient."""
         loss = closure() if closure is not None else None
         stream = torch.cuda.current_stream().cuda_stream
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
+                if lowrank is not None and p in lowrank:
+                    fa, fb = lowrank[p]
+                    kr = 0 if fa is None else fa.shape[0]
+                    if p.dim() != 2 or not p.is_contiguous() or kr > self.LOWRANK_MAX:
+                        raise RuntimeError("FusedNAdam: low-rank update needs a contiguous 2-D parameter and rank <= 64")
+                    if kr and (fa.shape[1] != p.shape[0] or fb.shape[1] != p.shape[1] or fb.shape[0] != kr
+                               or fa.stride(1) != 1 or fb.stride(1) != 1):
+                        raise RuntimeError("FusedNAdam: low-rank factors do not match the parameter")
+                    _lib.require_gpu(p, "FusedNAdam.step")
+                    st = self._state_for(p)
+                    st["step"] += 1
+                    cg, cm, bc2, st["mu_product"] = nadam_scalars(st["step"], st["mu_product"], group["lr"], b1, b2,
+                                                                  group["momentum_decay"])
+                    check(self._lib.tl_nadam_lowrank(ptr(p), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(fa), ptr(fb),
+                                                     kr, p.shape[0], p.shape[1], fa.stride(0) if kr else p.shape[0],
+                                                     fb.stride(0) if kr else p.shape[1], cg, cm, b1, b2, bc2,
+                                                     group["eps"], group["weight_decay"], grad_scale, stream),
+                          "tl_nadam_lowrank")
+                    continue
                 g = grads.get(p) if grads is not None else p.grad
                 if g is None:
                     continue

@@ -182,6 +182,12 @@ int tl_l1_mcd(const float* out, const float* targets, float* dout, float* stats,
 int tl_nadam(float* p, const float* g, float* m, float* v, int64_t n, float coef_grad, float coef_mom,
              float beta1, float beta2, float bias_corr2, float eps, float weight_decay, float grad_scale,
              void* stream);
+/* the same update for a parameter (rows x cols) whose gradient is low rank, g = fa^T . fb with
+ * fa (kr, rows), fb (kr, cols), kr <= 64: the gradient is formed in registers and never stored
+ * (label_lstm.weight_hh_l0: 5.4 GB less written and read per step).                              */
+int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
+                     int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
+                     float bias_corr2, float eps, float weight_decay, float grad_scale, void* stream);
 
 /* ---- tone dynamics gather (data_loading/utils.py:32-79) ----------------------------------- */
 /* labels[b][0][l] = syl[b]; labels[b][1][l] = table[tone[b]][l]; err flag set if tone out of range */

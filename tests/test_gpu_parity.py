@@ -88,7 +88,12 @@ def test_cnn_train_steps_match_reference_golden(dev):
         losses.append(st[2])
         mcds.append(st[3])
         if s == 0:
-            for k, gr in tr._grads.items():
+            grads_now = dict(tr._grads)
+            if model._engine.whh_factors is not None:
+                fa, fb = model._engine.whh_factors              # the optimiser consumed the factors, not a tensor
+                grads_now[model._engine.lowrank_param] = fa.t() @ fb
+            assert set(grads_now) == {k for k, _ in model.named_parameters()}
+            for k, gr in grads_now.items():
                 gr = gr.cpu().numpy()
                 if "grad1." + k in g:
                     assert rel_l2(gr, g["grad1." + k]) < 5e-3, k
@@ -567,3 +572,31 @@ def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
             assert rel_l2(d1.cpu().numpy(), d0.cpu().numpy()) < 1e-5
             assert rel_l2(w1.cpu().numpy(), w0.cpu().numpy()) < 1e-5
             assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-6
+
+
+def test_lowrank_nadam_equals_dense_nadam(dev):
+    """FusedNAdam with gradient factors (tl_nadam_lowrank) == FusedNAdam on the materialised gradient."""
+    from decode_tonal_langauge_amd.optim import FusedNAdam
+    g = torch.Generator(device=dev).manual_seed(3)
+    for rows, cols, kr in ((70, 260, 33), (64, 512, 5), (33, 4, 0)):
+        w0 = torch.randn(rows, cols, device=dev, generator=g)
+        pa, pb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+        oa = FusedNAdam([pa], lr=5e-3, weight_decay=0.004)
+        ob = FusedNAdam([pb], lr=5e-3, weight_decay=0.004)
+        for step in range(3):
+            if kr:
+                fa = torch.randn(kr, rows, device=dev, generator=g)
+                fb = torch.randn(kr, cols, device=dev, generator=g)
+                dense = fa.t() @ fb
+            else:
+                fa = fb = None
+                dense = torch.zeros(rows, cols, device=dev)
+            oa.step(grads={pa: dense.contiguous()}, grad_scale=0.5)
+            ob.step(grads={}, lowrank={pb: (fa, fb)}, grad_scale=0.5)
+        assert float((pa - pb).detach().abs().max()) < 2e-6 * max(1.0, float(pa.detach().abs().max()))
+        sa, sb = oa.state[pa], ob.state[pb]
+        assert sa["step"] == sb["step"] == 3
+        assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) < 1e-5
+        assert float((sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max()) < 1e-4 * float(sa["exp_avg_sq"].abs().max())
+    with pytest.raises(RuntimeError, match="rank"):
+        ob.step(grads={}, lowrank={pb: (torch.zeros(65, 33, device=dev), torch.zeros(65, 4, device=dev))})
