@@ -207,6 +207,24 @@ class CnnEngine:
     def _splitk(tiles: int, ksteps: int, target: int = 2048) -> int:
         return int(max(1, min(ksteps, (target + tiles - 1) // tiles, 1024)))
 
+    @staticmethod
+    def _splitk_rounds(tiles: int, ksteps: int, slots: int = 512, max_sk: int = 32) -> int:
+        """Split-K factor for the HBM-streaming GEMMs over W_hh: the workgroup count should fill whole
+        rounds of the 512 resident workgroup slots (256 CUs x 2) - a partial last round streams at a
+        fraction of the bandwidth.  Smallest factor whose last round is >= 95 % full with about two
+        rounds or more; failing that the fullest."""
+        cands = []
+        for sk in range(1, max(1, min(max_sk, ksteps)) + 1):
+            n = tiles * sk
+            cands.append((sk, n, n / (-(-n // slots) * slots)))
+        full = [c for c in cands if c[2] >= 0.95]
+        for sk, n, _ in full:
+            if n >= 1.9 * slots:
+                return sk
+        if full:
+            return full[-1][0]
+        return max(cands, key=lambda c: c[2])[0]
+
     # ------------------------------------------------------------------ weight packing
     def _pack_conv(self, w, cin_ld, flip_for_dgrad):
         """torch (O, I, J, 1) -> forward pack [J][O][cin_ld] or dgrad pack [J'][I_ld][O_ld] (J flipped)."""
@@ -407,10 +425,16 @@ class CnnEngine:
         w_ih, w_hh = prm["label_lstm.weight_ih_l0"], prm["label_lstm.weight_hh_l0"]
         b_ih, b_hh = prm["label_lstm.bias_ih_l0"], prm["label_lstm.bias_hh_l0"]
         bm = 32 if U <= 64 else 128
+        sk_f = self._splitk_rounds(((U + bm - 1) // bm) * ((4 * H + 127) // 128), (H + 31) // 32) if L > 1 else 1
+        slab_f = torch.empty(sk_f, U, 4 * H, **f32) if sk_f > 1 else None
         for t in range(L):
             if t > 0:
-                self._nt(A=ptr(self._h[t - 1]), Bw=ptr(w_hh), out=ptr(hh), M=U, A_rows=U, N=4 * H, K=H, lda=H,
-                         ldb=H, ldo=4 * H, loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm)
+                self._nt(A=ptr(self._h[t - 1]), Bw=ptr(w_hh), out=ptr(slab_f if sk_f > 1 else hh), M=U, A_rows=U,
+                         N=4 * H, K=H, lda=H, ldb=H, ldo=4 * H, loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm,
+                         splitk=sk_f, slab_stride=U * 4 * H)
+                if sk_f > 1:
+                    n = U * 4 * H
+                    self._permute(slab_f, hh, (1, 1, 1, n), (0, 0, 0, 1), nz=sk_f, zs=n)
             check(lib.tl_lstm_cell_fwd(ptr(hh) if t > 0 else None, ptr(xu[t]), ptr(w_ih), ptr(b_ih), ptr(b_hh),
                                        ptr(self._c[t - 1]) if t > 0 else None, ptr(self._act[t]), ptr(self._c[t]),
                                        ptr(self._h[t]), U, H, 2, 4 * H, st_), "tl_lstm_cell_fwd")
@@ -532,7 +556,7 @@ class CnnEngine:
         dhrec = torch.empty(U, H, **f32) if L > 1 else None
         if L > 1:
             if ldt <= 32:        # skinny streaming kernel: 32 x 512 tiles, 16-deep K stages
-                sk_h = self._splitk((H + 511) // 512, (4 * H + 15) // 16, 1024)
+                sk_h = self._splitk_rounds((H + 511) // 512, (4 * H + 15) // 16)
             else:
                 sk_h = self._splitk((ldt + 127) // 128 * ((H + 127) // 128), (4 * H + 31) // 32, 1024)
             slab_h = torch.empty(sk_h, ldt, H, **f32)
