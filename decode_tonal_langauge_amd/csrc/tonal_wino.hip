@@ -121,6 +121,17 @@ __device__ __forceinline__ void c1w_row(c1w_acc& a, const tl_nt_params& p, const
   if (p.c1kt > 2) a.s[2] = fmaf(dz, am ? x3 : x2, a.s[2]);
   a.b += dz;
 }
+// the same with the row's two bit words and four signal samples already in registers
+__device__ __forceinline__ void c1w_row_vals(c1w_acc& a, const tl_nt_params& p, uint32_t sword, uint32_t cword, float x0,
+                                             float x1, float x2, float x3, float y, int lr) {
+  const bool pos = (sword >> lr) & 1u;
+  const bool am = (cword >> lr) & 1u;
+  const float dz = pos ? y : y * p.slope;
+  a.s[0] = fmaf(dz, am ? x1 : x0, a.s[0]);
+  if (p.c1kt > 1) a.s[1] = fmaf(dz, am ? x2 : x1, a.s[1]);
+  if (p.c1kt > 2) a.s[2] = fmaf(dz, am ? x3 : x2, a.s[2]);
+  a.b += dz;
+}
 // block reduction over the row dimension: lanes lr / lr + 32 and the NWM waves that share a column;
 // red: LDS [NWM][NCOL][5].  Writes c1partial[tile][j][col] for the block's NCOL columns.
 template <int NWM, int NCOL>
@@ -728,20 +739,56 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
 
   // ---- epilogue: the four conv rows of a quad from its six products ----
   const long long Q0 = (R0 >> 2) + wm * 32 + 4 * lh;       // quad of accumulator element e = 0
-  const int t0 = (int)((4 * Q0) % p.Tp);
   const int col = n0 + wn * 32 + lr;
   const int colbase = n0 + wn * 32;
   const bool colok = col < p.N;
   float bv = 0.f;
   if constexpr (EPI == W_EPI_POOL) bv = (colok && p.bias) ? p.bias[col] : 0.f;
+  uint32_t wbits = 0, wsign = 0;
+  (void)wbits; (void)wsign;
+  // MASK: the 64 sign words this lane group needs (rows 4 (Q0 + qo) + h), one per lane, fetched up front
+  uint32_t swordA = 0, swordB = 0;
+  if constexpr (EPI == W_EPI_MASK) {
+    if (p.auxbits != nullptr) {
+      // lane lr holds the word of row index lr (e = lr >> 2, h = lr & 3) in A and of row index 32 + lr in B
+      const int eA = lr >> 2, eB = 8 + (lr >> 2), hh = lr & 3;
+      const long long RA = 4 * (Q0 + (eA & 3) + 8 * (eA >> 2)) + hh, RB = 4 * (Q0 + (eB & 3) + 8 * (eB >> 2)) + hh;
+      if (RA < p.M && colbase < p.N) swordA = p.auxbits[RA * (long long)p.ld_auxbits + (colbase >> 5)];
+      if (RB < p.M && colbase < p.N) swordB = p.auxbits[RB * (long long)p.ld_auxbits + (colbase >> 5)];
+    }
+  }
+  // C1WGRAD: per row two bit words and four signal samples.  Lane lr of each half-wave fetches them for
+  // row index lr (set A) and 32 + lr (set B) up front; the row loop reads them with lane shuffles
+  // instead of 6 dependent global loads per row.
+  uint32_t cwA = 0, cwB = 0;
+  f32x4 xsA = {0.f, 0.f, 0.f, 0.f}, xsB = xsA;
+  if constexpr (EPI == W_EPI_C1W) {
+    const int eA = lr >> 2, eB = 8 + (lr >> 2), hh = lr & 3;
+    const long long RA = 4 * (Q0 + (eA & 3) + 8 * (eA >> 2)) + hh, RB = 4 * (Q0 + (eB & 3) + 8 * (eB >> 2)) + hh;
+    c1w_cursor c;
+    if (RA < p.M && colbase < p.N) {
+      c.init(p, RA, colbase);
+      swordA = p.auxbits[c.wofs];
+      cwA = p.c1bits[c.wofs];
+      if (c.t < p.Tvalid) xsA = f32x4{p.c1x[c.xo], p.c1x[c.xo + 1], p.c1x[c.xo + 2], p.c1x[c.xo + 3]};
+    }
+    if (RB < p.M && colbase < p.N) {
+      c.init(p, RB, colbase);
+      swordB = p.auxbits[c.wofs];
+      cwB = p.c1bits[c.wofs];
+      if (c.t < p.Tvalid) xsB = f32x4{p.c1x[c.xo], p.c1x[c.xo + 1], p.c1x[c.xo + 2], p.c1x[c.xo + 3]};
+    }
+  }
   c1w_acc ca;
   ca.clear();
-  c1w_cursor cur;
-  if constexpr (EPI == W_EPI_C1W) cur.init(p, 4 * Q0, colbase);
+  c1w_cursor cur;                                          // time index of the quad without per-row divisions
+  if constexpr (EPI != W_EPI_MASK) cur.init(p, 4 * Q0, colbase);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int qo = (e & 3) + 8 * (e >> 2);
     const long long Q = Q0 + qo;
+    if constexpr (EPI != W_EPI_MASK)
+      if (e > 0) cur.advance(p, (e & 3) ? 4 : 20);           // quad offsets 0,1,2,3, 8,.. -> row steps 4,4,4,20
     const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
     const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
     float y[4];
@@ -755,23 +802,29 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
         const long long P = 2 * Q + h;                      // pooled row
         const float y0 = lrelu(y[2 * h] + bv, p.slope), y1 = lrelu(y[2 * h + 1] + bv, p.slope);
         const bool rowok = 2 * P < p.M;
-        const bool valid = rowok && ((t0 + 4 * qo + 2 * h) % p.Tp) < p.Tvalid;
+        const bool valid = rowok && (cur.t + 2 * h) < p.Tvalid;     // Tp % 4 == 0: a quad never wraps
         const bool sel = valid && colok && (y1 > y0);
         const float o = valid ? (sel ? y1 : y0) : 0.f;
         if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
+        // lane lr of each half-wave keeps the two bit words of pooled row number lr of this lane group
         const unsigned long long m = __ballot(sel);
         const unsigned long long ms = __ballot(o > 0.f);
-        if (lr == 0 && rowok && colbase < p.N) {
-          p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(m >> (32 * lh));
-          if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = (uint32_t)(ms >> (32 * lh));
+        if (lr == 2 * e + h) {
+          wbits = (uint32_t)(m >> (32 * lh));
+          wsign = (uint32_t)(ms >> (32 * lh));
         }
       }
     } else if constexpr (EPI == W_EPI_C1W) {
-      if (e > 0) cur.advance(p, (e & 3) ? 4 : 20);           // quad offsets 0,1,2,3, 8,.. -> row steps 4,4,4,20
-      if (4 * Q < p.M && colok) {                            // Tp % 4 == 0: the quad stays inside one sequence
+      {
+        const bool live = 4 * Q < p.M && colok;               // Tp % 4 == 0: the quad stays inside one sequence
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
-          if (cur.t + h < p.Tvalid) c1w_row(ca, p, cur, h, y[h], lr);
+        for (int h = 0; h < 4; ++h) {
+          const int src = ((4 * e + h) & 31) + 32 * lh;
+          const uint32_t sw = __shfl((e < 8) ? swordA : swordB, src), cw = __shfl((e < 8) ? cwA : cwB, src);
+          const f32x4 xs = (e < 8) ? xsA : xsB;
+          const float x0 = __shfl(xs[0], src), x1 = __shfl(xs[1], src), x2 = __shfl(xs[2], src), x3 = __shfl(xs[3], src);
+          if (live && cur.t + h < p.Tvalid) c1w_row_vals(ca, p, sw, cw, x0, x1, x2, x3, y[h], lr);
+        }
       }
     } else {
       const long long R = 4 * Q;
@@ -779,13 +832,25 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           bool pos;
-          if (p.auxbits != nullptr)
-            pos = (p.auxbits[(R + h) * (long long)p.ld_auxbits + (colbase >> 5)] >> lr) & 1u;
-          else
+          if (p.auxbits != nullptr) {
+            // word of row index 4 e + h: lane (4 e + h) & 31 of this half-wave holds it
+            const uint32_t mine = (e < 8) ? swordA : swordB;
+            const uint32_t word = __shfl(mine, ((4 * e + h) & 31) + 32 * lh);
+            pos = (word >> lr) & 1u;
+          } else {
             pos = p.aux[(R + h) * (long long)p.ldaux + col] > 0.f;
+          }
           p.out[(R + h) * (long long)p.ldo + col] = pos ? y[h] : y[h] * p.slope;
         }
       }
+    }
+  }
+  if constexpr (EPI == W_EPI_POOL) {
+    const int e = lr >> 1, h = lr & 1;
+    const long long P = 2 * (Q0 + (e & 3) + 8 * (e >> 2)) + h;
+    if (2 * P < p.M && colbase < p.N) {
+      p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = wbits;
+      if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = wsign;
     }
   }
   if constexpr (EPI == W_EPI_C1W) c1w_reduce_store<4, 64>(p, lds, ca, wm, wn * 32 + lr, lh, tm, col, colok);
