@@ -36,15 +36,22 @@ __device__ __forceinline__ void nt_epilogue(const tl_nt_params& p, f32x16 (&acc)
       const long long rbase = R0 + wm * (MI * 32) + mi * 32;
       if constexpr (EPI == EPI_POOL) {
         const float bv = (colok && p.bias) ? p.bias[col] : 0.f;
+        int tq = (int)((rbase + 4 * lh) % p.Tp);              // time index of row rbase + 4 lh; rows below step by 2 / 8
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const long long Rq = rbase + 8 * q + 4 * lh;        // even conv row of this lane's 4 rows
+          if (q > 0) {
+            tq += 8;
+            while (tq >= p.Tp) tq -= p.Tp;
+          }
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const float y0 = lrelu(acc[mi][ni][4 * q + 2 * e] + bv, p.slope);
             const float y1 = lrelu(acc[mi][ni][4 * q + 2 * e + 1] + bv, p.slope);
             const bool rowok = (Rq + 2 * e) < p.M;              // Tp, Tvalid even: the pair shares validity
-            const bool valid_e = rowok && (int)((Rq + 2 * e) % p.Tp) < p.Tvalid;
+            int te = tq + 2 * e;
+            if (te >= p.Tp) te -= p.Tp;
+            const bool valid_e = rowok && te < p.Tvalid;
             const bool sel = valid_e && colok && (y1 > y0);
             const float o = valid_e ? (sel ? y1 : y0) : 0.f;
             const long long prow = (Rq >> 1) + e;
@@ -62,16 +69,29 @@ __device__ __forceinline__ void nt_epilogue(const tl_nt_params& p, f32x16 (&acc)
         float bv = 0.f;
         if constexpr (EPI == EPI_STORE || EPI == EPI_LRELU) bv = (colok && p.bias && p.splitk == 1) ? p.bias[col] : 0.f;
         float* outp = p.out + (long long)z * p.slab_stride;
+        // MASK from sign bits: the 16 words this lane group needs (one per row) are fetched by lanes
+        // 0..15 of each half-wave up front and read back with a shuffle - no dependent load per row
+        uint32_t sword = 0;
+        if constexpr (EPI == EPI_MASK) {
+          if (p.auxbits != nullptr) {
+            const int es = lr & 15;
+            const long long Rs = rbase + (es & 3) + 8 * (es >> 2) + 4 * lh;
+            const int cb = n0 + wn * (NI * 32) + ni * 32;
+            if (Rs < p.M && cb < p.N) sword = p.auxbits[Rs * (long long)p.ld_auxbits + (cb >> 5)];
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const long long R = rbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          uint32_t word = 0;
+          if constexpr (EPI == EPI_MASK) word = __shfl(sword, e + 32 * lh);
           if (R < p.M && colok) {
             float v = acc[mi][ni][e] + bv;
             if constexpr (EPI == EPI_LRELU) v = lrelu(v, p.slope);
             if constexpr (EPI == EPI_MASK) {
               bool pos;
               if (p.auxbits != nullptr)
-                pos = (p.auxbits[R * (long long)p.ld_auxbits + (col >> 5)] >> (col & 31)) & 1u;
+                pos = (word >> lr) & 1u;
               else
                 pos = p.aux[R * (long long)p.ldaux + col] > 0.f;
               v = pos ? v : v * p.slope;
