@@ -863,6 +863,9 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
 // (the finalize step flips its sign).  Tile 128 (C_in) x 64 (C_out), wave tile 64 x 32 x 4
 // transforms = 128 accumulator registers, 2 workgroups per CU; a K-step is 32 rows = 16 pairs.
 // ------------------------------------------------------------------------------------------
+#ifndef WT_BATCH_XF
+#define WT_BATCH_XF 1      // 1: transforms of a k-step batched ahead of its MFMAs (conv2 wgrad 57.3 -> 54.2 ms)
+#endif
 constexpr int WT_BN = 64, WT_LDA = 128 + 4, WT_LDB = WT_BN + 4, WT_AR = W_BK + 2;
 
 __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
@@ -992,6 +995,27 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
   auto mfma_group = [&](const float (&fa)[4][2], const float (&fb)[2]) {
     const float e = fb[0], o = fb[1];
     const float b1 = e + o, b2 = e - o;
+#if WT_BATCH_XF
+    // all eight transformed operands first, then the eight MFMAs: no VALU -> MFMA read-after-write
+    // stall (s_nop) in front of every MFMA
+    float t[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const float d0 = fa[0][mi], d1 = fa[1][mi], d2 = fa[2][mi], d3 = fa[3][mi];
+      t[0][mi] = d0 - d2;
+      t[1][mi] = d1 + d2;
+      t[2][mi] = d2 - d1;
+      t[3][mi] = d1 - d3;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      acc[0][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[0][mi], e, acc[0][mi], 0, 0, 0);
+      acc[1][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[1][mi], b1, acc[1][mi], 0, 0, 0);
+      acc[2][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[2][mi], b2, acc[2][mi], 0, 0, 0);
+      acc[3][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(t[3][mi], o, acc[3][mi], 0, 0, 0);
+    }
+#else
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const float d0 = fa[0][mi], d1 = fa[1][mi], d2 = fa[2][mi], d3 = fa[3][mi];
@@ -1000,6 +1024,7 @@ __global__ __launch_bounds__(256, 2) void wino_tn_kernel(const tl_tn_params p) {
       acc[2][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2 - d1, b2, acc[2][mi], 0, 0, 0);
       acc[3][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1 - d3, o, acc[3][mi], 0, 0, 0);
     }
+#endif
   };
   // TAIL = false: steady state, the step prefetches the tiles of step s + 2 and writes those of
   // s + 1 to LDS unconditionally (no branch in the loop body); TAIL = true: the last <= 3 steps.
