@@ -69,7 +69,12 @@ class CnnClassifierEngine(CnnEngine):
                                ptr(self.bits[1]), None, S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_),
               "tl_conv1_fwd")
         for st, (w, b) in zip(self.stages, convs[1:]):
-            wp = self._cached(f"conv{st.idx}", w, lambda w=w, st=st: self._pack_conv(w, st.cin, False))
+            # pooled 3-tap stages run on the Winograd kernels of the synthesis engine (same TONAL_WINO switch)
+            wino, f43 = self._use_wino(st), self._use_wino43(st)
+            if wino:
+                wp = self._cached(f"conv{st.idx}w{int(f43)}", w, lambda w=w, f43=f43: self._pack_wino(w, True, f43))
+            else:
+                wp = self._cached(f"conv{st.idx}", w, lambda w=w, st=st: self._pack_conv(w, st.cin, False))
             src, dst = self.P[st.idx - 1], self.P[st.idx]
             kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(b), out=ptr(dst), M=S * st.tp_in, A_rows=src.shape[0],
                       N=st.cout, K=st.cin, lda=src.shape[1], ldb=st.cin, ldo=dst.shape[1], J=st.k, row_shift=0,
@@ -79,7 +84,7 @@ class CnnClassifierEngine(CnnEngine):
                 kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
             else:
                 kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
-            self._nt(**kw)
+            self._nt(fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino else "tl_gemm_nt_window", **kw)
         feat = self.P[self.stages[-1].idx]                       # [S*tp_last][ld_last] == [B][kflat_cls]
         w_fc1, b_fc1 = fc1
         lat, latC = self.lat, self.lat * self.C
