@@ -1,5 +1,7 @@
-// Winograd F(2,3) forms of the 3-tap (k,1) convolutions (conv2 / conv3 of the ECoG stack,
-// models/synthesis_models.py:91-97) on the fp32 matrix pipe of gfx950.
+// Winograd forms of the 3-tap (k,1) convolutions (conv2 / conv3 of the ECoG stack,
+// models/synthesis_models.py:91-97) on the fp32 matrix pipe of gfx950: F(2,3) for all three passes
+// (wino_nt_kernel, wino_tn_kernel) and F(4,3) for the forward / input-gradient passes
+// (wino43_nt_kernel, the default; its own header is further down).  F(2,3):
 //
 // The max-pool (2,1) that follows each of these convolutions groups the conv rows in pairs
 // (2P, 2P+1); a pair needs the four input rows d0..d3 = 2P .. 2P+3 and
