@@ -1,48 +1,128 @@
 """Headline benchmark: mel-frames/sec of the SynthesisModelCNN train step on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N ...            (no WORLD_SIZE in the environment: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[2] / SURVEY.md section 8d, "C3"): SynthesisModelCNN 128 ch x 400
-samples -> 80 mel bins, 4 tones x 2 syllables (L = 5 dynamics), batch 256 per GPU, reference
+samples -> 80 mel bins, 4 tones x 2 syllables (L = 5 dynamics), global batch 256, reference
 defaults (dropout 0.5, NAdam lr 5e-4, coupled weight decay 0.004), LogisticRegression tone /
 syllable classifiers on 8-channel slices, synthetic N(0,1) ECoG and 10*N(0,1) targets,
 random-init weights.  A "step" is the whole body of the reference's batch loop
 (models/synthesis_trainer.py:201-229): classifier forwards + argmax, label dynamics, forward,
-L1 on truncated targets, backward, (DP: gradient reduction), NAdam, loss + MCD accumulation.
-Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns 256 windows.
+L1 on truncated targets, backward, (DP: gradient exchange over RCCL), NAdam, loss + MCD.
+Inputs are resident in HBM before the timed region.
 
-Extra objects on the JSON line:
-  roofline     the dominant kernel of the step (the rocprofv3 kernel name with the largest total
-               time; one name covers its conv2 and conv3 launches): mean algorithmic FLOPs per
-               launch / mean launch time, measured with HIP events on the launch stream, against
-               the dense fp32 MFMA peak (157.3 TFLOP/s); `traffic` = HBM bytes per launch from the
-               committed rocprofv3 PMC passes (profiles/pmc_traffic.json).  Algorithmic FLOPs are
-               those of the direct convolution; the Winograd F(2,3) kernels issue 2/3
-               of them as MFMA work, so `achieved` can exceed `peak` - `mfma_pipe_frac` is the
-               utilisation of the matrix pipe itself.
+Scaling (``--scaling``): ``strong`` (default, what BASELINE config C4 names: the SAME global batch
+of 256 windows sharded by rows over the ranks) or ``weak`` (256 windows per rank).
+
+Objects on the JSON line beside the contract fields:
+  roofline     the dominant kernel family of the step (largest total time; one rocprofv3 kernel name
+               covers its conv2 and conv3 launches).  ``achieved`` = MFMA FLOPs the kernel ISSUES per
+               launch (the Winograd forms need 1/2 or 2/3 of the direct convolution's multiplies) /
+               mean launch time measured with HIP events on the launch stream; ``frac`` = achieved /
+               dense fp32 MFMA peak (157.3 TFLOP/s), always <= 1.  ``algorithmic_tflops`` is the same
+               time priced at the direct convolution's FLOPs.  ``step_mfma_issued_frac`` =
+               all MFMA FLOPs issued in one step / step time / peak.  ``traffic`` = HBM bytes per
+               launch from the rocprofv3 PMC passes committed under profiles/ (static file, named).
   cpu_baseline the CPU oracle (oracle/synthesis_oracle.py, PyTorch-CPU fp32 restatement of the
-               reference) timed on this box's host cores on a bounded sample of the same workload.
+               reference) timed on this box's host cores: 1 warm-up + 3 timed steps of the same model
+               at a bounded micro-batch; median, spread, threads and host RAM are reported.
+  c2_lite      BASELINE config C2 (SynthesisLite 32 ch x 200, batch 64) on the same GPU.
+  signal_c5    the preprocess/signal stage of config C5 (256 ch x 24 000 samples @ 400 Hz): Hilbert
+               envelope, filtfilt, FIR - kernel time by HIP events, algorithmic GB/s against the HBM
+               peak and (Hilbert: the bound that applies) fp64 vector FLOP/s against its peak.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 TONE_MAP = {"0": [3, 3, 3, 3, 3], "1": [1, 2, 3, 4, 5], "2": [3, 2, 1, 2, 4], "3": [5, 4, 3, 2, 1]}
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_FP64_VALU_TFLOPS = 78.6           # MI355X_MICROARCH.md, fp64 vector peak
+PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md, HBM3E
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256,
+                    help="global batch (strong scaling) / windows per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--channels", type=int, default=128)
+    ap.add_argument("--timepoints", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="micro-batch of the CPU-oracle leg")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the c2_lite / signal_c5 sub-results")
+    ap.add_argument("--dropout", type=float, default=None, help="default: the model's own default (0.5 / 0.3)")
+    ap.add_argument("--model", choices=["full", "lite"], default="full",
+                    help="full = SynthesisModelCNN (headline, C3); lite = SynthesisLite (use --channels 32 "
+                         "--timepoints 200 --batch 64 for BASELINE config C2)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N without torchrun
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    """Start one child process per GPU BEFORE this process makes any GPU call (the parent never
+    initialises HIP; it only counts devices, which does not).  Children get RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* and run this file; rank 0 prints the JSON line on the inherited stdout."""
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count()
+    share = os.environ.get("TONAL_BENCH_SHARE_GPU") == "1"      # rehearsal: all ranks on device 0 over gloo
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if share:
+            env["TONAL_DIST_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in pending:            # a rank died: its peers would block in the next collective
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
 def conv_flops(eng, stage_idx: int, B: int) -> float:
     """Algorithmic FLOPs of one conv stage pass (2 FLOP/MAC, valid rows only), SURVEY 8d."""
     st = eng.stages[stage_idx - 2]
@@ -62,62 +142,202 @@ def host_threads() -> int:
     return int(os.environ.get("TL_BENCH_CPU_THREADS", min(n, 32)))
 
 
-def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, budget_s: float = 40.0):
-    """Time the oracle's train step on the host cores (bounded sample)."""
+def host_ram_gb() -> float:
+    """Memory this process may use: cgroup limit if set, else MemTotal."""
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            return int(lim) / 2 ** 30
+    except (OSError, ValueError):
+        pass
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemTotal"):
+                return int(ln.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return float("nan")
+
+
+def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, warm: int = 1, timed: int = 3):
+    """The oracle's train step on the host cores: ``warm`` + ``timed`` steps of the same model at
+    micro-batch ``B_cpu`` (bounded sample: the full batch of 256 needs ~190 GB and minutes per step)."""
+    import torch
     from oracle import synthesis_oracle as so
     threads = host_threads()
     torch.set_num_threads(threads)
     params = {k: v.detach().to("cpu", copy=True) for k, v in model.named_parameters()}
     state = so.NAdamState(params)
     gen = torch.Generator().manual_seed(1234)
-    x = torch.randn(B_cpu, C, T, generator=gen)
-    tones = torch.randint(0, 4, (B_cpu,), generator=gen)
-    syls = torch.randint(0, 2, (B_cpu,), generator=gen)
-    lab = torch.tensor([[[int(s)] * 5, TONE_MAP[str(int(t))]] for t, s in zip(tones, syls)], dtype=torch.float32)
-    tgt = 10 * torch.randn(B_cpu, out_dim, generator=gen)
-    mask = (torch.rand(B_cpu, 64, model.latent_len, C, generator=gen) >= 0.5).float() * 2.0   # Dropout(0.5)
     times = []
-    t_all = time.perf_counter()
-    for _ in range(1):
+    for i in range(warm + timed):
+        x = torch.randn(B_cpu, C, T, generator=gen)
+        tones = torch.randint(0, 4, (B_cpu,), generator=gen)
+        syls = torch.randint(0, 2, (B_cpu,), generator=gen)
+        lab = torch.tensor([[[int(s)] * 5, TONE_MAP[str(int(t))]] for t, s in zip(tones, syls)], dtype=torch.float32)
+        tgt = 10 * torch.randn(B_cpu, out_dim, generator=gen)
+        mask = (torch.rand(B_cpu, 64, model.latent_len, C, generator=gen) >= 0.5).float() * 2.0   # Dropout(0.5)
         t0 = time.perf_counter()
         so.train_step("cnn", params, None, state, x, lab, tgt, dropout_mask=mask)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > budget_s:
-            break
-    best = min(times)
-    return {"value": B_cpu / best, "unit": "mel-frames/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} train step(s) of the CPU oracle at micro-batch {B_cpu} (same model, "
-                      f"C={C}, T={T}; best of {len(times)}: {best:.2f} s/step)"}
+        dt = time.perf_counter() - t0
+        if i >= warm:
+            times.append(dt)
+    med = statistics.median(times)
+    return {"value": B_cpu / med, "unit": "mel-frames/s", "cores": threads, "kind": "port",
+            "micro_batch": B_cpu, "warmup_steps": warm, "timed_steps": timed,
+            "s_per_step_median": round(med, 3), "s_per_step_min": round(min(times), 3),
+            "s_per_step_max": round(max(times), 3), "host_ram_gb": round(host_ram_gb(), 1),
+            "torch": torch.__version__,
+            "sample": f"{warm} warm-up + {timed} timed train steps of the CPU oracle at micro-batch {B_cpu} (same model, "
+                      f"C={C}, T={T}, dropout mask 0.5, NAdam on all 1.38 G parameters); value = micro-batch / median "
+                      f"step time.  Bounded sample: batch 256 needs ~190 GB of eager activations; a step costs "
+                      f"~9 s of batch-independent LSTM-weight + NAdam traffic plus ~1 s per window"}
 
 
+def event_ms(fn, iters: int, warm: int = 2):
+    """Mean wall time of ``fn`` in ms by HIP events on torch's current stream (where the kernels launch)."""
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def lite_subresult(dev, steps: int = 200, warm: int = 20):
+    """BASELINE config C2: SynthesisLite 32 ch x 200 samples -> 80 mel, batch 64, full trainer step."""
+    import torch
+    from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisLite
+    from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
+    B, C, T, D = 64, 32, 200, 80
+    torch.manual_seed(1234)
+    model = SynthesisLite(D, C, T)
+    tr = SynthesisTrainer(model, LogisticRegressionClassifier(8 * T, 4), LogisticRegressionClassifier(8 * T, 2),
+                          TONE_MAP, device=dev, verbose=False)
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    data = [(torch.randn(B, C, T, device=dev, generator=gen), torch.randn(B, 8, T, device=dev, generator=gen),
+             torch.randn(B, 8, T, device=dev, generator=gen), 10 * torch.randn(B, D, device=dev, generator=gen))
+            for _ in range(4)]
+    model.train()
+    for i in range(warm):
+        tr.train_step(*data[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.train_step(*data[i % 4])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / steps * 1e3
+    flop = 13.85e6 * B                               # SURVEY 8d: 13.85 MFLOP per window per train step
+    return {"workload": "SynthesisLite 32ch x 200t -> 80 mel, batch 64, dropout 0.3, NAdam, 919,312 params (C2)",
+            "value": round(B / (ms * 1e-3), 1), "unit": "mel-frames/s", "ms_per_step": round(ms, 4), "steps": steps,
+            "warmup": warm, "bound": "launch latency (~66 small kernels per step; tensors are KB-MB)",
+            "algorithmic_gflops": round(flop / (ms * 1e-3) / 1e9, 1),
+            "cpu_reference_ms_per_step": 19.0, "cpu_reference_note": "SURVEY section 6: reference trainer on 8 host cores"}
+
+
+def signal_subresult(dev, with_cpu: bool):
+    """C5 signal stage: frequency_filter methods on 256 ch x 24 000 float32 samples @ 400 Hz, in HBM."""
+    import numpy as np
+    import torch
+    from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
+    C, T, FS = 256, 24000, 400
+    x_np = np.random.default_rng(0).standard_normal((C, T)).astype(np.float32)
+    x = torch.from_numpy(x_np).to(dev)
+    out = {"shape": [C, T], "fs": FS, "dtype_in": "f32", "dtype_out": "f64"}
+    cases = [("hilbert", lambda: ff.hilbert_filter(x, FS, [70., 150.]), 8),
+             ("butter_filtfilt", lambda: ff.butter_filter(x, [0.3, 100], FS), 8),
+             ("fir390", lambda: ff.fir_bandpass_filter(x, FS, 390, [100.]), 4)]
+    for name, fn, s_out in cases:
+        ms = event_ms(fn, 10)
+        gb = C * T * (4 + s_out) / 1e9
+        rec = {"ms": round(ms, 4), "algorithmic_GBps": round(gb / ms * 1e3, 1),
+               "frac_of_hbm_peak": round(gb / ms * 1e3 / PEAK_HBM_GBPS, 4),
+               "channel_samples_per_s": round(C * T / ms * 1e3)}
+        if name == "hilbert":
+            taps = 209                                 # analytic_taps() at fs = 400 Hz, 70-150 Hz, tol 1e-13
+            try:
+                cfs, sds = ff.gaussian_bank([70., 150.], FS)[:2]
+                taps = int(ff.analytic_taps(T, FS, cfs, sds)[0].shape[1])
+            except Exception:                          # noqa: BLE001 - helper names are internal
+                pass
+            fl = 2.0 * 2 * 8 * taps * C * T            # 8 bands x taps complex FMAs (2 real FMA = 4 FLOP) per sample
+            rec.update({"bound": "fp64 VALU (time-domain 8-band complex Gabor bank, 557 FLOP/B: far right of the ridge)",
+                        "fp64_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "fp64_peak_tflops": PEAK_FP64_VALU_TFLOPS,
+                        "frac_of_fp64_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 4)})
+        elif name == "butter_filtfilt":
+            rec["bound"] = "latency (fp64 IIR recurrence, sequential in time)"
+        else:
+            rec["bound"] = "fp64 VALU (391-tap causal FIR)"
+        out[name] = rec
+    if with_cpu:
+        from oracle import signal_oracle as sg
+        rows = 32                                   # bounded sample: 32 of the 256 channels
+        t0 = time.perf_counter()
+        sg.hilbert_filter(x_np[:rows], FS, [70., 150.])
+        t1 = time.perf_counter()
+        sg.butter_filter(x_np[:rows], [0.3, 100], FS)
+        t2 = time.perf_counter()
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": f"{rows} of {C} channels, whole recording",
+                               "hilbert_channel_samples_per_s": round(rows * T / (t1 - t0)),
+                               "butter_channel_samples_per_s": round(rows * T / (t2 - t1))}
+    return out
+
+
+def step_issued_flops(eng, B: int, U: int, L: int) -> float:
+    """MFMA FLOPs one train step issues (forward + input gradient + weight gradient)."""
+    tot = 0.0
+    for st in eng.stages:
+        alg = conv_flops(eng, st.idx, B)
+        if eng._use_wino43(st):
+            f_nt = 0.5
+        elif eng._use_wino(st):
+            f_nt = 2.0 / 3.0
+        else:
+            f_nt = 1.0
+        f_tn = eng.wgrad_issue_factor(st) if hasattr(eng, "wgrad_issue_factor") else (2.0 / 3.0 if eng._use_wino(st) else 1.0)
+        tot += alg * (2 * f_nt + f_tn)
+    rows5 = B * eng.C * eng.lat
+    for cin_t, cin_ld, cout_t, cout_ld in eng.concat_dims:
+        tot += 3 * 2.0 * rows5 * cin_ld * cout_ld
+    tot += 3 * 2.0 * B * eng.kflat * eng.out_dim
+    # W_hh passes run on the U distinct label rows, padded to the 32-row tile
+    tot += 2 * (L - 1) * 2.0 * 32 * 4 * eng.H * eng.H
+    return tot
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="windows per GPU")
-    ap.add_argument("--channels", type=int, default=128)
-    ap.add_argument("--timepoints", type=int, default=400)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--dropout", type=float, default=None, help="default: the model's own default (0.5 / 0.3)")
-    ap.add_argument("--model", choices=["full", "lite"], default="full",
-                    help="full = SynthesisModelCNN (headline, C3); lite = SynthesisLite (use --channels 32 "
-                         "--timepoints 200 --batch 64 for BASELINE config C2)")
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
 
+    import torch
+    import torch.distributed as dist
     from decode_tonal_langauge_amd import parallel
     from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
     from decode_tonal_langauge_amd.models.synthesis_models import SynthesisLite, SynthesisModelCNN
     from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
 
     rank, world, local = parallel.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
-    B, C, T, D = args.batch, args.channels, args.timepoints, 80
+    C, T, D = args.channels, args.timepoints, 80
+    if args.scaling == "strong":
+        GB = args.batch
+        if GB < world:
+            raise SystemExit(f"global batch {GB} smaller than {world} ranks")
+    else:
+        GB = args.batch * world
+    B = len(range(*parallel.shard_rows(GB, rank, world).indices(GB)))       # rows of this rank
 
     # every rank draws the same 1.38 G initial weights on the host: share the cores between ranks
     torch.set_num_threads(max(1, host_threads() // max(world, 1)))
@@ -136,7 +356,6 @@ def main():
     # synthetic data, resident in HBM: every rank builds the same global batches and takes its shard
     gen = torch.Generator(device=dev).manual_seed(1234)
     nb = 4
-    GB = B * world
     data = []
     for _ in range(nb):
         data.append((torch.randn(GB, C, T, device=dev, generator=gen),
@@ -154,6 +373,8 @@ def main():
         trainer.train_step(*data[i % nb])
     if not args.no_kernel_timers and args.model == "full":
         eng.enable_timers(True)
+    if world > 1:
+        trainer.exchange_events = []
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -163,10 +384,15 @@ def main():
     tsum = eng.timer_summary() if getattr(eng, "timers", None) is not None else {}
     if hasattr(eng, "enable_timers"):
         eng.enable_timers(False)
+    exch_ms = None
+    if world > 1:
+        ev = trainer.exchange_events
+        trainer.exchange_events = None
+        exch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     if dist.is_initialized():
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt, exch_ms or 0.0], device=dev, dtype=torch.float64)
         parallel.all_reduce_(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, exch_ms = float(tt[0].item()), float(tt[1].item())
     ms_per_step = dt / args.steps * 1e3
     value = GB * args.steps / dt
 
@@ -174,23 +400,7 @@ def main():
         roof = None
         if tsum:
             # kernel families as rocprofv3 names them: one name covers the launches of several stages
-            if getattr(eng, "wino", False):
-                nt, nt_frac = ("wino43_nt_kernel", "F(4,3)") if getattr(eng, "wino43", False) else ("wino_nt_kernel", "F(2,3)")
-                fused = getattr(eng, "fuse_c1", False) and eng._c1_fusable()
-                fams = {f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {nt_frac})": ["conv2_fwd", "conv3_fwd"],
-                        "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))": ["conv2_wgrad", "conv3_wgrad"]}
-                if fused:       # the stage-2 launch carries the fused conv1 weight-gradient epilogue: its own kernel name
-                    fams[f"{nt}<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd {nt_frac})"] = ["conv2_dgrad"]
-                    fams[f"{nt}<UNPOOL,MASK> (conv3 input gradient, Winograd {nt_frac})"] = ["conv3_dgrad"]
-                else:
-                    fams[f"{nt}<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd {nt_frac})"] = ["conv2_dgrad", "conv3_dgrad"]
-                # MFMA FLOPs issued per algorithmic (direct-convolution) FLOP of each family
-                issued_of = {k: (0.5 if "F(4,3)" in k else 2.0 / 3.0) for k in fams}
-            else:
-                fams = {"nt_window_kernel<128,UNPOOL,MASK> (conv input-gradient)": ["conv2_dgrad", "conv3_dgrad", "conv4_dgrad"],
-                        "nt_window_kernel<128,DIRECT,POOL> (conv forward)": ["conv2_fwd", "conv3_fwd", "conv4_fwd"],
-                        "tn3_kernel<UNPOOL> (conv weight-gradient)": ["conv2_wgrad", "conv3_wgrad"]}
-                issued_of = {k: 1.0 for k in fams}
+            fams, issued_of = eng.kernel_families() if hasattr(eng, "kernel_families") else ({}, {})
             stats = {}
             for fam, tags in fams.items():
                 tags = [t for t in tags if t in tsum]
@@ -208,24 +418,44 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get(dom)
-            roof = {"bound": "mfma", "achieved": round(d["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(d["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
-                    "flops_per_launch": d["flops_per_launch"], "avg_launch_ms": round(d["avg_launch_ms"], 3),
-                    "launches_per_step": d["launches_per_step"],
+                    tj = json.load(f)
+                if dom in tj:
+                    traffic = dict(tj[dom], source="profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / "
+                                                   "WRITE_SIZE passes of this command, committed; not re-measured here)")
+            issued_tf = d["tflops"] * issued
+            U = getattr(eng, "_U", 8)
+            L = getattr(eng, "_L", 5)
+            step_issued = step_issued_flops(eng, B, U, L)
+            roof = {"bound": "mfma", "achieved": round(issued_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(issued_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
+                    "flops_issued_per_launch": d["flops_per_launch"] * issued,
+                    "avg_launch_ms": round(d["avg_launch_ms"], 3), "launches_per_step": d["launches_per_step"],
+                    "achieved_is": "MFMA FLOPs issued per launch / HIP-event launch time (<= peak by construction)",
+                    "algorithmic_tflops": round(d["tflops"], 2),
+                    "algorithmic_flops_per_launch": d["flops_per_launch"],
                     "flop_convention": "algorithmic = direct convolution, 2 FLOP/MAC over valid rows (SURVEY 8d)",
                     "mfma_issued_per_algorithmic_flop": round(issued, 4),
-                    "mfma_issued_tflops": round(d["tflops"] * issued, 2),
-                    "mfma_pipe_frac": round(d["tflops"] * issued / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "families": {k: {"tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms_per_step"], 2)}
+                    "step_mfma_issued_tflop": round(step_issued / 1e12, 3),
+                    "step_mfma_issued_frac": round(step_issued / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "families": {k: {"issued_tflops": round(v["tflops"] * issued_of[k], 2),
+                                     "frac": round(v["tflops"] * issued_of[k] / PEAK_FP32_MFMA_TFLOPS, 4),
+                                     "algorithmic_tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms_per_step"], 2)}
                                  for k, v in stats.items()},
                     "per_launch": {t: {"ms": round(tsum[t][1], 3),
-                                       "tflops": round(conv_flops(eng, int(t[4]), B) / (tsum[t][1] * 1e-3) / 1e12, 2)}
+                                       "algorithmic_tflops": round(conv_flops(eng, int(t[4]), B) / (tsum[t][1] * 1e-3) / 1e12, 2)}
                                    for t in sorted(tsum)}}
+        extras = {}
+        if world == 1 and args.model == "full" and not args.no_extras:
+            for key, fn in (("c2_lite", lambda: lite_subresult(dev)),
+                            ("signal_c5", lambda: signal_subresult(dev, not args.no_cpu_baseline))):
+                try:
+                    extras[key] = fn()
+                except Exception as e:      # noqa: BLE001 - a sub-result must not kill the headline line
+                    extras[key] = {"error": repr(e)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the 1-GPU run only
             try:
-                cpu = cpu_baseline(model, 2, C, T, D)
+                cpu = cpu_baseline(model, args.cpu_batch, C, T, D)
             except Exception as e:      # noqa: BLE001 - the baseline leg must not kill the bench line
                 cpu = {"value": None, "error": repr(e)}
         line = {
@@ -233,14 +463,17 @@ def main():
                       else "mel-frames/sec (train step) SynthesisLite",
             "value": round(value, 2), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{type(model).__name__} {C}ch x {T}t -> {D} mel, 4 tones x 2 syllables, L=5, "
-                                   f"batch {B} per GPU (global {GB}), dropout {drop}, NAdam, "
-                                   f"{model.get_nparams():,} params",
-                       "per_gpu_batch": B, "global_batch": GB, "parallelism": f"dp{world}"},
+                                   f"global batch {GB} ({args.scaling} scaling: {B} windows on rank 0), dropout {drop}, "
+                                   f"NAdam, {model.get_nparams():,} params",
+                       "per_gpu_batch": B, "global_batch": GB, "parallelism": f"dp{world}",
+                       "backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "exchange_ms_per_step": None if exch_ms is None else round(exch_ms, 3)},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        line.update(extras)
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

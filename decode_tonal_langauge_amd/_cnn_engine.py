@@ -251,6 +251,30 @@ class CnnEngine:
     def _use_wino43(self, st) -> bool:
         return self.wino43 and self._use_wino(st) and st.tp_in % 4 == 0
 
+    def wgrad_issue_factor(self, st) -> float:
+        """MFMA FLOPs the weight-gradient kernel of a stage issues per direct-convolution FLOP."""
+        return 2.0 / 3.0 if self._use_wino(st) else 1.0
+
+    def kernel_families(self):
+        """({rocprofv3 kernel family: [timer tags]}, {family: MFMA FLOPs issued per algorithmic FLOP})
+        for the conv stages - bench.py prices the HIP-event timers of ``enable_timers`` with it."""
+        if not self.wino:
+            fams = {"nt_window_kernel<128,UNPOOL,MASK> (conv input-gradient)": ["conv2_dgrad", "conv3_dgrad", "conv4_dgrad"],
+                    "nt_window_kernel<128,DIRECT,POOL> (conv forward)": ["conv2_fwd", "conv3_fwd", "conv4_fwd"],
+                    "tn3_kernel<UNPOOL> (conv weight-gradient)": ["conv2_wgrad", "conv3_wgrad"]}
+            return fams, {k: 1.0 for k in fams}
+        nt, form = ("wino43_nt_kernel", "F(4,3)") if self.wino43 else ("wino_nt_kernel", "F(2,3)")
+        fused = self.fuse_c1 and self._c1_fusable()
+        fams = {f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {form})": ["conv2_fwd", "conv3_fwd"],
+                "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))": ["conv2_wgrad", "conv3_wgrad"]}
+        if fused:       # the stage-2 launch carries the fused conv1 weight-gradient epilogue: its own kernel name
+            fams[f"{nt}<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd {form})"] = ["conv2_dgrad"]
+            fams[f"{nt}<UNPOOL,MASK> (conv3 input gradient, Winograd {form})"] = ["conv3_dgrad"]
+        else:
+            fams[f"{nt}<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd {form})"] = ["conv2_dgrad", "conv3_dgrad"]
+        issued = {k: (0.5 if "F(4,3)" in k else 2.0 / 3.0) for k in fams}
+        return fams, issued
+
     def _pack_wino(self, w, forward: bool, f43: bool = False):
         """torch (O, I, 3, 1) -> the 4 (F(2,3)) or 6 (F(4,3)) Winograd taps: forward [n][O][I] or
         input-gradient [n][I][O]."""
@@ -384,7 +408,9 @@ class CnnEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,
-                save: bool, seed: int = 0) -> torch.Tensor:
+                save: bool, seed: int = 0, row0: int = 0) -> torch.Tensor:
+        """``row0``: index of this shard's first window in the global batch (data parallel): the dropout
+        hash is indexed by the global element, so N ranks draw the masks of one process."""
         B, Cn, T = x.shape
         if Cn != self.C or T != self.T:
             raise ValueError(f"expected ECoG input (B, {self.C}, {self.T}), got {tuple(x.shape)}")
@@ -399,6 +425,7 @@ class CnnEngine:
         self.generation += 1
         p_drop = self.p_drop if training else 0.0
         self._p_drop_used, self._seed_used = p_drop, seed
+        self._drop_row0 = int(row0) * self.C * self.tp5
         self._x = x
         # ---- stage 1 (C_in = 1) ----
         w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
@@ -440,8 +467,8 @@ class CnnEngine:
                                        ptr(self._h[t]), U, H, 2, 4 * H, st_), "tl_lstm_cell_fwd")
         # ---- dropout + concat ----
         check(lib.tl_concat_pack(ptr(self.P[5]), ptr(self._h[L - 1]), ptr(self._uid), ptr(self.Xc), B, self.C,
-                                 self.tp5, self.lat, self.Cc, self.Lc, self.ld5, H, self.ldx, p_drop, seed, st_),
-              "tl_concat_pack")
+                                 self.tp5, self.lat, self.Cc, self.Lc, self.ld5, H, self.ldx, p_drop, seed,
+                                 self._drop_row0, st_), "tl_concat_pack")
         # ---- concat 1x1 stack ----
         src = self.Xc
         self._wc = []
@@ -545,8 +572,8 @@ class CnnEngine:
         dh_ext = torch.empty(U, H, **f32)
         check(lib.tl_concat_unpack_bwd(ptr(self.dXc), ptr(self.P[5]), ptr(order), ptr(offsets), ptr(self.G[5]),
                                        ptr(dh_ext), B, U, self.C, self.tp5, self.lat, self.Cc, self.Lc, self.ld5, H,
-                                       self.ldx, self.slope, self._p_drop_used, self._seed_used, st_),
-              "tl_concat_unpack_bwd")
+                                       self.ldx, self.slope, self._p_drop_used, self._seed_used, self._drop_row0,
+                                       st_), "tl_concat_unpack_bwd")
         # ---- LSTM BPTT on the distinct rows ----
         w_hh = prm["label_lstm.weight_hh_l0"]
         ldt = (U + 31) // 32 * 32

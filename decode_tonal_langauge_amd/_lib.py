@@ -75,9 +75,9 @@ SIGNATURES = {
     "tl_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "tl_lstm_ih_grad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "tl_concat_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint64, _P]),
+    "tl_concat_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint64, _L, _P]),
     "tl_concat_unpack_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F,
-                                  C.c_uint64, _P]),
+                                  C.c_uint64, _L, _P]),
     "tl_l1_mcd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "tl_nadam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_lowrank": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),

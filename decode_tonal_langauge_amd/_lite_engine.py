@@ -70,7 +70,7 @@ class LiteEngine:
         self._permute(part, dst, (1, 1, 1, ncols), (0, 0, 0, 1), nz=nblk, zs=nc4)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, t: Dict[str, torch.Tensor], x, labels, training: bool, save: bool, seed: int = 0):
+    def forward(self, t: Dict[str, torch.Tensor], x, labels, training: bool, save: bool, seed: int = 0, row0: int = 0):
         B, Cn, T = x.shape
         if Cn != self.C or T != self.T:
             raise ValueError(f"expected ECoG input (B, {self.C}, {self.T}), got {tuple(x.shape)}")
@@ -83,6 +83,7 @@ class LiteEngine:
         self.generation += 1
         self._B, self._x, self._training = B, x, training
         p_drop = self.p_drop if training else 0.0
+        seed = (seed + 0x9E3779B97F4A7C15 * int(row0)) & 0xFFFFFFFFFFFFFFFF      # data-parallel shards draw different masks
         self._p_used, self._seed = p_drop, seed
         CC, T1, T2, H = self.CC, self.T1, self.T2, self.H
         nt1, nt2 = (T + 63) // 64, (T1 + 63) // 64

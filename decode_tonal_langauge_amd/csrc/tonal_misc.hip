@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64) void lstm_ih_grad_wave_kernel(const float* __re
 __global__ __launch_bounds__(256) void concat_pack_kernel(const float* __restrict__ O5, const float* __restrict__ h,
                                                           const int32_t* __restrict__ uid, float* __restrict__ Xc, int B,
                                                           int C, int Tp, int lat, int Cc, int Lc, int ld5, int ldh, int ldx,
-                                                          float p_drop, uint64_t seed) {
+                                                          float p_drop, uint64_t seed, long long drop_row0) {
   const long long total = (long long)B * C * Tp * ldx;
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void concat_pack_kernel(const float* __restric
     if (t < lat) {
       if (col < Cc) {
         v = O5[row * ld5 + col];
-        if (p_drop > 0.f) v = u01(seed, (uint64_t)(row * Cc + col)) >= p_drop ? v * keep_scale : 0.f;
+        if (p_drop > 0.f) v = u01(seed, (uint64_t)((drop_row0 + row) * Cc + col)) >= p_drop ? v * keep_scale : 0.f;
       } else if (col < Cc + Lc) {
         v = h[(long long)uid[b] * ldh + ((long long)(col - Cc) * lat + t) * C + cch];
       }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void concat_pack_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void concat_g5_kernel(const float* __restrict__ dXc, const float* __restrict__ O5,
                                                         float* __restrict__ G5, long long rows, int Cc, int ld5, int ldx,
-                                                        float slope, float p_drop, uint64_t seed) {
+                                                        float slope, float p_drop, uint64_t seed, long long drop_row0) {
   const long long total = rows * Cc;
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void concat_g5_kernel(const float* __restrict_
     const int col = (int)(i % Cc);
     const long long row = i / Cc;
     float g = dXc[row * ldx + col];
-    if (p_drop > 0.f) g = u01(seed, (uint64_t)(row * Cc + col)) >= p_drop ? g * keep_scale : 0.f;
+    if (p_drop > 0.f) g = u01(seed, (uint64_t)((drop_row0 + row) * Cc + col)) >= p_drop ? g * keep_scale : 0.f;
     const float a = O5[row * ld5 + col];
     G5[row * ld5 + col] = a > 0.f ? g : g * slope;
   }
@@ -711,23 +711,24 @@ extern "C" int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih
 
 extern "C" int tl_concat_pack(const float* O5, const float* h, const int32_t* uid, float* Xc, int B, int C, int Tp,
                               int lat, int Cc, int Lc, int ld5, int ldh, int ldx, float p_drop, uint64_t seed,
-                              void* stream) {
+                              int64_t drop_row0, void* stream) {
   TL_REQUIRE(O5 && h && uid && Xc, "concat_pack: null pointer");
   TL_REQUIRE(ldx >= Cc + Lc && ld5 >= Cc && lat <= Tp && p_drop >= 0.f && p_drop < 1.f, "concat_pack: bad arguments");
   const long long total = (long long)B * C * Tp * ldx;
   hipLaunchKernelGGL(concat_pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, O5, h, uid, Xc, B,
-                     C, Tp, lat, Cc, Lc, ld5, ldh, ldx, p_drop, seed);
+                     C, Tp, lat, Cc, Lc, ld5, ldh, ldx, p_drop, seed, (long long)drop_row0);
   return check_launch("concat_pack");
 }
 
 extern "C" int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int32_t* members, const int32_t* offsets,
                                     float* G5, float* dh, int B, int U, int C, int Tp, int lat, int Cc, int Lc, int ld5,
-                                    int ldh, int ldx, float slope, float p_drop, uint64_t seed, void* stream) {
+                                    int ldh, int ldx, float slope, float p_drop, uint64_t seed, int64_t drop_row0,
+                                    void* stream) {
   TL_REQUIRE(dXc && O5 && members && offsets && G5 && dh, "concat_unpack_bwd: null pointer");
   TL_REQUIRE(ldx >= Cc + Lc && ld5 >= Cc && lat <= Tp && p_drop >= 0.f && p_drop < 1.f, "concat_unpack_bwd: bad arguments");
   const long long rows = (long long)B * C * Tp;
   hipLaunchKernelGGL(concat_g5_kernel, dim3(grid_for(rows * Cc)), dim3(256), 0, (hipStream_t)stream, dXc, O5, G5, rows,
-                     Cc, ld5, ldx, slope, p_drop, seed);
+                     Cc, ld5, ldx, slope, p_drop, seed, (long long)drop_row0);
   int rc = check_launch("concat_g5");
   if (rc) return rc;
   const long long total = (long long)U * Lc * lat * C;
@@ -763,7 +764,22 @@ extern "C" int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, c
   TL_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)fb) & 15) == 0, "nadam_lowrank: pointers must be 16-byte aligned");
   const unsigned gx = (unsigned)((rows + LR_TR - 1) / LR_TR), gy = (unsigned)((cols + LR_TC - 1) / LR_TC);
   TL_REQUIRE(gy <= 65535u, "nadam_lowrank: more than 16.7 M columns");
-  hipLaunchKernelGGL(nadam_lowrank_kernel, dim3(gx, gy), dim3(256), (size_t)kr * (LR_TR + LR_TC) * 4, (hipStream_t)stream, p,
+  const size_t lds = (size_t)kr * (LR_TR + LR_TC) * 4;
+  if (lds > 64 * 1024) {      // ranks 57..64 need 64.1 - 72 KB of the CU's 160 KB: raise the per-block limit once
+    static thread_local int raised_on = -1;
+    int devid = 0;
+    hipGetDevice(&devid);
+    if (raised_on != devid) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nadam_lowrank_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LR_MAXK * (LR_TR + LR_TC) * 4);
+      if (e != hipSuccess) {
+        set_error("nadam_lowrank: cannot raise the dynamic LDS limit for rank %d: %s", kr, hipGetErrorString(e));
+        return TL_ELAUNCH;
+      }
+      raised_on = devid;
+    }
+  }
+  hipLaunchKernelGGL(nadam_lowrank_kernel, dim3(gx, gy), dim3(256), lds, (hipStream_t)stream, p,
                      m, v, fa, fb, kr, rows, cols, ldfa, ldfb, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps,
                      weight_decay, grad_scale);
   return check_launch("nadam_lowrank");

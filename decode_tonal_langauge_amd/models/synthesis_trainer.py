@@ -104,18 +104,73 @@ class SynthesisTrainer:
                                         self._n_rows, self._L, torch.cuda.current_stream().cuda_stream),
               "tl_tone_dynamics")
         if self._need_check:
-            # a predicted tone may be absent from the mapping: keep the reference's immediate error
-            for t in tone.tolist():
-                if str(int(t)) not in self.tone_dynamic_mapping:
-                    raise ValueError(f"Tone {int(t)} not found in tone_dynamic_mapping."
-                                     f"Available tones in mapping: {list(self.tone_dynamic_mapping.keys())}")
+            # a predicted tone may be absent from the mapping: keep the reference's immediate error.  Under
+            # data parallelism the decision is taken by all ranks together (a rank that raised alone would
+            # leave its peers blocked in the next collective).
+            bad = [int(t) for t in tone.tolist() if str(int(t)) not in self.tone_dynamic_mapping]
+            flag = torch.tensor([bad[0] + 1 if bad else 0], dtype=torch.int64, device=self.device)
+            if self.dp:
+                parallel.all_reduce_(flag, op=torch.distributed.ReduceOp.MAX)
+            worst = int(flag.item())
+            if worst:
+                raise ValueError(f"Tone {worst - 1} not found in tone_dynamic_mapping."
+                                 f"Available tones in mapping: {list(self.tone_dynamic_mapping.keys())}")
         return labels
 
     def _shard(self, *tensors):
+        """Row shard of a global batch for this rank.  Sets ``self._row0`` (first global row of the shard)
+        and ``self._weight`` = (rows this rank contributes) / (rows of the global batch): the loss is a
+        mean over the GLOBAL batch, so a rank's gradient enters the all-reduce sum with that weight
+        (uneven shards of a ragged last batch included).  A batch with fewer rows than ranks leaves
+        some ranks without rows: they recompute row ``rank % n`` with weight 0, so every rank still
+        takes part in every collective - decided identically everywhere from the global row count."""
+        n = tensors[0].shape[0]
         if self.world == 1:
+            self._row0, self._weight = 0, 1.0
             return tensors
-        sl = parallel.shard_rows(tensors[0].shape[0], self.rank, self.world)
+        if n >= self.world:
+            sl = parallel.shard_rows(n, self.rank, self.world)
+            self._row0, self._weight = sl.start, (sl.stop - sl.start) / n
+        elif self.rank < n:
+            sl = slice(self.rank, self.rank + 1)
+            self._row0, self._weight = self.rank, 1.0 / n
+        else:
+            r = self.rank % n
+            sl = slice(r, r + 1)
+            self._row0, self._weight = r, 0.0
         return tuple(t[sl] for t in tensors)
+
+    def _loss_stats(self, out, targets, dout, ldd, trunc: int, stats=None) -> None:
+        """``tl_l1_mcd``: loss gradient (scaled by this rank's weight in the global mean) and the
+        L1 / MCD statistics.  Under data parallelism the per-rank statistics are accumulated with the
+        same weight so that their sum over ranks is the statistic of the global batch."""
+        stats = self._stats if stats is None else stats
+        B, D = out.shape
+        w = getattr(self, "_weight", 1.0)
+        if not self.dp:
+            check(self.lib.tl_l1_mcd(ptr(out), ptr(targets), ptr(dout), ptr(stats), B, D, ldd, trunc, 1.0,
+                                     torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
+            return
+        tmp = torch.zeros(4, dtype=torch.float32, device=out.device)
+        check(self.lib.tl_l1_mcd(ptr(out), ptr(targets), ptr(dout), ptr(tmp), B, D, ldd, trunc, float(w),
+                                 torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
+        stats[:2] += w * tmp[:2]
+        stats[2:] = w * tmp[2:]
+
+    def _timed(self, fn):
+        """Wrap an exchange-step call with HIP events when ``self.exchange_events`` is a list (bench.py)."""
+        events = getattr(self, "exchange_events", None)
+        if events is None:
+            return fn
+
+        def run(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            events.append((e0, e1))
+            return r
+        return run
 
     def _fused_step(self, inputs_non, inputs_label, targets) -> None:
         model = self.model
@@ -129,17 +184,16 @@ class SynthesisTrainer:
             # if its rank exceeds what the fused optimiser kernel takes (the engine then allocates it)
             self._grads = {k: torch.empty_like(v) for k, v in prm.items() if k != skip}
         prm.update(model._engine_buffers())
-        out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True, seed=model._next_seed())
+        out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True, seed=model._next_seed(),
+                          row0=getattr(self, "_row0", 0))
         B, D = out.shape
         dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)
-        check(self.lib.tl_l1_mcd(ptr(out), ptr(targets), ptr(dout), ptr(self._stats), B, D, eng.ldd, 1, 1.0,
-                                 torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
-        gather = parallel.gather_lowrank if self.dp else None
+        self._loss_stats(out, targets, dout, eng.ldd, 1)
+        gather = self._timed(parallel.gather_lowrank) if self.dp else None
         eng.backward(prm, dout, self._grads, gather_whh=gather, whh_factors=skip is not None)
-        scale = 1.0
+        scale = 1.0          # the 1/N of the global mean is already in dout (weight of this rank's rows)
         if self.dp:
-            parallel.allreduce_bucketed([g for k, g in self._grads.items() if k != skip])
-            scale = 1.0 / self.world
+            self._timed(parallel.allreduce_bucketed)([g for k, g in self._grads.items() if k != skip])
         factors = getattr(eng, "whh_factors", None)
         if factors is not None:          # the optimiser forms that gradient from its factors on the fly
             self.optimizer.step(grads={params[k]: self._grads[k] for k in names if k != skip}, grad_scale=scale,
@@ -153,16 +207,17 @@ class SynthesisTrainer:
         outputs = self.model(inputs_non, inputs_label)
         tgt = targets.long()
         loss = self.criterion(outputs, tgt)
-        loss.backward()
-        scale = 1.0
         if self.dp:
-            parallel.allreduce_bucketed([p.grad for p in self.model.parameters() if p.grad is not None])
-            scale = 1.0 / self.world
-        self.optimizer.step(grad_scale=scale)
+            (loss * getattr(self, "_weight", 1.0)).backward()
+            for p in self.model.parameters():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            self._timed(parallel.allreduce_bucketed)([p.grad for p in self.model.parameters()])
+        else:
+            loss.backward()
+        self.optimizer.step(grad_scale=1.0)
         out = outputs.detach().float().contiguous()
-        B, D = out.shape
-        check(self.lib.tl_l1_mcd(ptr(out), ptr(targets.float().contiguous()), None, ptr(self._stats), B, D, D, 1, 1.0,
-                                 torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
+        self._loss_stats(out, targets.float().contiguous(), None, out.shape[1], 1)
 
     def train_step(self, inputs_non, inputs_syllable, inputs_tone, targets) -> None:
         """One body of the batch loop (reference :201-229).  Loss / MCD go to ``self._stats``."""
@@ -195,8 +250,7 @@ class SynthesisTrainer:
                 nb += 1
             stats = self._stats.clone()
             if self.dp:
-                parallel.all_reduce_(stats)
-                stats /= self.world
+                parallel.all_reduce_(stats)          # per-rank statistics carry their weight in the global mean
             s = stats.tolist()                                  # the one host sync of the epoch
             epoch_loss, mcd = s[0] / max(nb, 1), s[1] / max(nb, 1)
             history.append((epoch_loss, mcd))

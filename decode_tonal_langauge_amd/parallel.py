@@ -128,10 +128,12 @@ def gather_lowrank(dg: torch.Tensor, h: torch.Tensor, keys: Optional[torch.Tenso
     Ranks pad to the common maximum with zero rows (which add nothing to dg^T . h).
 
     ``keys`` (k, m) identifies what each row's ``h`` was computed from (time step + label sequence):
-    rows of different ranks with equal keys have bit-identical ``h`` (same weights, same kernel, rows
-    are independent), so their ``dg`` rows are summed after the gather.  The reduction length of the
-    gradient GEMM then stays at the number of distinct (step, label) pairs of the GLOBAL batch instead
-    of growing with the number of ranks."""
+    rows of different ranks with equal keys carry the same ``h`` up to the summation order of the
+    kernel tiling a rank picked for its own number of distinct rows, so their ``dg`` rows are summed
+    after the gather and ONE representative ``h`` stands for the group - the first occurrence in
+    gathered (rank-major) order, chosen identically on every rank so the replicas stay in lockstep.
+    The reduction length of the gradient GEMM then stays at the number of distinct (step, label)
+    pairs of the GLOBAL batch instead of growing with the number of ranks."""
     if not active():
         return dg, h
     n = dist.get_world_size()
@@ -157,7 +159,8 @@ def gather_lowrank(dg: torch.Tensor, h: torch.Tensor, keys: Optional[torch.Tenso
     _, inverse = torch.unique(keys_all, dim=0, return_inverse=True)
     groups = int(inverse.max().item()) + 1
     dg_sum = torch.zeros(groups, dg.shape[1], dtype=dg.dtype, device=dg.device).index_add_(0, inverse, dg_all)
-    # any member of a group carries the group's h: scatter (last writer wins, all writers are equal)
-    h_rep = torch.zeros(groups, h.shape[1], dtype=h.dtype, device=h.device)
-    h_rep[inverse] = h_all
-    return dg_sum, h_rep
+    # representative h of a group: its first member in gathered order (deterministic on every rank)
+    pos = torch.arange(inverse.numel(), device=inverse.device, dtype=torch.int64)
+    first = torch.full((groups,), inverse.numel(), dtype=torch.int64, device=inverse.device)
+    first.scatter_reduce_(0, inverse, pos, reduce="amin")
+    return dg_sum, h_all.index_select(0, first)

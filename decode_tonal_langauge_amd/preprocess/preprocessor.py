@@ -1,0 +1,108 @@
+"""Step dispatcher of the preprocessing stage - the caller of the signal kernels (mirror of reference
+preprocess/preprocessor.py:8-70).
+
+Same contract as the reference: every step is ``{"module": dotted.path, "params": {...}}``; the step's
+parameters are merged onto ONE shared ``Namespace`` (a key that is already there raises ``ValueError``),
+the module is imported by name and its ``run(data, params)`` is called; steps may mutate the shared
+Namespace (``downsample`` rewrites ``signal_freq`` before ``frequency_filter`` reads it).
+
+MI355X addition: with ``resident=True`` a NumPy recording is moved to the GPU once, flows through
+every step as a device tensor (each step of ``preprocess/signal`` accepts one) and comes back once -
+instead of one PCIe round trip per step.  Module names of the reference layout
+(``preprocess.signal.<step>`` / the stale ``preprocess.<step>`` of the sample YAML) resolve to this
+package's kernels.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+from argparse import Namespace
+from copy import deepcopy
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+_PKG = __name__.rsplit(".", 1)[0]                      # decode_tonal_langauge_amd.preprocess
+_STEPS = ("downsample", "frequency_filter", "channel_zscore", "car_rereference", "rolling_zscore",
+          "zscore_rereference")
+
+
+def resolve_step_module(name: str):
+    """Import a step module by the name a config gives it.  ``preprocess.signal.X`` and ``preprocess.X``
+    (reference example_config.yaml:27,31,43) map onto this package; anything else is imported as is."""
+    tail = name.rsplit(".", 1)[-1]
+    if tail in _STEPS and (name.startswith("preprocess.") or name == tail):
+        name = f"{_PKG}.signal.{tail}"
+    return importlib.import_module(name)
+
+
+def preprocess_signal(data, steps: List[Dict], block_params: Namespace, figure_dir: Optional[str] = None,
+                      num_channels: int = 5, duration: float = 1.0, resident: bool = False):
+    """Apply the steps in order (reference :39-70).  Returns ``(data, block_params.signal_freq)``."""
+    was_np = isinstance(data, np.ndarray)
+    if resident and was_np:
+        import torch
+        data = torch.from_numpy(np.ascontiguousarray(data)).to("cuda")
+    for i, step in enumerate(steps):
+        module_name = step['module']
+        for key, value in step.get('params', {}).items():
+            if hasattr(block_params, key):
+                raise ValueError(f"Parameter '{key}' already exists in params. Please ensure no conflicting "
+                                 "parameter names in each preprocessing step.")
+            setattr(block_params, key, value)
+        before_freq = block_params.signal_freq
+        before = data if figure_dir is None else (data.copy() if isinstance(data, np.ndarray) else data.clone())
+        data = resolve_step_module(module_name).run(data, block_params)
+        if figure_dir and getattr(data, "ndim", 0) == 2:
+            _plot_step(before, before_freq, data, block_params.signal_freq, figure_dir, i, module_name,
+                       num_channels, duration)
+    if resident and was_np:
+        data = data.cpu().numpy()
+    return data, block_params.signal_freq
+
+
+def preprocess_modalities(data_dict: Dict, modalities_cfg: Dict, base_params: Namespace,
+                          figure_dir: Optional[str] = None, resident: bool = False) -> Dict:
+    """Per modality: copy the base parameters, take ``signal_freq`` from ``<modality>_sf``, run the
+    configured steps, write the data and the new sampling rate back (reference :8-36)."""
+    for modality, cfg in modalities_cfg.items():
+        mod_type = cfg.get("type")
+        mod_fig_dir = os.path.join(figure_dir, modality) if figure_dir else None
+        if mod_fig_dir:
+            os.makedirs(mod_fig_dir, exist_ok=True)
+        if mod_type is None:
+            raise KeyError(f"Modality '{modality}' missing 'type' field in config")
+        steps = cfg.get("preprocessing", {}).get("steps", [])
+        if not steps:
+            continue
+        params = deepcopy(base_params)
+        if mod_type != "signal":
+            raise ValueError(f"Modality '{modality}': unsupported type '{mod_type}' (only 'signal' is preprocessed)")
+        params.signal_freq = data_dict.get(f"{modality}_sf")
+        processed, freq = preprocess_signal(data_dict[modality], steps, params, figure_dir=mod_fig_dir,
+                                            resident=resident)
+        if freq is not None:
+            data_dict[f"{modality}_sf"] = freq
+        data_dict[modality] = processed
+    return data_dict
+
+
+def _plot_step(before, before_freq, after, after_freq, figure_dir, index, module_name, num_channels, duration) -> None:
+    """First ``duration`` seconds of the first channels before / after a step (reference :74-137 draws the
+    same comparison; plotting is outside the hot path and only runs when a figure directory is given)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    to_np = lambda a: a if isinstance(a, np.ndarray) else a.detach().cpu().numpy()
+    before, after = to_np(before), to_np(after)
+    n = min(num_channels, before.shape[0], after.shape[0])
+    fig, axes = plt.subplots(n, 2, figsize=(10, 2 * n), squeeze=False)
+    for c in range(n):
+        for ax, arr, fs, title in ((axes[c][0], before, before_freq, "before"), (axes[c][1], after, after_freq, "after")):
+            m = max(1, min(arr.shape[1], int(duration * fs)))
+            ax.plot(np.arange(m) / fs, arr[c, :m], linewidth=0.6)
+            if c == 0:
+                ax.set_title(f"{title} ({fs} Hz)")
+    fig.tight_layout()
+    fig.savefig(os.path.join(figure_dir, f"step_{index}_{module_name.rsplit('.', 1)[-1]}.png"), dpi=100)
+    plt.close(fig)

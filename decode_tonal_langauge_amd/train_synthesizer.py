@@ -27,6 +27,7 @@ import pandas as pd
 import torch
 from torch.utils.data import TensorDataset
 
+from . import parallel
 from .data_loading.dataloaders import split_dataset
 from .data_loading.utils import select_non_discriminative_channels
 from .models.deep_classifiers import CNNClassifier, CNNRNNClassifier
@@ -97,16 +98,24 @@ def train(params: Namespace) -> dict:
     """Body of the reference script (:137-400) on the MI355X trainer.  Returns the result row."""
     if not os.path.exists(params.sample_path):
         raise FileNotFoundError(f"Data file '{params.sample_path}' does not exist.")
+    # data parallel: one process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE).  The process group
+    # is created before any GPU call; rank r trains on cuda:LOCAL_RANK, every rank sees the same loaders
+    # (same seeds) and takes its row shard of each batch inside SynthesisTrainer; only rank 0 writes files.
+    rank, world, local = parallel.init_from_env()
+    if world > 1:
+        params.device = f"cuda:{local}"
     if 'cuda' in params.device and not torch.cuda.is_available():
         raise RuntimeError("CUDA is not available. Please use 'cpu' as device.")
+    chief = rank == 0
+    say = print if chief else (lambda *a, **k: None)
     for d in (params.figure_dir, params.audio_dir, os.path.dirname(params.result_file)):
-        if d and not os.path.exists(d):
+        if chief and d and not os.path.exists(d):
             os.makedirs(d)
     with open(params.channel_file, 'r') as f:
         channel_selections = json.load(f)
     non_disc = select_non_discriminative_channels(channel_selections,
                                                   ['tone_discriminative', 'syllable_discriminative'])
-    print('Found {} non-discriminative channels.'.format(len(non_disc)))
+    say('Found {} non-discriminative channels.'.format(len(non_disc)))
     with open(params.config_file, 'r') as f:
         config = json.load(f)
     mel_kwargs = config['mel_kwargs']
@@ -119,7 +128,7 @@ def train(params: Namespace) -> dict:
     ecog_syl = ecog[:, channel_selections['syllable_discriminative'], :]
     ecog_tone = ecog[:, channel_selections['tone_discriminative'], :]
     mels = _mels_from_dataset(dataset, params, mel_kwargs)
-    print('Number of Mel spectrogram coefficients', mels.shape[1:])
+    say('Number of Mel spectrogram coefficients', mels.shape[1:])
     mels_dim = mels.shape[1]
     seq_length = ecog.shape[2]
 
@@ -136,7 +145,7 @@ def train(params: Namespace) -> dict:
 
     n_samples, n_channels, n_timepoints = ecog_non.shape
     if params.verbose > 0:
-        print(f"Prepared {n_samples} ECoG samples with shape {ecog.shape[1:]}")
+        say(f"Prepared {n_samples} ECoG samples with shape {ecog.shape[1:]}")
     tds = TensorDataset(torch.tensor(ecog_non, dtype=torch.float32), torch.tensor(ecog_syl, dtype=torch.float32),
                         torch.tensor(ecog_tone, dtype=torch.float32), torch.tensor(mels, dtype=torch.float32))
 
@@ -157,15 +166,15 @@ def train(params: Namespace) -> dict:
                              f"Supported models: {synthesis_models}.")
         trainer = SynthesisTrainer(synthesize_model=model, syllable_model=syllable_model, tone_model=tone_model,
                                    device=params.device, tone_dynamic_mapping=tone_dynamic_mapping,
-                                   learning_rate=params.lr, verbose=params.verbose > 0 and i == 0,
+                                   learning_rate=params.lr, verbose=chief and params.verbose > 0 and i == 0,
                                    train_classifiers=train_classifiers)
         if params.verbose > 0:
-            print(f"Training synthesizer with seed {seed}...")
-        history = trainer.train(loaders[0], params.epochs, verbose=params.verbose > 1)
+            say(f"Training synthesizer with seed {seed}...")
+        history = trainer.train(loaders[0], params.epochs, verbose=chief and params.verbose > 1)
         mcd, recon_mels, origin_mels = trainer.evaluate(loaders[1])
         mcds.append(mcd)
         if params.verbose > 0:
-            print(f"Finished trial {i+1} / {params.repeat}. MCD: {mcd:.4f} dB")
+            say(f"Finished trial {i+1} / {params.repeat}. MCD: {mcd:.4f} dB")
         losses.append([loss for loss, _ in history])
 
     mean_mcd, std_mcd = float(np.mean(mcds)), float(np.std(mcds))
@@ -178,7 +187,10 @@ def train(params: Namespace) -> dict:
         'batch_size': params.batch_size, 'epochs': params.epochs, 'learning_rate': params.lr,
         'mcd_mean': mean_mcd, 'mcd_std': std_mcd, 'all_mcds': str(mcds),
     }
-    df = pd.DataFrame([results])
+    results['losses'] = losses
+    if not chief:
+        return results
+    df = pd.DataFrame([{k: v for k, v in results.items() if k != 'losses'}])
     if os.path.exists(params.result_file):
         df.to_csv(params.result_file, mode='a', header=False, index=False)
     else:
@@ -192,7 +204,6 @@ def train(params: Namespace) -> dict:
         print("Saved training losses figure to ", path)
     if params.audio_dir:
         np.savez(os.path.join(params.audio_dir, 'mels.npz'), origin=origin_mels[:10], recon=recon_mels[:10])
-    results['losses'] = losses
     return results
 
 

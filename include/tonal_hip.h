@@ -162,14 +162,17 @@ int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih, float* db
 
 /* ---- concat / dropout glue (models/synthesis_models.py:107,160-170) ----------------------- */
 /* Xc[row][0:Cc] = O5[row][0:Cc] * keep(row,ch); Xc[row][Cc+lc] = h[uid[b]][lc*lat*C + t*C + c];
- * remaining pad columns = 0.  keep = 1 if p_drop == 0 else Bernoulli via counter hash.      */
+ * remaining pad columns = 0.  keep = 1 if p_drop == 0 else Bernoulli via a counter hash of
+ * (seed, (drop_row0 + row)*Cc + ch): drop_row0 = first row of this rank's shard in the GLOBAL
+ * batch (b0*C*Tp), so a data-parallel run draws the masks of the single-process run.        */
 int tl_concat_pack(const float* O5, const float* h, const int32_t* uid, float* Xc,
                    int B, int C, int Tp, int lat, int Cc, int Lc, int ld5, int ldh, int ldx,
-                   float p_drop, uint64_t seed, void* stream);
+                   float p_drop, uint64_t seed, int64_t drop_row0, void* stream);
 /* backward: G5[row][ch] = dXc[row][ch]*keep*lrelu'(O5); dh[u][..] = sum_{b in u} dXc[..][Cc+lc] */
 int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int32_t* members, const int32_t* offsets,
                          float* G5, float* dh, int B, int U, int C, int Tp, int lat, int Cc, int Lc,
-                         int ld5, int ldh, int ldx, float slope, float p_drop, uint64_t seed, void* stream);
+                         int ld5, int ldh, int ldx, float slope, float p_drop, uint64_t seed, int64_t drop_row0,
+                         void* stream);
 
 /* ---- loss / metric (models/synthesis_trainer.py:14-43,140,222-229) ------------------------ */
 /* targets are truncated toward zero when trunc_targets != 0 (the reference's .long()).

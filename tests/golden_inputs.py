@@ -87,3 +87,18 @@ def c1_subject(N: int = 400, C: int = 16, T: int = 100, seed: int = 2024):
     ecog[syllable == 1] += np.linspace(-0.4, 0.4, T, dtype=np.float32)
     return {"ecog": ecog, "ecog_sf": np.array(100), "tone": tone, "syllable": syllable,
             "ecog_rest": rng.standard_normal((N, C, T)).astype(np.float32)}
+
+
+#: golden G13: the step list handed to the reference's preprocess_signal (module names as in the reference tree)
+CHAIN_STEPS = [
+    {"module": "preprocess.signal.downsample", "params": {"downsample_freq": 400}},
+    {"module": "preprocess.signal.car_rereference", "params": {"exclude_channels": [2]}},
+    {"module": "preprocess.signal.frequency_filter", "params": {"bands": [
+        {"method": "hilbert", "params": {"freq_ranges": [70., 150.], "envelope": True}},
+        {"method": "butter", "params": {"freqs": [0.3, 100], "filter_type": "bandpass"}}]}},
+    {"module": "preprocess.signal.channel_zscore", "params": {}},
+]
+
+
+def chain_input():
+    return np.random.default_rng(11).standard_normal((6, 3000)) * 2.0 + 0.3

@@ -194,3 +194,74 @@ def test_deep_classifier_mirrors_shapes_and_errors():
         CNNRNNClassifier(input_channels=3, input_length=100, n_classes=4, lstm_dim=250)
     with pytest.raises(ValueError, match="Expected 3 channels"):
         r(torch.randn(2, 4, 100))
+
+
+def test_preprocess_dispatcher_host_logic():
+    """preprocess_signal's contract (reference preprocess/preprocessor.py:39-70) with CPU stand-in steps:
+    lookup by module name, one shared Namespace, steps may mutate it, duplicate keys are refused."""
+    import sys
+    import types
+    from argparse import Namespace
+    import numpy as np
+    from decode_tonal_langauge_amd.preprocess import preprocessor as pp
+    halve = types.ModuleType("fake_steps_halve")
+
+    def run_halve(data, params):
+        params.signal_freq = params.signal_freq // params.factor
+        return data[:, ::params.factor]
+    halve.run = run_halve
+    scale = types.ModuleType("fake_steps_scale")
+    scale.run = lambda data, params: data * params.gain * params.signal_freq        # reads the mutated rate
+    sys.modules["fake_steps_halve"], sys.modules["fake_steps_scale"] = halve, scale
+    try:
+        x = np.arange(24, dtype=np.float64).reshape(2, 12)
+        prm = Namespace(signal_freq=1000)
+        steps = [{"module": "fake_steps_halve", "params": {"factor": 2}}, {"module": "fake_steps_scale", "params": {"gain": 3.0}}]
+        out, freq = pp.preprocess_signal(x, steps, prm)
+        assert freq == 500 and np.array_equal(out, x[:, ::2] * 3.0 * 500)
+        assert prm.factor == 2 and prm.gain == 3.0
+        with pytest.raises(ValueError, match="'factor' already exists"):
+            pp.preprocess_signal(x, steps + [{"module": "fake_steps_halve", "params": {"factor": 2}}], Namespace(signal_freq=1000))
+        dd = pp.preprocess_modalities({"ecog": x, "ecog_sf": 1000, "audio": x, "audio_sf": 8},
+                                      {"ecog": {"type": "signal", "preprocessing": {"steps": steps}},
+                                       "audio": {"type": "signal"}}, Namespace())
+        assert dd["ecog_sf"] == 500 and dd["audio_sf"] == 8 and dd["ecog"].shape == (2, 6)
+    finally:
+        del sys.modules["fake_steps_halve"], sys.modules["fake_steps_scale"]
+    # the reference tree's module names (and the sample YAML's stale ones) resolve to this package
+    for name in ("preprocess.signal.frequency_filter", "preprocess.downsample", "channel_zscore"):
+        mod = pp.resolve_step_module(name)
+        assert mod.__name__.startswith("decode_tonal_langauge_amd.preprocess.signal.") and hasattr(mod, "run")
+
+
+def test_trainer_row_shards_cover_ragged_batches():
+    """SynthesisTrainer._shard: weights sum to 1 and rows partition the batch for every (rows, ranks),
+    including batches with fewer rows than ranks (spare ranks recompute a row with weight 0)."""
+    import torch
+    from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
+    for world in (2, 3, 8):
+        for n in (1, 2, 5, 7, 8, 9, 16, 17):
+            seen, wsum = [], 0.0
+            for rank in range(world):
+                tr = SynthesisTrainer.__new__(SynthesisTrainer)
+                tr.rank, tr.world = rank, world
+                (rows,) = tr._shard(torch.arange(n))
+                assert rows.numel() >= 1                      # nobody sits out a collective
+                wsum += tr._weight
+                if tr._weight > 0:
+                    assert abs(tr._weight - rows.numel() / n) < 1e-12 and int(rows[0]) == tr._row0
+                    seen += rows.tolist()
+            assert sorted(seen) == list(range(n)) and abs(wsum - 1.0) < 1e-12, (world, n)
+
+
+def test_bench_launcher_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` without WORLD_SIZE starts the ranks itself; on a box without N GPUs it
+    must fail loudly (non-zero) instead of timing one GPU."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2))], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr

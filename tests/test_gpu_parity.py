@@ -112,8 +112,9 @@ def test_cnn_train_steps_match_reference_golden(dev):
         # NAdam divides by sqrt(v): after 3 steps the update of a bias whose gradient is tiny carries the
         # rounding noise of any independent fp32 summation order at the 2-3e-3 level (direct MFMA form
         # 1.8e-3 / 3.2e-3, F(2,3) 1.8e-3 / 3.2e-3, F(4,3) 2.5e-3 / 1.0e-3 on concat_conv_block.4.bias /
-        # ecog_conv_block.9.bias; scripts/update_parity.py) - bound at 2x that floor
-        tol = 5e-2 if k.startswith("ecog_conv_block") else 5e-3
+        # ecog_conv_block.9.bias; scripts/update_parity.py).  Only those two bias vectors get the wide
+        # bound; every other tensor of the block is held to 5e-3
+        tol = 5e-2 if k in ("ecog_conv_block.9.bias", "concat_conv_block.4.bias") else 5e-3
         if "final." + k in g:
             assert gi.update_rel_l2(fin, g["final." + k], init[k]) < tol, k
         else:

@@ -1,0 +1,171 @@
+"""GPU tests of the callers either side of the kernels:
+
+* golden G12: the deep classifiers' HIP inference path against the REFERENCE's eval forward
+  (models/deep_classifiers.py:17-155, 158-343) for seeded weights - not against this package's own graph;
+* golden G13: the step dispatcher (reference preprocess/preprocessor.py:39-70) over four steps on one
+  shared, mutated Namespace;
+* BASELINE config C5 assembled end to end at reduced width / batch: raw ECoG -> Hilbert high-gamma ->
+  400-sample epochs -> CNNClassifier / CNNRNNClassifier labels -> SynthesisModelCNN train step, against
+  the CPU oracle chain on the same inputs.
+"""
+import os
+from argparse import Namespace
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_inputs as gi
+from tests.test_gpu_parity import rel, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PKG = "decode_tonal_langauge_amd"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch.device("cuda:0")
+
+
+def test_deep_classifiers_hip_forward_matches_reference_golden(dev):
+    from decode_tonal_langauge_amd.models import CNNClassifier, CNNRNNClassifier
+    g = np.load(os.path.join(GOLD, "g12_deep_classifiers.npz"))
+    for i in range(2):
+        Cn, T, ncls, B, seed = (int(v) for v in g[f"cnn{i}.cfg"])
+        torch.manual_seed(seed)
+        clf = CNNClassifier(input_channels=Cn, input_length=T, n_classes=ncls).eval()
+        x = torch.randn(B, Cn, T)
+        assert list(clf.state_dict().keys()) == list(g[f"cnn{i}.keys"])
+        assert clf.get_nparams() == int(g[f"cnn{i}.nparams"]) and clf.latent_length == int(g[f"cnn{i}.latent"])
+        clf.to(dev)
+        with torch.no_grad():
+            out = clf(x.to(dev))
+        assert clf._hip is not None, "HIP path was not taken"
+        assert out.shape == g[f"cnn{i}.out"].shape
+        assert float(np.abs(out.cpu().numpy() - g[f"cnn{i}.out"]).max()) < 2e-5
+        # feature map of the conv trunk (reference layout (B, 256, t, C)) from the engine buffer
+        eng = clf._hip
+        last = eng.stages[-1]
+        feat = eng.P[last.idx].view(B, Cn, eng.tp_last, eng.ld_last)[:, :, :eng.lat, :eng.c_last].permute(0, 3, 2, 1)
+        assert rel(feat.cpu().numpy(), g[f"cnn{i}.feat"]) < 1e-4
+    for i in range(2):
+        Cn, T, ncls, B, ld, seed = (int(v) for v in g[f"cnnrnn{i}.cfg"])
+        torch.manual_seed(seed)
+        clf = CNNRNNClassifier(input_channels=Cn, input_length=T, n_classes=ncls, lstm_dim=ld).eval()
+        x = torch.randn(B, Cn, T)
+        assert list(clf.state_dict().keys()) == list(g[f"cnnrnn{i}.keys"])
+        assert clf.get_nparams() == int(g[f"cnnrnn{i}.nparams"])
+        clf.to(dev)
+        with torch.no_grad():
+            out = clf(x.to(dev))
+        assert clf._hip is not None, "HIP path was not taken"
+        assert float(np.abs(out.cpu().numpy() - g[f"cnnrnn{i}.out"]).max()) < 5e-5
+        h1 = getattr(clf._hip, "last_h1", None)
+        if h1 is not None:                                    # first LSTM's final state from the HIP kernel
+            assert rel(h1.cpu().numpy(), g[f"cnnrnn{i}.h1"]) < 1e-4
+
+
+def _chain_steps():
+    return deepcopy(gi.CHAIN_STEPS)
+
+
+def test_preprocess_dispatch_chain_matches_reference_golden(dev):
+    """downsample -> car_rereference -> frequency_filter -> channel_zscore, looked up by module name and
+    run on ONE shared Namespace exactly like the reference's preprocess_signal."""
+    from decode_tonal_langauge_amd.preprocess import preprocessor
+    g = np.load(os.path.join(GOLD, "g13_preprocess_chain.npz"))
+    x = gi.chain_input()
+    assert abs(gi.checksum(x) - float(g["in_checksum"])) < 1e-9 * float(g["in_checksum"])
+    # (a) the reference's module names resolve to this package's kernels
+    prm = Namespace(signal_freq=1000)
+    out, freq = preprocessor.preprocess_signal(x.copy(), _chain_steps(), prm)
+    assert freq == 400 and prm.signal_freq == 400 and isinstance(out, np.ndarray)
+    assert out.shape == g["out"].shape == (12, 1200)
+    assert rel(out, g["out"]) < 1e-8                          # butter band of the chain: 1e-9 on its own, z-scored after
+    # every step's keys were merged onto the shared Namespace
+    assert prm.downsample_freq == 400 and prm.exclude_channels == [2] and len(prm.bands) == 2
+    # (b) fully qualified module names + device-resident chain (one upload, one download)
+    steps = _chain_steps()
+    for s in steps:
+        s["module"] = f"{PKG}." + s["module"]
+    out2, _ = preprocessor.preprocess_signal(x.copy(), steps, Namespace(signal_freq=1000), resident=True)
+    assert np.array_equal(out2, out)
+    # (c) a CUDA tensor in gives a CUDA tensor out
+    out3, _ = preprocessor.preprocess_signal(torch.from_numpy(x).to(dev), _chain_steps(), Namespace(signal_freq=1000))
+    assert isinstance(out3, torch.Tensor) and out3.is_cuda and np.array_equal(out3.cpu().numpy(), out)
+    # (d) a step parameter that is already on the Namespace is refused (reference :46-52)
+    with pytest.raises(ValueError, match="already exists"):
+        preprocessor.preprocess_signal(x.copy(), _chain_steps(), Namespace(signal_freq=1000, downsample_freq=200))
+    dup = _chain_steps() + [{"module": "preprocess.signal.car_rereference", "params": {"exclude_channels": []}}]
+    with pytest.raises(ValueError, match="exclude_channels"):
+        preprocessor.preprocess_signal(x.copy(), dup, Namespace(signal_freq=1000))
+    # (e) preprocess_modalities: sampling rate taken from / written back to <modality>_sf
+    dd = {"ecog": x.copy(), "ecog_sf": 1000}
+    cfg = {"ecog": {"type": "signal", "preprocessing": {"steps": _chain_steps()}}}
+    dd = preprocessor.preprocess_modalities(dd, cfg, Namespace())
+    assert dd["ecog_sf"] == 400 and np.array_equal(dd["ecog"], out)
+    with pytest.raises(KeyError, match="type"):
+        preprocessor.preprocess_modalities({"a": x, "a_sf": 1}, {"a": {}}, Namespace())
+
+
+def test_c5_end_to_end_against_oracle_chain(dev):
+    """Config C5 at reduced width and batch: 64-channel raw ECoG (N(0,1), 400 Hz) -> frequency_filter.run
+    (Hilbert 70-150 Hz envelope) -> 400-sample epochs -> 32 channels to the synthesiser, 16 + 16 to the
+    CNN (syllable) / CNN-RNN (tone) classifiers -> one SynthesisTrainer step.  The CPU side is the oracle
+    chain: signal oracle, the classifier modules' own CPU graph (bit-identical to the reference, golden
+    G12), prepare_tone_dynamics, synthesis oracle."""
+    from decode_tonal_langauge_amd.models import CNNClassifier, CNNRNNClassifier, SynthesisModelCNN, SynthesisTrainer
+    from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
+    from oracle import signal_oracle as sg
+    from oracle import synthesis_oracle as so
+    Craw, T, NB = 64, 400, 6
+    raw = np.random.default_rng(21).standard_normal((Craw, T * NB)).astype(np.float32)
+    bands = [{"method": "hilbert", "params": {"freq_ranges": [70., 150.], "envelope": True}}]
+    hg = ff.run(torch.from_numpy(raw).to(dev), Namespace(signal_freq=400, bands=bands))        # (64, 2400) on device
+    hg_ref = sg.run(raw, Namespace(signal_freq=400, bands=bands))
+    assert hg.shape == (Craw, T * NB) and rel(hg.cpu().numpy(), hg_ref) < 1e-5                # float32 input
+    # epochs (B, C, T); z-score per channel so the classifiers see O(1) inputs
+    hgz = (hg - hg.mean(dim=1, keepdim=True)) / hg.std(dim=1, keepdim=True)
+    ep = hgz.view(Craw, NB, T).permute(1, 0, 2).float().contiguous()
+    e_non, e_syl, e_tone = ep[:, :32].contiguous(), ep[:, 32:48].contiguous(), ep[:, 48:].contiguous()
+    tgt = 10 * torch.randn(NB, 80, generator=torch.Generator().manual_seed(4))
+    torch.manual_seed(9)
+    syl = CNNClassifier(input_channels=16, input_length=T, n_classes=2)
+    tone = CNNRNNClassifier(input_channels=16, input_length=T, n_classes=4, lstm_dim=800)
+    model = SynthesisModelCNN(80, 32, T, dropout=0.0)
+    params = {k: v.detach().clone() for k, v in model.named_parameters()}
+    # ---- CPU oracle chain on the same epochs ----
+    with torch.no_grad():
+        p_tone = tone.eval()(e_tone.cpu())
+        p_syl = syl.eval()(e_syl.cpu())
+    # argmax is only comparable where the CPU scores are not tied to rounding
+    top2 = lambda p: torch.topk(p, 2, dim=1).values
+    margin = min(float((top2(p_tone)[:, 0] - top2(p_tone)[:, 1]).min()), float((top2(p_syl)[:, 0] - top2(p_syl)[:, 1]).min()))
+    lab_ref = torch.tensor(so.prepare_tone_dynamics(gi.TONE_MAP, p_tone.argmax(1).numpy(), p_syl.argmax(1).numpy()),
+                           dtype=torch.float32)
+    st = so.NAdamState(params)
+    loss_ref, mcd_ref, g_ref, _o = so.train_step("cnn", params, None, st, e_non.cpu(), lab_ref, tgt, return_grads=True)
+    # ---- the MI355X trainer ----
+    tr = SynthesisTrainer(model, tone, syl, gi.TONE_MAP, device=dev, verbose=False)
+    with torch.no_grad():
+        s_tone, s_syl = tr.tone_model(e_tone), tr.syllable_model(e_syl)
+    assert tone._hip is not None and syl._hip is not None, "classifier HIP paths were not taken"
+    assert float((s_tone.cpu() - p_tone).abs().max()) < 1e-4 and float((s_syl.cpu() - p_syl).abs().max()) < 1e-4
+    lab = tr._labels(e_tone, e_syl)
+    if margin > 1e-3:
+        assert torch.equal(lab.cpu(), lab_ref)
+    model.train()
+    tr._stats.zero_()
+    tr.train_step(e_non, e_syl, e_tone, tgt)
+    stats = tr._stats.cpu().numpy()
+    if margin > 1e-3:
+        assert abs(stats[2] - loss_ref) < 1e-4 * abs(loss_ref)
+        assert abs(stats[3] - mcd_ref) < 1e-4 * abs(mcd_ref)
+        for k, gr in tr._grads.items():
+            assert rel_l2(gr.cpu().numpy(), g_ref[k].numpy()) < 5e-3, k
+    else:                                                     # tie within rounding: labels may legitimately differ
+        assert np.isfinite(stats).all()

@@ -182,3 +182,76 @@ def test_g7_other_signal_steps():
     assert fs == 400 and rel(ds, g["downsample"]) < 1e-12
     assert rel(sg.downsample(x.astype(np.float32), 1000)[0], g["downsample_f32"]) < 1e-5
     assert rel(sg.downsample(x[:, :601], 300, 400)[0], g["downsample_up"]) < 1e-12
+
+
+def _g_sample(g, full):
+    if full in g.files:
+        return g[full], None
+    key = next(k for k in g.files if k.startswith(full + "@s") and not k.endswith("@sum"))
+    return g[key], int(key.rsplit("@s", 1)[1])
+
+
+def test_g11_c3_shape_conv_stack():
+    """Golden G11 (reference train step at the north-star shape, B = 2): the oracle's ECoG conv stack on
+    the same input.  The five conv layers are the first modules the constructor draws, so seeding and
+    building only them reproduces the golden's conv weights without the 5.4 GB LSTM."""
+    g = np.load(os.path.join(GOLD, "g11_c3_step.npz"))
+    D, C, T, B = (int(v) for v in g["dims"])
+    xs, _t, _s, labs, tg = gi.train_batches(1, B, C, T, seed=int(g["data_seed"]))
+    assert abs(gi.checksum(xs[0], labs[0], tg[0]) - float(g["in_checksum"])) < 1e-6 * float(g["in_checksum"])
+    torch.manual_seed(0)
+    p = {}
+    cin = 1
+    for idx, (cout, k, _pool) in zip((0, 3, 6, 9, 12), so.ECOG_STAGES):
+        conv = torch.nn.Conv2d(cin, cout or 64, kernel_size=(k, 1))
+        p[f"ecog_conv_block.{idx}.weight"], p[f"ecog_conv_block.{idx}.bias"] = conv.weight.detach(), conv.bias.detach()
+        cin = cout or 64
+    x = xs[0].unsqueeze(1).permute(0, 1, 3, 2)
+    with torch.no_grad():
+        for si, (idx, (_c, _k, pool)) in enumerate(zip((0, 3, 6, 9, 12), so.ECOG_STAGES)):
+            x = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(
+                x, p[f"ecog_conv_block.{idx}.weight"], p[f"ecog_conv_block.{idx}.bias"]), 0.01)
+            if pool:
+                x = torch.nn.functional.max_pool2d(x, (2, 1), (2, 1))
+            ref, stride = _g_sample(g, f"act.ecog{si + 1}")
+            got = x.reshape(-1)[::stride].numpy() if stride else x.numpy()
+            assert rel(got, ref.reshape(got.shape)) < 1e-5, si
+    assert x.shape == (B, 64, 24, C)
+    # keys of the golden cover every parameter's gradient and final value
+    names = list(so.cnn_param_shapes(D, C, T))
+    for n in names:
+        assert any(k.startswith("grad." + n) for k in g.files) and any(k.startswith("final." + n) for k in g.files), n
+
+
+def test_g12_deep_classifier_mirrors_cpu_graph():
+    """The mirror modules' own (CPU, stock torch) graph against the reference's outputs: same seeds,
+    same state_dict keys, same numbers - this is what makes them usable as the C5 oracle."""
+    from decode_tonal_langauge_amd.models.deep_classifiers import CNNClassifier, CNNRNNClassifier
+    g = np.load(os.path.join(GOLD, "g12_deep_classifiers.npz"))
+    for i in range(2):
+        C, T, ncls, B, seed = (int(v) for v in g[f"cnn{i}.cfg"])
+        torch.manual_seed(seed)
+        net = CNNClassifier(input_channels=C, input_length=T, n_classes=ncls).eval()
+        x = torch.randn(B, C, T)
+        with torch.no_grad():
+            assert rel(net(x), g[f"cnn{i}.out"]) < 1e-6
+        assert list(net.state_dict().keys()) == list(g[f"cnn{i}.keys"])
+    for i in range(2):
+        C, T, ncls, B, ld, seed = (int(v) for v in g[f"cnnrnn{i}.cfg"])
+        torch.manual_seed(seed)
+        net = CNNRNNClassifier(input_channels=C, input_length=T, n_classes=ncls, lstm_dim=ld).eval()
+        x = torch.randn(B, C, T)
+        with torch.no_grad():
+            assert rel(net(x), g[f"cnnrnn{i}.out"]) < 1e-6
+        assert list(net.state_dict().keys()) == list(g[f"cnnrnn{i}.keys"])
+
+
+def test_g13_preprocess_chain_oracle():
+    g = np.load(os.path.join(GOLD, "g13_preprocess_chain.npz"))
+    x = gi.chain_input()
+    assert abs(gi.checksum(x) - float(g["in_checksum"])) < 1e-9 * float(g["in_checksum"])
+    d, f = sg.downsample(x, 1000, 400)
+    d = sg.car_rereference(d, [2])
+    d = sg.run(d, Namespace(signal_freq=f, bands=gi.CHAIN_STEPS[2]["params"]["bands"]))
+    d = sg.channel_zscore(d)
+    assert f == int(g["freq"]) and rel(d, g["out"]) < 1e-10
