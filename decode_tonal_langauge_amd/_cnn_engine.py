@@ -100,6 +100,9 @@ class CnnEngine:
         mode = os.environ.get("TONAL_WINO", "4")
         self.wino = mode != "0"
         self.wino43 = mode == "4"
+        # weight gradient: F(4,3) with the transforms applied at LDS-staging time (tonal_wino43_tn.hip; half
+        # the direct-form MFMA work) under TONAL_WINO=4 unless TONAL_WINO_TN=2 asks for the F(2,3) kernel
+        self.wino43_tn = self.wino43 and os.environ.get("TONAL_WINO_TN", "4") == "4"
         # fold the first stage's weight gradient into the stage-2 input-gradient epilogue (Winograd kernels)
         self.fuse_c1 = os.environ.get("TONAL_FUSE_C1", "1") != "0"
         self._B = None
@@ -251,8 +254,13 @@ class CnnEngine:
     def _use_wino43(self, st) -> bool:
         return self.wino43 and self._use_wino(st) and st.tp_in % 4 == 0
 
+    def _use_wino43_tn(self, st) -> bool:
+        return self.wino43_tn and self._use_wino43(st)
+
     def wgrad_issue_factor(self, st) -> float:
         """MFMA FLOPs the weight-gradient kernel of a stage issues per direct-convolution FLOP."""
+        if self._use_wino43_tn(st):
+            return 0.5
         return 2.0 / 3.0 if self._use_wino(st) else 1.0
 
     def kernel_families(self):
@@ -265,15 +273,16 @@ class CnnEngine:
             return fams, {k: 1.0 for k in fams}
         nt, form = ("wino43_nt_kernel", "F(4,3)") if self.wino43 else ("wino_nt_kernel", "F(2,3)")
         fused = self.fuse_c1 and self._c1_fusable()
-        fams = {f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {form})": ["conv2_fwd", "conv3_fwd"],
-                "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))": ["conv2_wgrad", "conv3_wgrad"]}
+        tn = "wino43_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3))" if self.wino43_tn else \
+            "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))"
+        fams = {f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {form})": ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}
         if fused:       # the stage-2 launch carries the fused conv1 weight-gradient epilogue: its own kernel name
             fams[f"{nt}<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd {form})"] = ["conv2_dgrad"]
             fams[f"{nt}<UNPOOL,MASK> (conv3 input gradient, Winograd {form})"] = ["conv3_dgrad"]
         else:
             fams[f"{nt}<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd {form})"] = ["conv2_dgrad", "conv3_dgrad"]
         issued = {k: (0.5 if "F(4,3)" in k else 2.0 / 3.0) for k in fams}
-        return fams, issued
+        return fams, issued          # (mixed shapes: a stage the F(4,3) forms do not cover falls back per stage)
 
     def _pack_wino(self, w, forward: bool, f43: bool = False):
         """torch (O, I, 3, 1) -> the 4 (F(2,3)) or 6 (F(4,3)) Winograd taps: forward [n][O][I] or
@@ -326,6 +335,25 @@ class CnnEngine:
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
         nd = _r4(st.cout)
+        if self._use_wino43_tn(st):
+            # F(4,3): 64 x 64 tiles, 6 transform accumulators; about four rounds of the 512 resident workgroups
+            tiles = ((st.cin + 63) // 64) * ((nd + 63) // 64)
+            sk = self._splitk(tiles, (rows_in + 31) // 32, 2048)
+            slab = torch.empty(sk, 6 * st.cin, ldg, **f32)
+            self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino43_tn", A=ptr(Xin), B=ptr(Gs), slab=ptr(slab),
+                     Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=st.cin,
+                     ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk, slab_stride=6 * st.cin * ldg,
+                     loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
+            if sk > 1:
+                red = torch.empty(6 * st.cin, ldg, **f32)
+                n = 6 * st.cin * ldg
+                self._permute(slab, red, (1, 1, 1, n), (0, 0, 0, 1), nz=sk, zs=n)
+            else:
+                red = slab
+            check(self.lib.tl_wino43_wgrad_finalize(ptr(red), ptr(gw), st.cout, st.cin, ldg, self._stream()),
+                  "tl_wino43_wgrad_finalize")
+            self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
+            return
         if self._use_wino(st):
             tiles = ((st.cin + 127) // 128) * ((nd + 63) // 64)
             sk = self._splitk(tiles, (rows_in + 31) // 32, 1024)

@@ -66,6 +66,8 @@ SIGNATURES = {
     "tl_conv3_wino43_nt": (_I, [C.POINTER(NtParams), _P]),
     "tl_conv3_wino_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
+    "tl_conv3_wino43_tn": (_I, [C.POINTER(TnParams), _P]),
+    "tl_wino43_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_sizeof_nt_params": (_I, []),
     "tl_sizeof_tn_params": (_I, []),
     "tl_conv1_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),

@@ -768,7 +768,7 @@ extern "C" int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, c
   if (lds > 64 * 1024) {      // ranks 57..64 need 64.1 - 72 KB of the CU's 160 KB: raise the per-block limit once
     static thread_local int raised_on = -1;
     int devid = 0;
-    hipGetDevice(&devid);
+    (void)hipGetDevice(&devid);
     if (raised_on != devid) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nadam_lowrank_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LR_MAXK * (LR_TR + LR_TC) * 4);

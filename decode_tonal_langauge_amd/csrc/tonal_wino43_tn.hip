@@ -1,0 +1,298 @@
+// Winograd F(4,3) weight gradient of the pooled 3-tap convolutions (conv2 / conv3 of the ECoG stack,
+// models/synthesis_models.py:91-97; their dW in loss.backward(), models/synthesis_trainer.py:226) on the
+// fp32 matrix pipe of gfx950.
+//
+// By the transposition principle the weight gradient of y = A^T[(G g) . (B^T d)] is
+//     dg = G^T [ sum_quads (B^T d) (x) (A dy) ]
+// with, per quad Q (conv rows 4Q..4Q+3, input rows d0..d5 = 4Q..4Q+5),
+//     V = B^T d :  V0 = 4d0 - 5d2 + d4        V1 = -4d1 - 4d2 + d3 + d4    V2 = 4d1 - 4d2 - d3 + d4
+//                  V3 = -2d1 - d2 + 2d3 + d4  V4 = 2d1 - d2 - 2d3 + d4     V5 = 4d1 - 5d3 + d5
+//     Y = A dy  :  Y0 = dy0   Y1 = dy0+dy1+dy2+dy3   Y2 = dy0-dy1+dy2-dy3
+//                  Y3 = dy0+2dy1+4dy2+8dy3   Y4 = dy0-2dy1+4dy2-8dy3   Y5 = dy3
+// i.e. six accumulated outer products [C_in x C_out] per quad instead of the twelve of the direct form
+// (F(2,3): eight): half the MFMA work.  dy is the un-pooled dZ: of each pool pair exactly one row is the
+// pooled gradient (arg-max bit), so Y needs two loads and a handful of selects.
+//
+// Both transforms are applied ONCE, by the thread that stages the operand from global memory into LDS
+// (transform-at-staging): the LDS tiles hold V and Y, and the MFMA loop is a pure GEMM loop - one
+// ds_read_b32 per operand, no VALU between the MFMAs.  (The F(2,3) kernel transforms fragments in the
+// consumer loop, every wave redoing it; for F(4,3) that costs 3.7 VALU ops per MFMA.)
+//
+// Workgroup: 4 waves as 2 (C_in) x 2 (C_out), tile 64 x 64, wave tile 32 x 32 x 6 transforms = 96
+// accumulator registers; 48 KB LDS -> two or three independent workgroups per CU (their barriers and
+// epilogues overlap).  A K-step is 8 quads = 32 conv rows; waves 0-1 stage V (6 row loads of 4 channels
+// -> 6 transformed float4), waves 2-3 stage Y; global loads run two K-steps ahead.  LDS layout
+// [transform][quad][64 channels]; rows of odd quads are stored with the two 32-channel halves swapped so
+// that the two lane halves of a fragment read (quad 2s / 2s + 1) hit disjoint banks without padding.
+#include "tonal_common.h"
+#include <type_traits>
+
+namespace tl {
+
+constexpr int T4_BM = 64, T4_BN = 64, T4_Q = 8;          // C_in tile, C_out tile, quads per K-step
+constexpr int T4_PLANE = T4_Q * 64;                       // floats per transform plane
+constexpr int T4_TILE = 6 * T4_PLANE;                     // floats per operand tile (12 KB)
+
+__global__ __launch_bounds__(256, 2) void wino43_tn_kernel(const tl_tn_params p) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * T4_TILE];
+  float* As = lds;                       // [2][6][8][64]  V
+  float* Bs = lds + 2 * T4_TILE;         // [2][6][8][64]  Y
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int ntm = (p.Mdim + T4_BM - 1) / T4_BM, ntn = (p.Ndim + T4_BN - 1) / T4_BN;
+  const long long tiles = (long long)ntm * ntn;
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {   // XCD-aware order: the workgroups of one reduction split (same activation / gradient rows, all
+      // C_in x C_out tiles) are resident on one XCD together, so its L2 serves the 8-fold panel re-reads
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int z = (int)(bid / tiles);
+  const int tt = (int)(bid % tiles);
+  const int m0 = (tt / ntn) * T4_BM, n0 = (tt % ntn) * T4_BN;
+
+  const long long quads_all = p.Krows >> 2;
+  const long long ksteps_all = (quads_all + T4_Q - 1) / T4_Q;
+  const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const long long nsteps = ks_end > ks_begin ? ks_end - ks_begin : 0;
+
+  // ---- staging roles: waves 0-1 stage V (activation rows), waves 2-3 stage Y (dZ).  The role is wave
+  // uniform and the whole K loop is instantiated once per role behind a scalar branch, so each copy is one
+  // straight-line block in which the scheduler interleaves that role's loads / transforms with the MFMAs
+  // (exec-masked role code inside a shared loop left the matrix pipe idle through the transform blocks;
+  // giving every thread half of both roles doubled the vector-memory instructions per MFMA, which is what
+  // bounded that version: without its global loads it ran at 91 % of the pipe, with them at 64 %). ----
+  auto body = [&](auto ROLE) {
+    constexpr bool roleA = decltype(ROLE)::value;
+    f32x16 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const int task = tid & 127;
+    const int qi = task >> 4, c4 = task & 15;                 // quad of the K-step, 4-channel group
+    const int sw = ((c4 * 4) ^ ((qi & 1) << 5));              // swizzled channel position inside the 64-wide row
+    // A: rows 4 q .. 4 q + 5 of the activation matrix, clamped into it (a clamped row only ever meets dy = 0
+    // or enters through the Winograd identity, which holds for any finite d)
+    const long long a_last = (p.A_rows < p.Krows + 2 ? p.A_rows : p.Krows + 2) - 1;
+    const int acol = m0 + ((m0 + c4 * 4) < p.Mdim ? c4 * 4 : 0);
+    // B: pooled rows 2 q, 2 q + 1 and their arg-max nibbles
+    const long long b_last = p.B_rows - 1;
+    const int ncol = n0 + c4 * 4;
+    const bool bnok = ncol < p.Ndim;
+    const int ncolc = bnok ? ncol : n0;
+    long long quad = ks_begin * T4_Q + qi;                    // quad the NEXT load fetches for this thread
+    int tq = (int)((4 * quad) % p.Tp);                        // time index of its first conv row
+    const int dstep = (4 * T4_Q) % p.Tp;
+
+    struct stage_regs {
+      f32x4 r[roleA ? 6 : 2];
+      uint32_t f;     // B role: bits 0-3 arg-max nibble of pair a, 4-7 of pair b, 8 / 9 pair valid
+    };
+    stage_regs rP, rQ;
+    rP.f = rQ.f = 0;
+
+    auto load_regs = [&](auto FAST, stage_regs& r) {
+      constexpr bool fast = decltype(FAST)::value;
+      if constexpr (roleA) {
+        const long long row0 = 4 * quad;
+        if constexpr (fast) {
+          const float* base = p.A + row0 * (long long)p.lda + acol;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) r.r[j] = *reinterpret_cast<const f32x4*>(base + (long long)j * p.lda);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            long long row = row0 + j;
+            row = row < a_last ? row : a_last;
+            r.r[j] = *reinterpret_cast<const f32x4*>(p.A + row * (long long)p.lda + acol);
+          }
+        }
+      } else {
+        long long pa = 2 * quad, pb = 2 * quad + 1;
+        bool va = bnok && tq < p.Tvalid, vb = bnok && tq + 2 < p.Tvalid;
+        if constexpr (!fast) {
+          va = va && 4 * quad < p.Krows && pa <= b_last;
+          vb = vb && 4 * quad + 2 < p.Krows && pb <= b_last;
+          pa = pa < b_last ? pa : b_last;
+          pb = pb < b_last ? pb : b_last;
+        }
+        r.r[0] = *reinterpret_cast<const f32x4*>(p.B + pa * (long long)p.ldb + ncolc);
+        r.r[1] = *reinterpret_cast<const f32x4*>(p.B + pb * (long long)p.ldb + ncolc);
+        const uint32_t na = (p.bbits[pa * (long long)p.ld_bbits + (ncolc >> 5)] >> (ncolc & 31)) & 0xFu;
+        const uint32_t nb = (p.bbits[pb * (long long)p.ld_bbits + (ncolc >> 5)] >> (ncolc & 31)) & 0xFu;
+        r.f = na | (nb << 4) | (va ? 0x100u : 0u) | (vb ? 0x200u : 0u);
+      }
+      quad += T4_Q;
+      tq += dstep;
+      if (tq >= p.Tp) tq -= p.Tp;
+    };
+
+    auto store_regs = [&](const stage_regs& r, int buf) {
+      f32x4 o[6];
+      float* dst;
+      if constexpr (roleA) {
+        const f32x4 d0 = r.r[0], d1 = r.r[1], d2 = r.r[2], d3 = r.r[3], d4 = r.r[4], d5 = r.r[5];
+        const f32x4 s1 = d4 - 4.f * d2, s2 = d3 - 4.f * d1, s3 = d4 - d2, t = d3 - d1;
+        o[0] = 4.f * d0 + (d4 - 5.f * d2);
+        o[1] = s1 + s2;
+        o[2] = s1 - s2;
+        o[3] = s3 + 2.f * t;
+        o[4] = s3 - 2.f * t;
+        o[5] = (4.f * d1 - 5.f * d3) + d5;
+        dst = As + buf * T4_TILE;
+      } else {
+        const uint32_t f = r.f;
+        const bool va = (f & 0x100u) != 0, vb = (f & 0x200u) != 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool oa = (f >> c) & 1u, ob = (f >> (4 + c)) & 1u;
+          const float a = va ? r.r[0][c] : 0.f, b = vb ? r.r[1][c] : 0.f;
+          const float sa = oa ? -a : a, sb = ob ? -b : b;          // dy0 - dy1, dy2 - dy3
+          o[0][c] = oa ? 0.f : a;
+          o[1][c] = a + b;
+          o[2][c] = sa + sb;
+          o[3][c] = (oa ? 2.f * a : a) + (ob ? 8.f * b : 4.f * b);
+          o[4][c] = (oa ? -2.f * a : a) + (ob ? -8.f * b : 4.f * b);
+          o[5][c] = ob ? b : 0.f;
+        }
+        dst = Bs + buf * T4_TILE;
+      }
+      dst += qi * 64 + sw;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(dst + i * T4_PLANE) = o[i];
+    };
+
+    // ---- MFMA side: k-slice sl of a K-step = quads 2 sl (lanes 0-31) and 2 sl + 1 (lanes 32-63) ----
+    const int a_off = lh * 64 + ((wm * 32 + lr) ^ (lh << 5));
+    const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
+    float fa0[6], fb0[6], fa1[6], fb1[6];
+    auto load_frag = [&](float (&fa)[6], float (&fb)[6], int buf, int sl) {
+      const float* a_s = As + buf * T4_TILE + sl * 128 + a_off;
+      const float* b_s = Bs + buf * T4_TILE + sl * 128 + b_off;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        fa[i] = a_s[i * T4_PLANE];
+        fb[i] = b_s[i * T4_PLANE];
+      }
+    };
+    auto mfma6 = [&](const float (&fa)[6], const float (&fb)[6]) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[i], 0, 0, 0);
+    };
+
+    // One K-step.  The tiles of step s + 2 are requested at the top, the MFMAs of slice 3 of the previous
+    // step (carried in registers across the barrier) run while the first fragments of this step arrive,
+    // the operands of step s + 1 are transformed and written to the other LDS buffer mid-step.
+    auto kstep = [&](auto TAIL, long long s, stage_regs& r_ld, const stage_regs& r_st) {
+      constexpr bool tail = decltype(TAIL)::value;
+      const int buf = (int)(s & 1);
+      load_frag(fa0, fb0, buf, 0);
+      if constexpr (!tail) load_regs(std::true_type{}, r_ld);
+      else if (s + 2 < nsteps) load_regs(std::false_type{}, r_ld);
+      // keep the global loads HERE: left alone, the scheduler sinks them two K-steps down, next to the
+      // transform that consumes them (shorter live ranges), and the prefetch becomes an exposed round trip
+      __builtin_amdgcn_sched_barrier(0);
+      mfma6(fa1, fb1);                                        // slice 3 of the previous step
+      load_frag(fa1, fb1, buf, 1);
+      mfma6(fa0, fb0);
+      load_frag(fa0, fb0, buf, 2);
+      mfma6(fa1, fb1);
+      if (!tail || s + 1 < nsteps) store_regs(r_st, buf ^ 1);
+      load_frag(fa1, fb1, buf, 3);
+      mfma6(fa0, fb0);
+      __syncthreads();
+    };
+    using Y = std::true_type;
+    using N = std::false_type;
+
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = 0.f;         // carried slice of step -1: adds nothing
+
+    if (nsteps > 0) {
+      load_regs(N{}, rP);
+      store_regs(rP, 0);
+      if (nsteps > 1) load_regs(N{}, rQ);
+    }
+    __syncthreads();
+    long long s = 0;
+    // steady state: every row a step fetches (two steps ahead) lies inside both matrices
+    const bool whole = p.A_rows >= p.Krows && 2 * p.B_rows >= p.Krows;      // (fetched rows stay >= 64 short of Krows)
+    if (whole)
+      for (; s + 5 < nsteps; s += 2) {
+        kstep(N{}, s, rP, rQ);
+        kstep(N{}, s + 1, rQ, rP);
+      }
+    for (; s < nsteps; s += 2) {
+      kstep(Y{}, s, rP, rQ);
+      if (s + 1 < nsteps) kstep(Y{}, s + 1, rQ, rP);
+    }
+    mfma6(fa1, fb1);
+
+    float* out = p.slab + (long long)z * p.slab_stride;
+    const int col = n0 + wn * 32 + lr;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m < p.Mdim && col < p.Ndim) out[((long long)i * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
+      }
+  };
+  if (__builtin_amdgcn_readfirstlane(wave) < 2) body(std::true_type{});
+  else body(std::false_type{});
+}
+
+// dW (O, I, 3) = G^T M from the reduced transforms red[6][I][ld]:
+//   G^T = [ 1/4 -1/6 -1/6 1/24  1/24 0 ;  0 -1/6 1/6 1/12 -1/12 0 ;  0 -1/6 -1/6 1/6 1/6 1 ]
+__global__ void wino43_wgrad_finalize_kernel(const float* __restrict__ red, float* __restrict__ gw, int O, int I, int ld) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)O * I) return;
+  const int i = (int)(idx / O), o = (int)(idx % O);
+  const long long plane = (long long)I * ld;
+  const float* s = red + (long long)i * ld + o;
+  const float m0 = s[0], m1 = s[plane], m2 = s[2 * plane], m3 = s[3 * plane], m4 = s[4 * plane], m5 = s[5 * plane];
+  const float a12 = m1 + m2, s12 = m2 - m1, a34 = m3 + m4, s34 = m3 - m4;
+  float* d = gw + ((long long)o * I + i) * 3;
+  d[0] = 0.25f * m0 - (1.f / 6.f) * a12 + (1.f / 24.f) * a34;
+  d[1] = (1.f / 6.f) * s12 + (1.f / 12.f) * s34;
+  d[2] = (1.f / 6.f) * (a34 - a12) + m5;
+}
+
+}  // namespace tl
+
+extern "C" int tl_conv3_wino43_tn(const tl_tn_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "wino43_tn: null params");
+  tl_tn_params p = *pp;
+  if (p.splitk < 1) p.splitk = 1;
+  TL_REQUIRE(p.A && p.B && p.slab && p.bbits, "wino43_tn: null A/B/bbits/slab");
+  TL_REQUIRE(p.J == 3 && p.loader == 1, "wino43_tn: 3 taps, UNPOOL loader only");
+  TL_REQUIRE(p.Krows > 0 && p.Krows % 4 == 0 && p.Mdim > 0 && p.Ndim > 0, "wino43_tn: bad sizes (Krows %% 4 must be 0)");
+  TL_REQUIRE(p.Krows + 64 < (1LL << 31), "wino43_tn: more than 2^31 reduction rows");
+  TL_REQUIRE(p.A_rows > 0 && p.B_rows > 0, "wino43_tn: empty operand");
+  TL_REQUIRE(p.Mdim % 4 == 0 && p.Ndim % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino43_tn: dims/ld must be multiples of 4");
+  TL_REQUIRE(p.lda >= p.Mdim && p.ldb >= p.Ndim && p.ldc >= p.Ndim, "wino43_tn: leading dimension too small");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 4 == 0 && p.Tvalid % 2 == 0, "wino43_tn: Tp %% 4 == 0 and an even Tvalid needed");
+  TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim, "wino43_tn: bbits row too short");
+  TL_REQUIRE(p.splitk <= 65535, "wino43_tn: splitk too large");
+  TL_REQUIRE(p.splitk == 1 || p.slab_stride >= 6LL * p.Mdim * p.ldc, "wino43_tn: slab_stride smaller than 6*Mdim*ldc");
+  const long long t = (long long)((p.Mdim + T4_BM - 1) / T4_BM) * ((p.Ndim + T4_BN - 1) / T4_BN);
+  TL_REQUIRE(t < (1LL << 31), "wino43_tn: grid too large");
+  hipLaunchKernelGGL(wino43_tn_kernel, dim3((unsigned)t, (unsigned)p.splitk, 1), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("wino43_tn");
+}
+
+extern "C" int tl_wino43_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(red && gw && O > 0 && I > 0 && ld >= O, "wino43_wgrad_finalize: bad arguments");
+  const long long n = (long long)O * I;
+  hipLaunchKernelGGL(wino43_wgrad_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     red, gw, O, I, ld);
+  return check_launch("wino43_wgrad_finalize");
+}

@@ -116,6 +116,9 @@ int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
  *   tl_wino_wgrad_finalize red [4][I][ld] (slabs summed by the caller) -> dW (O, I, 3, 1)
  *   tl_wino43_weights / tl_conv3_wino43_nt: the F(4,3) form of the same two NT passes (6 contractions
  *                          per 4 conv rows; taps [6][N][ldb]; M and Tp multiples of 4)
+ *   tl_conv3_wino43_tn / tl_wino43_wgrad_finalize: the F(4,3) form of the weight gradient (6 outer
+ *                          products per 4 conv rows; slab[z][6][Mdim][ldc], slab_stride >= 6*Mdim*ldc;
+ *                          Krows and Tp multiples of 4); red [6][I][ld] -> dW (O, I, 3, 1)
  * ------------------------------------------------------------------------------------------ */
 int tl_wino_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
 int tl_wino43_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
@@ -123,6 +126,8 @@ int tl_conv3_wino43_nt(const tl_nt_params* p, void* stream);
 int tl_conv3_wino_nt(const tl_nt_params* p, void* stream);
 int tl_conv3_wino_tn(const tl_tn_params* p, void* stream);
 int tl_wino_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
+int tl_conv3_wino43_tn(const tl_tn_params* p, void* stream);
+int tl_wino43_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
 int tl_sizeof_nt_params(void);
 int tl_sizeof_tn_params(void);

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--stages", default="2,3")
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--passes", default="fwd,dgrad,wgrad")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
@@ -35,6 +36,8 @@ for si in [int(s) for s in args.stages.split(",")]:
     fl = 2.0 * B * eng.C * st.tc * st.k * st.cin * st.cout
     for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("dgrad", lambda: eng.stage_dgrad(st, w)),
                      ("wgrad", lambda: eng.stage_wgrad(st, gw, gb))):
+        if name not in args.passes.split(","):
+            continue
         fn(); torch.cuda.synchronize()
         eng.enable_timers(True)
         for _ in range(args.iters):
