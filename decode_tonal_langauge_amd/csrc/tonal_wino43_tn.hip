@@ -20,8 +20,8 @@
 //
 // Workgroup: 4 waves as 2 (C_in) x 2 (C_out), tile 64 x 64, wave tile 32 x 32 x 6 transforms = 96
 // accumulator registers; 48 KB LDS -> two or three independent workgroups per CU (their barriers and
-// epilogues overlap).  A K-step is 8 quads = 32 conv rows; waves 0-1 stage V (6 row loads of 4 channels
-// -> 6 transformed float4), waves 2-3 stage Y; global loads run two K-steps ahead.  LDS layout
+// epilogues overlap).  A K-step is 8 quads = 32 conv rows; every thread stages one (quad, channel pair) of
+// V (6 row loads -> 6 transformed float2) and one of Y; global loads run two K-steps ahead.  LDS layout
 // [transform][quad][64 channels]; rows of odd quads are stored with the two 32-channel halves swapped so
 // that the two lane halves of a fragment read (quad 2s / 2s + 1) hit disjoint banks without padding.
 #include "tonal_common.h"
@@ -29,6 +29,9 @@
 
 namespace tl {
 
+#ifndef T4_PIN
+#define T4_PIN 1          // 1: scheduling fence after the global loads of a K-step (see kstep)
+#endif
 constexpr int T4_BM = 64, T4_BN = 64, T4_Q = 8;          // C_in tile, C_out tile, quads per K-step
 constexpr int T4_PLANE = T4_Q * 64;                       // floats per transform plane
 constexpr int T4_TILE = 6 * T4_PLANE;                     // floats per operand tile (12 KB)
@@ -60,192 +63,206 @@ __global__ __launch_bounds__(256, 2) void wino43_tn_kernel(const tl_tn_params p)
   if (ks_end > ksteps_all) ks_end = ksteps_all;
   const long long nsteps = ks_end > ks_begin ? ks_end - ks_begin : 0;
 
-  // ---- staging roles: waves 0-1 stage V (activation rows), waves 2-3 stage Y (dZ).  The role is wave
-  // uniform and the whole K loop is instantiated once per role behind a scalar branch, so each copy is one
-  // straight-line block in which the scheduler interleaves that role's loads / transforms with the MFMAs
-  // (exec-masked role code inside a shared loop left the matrix pipe idle through the transform blocks;
-  // giving every thread half of both roles doubled the vector-memory instructions per MFMA, which is what
-  // bounded that version: without its global loads it ran at 91 % of the pipe, with them at 64 %). ----
-  auto body = [&](auto ROLE) {
-    constexpr bool roleA = decltype(ROLE)::value;
-    f32x16 acc[6];
+  f32x16 acc[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    const int task = tid & 127;
-    const int qi = task >> 4, c4 = task & 15;                 // quad of the K-step, 4-channel group
-    const int sw = ((c4 * 4) ^ ((qi & 1) << 5));              // swizzled channel position inside the 64-wide row
-    // A: rows 4 q .. 4 q + 5 of the activation matrix, clamped into it (a clamped row only ever meets dy = 0
-    // or enters through the Winograd identity, which holds for any finite d)
-    const long long a_last = (p.A_rows < p.Krows + 2 ? p.A_rows : p.Krows + 2) - 1;
-    const int acol = m0 + ((m0 + c4 * 4) < p.Mdim ? c4 * 4 : 0);
-    // B: pooled rows 2 q, 2 q + 1 and their arg-max nibbles
-    const long long b_last = p.B_rows - 1;
-    const int ncol = n0 + c4 * 4;
-    const bool bnok = ncol < p.Ndim;
-    const int ncolc = bnok ? ncol : n0;
-    long long quad = ks_begin * T4_Q + qi;                    // quad the NEXT load fetches for this thread
-    int tq = (int)((4 * quad) % p.Tp);                        // time index of its first conv row
-    const int dstep = (4 * T4_Q) % p.Tp;
+  // ---- staging: every thread transforms one (quad, channel pair) of V and one of Y per K-step: the same
+  // branch-free instruction stream in all four waves, which the scheduler interleaves with the MFMAs.
+  // Measured alternatives at the conv2 shape (this form: 50.5 ms): roles split by wave with float4 tasks
+  // inside a shared loop (exec-masked transform blocks the matrix pipe idles through) 53.0 ms; the same
+  // split with the whole K loop instantiated per role behind a scalar branch 52.3 ms; a 128 x 128 tile
+  // with one wave per SIMD and 384 accumulators does not fit the register file (850 spilled registers). ----
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int qi = tid >> 5, c2 = tid & 31;                   // quad of the K-step, channel pair
+  const int sw = ((c2 * 2) ^ ((qi & 1) << 5));              // swizzled channel position inside the 64-wide row
+  // A: rows 4 q .. 4 q + 5 of the activation matrix, clamped into it (a clamped row only ever meets dy = 0
+  // or enters through the Winograd identity, which holds for any finite d)
+  const long long a_last = (p.A_rows < p.Krows + 2 ? p.A_rows : p.Krows + 2) - 1;
+  const int acol = m0 + ((m0 + c2 * 2) < p.Mdim ? c2 * 2 : 0);
+  // B: pooled rows 2 q, 2 q + 1 and their arg-max bits
+  const long long b_last = p.B_rows - 1;
+  const int ncol = n0 + c2 * 2;
+  const bool bnok = ncol < p.Ndim;
+  const int ncolc = bnok ? ncol : n0;
+  long long quad = ks_begin * T4_Q + qi;                    // quad the NEXT load fetches for this thread
+  int tq = (int)((4 * quad) % p.Tp);                        // time index of its first conv row
+  const int dstep = (4 * T4_Q) % p.Tp;
+  long long ld_q0 = ks_begin * T4_Q;                        // first quad of the K-step the next load fetches (uniform)
+  const unsigned a_toff = (unsigned)(qi * 4 * p.lda + (acol - m0));
+  const unsigned b_toff = (unsigned)(qi * 2 * p.ldb + (ncolc - n0));
+  const unsigned w_toff = (unsigned)(qi * 2 * p.ld_bbits + (ncolc >> 5));
 
-    struct stage_regs {
-      f32x4 r[roleA ? 6 : 2];
-      uint32_t f;     // B role: bits 0-3 arg-max nibble of pair a, 4-7 of pair b, 8 / 9 pair valid
-    };
-    stage_regs rP, rQ;
-    rP.f = rQ.f = 0;
-
-    auto load_regs = [&](auto FAST, stage_regs& r) {
-      constexpr bool fast = decltype(FAST)::value;
-      if constexpr (roleA) {
-        const long long row0 = 4 * quad;
-        if constexpr (fast) {
-          const float* base = p.A + row0 * (long long)p.lda + acol;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) r.r[j] = *reinterpret_cast<const f32x4*>(base + (long long)j * p.lda);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            long long row = row0 + j;
-            row = row < a_last ? row : a_last;
-            r.r[j] = *reinterpret_cast<const f32x4*>(p.A + row * (long long)p.lda + acol);
-          }
-        }
-      } else {
-        long long pa = 2 * quad, pb = 2 * quad + 1;
-        bool va = bnok && tq < p.Tvalid, vb = bnok && tq + 2 < p.Tvalid;
-        if constexpr (!fast) {
-          va = va && 4 * quad < p.Krows && pa <= b_last;
-          vb = vb && 4 * quad + 2 < p.Krows && pb <= b_last;
-          pa = pa < b_last ? pa : b_last;
-          pb = pb < b_last ? pb : b_last;
-        }
-        r.r[0] = *reinterpret_cast<const f32x4*>(p.B + pa * (long long)p.ldb + ncolc);
-        r.r[1] = *reinterpret_cast<const f32x4*>(p.B + pb * (long long)p.ldb + ncolc);
-        const uint32_t na = (p.bbits[pa * (long long)p.ld_bbits + (ncolc >> 5)] >> (ncolc & 31)) & 0xFu;
-        const uint32_t nb = (p.bbits[pb * (long long)p.ld_bbits + (ncolc >> 5)] >> (ncolc & 31)) & 0xFu;
-        r.f = na | (nb << 4) | (va ? 0x100u : 0u) | (vb ? 0x200u : 0u);
-      }
-      quad += T4_Q;
-      tq += dstep;
-      if (tq >= p.Tp) tq -= p.Tp;
-    };
-
-    auto store_regs = [&](const stage_regs& r, int buf) {
-      f32x4 o[6];
-      float* dst;
-      if constexpr (roleA) {
-        const f32x4 d0 = r.r[0], d1 = r.r[1], d2 = r.r[2], d3 = r.r[3], d4 = r.r[4], d5 = r.r[5];
-        const f32x4 s1 = d4 - 4.f * d2, s2 = d3 - 4.f * d1, s3 = d4 - d2, t = d3 - d1;
-        o[0] = 4.f * d0 + (d4 - 5.f * d2);
-        o[1] = s1 + s2;
-        o[2] = s1 - s2;
-        o[3] = s3 + 2.f * t;
-        o[4] = s3 - 2.f * t;
-        o[5] = (4.f * d1 - 5.f * d3) + d5;
-        dst = As + buf * T4_TILE;
-      } else {
-        const uint32_t f = r.f;
-        const bool va = (f & 0x100u) != 0, vb = (f & 0x200u) != 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const bool oa = (f >> c) & 1u, ob = (f >> (4 + c)) & 1u;
-          const float a = va ? r.r[0][c] : 0.f, b = vb ? r.r[1][c] : 0.f;
-          const float sa = oa ? -a : a, sb = ob ? -b : b;          // dy0 - dy1, dy2 - dy3
-          o[0][c] = oa ? 0.f : a;
-          o[1][c] = a + b;
-          o[2][c] = sa + sb;
-          o[3][c] = (oa ? 2.f * a : a) + (ob ? 8.f * b : 4.f * b);
-          o[4][c] = (oa ? -2.f * a : a) + (ob ? -8.f * b : 4.f * b);
-          o[5][c] = ob ? b : 0.f;
-        }
-        dst = Bs + buf * T4_TILE;
-      }
-      dst += qi * 64 + sw;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(dst + i * T4_PLANE) = o[i];
-    };
-
-    // ---- MFMA side: k-slice sl of a K-step = quads 2 sl (lanes 0-31) and 2 sl + 1 (lanes 32-63) ----
-    const int a_off = lh * 64 + ((wm * 32 + lr) ^ (lh << 5));
-    const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
-    float fa0[6], fb0[6], fa1[6], fb1[6];
-    auto load_frag = [&](float (&fa)[6], float (&fb)[6], int buf, int sl) {
-      const float* a_s = As + buf * T4_TILE + sl * 128 + a_off;
-      const float* b_s = Bs + buf * T4_TILE + sl * 128 + b_off;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        fa[i] = a_s[i * T4_PLANE];
-        fb[i] = b_s[i * T4_PLANE];
-      }
-    };
-    auto mfma6 = [&](const float (&fa)[6], const float (&fb)[6]) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[i], 0, 0, 0);
-    };
-
-    // One K-step.  The tiles of step s + 2 are requested at the top, the MFMAs of slice 3 of the previous
-    // step (carried in registers across the barrier) run while the first fragments of this step arrive,
-    // the operands of step s + 1 are transformed and written to the other LDS buffer mid-step.
-    auto kstep = [&](auto TAIL, long long s, stage_regs& r_ld, const stage_regs& r_st) {
-      constexpr bool tail = decltype(TAIL)::value;
-      const int buf = (int)(s & 1);
-      load_frag(fa0, fb0, buf, 0);
-      if constexpr (!tail) load_regs(std::true_type{}, r_ld);
-      else if (s + 2 < nsteps) load_regs(std::false_type{}, r_ld);
-      // keep the global loads HERE: left alone, the scheduler sinks them two K-steps down, next to the
-      // transform that consumes them (shorter live ranges), and the prefetch becomes an exposed round trip
-      __builtin_amdgcn_sched_barrier(0);
-      mfma6(fa1, fb1);                                        // slice 3 of the previous step
-      load_frag(fa1, fb1, buf, 1);
-      mfma6(fa0, fb0);
-      load_frag(fa0, fb0, buf, 2);
-      mfma6(fa1, fb1);
-      if (!tail || s + 1 < nsteps) store_regs(r_st, buf ^ 1);
-      load_frag(fa1, fb1, buf, 3);
-      mfma6(fa0, fb0);
-      __syncthreads();
-    };
-    using Y = std::true_type;
-    using N = std::false_type;
-
-#pragma unroll
-    for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = 0.f;         // carried slice of step -1: adds nothing
-
-    if (nsteps > 0) {
-      load_regs(N{}, rP);
-      store_regs(rP, 0);
-      if (nsteps > 1) load_regs(N{}, rQ);
-    }
-    __syncthreads();
-    long long s = 0;
-    // steady state: every row a step fetches (two steps ahead) lies inside both matrices
-    const bool whole = p.A_rows >= p.Krows && 2 * p.B_rows >= p.Krows;      // (fetched rows stay >= 64 short of Krows)
-    if (whole)
-      for (; s + 5 < nsteps; s += 2) {
-        kstep(N{}, s, rP, rQ);
-        kstep(N{}, s + 1, rQ, rP);
-      }
-    for (; s < nsteps; s += 2) {
-      kstep(Y{}, s, rP, rQ);
-      if (s + 1 < nsteps) kstep(Y{}, s + 1, rQ, rP);
-    }
-    mfma6(fa1, fb1);
-
-    float* out = p.slab + (long long)z * p.slab_stride;
-    const int col = n0 + wn * 32 + lr;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m < p.Mdim && col < p.Ndim) out[((long long)i * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
-      }
+  struct stage_regs {
+    f32x2 d[6], g[2];
+    uint32_t wa, wb;  // arg-max words of the two pooled rows (bits of this thread's channel pair at ncolc & 31)
+    uint32_t ok;      // bit 0 / 1: pair a / b holds a valid gradient
   };
-  if (__builtin_amdgcn_readfirstlane(wave) < 2) body(std::true_type{});
-  else body(std::false_type{});
+  stage_regs rP, rQ;
+
+  auto load_regs = [&](auto FAST, stage_regs& r) {
+    constexpr bool fast = decltype(FAST)::value;
+    const long long row0 = 4 * quad;
+    long long pa = 2 * quad, pb = 2 * quad + 1;
+    bool va = bnok && tq < p.Tvalid, vb = bnok && tq + 2 < p.Tvalid;
+    if constexpr (fast) {
+      // wave-uniform row base (scalar registers, advanced per step) + a per-thread 32-bit offset that is fixed
+      // for the whole kernel: no 64-bit vector address arithmetic in the loop
+      const float* au = p.A + (ld_q0 * 4) * (long long)p.lda + m0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) r.d[j] = *reinterpret_cast<const f32x2*>(au + (long long)j * p.lda + a_toff);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        long long row = row0 + j;
+        row = row < a_last ? row : a_last;
+        r.d[j] = *reinterpret_cast<const f32x2*>(p.A + row * (long long)p.lda + acol);
+      }
+      va = va && 4 * quad < p.Krows && pa <= b_last;
+      vb = vb && 4 * quad + 2 < p.Krows && pb <= b_last;
+      pa = pa < b_last ? pa : b_last;
+      pb = pb < b_last ? pb : b_last;
+    }
+    if constexpr (fast) {
+      const float* bu = p.B + (ld_q0 * 2) * (long long)p.ldb + n0;
+      const uint32_t* wu = p.bbits + (ld_q0 * 2) * (long long)p.ld_bbits;
+      r.g[0] = *reinterpret_cast<const f32x2*>(bu + b_toff);
+      r.g[1] = *reinterpret_cast<const f32x2*>(bu + p.ldb + b_toff);
+      r.wa = wu[w_toff];
+      r.wb = wu[p.ld_bbits + w_toff];
+    } else {
+      r.g[0] = *reinterpret_cast<const f32x2*>(p.B + pa * (long long)p.ldb + ncolc);
+      r.g[1] = *reinterpret_cast<const f32x2*>(p.B + pb * (long long)p.ldb + ncolc);
+      r.wa = p.bbits[pa * (long long)p.ld_bbits + (ncolc >> 5)];
+      r.wb = p.bbits[pb * (long long)p.ld_bbits + (ncolc >> 5)];
+    }
+    r.ok = (va ? 1u : 0u) | (vb ? 2u : 0u);
+    ld_q0 += T4_Q;
+    quad += T4_Q;
+    tq += dstep;
+    if (tq >= p.Tp) tq -= p.Tp;
+  };
+
+  auto store_a = [&](const stage_regs& r, int buf) {
+    const f32x2 d0 = r.d[0], d1 = r.d[1], d2 = r.d[2], d3 = r.d[3], d4 = r.d[4], d5 = r.d[5];
+    const f32x2 s1 = d4 - 4.f * d2, s2 = d3 - 4.f * d1, s3 = d4 - d2, t = d3 - d1;
+    f32x2 o[6];
+    o[0] = 4.f * d0 + (d4 - 5.f * d2);
+    o[1] = s1 + s2;
+    o[2] = s1 - s2;
+    o[3] = s3 + 2.f * t;
+    o[4] = s3 - 2.f * t;
+    o[5] = (4.f * d1 - 5.f * d3) + d5;
+    float* dst = As + buf * T4_TILE + qi * 64 + sw;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(dst + i * T4_PLANE) = o[i];
+  };
+  // Y from the two pooled gradients a, b of the quad and their arg-max bits: the un-pooled rows are
+  // dy0 = a (bit clear) | dy1 = a (bit set), dy2 / dy3 likewise from b - selected with bit masks (v_bfe_i32
+  // + v_and) instead of compare / select pairs
+  auto store_b = [&](const stage_regs& r, int buf) {
+    const int sh = ncolc & 31;
+    f32x2 o[6];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t ma = (uint32_t)__builtin_amdgcn_sbfe((int)r.wa, sh + c, 1);      // all ones if the odd row won
+      const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)r.wb, sh + c, 1);
+      const uint32_t ua = (r.ok & 1u) ? __float_as_uint(r.g[0][c]) : 0u, ub = (r.ok & 2u) ? __float_as_uint(r.g[1][c]) : 0u;
+      const float e_a = __uint_as_float(ua & ~ma), o_a = __uint_as_float(ua & ma);
+      const float e_b = __uint_as_float(ub & ~mb), o_b = __uint_as_float(ub & mb);
+      o[0][c] = e_a;
+      o[1][c] = (e_a + o_a) + (e_b + o_b);
+      o[2][c] = (e_a - o_a) + (e_b - o_b);
+      o[3][c] = fmaf(4.f, fmaf(2.f, o_b, e_b), fmaf(2.f, o_a, e_a));
+      o[4][c] = fmaf(4.f, fmaf(-2.f, o_b, e_b), fmaf(-2.f, o_a, e_a));
+      o[5][c] = o_b;
+    }
+    float* dst = Bs + buf * T4_TILE + qi * 64 + sw;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(dst + i * T4_PLANE) = o[i];
+  };
+
+  // ---- MFMA side: k-slice sl of a K-step = quads 2 sl (lanes 0-31) and 2 sl + 1 (lanes 32-63) ----
+  const int a_off = lh * 64 + ((wm * 32 + lr) ^ (lh << 5));
+  const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
+  float fa0[6], fb0[6], fa1[6], fb1[6];
+  auto load_frag = [&](float (&fa)[6], float (&fb)[6], int buf, int sl) {
+    const float* a_s = As + buf * T4_TILE + sl * 128 + a_off;
+    const float* b_s = Bs + buf * T4_TILE + sl * 128 + b_off;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      fa[i] = a_s[i * T4_PLANE];
+      fb[i] = b_s[i * T4_PLANE];
+    }
+  };
+  auto mfma6 = [&](const float (&fa)[6], const float (&fb)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[i], 0, 0, 0);
+  };
+
+  // One K-step.  The tiles of step s + 2 are requested at the top, the MFMAs of slice 3 of the previous
+  // step (carried in registers across the barrier) run while the first fragments of this step arrive,
+  // the operands of step s + 1 are transformed and written to the other LDS buffer mid-step.
+  auto kstep = [&](auto TAIL, long long s, stage_regs& r_ld, const stage_regs& r_st) {
+    constexpr bool tail = decltype(TAIL)::value;
+    const int buf = (int)(s & 1);
+    load_frag(fa0, fb0, buf, 0);
+    if constexpr (!tail) load_regs(std::true_type{}, r_ld);
+    else if (s + 2 < nsteps) load_regs(std::false_type{}, r_ld);
+#if T4_PIN
+    // keep the global loads HERE: left alone, the scheduler sinks them two K-steps down, next to the
+    // transform that consumes them (shorter live ranges), and the prefetch becomes an exposed round trip
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    mfma6(fa1, fb1);                                        // slice 3 of the previous step
+    load_frag(fa1, fb1, buf, 1);
+    mfma6(fa0, fb0);
+    if (!tail || s + 1 < nsteps) store_a(r_st, buf ^ 1);
+    load_frag(fa0, fb0, buf, 2);
+    mfma6(fa1, fb1);
+    if (!tail || s + 1 < nsteps) store_b(r_st, buf ^ 1);
+    load_frag(fa1, fb1, buf, 3);
+    mfma6(fa0, fb0);
+    __syncthreads();
+  };
+  using Y = std::true_type;
+  using N = std::false_type;
+
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = 0.f;         // carried slice of step -1: adds nothing
+
+  if (nsteps > 0) {
+    load_regs(N{}, rP);
+    store_a(rP, 0);
+    store_b(rP, 0);
+    if (nsteps > 1) load_regs(N{}, rQ);
+  }
+  __syncthreads();
+  long long s = 0;
+  // steady state: every row a step fetches (two steps ahead) lies inside both matrices
+  const bool whole = p.A_rows >= p.Krows && 2 * p.B_rows >= p.Krows;      // (fetched rows stay >= 64 short of Krows)
+  if (whole)
+    for (; s + 5 < nsteps; s += 2) {
+      kstep(N{}, s, rP, rQ);
+      kstep(N{}, s + 1, rQ, rP);
+    }
+  for (; s < nsteps; s += 2) {
+    kstep(Y{}, s, rP, rQ);
+    if (s + 1 < nsteps) kstep(Y{}, s + 1, rQ, rP);
+  }
+  mfma6(fa1, fb1);
+
+  float* out = p.slab + (long long)z * p.slab_stride;
+  const int col = n0 + wn * 32 + lr;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m < p.Mdim && col < p.Ndim) out[((long long)i * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
+    }
 }
 
 // dW (O, I, 3) = G^T M from the reduced transforms red[6][I][ld]:
