@@ -8,6 +8,7 @@ which is how the synthesis trainer uses it (reference models/synthesis_trainer.p
 outputs are arg-maxed and the classifiers are never updated)."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -122,6 +123,87 @@ class CnnClassifierEngine(CnnEngine):
         return torch.sigmoid(out)
 
 
+def _launch_nt(lib, fn: str = "tl_gemm_nt_window", **kw) -> None:
+    """One NT windowed-GEMM launch on torch's current stream (fields of ``NtParams`` by keyword)."""
+    import ctypes as C
+    from ._lib import NtParams
+    p = NtParams()
+    p.splitk, p.bm, p.J, p.Tp, p.Tvalid, p.slope = 1, 128, 1, 1, 1, 0.0
+    for k, v in kw.items():
+        setattr(p, k, v)
+    check(getattr(lib, fn)(C.byref(p), torch.cuda.current_stream().cuda_stream), fn)
+
+
+class LstmInferEngine:
+    """Last hidden state of a one-layer ``nn.LSTM(batch_first=True)`` with zero initial state, forward only -
+    the two LSTMs of ``CNNRNNClassifier`` (reference models/deep_classifiers.py:230-233, 263-264, 294-296,
+    316-318), which the synthesis trainer runs once per train step without gradients.
+
+    Two phases, both on the fp32 MFMA GEMM kernel:
+      1. the input projection of EVERY time step in one GEMM:  Xp = X W_ih^T + (b_ih + b_hh)   (B*T rows);
+      2. per time step  h_{t-1} W_hh^T  as a skinny split-K GEMM (32-row tiles, about one workgroup per CU:
+         W_hh - 10 MB for hidden 800 - streams from L2) and one
+         ``tl_lstm_cell_infer`` launch that sums the split-K slabs, adds Xp[t] and updates c, h in place -
+         all T steps enqueued by one C call (``tl_lstm_infer_seq``).
+    The sequence is latency bound (T dependent steps); two small launches per step.  Hidden and input widths
+    that are not multiples of 4 are zero-padded in the packed weights (a padded unit has i = f = o = 1/2,
+    g = 0, so its c and h stay exactly 0 and feed nothing)."""
+
+    def __init__(self, in_dim: int, hidden: int):
+        from . import _lib
+        self.lib = _lib.load()
+        self.in_dim, self.H = in_dim, hidden
+        self.Kp, self.Hp = _r4(in_dim), _r4(hidden)
+        self._packed = None
+
+    def _weights(self, w_ih, w_hh, b_ih, b_hh):
+        ver = tuple((t._version, t.data_ptr()) for t in (w_ih, w_hh, b_ih, b_hh))
+        if self._packed is None or self._packed[0] != ver:
+            H, Hp, Kp, dev = self.H, self.Hp, self.Kp, w_hh.device
+            wi = torch.zeros(4, Hp, Kp, dtype=torch.float32, device=dev)
+            wi[:, :H, :self.in_dim] = w_ih.detach().float().view(4, H, self.in_dim)
+            wh = torch.zeros(4, Hp, Hp, dtype=torch.float32, device=dev)
+            wh[:, :H, :H] = w_hh.detach().float().view(4, H, H)
+            bs = torch.zeros(4, Hp, dtype=torch.float32, device=dev)
+            bs[:, :H] = (b_ih.detach().float() + b_hh.detach().float()).view(4, H)
+            self._packed = (ver, wi.view(4 * Hp, Kp), wh.view(4 * Hp, Hp), bs.view(4 * Hp))
+        return self._packed[1:]
+
+    @torch.no_grad()
+    def last_hidden(self, x_seq: torch.Tensor, w_ih, w_hh, b_ih, b_hh) -> torch.Tensor:
+        """x_seq (B, T, in_dim) -> h_T (B, hidden)."""
+        B, T, D = x_seq.shape
+        if D != self.in_dim:
+            raise ValueError(f"expected input width {self.in_dim}, got {D}")
+        dev = x_seq.device
+        wi, wh, bs = self._weights(w_ih, w_hh, b_ih, b_hh)
+        H, Hp, Kp = self.H, self.Hp, self.Kp
+        f32 = dict(dtype=torch.float32, device=dev)
+        x = x_seq.float()
+        if Kp != D:
+            xp_in = torch.zeros(B, T, Kp, **f32)
+            xp_in[:, :, :D] = x
+            x = xp_in
+        x = x.contiguous()
+        rows = B * T
+        xp = torch.empty(rows, 4 * Hp, **f32)
+        # phase 1: every step's input projection + both biases
+        _launch_nt(self.lib, A=ptr(x), Bw=ptr(wi), bias=ptr(bs), out=ptr(xp), M=rows, A_rows=rows, N=4 * Hp, K=Kp,
+                   lda=Kp, ldb=Kp, ldo=4 * Hp, loader=LOAD_DIRECT, epilogue=EPI_STORE)
+        h = torch.empty(B, Hp, **f32)
+        c = torch.empty(B, Hp, **f32)
+        tiles = ((B + 31) // 32) * ((4 * Hp + 127) // 128)
+        # split factor: about one workgroup per CU.  Measured on the C5 shapes (hidden 800, batch 64, 400 steps):
+        # 2 -> 9.2 ms, 4 -> 8.0, 6 -> 8.4, 10 -> 10.4, 20 (whole rounds of 512) -> 16.3; MIOpen 9.0 ms
+        sk = int(os.environ.get("TONAL_LSTM_SK", "0")) or max(1, 224 // tiles)
+        sk = max(1, min(sk, (Hp + 31) // 32))
+        slab = torch.empty(sk, B, 4 * Hp, **f32)
+        # phase 2: the T dependent steps, enqueued from C in one call (tl_lstm_infer_seq)
+        check(self.lib.tl_lstm_infer_seq(ptr(xp), T * 4 * Hp, ptr(wh), ptr(h), ptr(c), ptr(slab), sk, B, Hp, T,
+                                         torch.cuda.current_stream().cuda_stream), "tl_lstm_infer_seq")
+        return h[:, :H] if Hp != H else h
+
+
 class CnnRnnConvEngine:
     """Convolutional trunk of ``CNNRNNClassifier`` (reference models/deep_classifiers.py:230-259, 294-312)
     on the HIP kernels, forward only: the two (7,1) conv + LeakyReLU + (2,1) max-pool branches
@@ -182,6 +264,19 @@ class CnnRnnConvEngine:
         p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = self.K, 0, self.Tp, self.Tp, self.slope
         p.loader, p.epilogue, p.splitk, p.bm = LOAD_DIRECT, EPI_LRELU, 1, 128
         check(self.lib.tl_gemm_nt_window(C.byref(p), torch.cuda.current_stream().cuda_stream), "tl_gemm_nt_window")
+
+    @torch.no_grad()
+    def linear(self, a: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """a (B, K) @ w (N, K)^T + b on the NT GEMM kernel (the classifier's output layer)."""
+        a = a.contiguous().float()
+        B, K = a.shape
+        if K % 4 != 0:
+            raise ValueError("linear: the feature width must be a multiple of 4")
+        N = w.shape[0]
+        out = torch.empty(B, N, dtype=torch.float32, device=a.device)
+        _launch_nt(self.lib, A=ptr(a), Bw=ptr(w.contiguous()), bias=ptr(b), out=ptr(out), M=B, A_rows=B, N=N, K=K, lda=K,
+                   ldb=K, ldo=N, loader=LOAD_DIRECT, epilogue=EPI_STORE)
+        return out
 
     @torch.no_grad()
     def features(self, x: torch.Tensor, h1: torch.Tensor, block1, block2, conv3a, conv3b) -> torch.Tensor:

@@ -121,20 +121,25 @@ class CNNRNNClassifier(ClassifierModel):
         if T != self.input_length:
             raise ValueError(f"Expected input length {self.input_length}, got {T}.")
         xt = x.permute(0, 2, 1)                            # (B, T, C)
-        h1 = self.lstm1(xt)[0][:, -1, :]                   # (B, lstm_dim)
         needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         slope = self.conv_pool_block1[1].negative_slope
         if x.is_cuda and not needs_graph and not (self.training and self.conv_block3[5].p > 0) and slope >= 0:
-            # inference on CUDA (how the synthesis trainer calls the classifiers): the convolutional trunk
-            # runs on the HIP kernels, the two LSTMs and the output layer stay library calls
+            # inference on CUDA (how the synthesis trainer calls the classifiers): everything on the HIP
+            # kernels - both LSTMs (LstmInferEngine), the convolutional trunk, the output layer
             if self._hip is None:
-                from .._classifier_engine import CnnRnnConvEngine
+                from .._classifier_engine import CnnRnnConvEngine, LstmInferEngine
                 self._hip = CnnRnnConvEngine(C, T, self.lstm1.hidden_size, slope)
+                self._hip_lstm1 = LstmInferEngine(C, self.lstm1.hidden_size)
+                self._hip_lstm2 = LstmInferEngine(self.lstm2.input_size, self.lstm2.hidden_size)
             wb = lambda m: (m.weight.detach(), m.bias.detach())
+            lw = lambda m: (m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0)
+            h1 = self._hip_lstm1.last_hidden(xt, *lw(self.lstm1))
+            self._hip.last_h1 = h1
             f = self._hip.features(x, h1, wb(self.conv_pool_block1[0]), wb(self.conv_pool_block2[0]),
                                    wb(self.conv_block3[0]), wb(self.conv_block3[2]))
-            h2 = self.lstm2(f)[0][:, -1, :]
-            return torch.sigmoid(self.output(h2))
+            h2 = self._hip_lstm2.last_hidden(f, *lw(self.lstm2))
+            return torch.sigmoid(self._hip.linear(h2, self.output.weight.detach(), self.output.bias.detach()))
+        h1 = self.lstm1(xt)[0][:, -1, :]                   # (B, lstm_dim)
         a = self.conv_pool_block1(xt.unsqueeze(1))         # (B, 1024, t, C)
         b = self.conv_pool_block2(h1.reshape(B, 1, T, -1))  # (B, 1024, t, lstm_dim // T)
         f = self.conv_block3(torch.cat((b, a), dim=3))     # (B, 256, t', w)

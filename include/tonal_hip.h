@@ -156,6 +156,17 @@ int tl_colsum(const float* G, float* partial, int nblk, int64_t rows, int ncols,
 int tl_lstm_cell_fwd(const float* hh, const float* x_t, const float* w_ih, const float* b_ih,
                      const float* b_hh, const float* c_prev, float* act, float* c, float* h,
                      int U, int H, int in_dim, int ld_hh, void* stream);
+/* inference-only step (models/deep_classifiers.py:230-233,294-296,316-318: the CNN-RNN classifier's two
+ * LSTMs, run forward-only by the synthesis trainer): pre = xp[u*xp_row_stride + gate*H + k] (input
+ * projection + both biases, pre-computed for every step by one GEMM) + sum_z slab[z][u][gate*H + k] (the
+ * split-K slabs of h_{t-1} W_hh^T; nsplit = 0 with first != 0 for t = 0); c, h (U,H) updated in place. */
+int tl_lstm_cell_infer(const float* slab, int nsplit, int64_t slab_stride, const float* xp,
+                       int64_t xp_row_stride, float* c, float* h, int U, int H, int first, void* stream);
+/* all T steps of such an LSTM enqueued by one call: per step the skinny GEMM h W_hh^T (tl_gemm_nt_window,
+ * 32-row tiles, nsplit split-K slabs of (B,4H) in `slab`) and tl_lstm_cell_infer.  xp rows are (b, t):
+ * xp_row_stride = T*4H or more.  h, c (B,H) need not be initialised; on return they hold h_T, c_T.   */
+int tl_lstm_infer_seq(const float* xp, int64_t xp_row_stride, const float* w_hh, float* h, float* c,
+                      float* slab, int nsplit, int B, int H, int T, void* stream);
 /* backward of the same step: dh, dc_next -> dgates (U,4H) row-major and transposed (4H,ldt),
  * dc_prev.  c_prev may be null (t = 0).                                                     */
 int tl_lstm_cell_bwd(const float* dh, const float* dh_rec, const float* dc_next, const float* act,

@@ -43,3 +43,23 @@ with torch.no_grad():
 print(json.dumps({"config": "C5 rehearsal, 1 GPU", "per_gpu_batch": B, "signal_ms_256x24000": round(t_sig * 1e3, 3),
                   "train_step_ms": round(t_step * 1e3, 2), "of_which_classifier_forwards_ms": round(t_cls * 1e3, 2),
                   "mel_frames_per_s": round(B / t_step, 1), "loss": float(tr._stats[2])}))
+# per-classifier split (HIP-event timed, 3 repetitions each)
+def _ev(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+with torch.no_grad():
+    lw = lambda m: (m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0)
+    parts = {"cnn_classifier_ms": _ev(lambda: tr.syllable_model(x_syl)), "cnnrnn_classifier_ms": _ev(lambda: tr.tone_model(x_tone))}
+    if getattr(tone, "_hip_lstm1", None) is not None:
+        xt = x_tone.permute(0, 2, 1)
+        parts["cnnrnn_lstm1_ms"] = _ev(lambda: tone._hip_lstm1.last_hidden(xt, *lw(tone.lstm1)))
+        f = torch.randn(B, tone._hip.tq, tone.lstm2.input_size, device=dev)
+        parts["cnnrnn_lstm2_ms"] = _ev(lambda: tone._hip_lstm2.last_hidden(f, *lw(tone.lstm2)))
+        parts["stock_lstm1_ms"] = _ev(lambda: tone.lstm1(xt))
+        parts["stock_lstm2_ms"] = _ev(lambda: tone.lstm2(f))
+print(json.dumps({k: round(v, 3) for k, v in parts.items()}))
