@@ -336,9 +336,13 @@ class CnnEngine:
         ldg = Gs.shape[1]
         nd = _r4(st.cout)
         if self._use_wino43_tn(st):
-            # F(4,3): 64 x 64 tiles, 6 transform accumulators; about four rounds of the 512 resident workgroups
+            # F(4,3): 64 x 64 tiles, 6 transform accumulators.  Many short reduction splits (16 rounds of the 512
+            # resident workgroups) rather than few long ones: the 64 workgroups of one split re-read each
+            # other's activation / gradient panels through their XCD's L2, which only works while they stay
+            # in step - measured HBM-side reads per conv2 launch 64.6 GB at 4 rounds, 31.4 GB at 16, 27.4 GB
+            # (+ 3.2 GB of slab reduction) at 64; the time is the same (50.3 - 51.1 ms)
             tiles = ((st.cin + 63) // 64) * ((nd + 63) // 64)
-            sk = self._splitk(tiles, (rows_in + 31) // 32, 2048)
+            sk = self._splitk(tiles, (rows_in + 31) // 32, int(os.environ.get("TONAL_TN_TARGET", "8192")))
             slab = torch.empty(sk, 6 * st.cin, ldg, **f32)
             self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino43_tn", A=ptr(Xin), B=ptr(Gs), slab=ptr(slab),
                      Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=st.cin,
