@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void wino43_tn_kernel(const tl_tn_params p)
     const int buf = (int)(s & 1);
     load_frag(fa0, fb0, buf, 0);
     if constexpr (!tail) load_regs(std::true_type{}, r_ld);
-    else if (s + 2 < nsteps) load_regs(std::false_type{}, r_ld);
+    else if (s + 3 < nsteps) load_regs(std::false_type{}, r_ld);
 #if T4_PIN
     // keep the global loads HERE: left alone, the scheduler sinks them two K-steps down, next to the
     // transform that consumes them (shorter live ranges), and the prefetch becomes an exposed round trip
@@ -233,24 +233,29 @@ __global__ __launch_bounds__(256, 2) void wino43_tn_kernel(const tl_tn_params p)
 #pragma unroll
   for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = 0.f;         // carried slice of step -1: adds nothing
 
+  // three register sets: the loads of step s + 3 are issued at the top of step s
+  stage_regs rR;
   if (nsteps > 0) {
     load_regs(N{}, rP);
     store_a(rP, 0);
     store_b(rP, 0);
     if (nsteps > 1) load_regs(N{}, rQ);
+    if (nsteps > 2) load_regs(N{}, rR);
   }
   __syncthreads();
   long long s = 0;
-  // steady state: every row a step fetches (two steps ahead) lies inside both matrices
-  const bool whole = p.A_rows >= p.Krows && 2 * p.B_rows >= p.Krows;      // (fetched rows stay >= 64 short of Krows)
+  const bool whole = p.A_rows >= p.Krows && 2 * p.B_rows >= p.Krows;
+  // kstep(s, ld, st): loads step s + 3 into ld (the set that held step s, already in LDS), stores st = step s + 1
   if (whole)
-    for (; s + 5 < nsteps; s += 2) {
+    for (; s + 8 < nsteps; s += 3) {
       kstep(N{}, s, rP, rQ);
-      kstep(N{}, s + 1, rQ, rP);
+      kstep(N{}, s + 1, rQ, rR);
+      kstep(N{}, s + 2, rR, rP);
     }
-  for (; s < nsteps; s += 2) {
+  for (; s < nsteps; s += 3) {
     kstep(Y{}, s, rP, rQ);
-    if (s + 1 < nsteps) kstep(Y{}, s + 1, rQ, rP);
+    if (s + 1 < nsteps) kstep(Y{}, s + 1, rQ, rR);
+    if (s + 2 < nsteps) kstep(Y{}, s + 2, rR, rP);
   }
   mfma6(fa1, fb1);
 
