@@ -45,6 +45,20 @@ def test_abi_argument_validation_without_gpu():
     assert lib.tl_filtfilt_f64(16, 1, 16, 16, 16, 16, 16, 2, 20, 9, None) == -1
     assert b"padlen" in lib.tl_last_error()
     assert lib.tl_gauss_envelope(16, 1, 16, 16, 2, 100, 8, 200, 0, 1, None) == -1
+    # round-2 entry points: F(4,3) weight gradient, inference LSTM
+    assert lib.tl_conv3_wino43_tn(None, None) == -1
+    t = _lib.TnParams()
+    t.A = t.B = t.slab = t.bbits = 16
+    t.J, t.loader, t.Krows, t.Mdim, t.Ndim, t.lda, t.ldb, t.ldc, t.Tp, t.Tvalid = 3, 1, 30, 64, 64, 64, 64, 64, 4, 2
+    t.A_rows, t.B_rows, t.ld_bbits = 32, 16, 2
+    assert lib.tl_conv3_wino43_tn(C.byref(t), None) == -1 and b"Krows" in lib.tl_last_error()      # Krows % 4
+    t.Krows, t.Tp = 32, 6
+    assert lib.tl_conv3_wino43_tn(C.byref(t), None) == -1 and b"Tp" in lib.tl_last_error()
+    assert lib.tl_wino43_wgrad_finalize(None, None, 4, 4, 4, None) == -1
+    assert lib.tl_lstm_cell_infer(None, 0, 0, None, 0, None, None, 4, 8, 1, None) == -1
+    assert lib.tl_lstm_cell_infer(None, 0, 0, 16, 16, 16, 16, 4, 8, 0, None) == -1 and b"recurrent" in lib.tl_last_error()
+    assert lib.tl_lstm_infer_seq(16, 10, 16, 16, 16, 16, 1, 4, 6, 3, None) == -1 and b"multiple of 4" in lib.tl_last_error()
+    assert lib.tl_lstm_infer_seq(16, 10, 16, 16, 16, 16, 1, 4, 8, 3, None) == -1 and b"row stride" in lib.tl_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(-1, "x")
 

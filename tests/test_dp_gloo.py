@@ -35,6 +35,18 @@ def _worker(rank, world, port, q):
     localk = dgk.t() @ h_pool[pick]
     dist.all_reduce(localk)
     ok = ok and dgm.shape[0] == 6 and torch.allclose(dgm.t() @ hm, localk, rtol=1e-5, atol=1e-5)   # 5 keys + the pad key
+    # equal keys whose h differs in the last bits between ranks (different tilings): every rank must pick the SAME
+    # representative - the first occurrence in gathered order, i.e. rank 0's row - or the replicas drift apart
+    hp = h_pool[pick] + (1e-6 * rank)
+    _dg2, hm2 = parallel.gather_lowrank(dgk, hp, key_pool[pick])
+    mine_h = hm2.clone()
+    both = [torch.empty_like(mine_h) for _ in range(world)]
+    dist.all_gather(both, mine_h)
+    ok = ok and torch.equal(both[0], both[1])
+    shared = [k for k in (2, 4)]                      # keys held by both ranks: rank 0's (unperturbed) h must win
+    for k in shared:
+        row = (hm2 - h_pool[k]).abs().sum(dim=1).argmin()
+        ok = ok and torch.equal(hm2[row], h_pool[k])
     sl = parallel.shard_rows(10, rank, world)
     ok = ok and (sl.stop - sl.start == 5)
     q.put((rank, bool(ok)))
