@@ -440,9 +440,13 @@ class CnnEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,
-                save: bool, seed: int = 0, row0: int = 0) -> torch.Tensor:
+                save: bool, seed: int = 0, row0: int = 0, label_ids: Optional[torch.Tensor] = None,
+                label_table: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``row0``: index of this shard's first window in the global batch (data parallel): the dropout
-        hash is indexed by the global element, so N ranks draw the masks of one process."""
+        hash is indexed by the global element, so N ranks draw the masks of one process.
+        ``label_ids`` (B,) int32 + ``label_table`` (U, 2, L): the caller already knows the distinct label
+        sequences (the trainer builds them from (tone, syllable) class pairs) - ``labels[b] == label_table[ids[b]]``;
+        the LSTM then runs on the table rows and no ``torch.unique`` (a host synchronisation) is needed."""
         B, Cn, T = x.shape
         if Cn != self.C or T != self.T:
             raise ValueError(f"expected ECoG input (B, {self.C}, {self.T}), got {tuple(x.shape)}")
@@ -469,7 +473,10 @@ class CnnEngine:
         # ---- label LSTM on the distinct label sequences ----
         L = labels.shape[2]
         flat = labels.reshape(B, 2 * L)
-        uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
+        if label_ids is not None and label_table is not None:
+            uniq, inv = label_table.reshape(label_table.shape[0], 2 * L).float(), label_ids
+        else:
+            uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
         U = uniq.shape[0]
         self._U, self._L = U, L
         self._uid = inv.to(torch.int32).contiguous()
@@ -598,7 +605,8 @@ class CnnEngine:
                          lda=cout_ld, ldb=cout_ld, ldo=cin_ld, loader=LOAD_DIRECT, epilogue=EPI_STORE)
         # ---- un-concat: G5 (dropout + lrelu') and dh summed over duplicates ----
         order = torch.argsort(self._uid, stable=True).to(torch.int32)
-        counts = torch.bincount(self._uid, minlength=U)
+        counts = torch.zeros(U, dtype=torch.int32, device=dev)           # (torch.bincount synchronises)
+        counts.scatter_add_(0, self._uid.long(), torch.ones_like(self._uid))
         offsets = torch.zeros(U + 1, dtype=torch.int32, device=dev)
         offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
         dh_ext = torch.empty(U, H, **f32)

@@ -87,6 +87,17 @@ class SynthesisTrainer:
         n_cls = getattr(self.tone_model, "n_classes", None)
         self._need_check = n_cls is None or any(str(t) not in tone_dynamic_mapping for t in range(n_cls))
         self._table = table.to(self.device)
+        # every (tone, syllable) class pair as a label sequence: the synthesis model's LSTM runs on these rows and
+        # the batch gathers from them by id = tone * n_syllables + syllable (no torch.unique, no host sync per step)
+        n_syl = getattr(self.syllable_model, "n_classes", None)
+        self._pair_table = None
+        if not self._need_check and n_syl is not None and n_syl >= 1 and self._n_rows * n_syl <= 16:
+            syl_col = torch.arange(n_syl, dtype=torch.float32).view(1, n_syl, 1).expand(self._n_rows, n_syl, self._L)
+            dyn = table[:self._n_rows].view(self._n_rows, 1, self._L).expand(self._n_rows, n_syl, self._L)
+            self._pair_table = torch.stack([syl_col, dyn], dim=2).reshape(self._n_rows * n_syl, 2, self._L).contiguous() \
+                .to(self.device)
+            self._n_syl = int(n_syl)
+        self._pair_ids = None
         self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._stats = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._grads = None
@@ -100,6 +111,9 @@ class SynthesisTrainer:
         syl = torch.argmax(self.syllable_model(inputs_syllable), dim=1).contiguous()
         B = tone.shape[0]
         labels = torch.empty(B, 2, self._L, dtype=torch.float32, device=self.device)
+        self._pair_ids = None
+        if self._pair_table is not None:          # ids are valid for exactly this label tensor
+            self._pair_ids = ((tone * self._n_syl + syl).to(torch.int32), labels)
         check(self.lib.tl_tone_dynamics(ptr(tone), ptr(syl), ptr(self._table), ptr(labels), ptr(self._err), B,
                                         self._n_rows, self._L, torch.cuda.current_stream().cuda_stream),
               "tl_tone_dynamics")
@@ -184,8 +198,12 @@ class SynthesisTrainer:
             # if its rank exceeds what the fused optimiser kernel takes (the engine then allocates it)
             self._grads = {k: torch.empty_like(v) for k, v in prm.items() if k != skip}
         prm.update(model._engine_buffers())
+        kw = {}
+        ids = getattr(self, "_pair_ids", None)
+        if ids is not None and ids[1] is inputs_label and getattr(eng, "lowrank_param", None) is not None:
+            kw = dict(label_ids=ids[0], label_table=self._pair_table)             # CNN engine: skip torch.unique
         out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True, seed=model._next_seed(),
-                          row0=getattr(self, "_row0", 0))
+                          row0=getattr(self, "_row0", 0), **kw)
         B, D = out.shape
         dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)
         self._loss_stats(out, targets, dout, eng.ldd, 1)
