@@ -88,6 +88,10 @@ class CnnEngine:
         self.kflat = n_channels * self.tp5 * self.ldy5
         self.ldd = _r4(output_dim)
         self.lowrank_param = "label_lstm.weight_hh_l0"   # reduced via gathered factors under DP
+        # data-parallel row shard of the label LSTM (rank, world) - set by the trainer (parallel.py docstring);
+        # used for a step when the caller hands the label table (identical distinct rows on every rank)
+        self.lstm_shard = None
+        self._sh = None
         self.timers = None
         # Winograd kernels for the pooled 3-tap stages.  TONAL_WINO selects the form:
         #   0  direct-form MFMA kernels (the parity partner)
@@ -491,10 +495,32 @@ class CnnEngine:
         w_ih, w_hh = prm["label_lstm.weight_ih_l0"], prm["label_lstm.weight_hh_l0"]
         b_ih, b_hh = prm["label_lstm.bias_ih_l0"], prm["label_lstm.bias_hh_l0"]
         bm = 32 if U <= 64 else 128
-        sk_f = self._splitk_rounds(((U + bm - 1) // bm) * ((4 * H + 127) // 128), (H + 31) // 32) if L > 1 else 1
-        slab_f = torch.empty(sk_f, U, 4 * H, **f32) if sk_f > 1 else None
+        # row shard of W_hh for this step: needs the caller's label table (same U rows on every rank), an even
+        # split of the 4H gate rows and a factor rank the fused optimiser takes
+        self._sh = None
+        if (self.lstm_shard is not None and label_table is not None and training and L > 1 and (L - 1) * U <= 64
+                and (4 * H) % (4 * self.lstm_shard[1]) == 0):
+            rk, wd = self.lstm_shard
+            self._sh = (rk * (4 * H // wd), 4 * H // wd, wd)
+        nloc = self._sh[1] if self._sh else 4 * H
+        sk_f = self._splitk_rounds(((U + bm - 1) // bm) * ((nloc + 127) // 128), (H + 31) // 32) if L > 1 else 1
+        slab_f = torch.empty(sk_f, U, nloc, **f32) if sk_f > 1 else None
+        if self._sh:
+            from . import parallel
+            hh_loc = torch.empty(U, nloc, **f32)
+            hh_all = torch.empty(self._sh[2], U, nloc, **f32)
         for t in range(L):
-            if t > 0:
+            if t > 0 and self._sh:
+                # this rank's gate rows of h W_hh^T, all-gathered: every rank then holds the full (U, 4H) product
+                r0, R, wd = self._sh
+                self._nt(A=ptr(self._h[t - 1]), Bw=w_hh.data_ptr() + 4 * r0 * H, out=ptr(slab_f if sk_f > 1 else hh_loc),
+                         M=U, A_rows=U, N=R, K=H, lda=H, ldb=H, ldo=R, loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm,
+                         splitk=sk_f, slab_stride=U * R)
+                if sk_f > 1:
+                    self._permute(slab_f, hh_loc, (1, 1, 1, U * R), (0, 0, 0, 1), nz=sk_f, zs=U * R)
+                parallel.all_gather_blocks(hh_all, hh_loc)
+                self._permute(hh_all, hh, (1, U, wd, R), (0, R, U * R, 1))
+            elif t > 0:
                 self._nt(A=ptr(self._h[t - 1]), Bw=ptr(w_hh), out=ptr(slab_f if sk_f > 1 else hh), M=U, A_rows=U,
                          N=4 * H, K=H, lda=H, ldb=H, ldo=4 * H, loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm,
                          splitk=sk_f, slab_stride=U * 4 * H)
@@ -615,6 +641,10 @@ class CnnEngine:
                                        self.ldx, self.slope, self._p_drop_used, self._seed_used, self._drop_row0,
                                        st_), "tl_concat_unpack_bwd")
         # ---- LSTM BPTT on the distinct rows ----
+        sh = self._sh
+        if sh:      # every rank runs the same BPTT on the gradient of the GLOBAL batch
+            from . import parallel
+            parallel.all_reduce_(dh_ext)
         w_hh = prm["label_lstm.weight_hh_l0"]
         ldt = (U + 31) // 32 * 32
         dg = torch.empty(L, U, 4 * H, **f32)
@@ -622,17 +652,26 @@ class CnnEngine:
         dc = [torch.empty(U, H, **f32), torch.empty(U, H, **f32)]
         dhrec = torch.empty(U, H, **f32) if L > 1 else None
         if L > 1:
+            kloc = sh[1] if sh else 4 * H                      # gate rows this rank contracts over
             if ldt <= 32:        # skinny streaming kernel: 32 x 512 tiles, 16-deep K stages
-                sk_h = self._splitk_rounds((H + 511) // 512, (4 * H + 15) // 16)
+                sk_h = self._splitk_rounds((H + 511) // 512, (kloc + 15) // 16)
             else:
-                sk_h = self._splitk((ldt + 127) // 128 * ((H + 127) // 128), (4 * H + 31) // 32, 1024)
+                sk_h = self._splitk((ldt + 127) // 128 * ((H + 127) // 128), (kloc + 31) // 32, 1024)
             slab_h = torch.empty(sk_h, ldt, H, **f32)
         for t in range(L - 1, -1, -1):
             check(lib.tl_lstm_cell_bwd(ptr(dh_ext) if t == L - 1 else None, ptr(dhrec) if t < L - 1 else None,
                                        ptr(dc[(t + 1) & 1]) if t < L - 1 else None, ptr(self._act[t]), ptr(self._c[t]),
                                        ptr(self._c[t - 1]) if t > 0 else None, ptr(dg[t]),
                                        ptr(dgt) if t > 0 else None, ptr(dc[t & 1]), U, H, ldt, st_), "tl_lstm_cell_bwd")
-            if t > 0:
+            if t > 0 and sh:
+                # partial dgates . W_hh over this rank's gate rows, summed over the ranks
+                r0, R, _wd = sh
+                self._tn(A=dgt.data_ptr() + 4 * r0 * ldt, B=w_hh.data_ptr() + 4 * r0 * H, slab=ptr(slab_h), Krows=R,
+                         A_rows=R, B_rows=R, Mdim=ldt, Ndim=H, lda=ldt, ldb=H, ldc=H, loader=LOAD_DIRECT, splitk=sk_h,
+                         slab_stride=ldt * H)
+                self._permute(slab_h, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=sk_h, zs=ldt * H)
+                parallel.all_reduce_(dhrec)
+            elif t > 0:
                 self._tn(A=ptr(dgt), B=ptr(w_hh), slab=ptr(slab_h), Krows=4 * H, A_rows=4 * H, B_rows=4 * H, Mdim=ldt,
                          Ndim=H, lda=ldt, ldb=H, ldc=H, loader=LOAD_DIRECT, splitk=sk_h, slab_stride=ldt * H)
                 self._permute(slab_h, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=sk_h, zs=ldt * H)
@@ -643,13 +682,22 @@ class CnnEngine:
         if L > 1:
             kr = (L - 1) * U
             fa, fb = dg[1:].reshape(kr, 4 * H), self._h[:L - 1].reshape(kr, H)
-            if gather_whh is not None:
+            if sh:
+                # dgates already belong to the global batch (identical on every rank): this rank updates its own
+                # rows of W_hh from the matching columns of the factor - nothing to gather
+                if not whh_factors:
+                    raise RuntimeError("the row-sharded label LSTM needs the factored W_hh update (whh_factors=True)")
+                self.whh_factors = (fa[:, sh[0]:sh[0] + sh[1]], fb.contiguous(), sh[0], sh[1])
+                fa = fb = None
+            elif gather_whh is not None:
                 # key of row (t, u): the step and the label sequence h_t was unrolled from
                 steps = torch.arange(L - 1, device=dev, dtype=torch.float32).repeat_interleave(U).unsqueeze(1)
                 keys = torch.cat([steps, self._xu.permute(1, 0, 2).reshape(U, 2 * L).repeat(L - 1, 1)], dim=1)
                 fa, fb = gather_whh(fa, fb, keys)
                 kr = fa.shape[0]
-            if whh_factors and kr <= 64:
+            if sh:
+                pass
+            elif whh_factors and kr <= 64:
                 # hand the factors to the optimiser (tl_nadam_lowrank): the 5.4 GB gradient is never formed
                 self.whh_factors = (fa.contiguous(), fb.contiguous())
             else:

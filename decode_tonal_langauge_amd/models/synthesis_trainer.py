@@ -103,6 +103,10 @@ class SynthesisTrainer:
         self._grads = None
         self.rank, self.world = parallel.world()
         self.dp = parallel.active()
+        self._whh_dirty = False
+        eng = getattr(self.model, "_engine", None)
+        if self.dp and eng is not None and hasattr(eng, "lstm_shard") and self._pair_table is not None:
+            eng.lstm_shard = (self.rank, self.world)        # row-sharded label LSTM (parallel.py docstring)
 
     # ------------------------------------------------------------------ helpers
     def _labels(self, inputs_tone, inputs_syllable) -> torch.Tensor:
@@ -211,7 +215,13 @@ class SynthesisTrainer:
         eng.backward(prm, dout, self._grads, gather_whh=gather, whh_factors=skip is not None)
         scale = 1.0          # the 1/N of the global mean is already in dout (weight of this rank's rows)
         if self.dp:
-            self._timed(parallel.allreduce_bucketed)([g for k, g in self._grads.items() if k != skip])
+            sharded = getattr(eng, "_sh", None) is not None
+            # with the row-sharded LSTM its dgates - hence the W_ih / bias gradients - already belong to the global
+            # batch on every rank: they stay out of the all-reduce
+            local_only = ("label_lstm.weight_ih_l0", "label_lstm.bias_ih_l0", "label_lstm.bias_hh_l0") if sharded else ()
+            self._timed(parallel.allreduce_bucketed)([g for k, g in self._grads.items()
+                                                      if k != skip and k not in local_only])
+            self._whh_dirty = self._whh_dirty or sharded
         factors = getattr(eng, "whh_factors", None)
         if factors is not None:          # the optimiser forms that gradient from its factors on the fly
             self.optimizer.step(grads={params[k]: self._grads[k] for k in names if k != skip}, grad_scale=scale,
@@ -236,6 +246,17 @@ class SynthesisTrainer:
         self.optimizer.step(grad_scale=1.0)
         out = outputs.detach().float().contiguous()
         self._loss_stats(out, targets.float().contiguous(), None, out.shape[1], 1)
+
+    def sync_parameters(self) -> None:
+        """Re-assemble parameters that data-parallel ranks update shard-wise (the row-sharded ``weight_hh_l0``):
+        afterwards every rank holds the full, current model (``state_dict``, ``evaluate``)."""
+        if not self._whh_dirty:
+            return
+        eng = self.model._engine
+        p = dict(self.model.named_parameters())[eng.lowrank_param]
+        rows = p.shape[0] // self.world
+        parallel.all_gather_param_rows_(p.data, self.rank * rows, rows)
+        self._whh_dirty = False
 
     def train_step(self, inputs_non, inputs_syllable, inputs_tone, targets) -> None:
         """One body of the batch loop (reference :201-229).  Loss / MCD go to ``self._stats``."""
@@ -266,6 +287,7 @@ class SynthesisTrainer:
             for inputs_non, inputs_syllable, inputs_tone, targets in train_loader:
                 self.train_step(inputs_non, inputs_syllable, inputs_tone, targets)
                 nb += 1
+            self.sync_parameters()
             stats = self._stats.clone()
             if self.dp:
                 parallel.all_reduce_(stats)          # per-rank statistics carry their weight in the global mean
@@ -277,6 +299,7 @@ class SynthesisTrainer:
         return history
 
     def evaluate(self, test_loader: DataLoader):
+        self.sync_parameters()
         self.model.eval()
         self.tone_model.eval()
         self.syllable_model.eval()

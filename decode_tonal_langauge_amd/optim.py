@@ -36,13 +36,18 @@ class FusedNAdam(torch.optim.Optimizer):
                                       momentum_decay=momentum_decay))
         self._lib = _lib.load()
 
-    def _state_for(self, p):
+    def _state_for(self, p, shard_rows=None):
+        """``shard_rows`` = (row0, rows): this rank owns (and keeps moments for) only those rows of ``p``."""
         st = self.state[p]
         if not st:
             st["step"] = 0
             st["mu_product"] = 1.0
-            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            like = p if shard_rows is None else p[shard_rows[0]:shard_rows[0] + shard_rows[1]]
+            st["exp_avg"] = torch.zeros_like(like, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(like, memory_format=torch.preserve_format)
+            st["shard_rows"] = shard_rows
+        elif st.get("shard_rows") != shard_rows:
+            raise RuntimeError("FusedNAdam: the row shard of a parameter cannot change between steps")
         return st
 
     LOWRANK_MAX = 64          # largest factor rank tl_nadam_lowrank takes
@@ -53,27 +58,34 @@ class FusedNAdam(torch.optim.Optimizer):
         """``grads`` optionally maps parameter -> gradient tensor (fused trainer path, no ``.grad``).
         ``lowrank`` maps a 2-D parameter (rows, cols) to factors ``(fa (k, rows), fb (k, cols))`` of its
         gradient ``fa^T . fb``, k <= LOWRANK_MAX (or ``(None, None)`` for a zero gradient): the update is
-        applied without materialising the gradient."""
+        applied without materialising the gradient.  ``(fa (k, n), fb, row0, n)`` updates only rows
+        [row0, row0 + n) of the parameter (a data-parallel rank that owns a row shard of it)."""
         loss = closure() if closure is not None else None
         stream = torch.cuda.current_stream().cuda_stream
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
                 if lowrank is not None and p in lowrank:
-                    fa, fb = lowrank[p]
+                    spec = lowrank[p]
+                    fa, fb = spec[0], spec[1]
+                    shard = (int(spec[2]), int(spec[3])) if len(spec) > 2 else None
                     kr = 0 if fa is None else fa.shape[0]
                     if p.dim() != 2 or not p.is_contiguous() or kr > self.LOWRANK_MAX:
                         raise RuntimeError("FusedNAdam: low-rank update needs a contiguous 2-D parameter and rank <= 64")
-                    if kr and (fa.shape[1] != p.shape[0] or fb.shape[1] != p.shape[1] or fb.shape[0] != kr
+                    row0, rows = shard if shard is not None else (0, p.shape[0])
+                    if row0 < 0 or rows < 1 or row0 + rows > p.shape[0]:
+                        raise RuntimeError("FusedNAdam: row shard outside the parameter")
+                    if kr and (fa.shape[1] != rows or fb.shape[1] != p.shape[1] or fb.shape[0] != kr
                                or fa.stride(1) != 1 or fb.stride(1) != 1):
                         raise RuntimeError("FusedNAdam: low-rank factors do not match the parameter")
                     _lib.require_gpu(p, "FusedNAdam.step")
-                    st = self._state_for(p)
+                    st = self._state_for(p, shard)
                     st["step"] += 1
                     cg, cm, bc2, st["mu_product"] = nadam_scalars(st["step"], st["mu_product"], group["lr"], b1, b2,
                                                                   group["momentum_decay"])
-                    check(self._lib.tl_nadam_lowrank(ptr(p), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(fa), ptr(fb),
-                                                     kr, p.shape[0], p.shape[1], fa.stride(0) if kr else p.shape[0],
+                    check(self._lib.tl_nadam_lowrank(p.data_ptr() + 4 * row0 * p.shape[1], ptr(st["exp_avg"]),
+                                                     ptr(st["exp_avg_sq"]), ptr(fa), ptr(fb),
+                                                     kr, rows, p.shape[1], fa.stride(0) if kr else rows,
                                                      fb.stride(0) if kr else p.shape[1], cg, cm, b1, b2, bc2,
                                                      group["eps"], group["weight_decay"], grad_scale, stream),
                           "tl_nadam_lowrank")

@@ -7,7 +7,15 @@ Windows are independent, so a global batch is sharded by rows (rank r takes rows
  * ``weight_hh_l0`` (98.7 % of the parameters, 5.5 GB at the north-star shape) is never
    all-reduced: its gradient is ``dgates^T . h`` with at most (L-1)*U rows per rank, so the
    ranks all-gather those low-rank factors (a few MB) and each computes the full-batch gradient
-   locally with the TN GEMM kernel.
+   locally with the TN GEMM kernel;
+ * when the trainer knows the distinct label sequences up front (the usual case), the label LSTM is
+   instead SHARDED by gate rows ("preferred refinement"): rank r streams, and keeps
+   NAdam moments for, only rows [r*4H/N, (r+1)*4H/N) of ``weight_hh_l0``; per LSTM step the ranks
+   all-gather their slice of h W_hh^T (U x 4H/N floats each) in the forward pass and all-reduce the
+   partial dgates W_hh (U x H) in the backward pass; the cell updates run redundantly on every rank, so
+   the replicas stay in lockstep.  This divides the per-rank W_hh traffic (8 streams of 5.4 GB + 33 GB of
+   NAdam per step at the north-star shape) by N.  ``SynthesisTrainer.sync_parameters()`` re-assembles
+   the full weight on every rank (end of ``train``, before ``evaluate`` / ``state_dict``).
 """
 from __future__ import annotations
 
@@ -75,6 +83,26 @@ def _all_gather_rows(out: torch.Tensor, t: torch.Tensor) -> None:
         out.copy_(ho)
     else:
         dist.all_gather_into_tensor(out, t)
+
+
+def all_gather_blocks(out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """``out`` (world, *t.shape) <- every rank's ``t`` (equal shapes)."""
+    t2 = t.contiguous().view(-1, t.shape[-1])
+    _all_gather_rows(out.view(-1, t.shape[-1]), t2)         # (world * rows, cols): the layout both backends accept
+    return out
+
+
+def all_gather_param_rows_(p: torch.Tensor, row0: int, rows: int) -> torch.Tensor:
+    """In place: every rank contributes rows [row0, row0 + rows) of ``p`` (equal, rank-ordered row shards) and
+    receives all others - re-assembles a parameter whose rows were updated shard-wise."""
+    mine = p[row0:row0 + rows]
+    if p.is_cuda and _staged():
+        ho = torch.empty(p.shape, dtype=p.dtype)
+        dist.all_gather_into_tensor(ho, mine.detach().cpu().contiguous())
+        p.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(p, mine)        # in place: the input is this rank's chunk of the output
+    return p
 
 
 def shard_rows(n: int, rank: int, nranks: int) -> slice:

@@ -47,6 +47,16 @@ def _worker(rank, world, port, q):
     for k in shared:
         row = (hm2 - h_pool[k]).abs().sum(dim=1).argmin()
         ok = ok and torch.equal(hm2[row], h_pool[k])
+    # row-sharded parameter: blocks gathered rank-major, rows re-assembled in place
+    blk = torch.full((3, 4), float(rank + 1))
+    allb = parallel.all_gather_blocks(torch.empty(world, 3, 4), blk)
+    ok = ok and torch.equal(allb[0], torch.full((3, 4), 1.0)) and torch.equal(allb[1], torch.full((3, 4), 2.0))
+    torch.manual_seed(42)
+    full = torch.randn(8, 5)
+    mine_p = torch.zeros(8, 5)
+    mine_p[rank * 4:(rank + 1) * 4] = full[rank * 4:(rank + 1) * 4]       # this rank holds only its rows up to date
+    parallel.all_gather_param_rows_(mine_p, rank * 4, 4)
+    ok = ok and torch.equal(mine_p, full)
     sl = parallel.shard_rows(10, rank, world)
     ok = ok and (sl.stop - sl.start == 5)
     q.put((rank, bool(ok)))

@@ -38,9 +38,11 @@ def _worker(rank, world, port, q, sizes=(8, 8), dropout=0.0):
     model.train()
     for b in batches:
         tr.train_step(*b)
+    sharded = model._engine._sh is not None          # the label LSTM ran row-sharded over the two ranks
+    tr.sync_parameters()                             # re-assemble the shard-wise updated W_hh on every rank
     torch.cuda.synchronize()
     # numpy (pickled by value): torch tensors would be shared through fds that die with this process
-    q.put((rank, {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}, tr._stats.cpu().numpy()))
+    q.put((rank, {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}, tr._stats.cpu().numpy(), sharded))
     torch.distributed.destroy_process_group()
 
 
@@ -58,14 +60,15 @@ def test_two_rank_training_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = [q.get(timeout=150) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     torch.manual_seed(0)
     from decode_tonal_langauge_amd.models import SynthesisModelCNN
     init = {k: v.detach().clone() for k, v in SynthesisModelCNN(80, 8, 100, dropout=0.0).named_parameters()}
-    for rank, params, stats in res:
+    for rank, params, stats, sharded in res:
+        assert sharded, "the trainer knows the label table: the LSTM must have run row-sharded"
         for k in ref:
             upd = (ref[k] - init[k]).double()
             err = float((torch.from_numpy(params[k]).double() - ref[k].double()).norm() / max(float(upd.norm()), 1e-30))
@@ -96,14 +99,15 @@ def test_two_rank_training_ragged_batches_with_dropout():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sizes, drop)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = [q.get(timeout=150) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     torch.manual_seed(0)
     from decode_tonal_langauge_amd.models import SynthesisModelCNN
     init = {k: v.detach().clone() for k, v in SynthesisModelCNN(80, 8, 100, dropout=drop).named_parameters()}
-    for rank, params, stats in res:
+    for rank, params, stats, sharded in res:
+        assert sharded
         for k in ref:
             upd = (ref[k] - init[k]).double()
             err = float((torch.from_numpy(params[k]).double() - ref[k].double()).norm() / max(float(upd.norm()), 1e-30))
