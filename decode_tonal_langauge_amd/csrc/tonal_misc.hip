@@ -76,6 +76,70 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   }
 }
 
+// Same stage with 16-byte stores: a thread owns FOUR consecutive output channels (C1 / 4 threads per row, several
+// rows per pass), so a pooled row leaves as 2 KB of contiguous dwordx4 stores instead of 4-byte ones, and the
+// arg-max / sign words are assembled from the 8 lanes x 4 bits that make up 32 channels with three xor-shuffles.
+// Used when C1 is a multiple of 128 (the 512- and 1024-wide stages of the models); HBM-write bound.
+__global__ __launch_bounds__(256) void conv1_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ P,
+                                                           uint32_t* __restrict__ bits, uint32_t* __restrict__ sign,
+                                                           long long S, int T, int kt, int C1, int Tp, int Tout,
+                                                           float slope) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const long long seq = blockIdx.x;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
+  __syncthreads();
+  const int groups = C1 >> 2;                    // threads per row (<= 256, a multiple of 32)
+  const int rpp = 256 / groups;                  // rows per pass
+  const int g = threadIdx.x % groups, rsub = threadIdx.x / groups;
+  const int o = 4 * g;
+  float wv[4][MAXKT], bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bv[c] = b[o + c];
+#pragma unroll
+    for (int j = 0; j < MAXKT; ++j) wv[c][j] = j < kt ? w[(o + c) * kt + j] : 0.f;
+  }
+  const int sh = 4 * (threadIdx.x & 7);
+  for (int p0 = 0; p0 < Tp; p0 += rpp) {
+    const int p = p0 + rsub;                     // Tp % rpp may be non-zero: guard the stores, keep the shuffles uniform
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    uint32_t nib = 0, nsg = 0;
+    if (p < Tout) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXKT; ++j)
+          if (j < kt) {
+            z0 = fmaf(wv[c][j], xs[2 * p + j], z0);
+            z1 = fmaf(wv[c][j], xs[2 * p + 1 + j], z1);
+          }
+        const float y0 = lrelu(z0 + bv[c], slope), y1 = lrelu(z1 + bv[c], slope);
+        const bool sel = y1 > y0;
+        const float v = sel ? y1 : y0;
+        out[c] = v;
+        nib |= (sel ? 1u : 0u) << c;
+        nsg |= (v > 0.f ? 1u : 0u) << c;
+      }
+    }
+    uint32_t wb = nib << sh, ws = nsg << sh;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      wb |= __shfl_xor(wb, m);
+      ws |= __shfl_xor(ws, m);
+    }
+    if (p < Tp) {
+      const long long row = seq * Tp + p;
+      *reinterpret_cast<f32x4*>(P + row * C1 + o) = out;
+      if ((threadIdx.x & 7) == 0) {
+        bits[row * (C1 >> 5) + (o >> 5)] = wb;
+        if (sign != nullptr) sign[row * (C1 >> 5) + (o >> 5)] = ws;
+      }
+    }
+  }
+}
+
 // conv1 weight/bias gradient partials: block handles a contiguous range of sequences;
 // thread owns channels tid and tid + 256 (C1 <= 512), barriers are outside every guard.
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ G,
@@ -649,8 +713,12 @@ extern "C" int tl_conv1_fwd(const float* x, const float* w, const float* b, floa
   TL_REQUIRE(C1 % 64 == 0, "conv1_fwd: C1 must be a multiple of 64");
   TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_fwd: Tout/Tp/T inconsistent (%d,%d,%d)", Tout, Tp, T);
   TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_fwd: T too large for the LDS window");
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,
-                     bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+  if (C1 % 128 == 0 && C1 <= 1024 && (C1 & (C1 - 1)) == 0)      // 256 % (C1 / 4) == 0: whole rows per pass
+    hipLaunchKernelGGL(conv1_fwd_v4_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,
+                       bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+  else
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,
+                       bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
   return check_launch("conv1_fwd");
 }
 
