@@ -348,10 +348,12 @@ class CnnEngine:
             tiles = ((st.cin + 63) // 64) * ((nd + 63) // 64)
             sk = self._splitk(tiles, (rows_in + 31) // 32, int(os.environ.get("TONAL_TN_TARGET", "8192")))
             slab = torch.empty(sk, 6 * st.cin, ldg, **f32)
+            bias_part = torch.empty(sk, nd, **f32)     # the kernel's Y1 = sum of the quad's dZ rows doubles as the bias gradient
             self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino43_tn", A=ptr(Xin), B=ptr(Gs), slab=ptr(slab),
                      Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=st.cin,
                      ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk, slab_stride=6 * st.cin * ldg,
-                     loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
+                     loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout,
+                     colsum=ptr(bias_part))
             if sk > 1:
                 red = torch.empty(6 * st.cin, ldg, **f32)
                 n = 6 * st.cin * ldg
@@ -360,7 +362,7 @@ class CnnEngine:
                 red = slab
             check(self.lib.tl_wino43_wgrad_finalize(ptr(red), ptr(gw), st.cout, st.cin, ldg, self._stream()),
                   "tl_wino43_wgrad_finalize")
-            self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
+            self._permute(bias_part, gb, (1, 1, 1, st.cout), (0, 0, 0, 1), nz=sk, zs=nd)
             return
         if self._use_wino(st):
             tiles = ((st.cin + 127) // 128) * ((nd + 63) // 64)

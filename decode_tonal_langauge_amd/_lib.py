@@ -45,6 +45,7 @@ class TnParams(C.Structure):
         ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ld_bbits", C.c_int),
         ("J", C.c_int), ("Tp", C.c_int), ("Tvalid", C.c_int), ("loader", C.c_int),
         ("splitk", C.c_int), ("slab_stride", C.c_int64),
+        ("colsum", C.c_void_p),
     ]
 
 

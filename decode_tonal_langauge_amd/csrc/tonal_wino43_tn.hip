@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void wino43_tn_kernel(const tl_tn_params p)
     uint32_t ok;      // bit 0 / 1: pair a / b holds a valid gradient
   };
   stage_regs rP, rQ;
+  f32x2 bsum = {0.f, 0.f};          // running column sums of dZ (bias gradient) of this thread's channel pair
 
   auto load_regs = [&](auto FAST, stage_regs& r) {
     constexpr bool fast = decltype(FAST)::value;
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void wino43_tn_kernel(const tl_tn_params p)
       o[4][c] = fmaf(4.f, fmaf(-2.f, o_b, e_b), fmaf(-2.f, o_a, e_a));
       o[5][c] = o_b;
     }
+    bsum += o[1];                                        // Y1 = dy0 + dy1 + dy2 + dy3: the bias gradient of the quad
     float* dst = Bs + buf * T4_TILE + qi * 64 + sw;
 #pragma unroll
     for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(dst + i * T4_PLANE) = o[i];
@@ -259,6 +261,19 @@ __global__ __launch_bounds__(256, 2) void wino43_tn_kernel(const tl_tn_params p)
   }
   mfma6(fa1, fb1);
 
+  // bias-gradient partial sums: the workgroups of the first C_in tile write the column sums of their split
+  if (p.colsum != nullptr && m0 == 0) {
+    __syncthreads();                                         // all fragment reads of the last step are done
+    float* red = lds;                                        // [8 quads][64 channels]
+    *reinterpret_cast<f32x2*>(red + qi * 64 + c2 * 2) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < T4_Q; ++q) t += red[q * 64 + tid];
+      if (n0 + tid < p.Ndim) p.colsum[(long long)z * p.Ndim + n0 + tid] = t;
+    }
+  }
   float* out = p.slab + (long long)z * p.slab_stride;
   const int col = n0 + wn * 32 + lr;
 #pragma unroll

@@ -98,6 +98,8 @@ typedef struct {
   int Tp, Tvalid;
   int loader;
   int splitk; int64_t slab_stride;
+  float* colsum;      /* optional (tl_conv3_wino43_tn): colsum[z][n] = sum over split z of the un-pooled
+                         dZ column n (the bias gradient partial sums; Ndim floats per split), or null */
 } tl_tn_params;
 int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
 
