@@ -229,7 +229,11 @@ class CnnRnnConvEngine:
         self.tq = self.tb // 3                                # after pool (3,1)
         if self.tq < 1:
             raise ValueError("input_length too small for the CNN-RNN convolution stack")
-        self.Tp = (self.t1 + 1) // 2 * 2
+        self.Tp = (self.t1 + 3) // 4 * 4
+        # 7-tap stack: three F(4,3) segments per convolution (default) or the direct 7-tap window GEMM
+        self.conv7_form = os.environ.get("TONAL_CONV7", "wino43")
+        if self.conv7_form not in ("wino43", "direct"):
+            raise ValueError("TONAL_CONV7 must be wino43 or direct")
         self._packed: Dict[str, Tuple[tuple, torch.Tensor]] = {}
         self._B = None
 
@@ -249,21 +253,36 @@ class CnnRnnConvEngine:
         self.Pa, self.bits_a = z(B * self.C * self.Tp, 1024), zi(B * self.C * self.Tp, 32)
         self.Pb, self.bits_b = z(B * self.w1 * self.Tp, 1024), zi(B * self.w1 * self.Tp, 32)
         rows = B * self.W * self.Tp
-        self.Y1, self.Y2 = z(rows, 512), z(rows, 256)
+        # + 8 rows: the segmented convolution reads up to 6 rows past the last row it is asked about
+        self.P, self.Y1, self.Y2 = z(rows + 8, 1024), z(rows + 8, 512), z(rows, 256)
 
-    def _conv7(self, src, w, b, dst, cin, cout, key):
-        def pack():
-            return w.detach().reshape(cout, cin, self.K).permute(2, 0, 1).contiguous()       # [J][O][I]
-        wp = self._cached(key, w, pack)
+    def _conv7(self, src, w, b, dst, cin, cout, key, rows):
+        """dst[r] = lrelu(sum_j w[:, :, j] src[r + j] + b) for r < rows; src holds rows + 8 rows."""
         from ._lib import NtParams
         import ctypes as C
+        st_ = torch.cuda.current_stream().cuda_stream
+        wino = self.conv7_form == "wino43" and cin % 32 == 0
+
+        def pack():
+            if not wino:
+                return w.detach().reshape(cout, cin, self.K).permute(2, 0, 1).contiguous()   # [J][O][I]
+            wp = torch.empty(6, cout, 3 * cin, dtype=torch.float32, device=w.device)
+            check(self.lib.tl_wino43_weights7(ptr(w.detach().reshape(cout, cin, self.K).contiguous()), ptr(wp), cout, cin,
+                                              self.K, st_), "tl_wino43_weights7")
+            return wp
+        wp = self._cached(key + self.conv7_form, w, pack)
         p = NtParams()
         p.A, p.Bw, p.bias, p.out = ptr(src), ptr(wp), ptr(b.detach()), ptr(dst)
-        p.M = p.A_rows = src.shape[0]
-        p.N, p.K, p.lda, p.ldb, p.ldo = cout, cin, cin, cin, cout
+        p.M, p.A_rows = rows, rows + 2
+        p.N, p.K, p.lda, p.ldo = cout, cin, cin, cout
         p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = self.K, 0, self.Tp, self.Tp, self.slope
         p.loader, p.epilogue, p.splitk, p.bm = LOAD_DIRECT, EPI_LRELU, 1, 128
-        check(self.lib.tl_gemm_nt_window(C.byref(p), torch.cuda.current_stream().cuda_stream), "tl_gemm_nt_window")
+        if wino:
+            p.ldb = 3 * cin
+            check(self.lib.tl_conv7_wino43_nt(C.byref(p), st_), "tl_conv7_wino43_nt")
+        else:
+            p.ldb, p.A_rows = cin, rows + 8
+            check(self.lib.tl_gemm_nt_window(C.byref(p), st_), "tl_gemm_nt_window")
 
     @torch.no_grad()
     def linear(self, a: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -295,9 +314,11 @@ class CnnRnnConvEngine:
                                    ptr(bits), None, n, self.T, self.K, 1024, self.Tp, self.t1, self.slope, st_),
                   "tl_conv1_fwd")
         row = self.Tp * 1024
-        P = torch.cat((self.Pb.view(B, self.w1, row), self.Pa.view(B, self.C, row)), dim=1).view(B * self.W * self.Tp, 1024)
-        self._conv7(P, conv3a[0], conv3a[1], self.Y1, 1024, 512, "conv3a")
-        self._conv7(self.Y1, conv3b[0], conv3b[1], self.Y2, 512, 256, "conv3b")
+        rows = B * self.W * self.Tp
+        torch.cat((self.Pb.view(B, self.w1, row), self.Pa.view(B, self.C, row)), dim=1,
+                  out=self.P[:rows].view(B, self.W, row))
+        self._conv7(self.P, conv3a[0], conv3a[1], self.Y1, 1024, 512, "conv3a", rows)
+        self._conv7(self.Y1, conv3b[0], conv3b[1], self.Y2, 512, 256, "conv3b", rows)
         y = self.Y2.view(B, self.W, self.Tp, 256)[:, :, :3 * self.tq]
         y = y.reshape(B, self.W, self.tq, 3, 256).amax(dim=3)                          # MaxPool (3,1)
         f = y.permute(0, 3, 2, 1).contiguous()                                         # (B, 256, t', W)

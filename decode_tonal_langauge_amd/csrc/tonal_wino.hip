@@ -32,7 +32,7 @@
 namespace tl {
 
 enum { W_LOAD_DIRECT = 0, W_LOAD_UNPOOL = 1 };
-enum { W_EPI_POOL = 2, W_EPI_MASK = 3, W_EPI_C1W = 4 };        // numbering of tl_nt_params.epilogue
+enum { W_EPI_LRELU = 1, W_EPI_POOL = 2, W_EPI_MASK = 3, W_EPI_C1W = 4 };   // numbering of tl_nt_params.epilogue
 
 constexpr int W_BP = 128;            // output pairs per workgroup (256 conv rows)
 constexpr int W_BN = 128;            // output columns per workgroup
@@ -521,7 +521,28 @@ __global__ void wino43_weights_kernel(const float* __restrict__ w, float* __rest
   }
 }
 
-template <int LOADER, int EPI>
+// taps-wide filter (O, I, taps) -> [6][O][nseg I]: segment s (columns s I ..) = F(4,3) transform of taps 3s..3s+2
+__global__ void wino43_weights7_kernel(const float* __restrict__ w, float* __restrict__ fwd, int O, int I, int taps, int nseg) {
+  const long long n = (long long)O * nseg * I;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % ((long long)nseg * I));
+  const long long o = idx / ((long long)nseg * I);
+  const int seg = c / I, i = c % I;
+  const float* s = w + (o * I + i) * taps + 3 * seg;
+  const float g0 = s[0], g1 = (3 * seg + 1 < taps) ? s[1] : 0.f, g2 = (3 * seg + 2 < taps) ? s[2] : 0.f;
+  const float sm = g0 + g2;
+  fwd[idx] = 0.25f * g0;
+  fwd[n + idx] = (-1.f / 6.f) * (sm + g1);
+  fwd[2 * n + idx] = (-1.f / 6.f) * (sm - g1);
+  fwd[3 * n + idx] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+  fwd[4 * n + idx] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+  fwd[5 * n + idx] = g2;
+}
+
+// NSEG > 1: a (3 NSEG - 2 .. 3 NSEG)-tap convolution as NSEG three-tap segments accumulated in the same
+// six products - segment s reads the input rows shifted by 3 s and the weight columns [s K, (s+1) K).
+template <int LOADER, int EPI, int NSEG = 1>
 __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p) {
   constexpr int NTHR = 512;
   constexpr int PLANE = W4_QR * W4_LD;
@@ -553,7 +574,8 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
   const int tn = (int)(bid % ntn);
   const long long R0 = tm * (4 * W4_BQ);
   const int n0 = tn * W4_BN;
-  const int nsteps = p.K / W4_BK;                         // host-checked: K % 16 == 0, K >= 16
+  const int cps = p.K / W4_BK;                            // host-checked: K % 16 == 0, K >= 16
+  const int nsteps = NSEG * cps;
 
   f32x16 acc[6];
 #pragma unroll
@@ -597,7 +619,15 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
   }
 
   auto load_a = [&](f32x4 (&ra)[A_F4], uint32_t (&rbits)[A_F4], int step) {
-    const int kc = step * W4_BK;
+    const auto kc = [&] {
+      if constexpr (NSEG > 1) {
+        static_assert(NSEG <= 3 && LOADER == W_LOAD_DIRECT, "segments: direct loader, at most three");
+        const int seg = (step >= cps) + (step >= 2 * cps);
+        return step * W4_BK + seg * (3LL * p.lda - p.K);  // next three input rows, channel 0
+      } else {
+        return step * W4_BK;
+      }
+    }();
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {                      // branch-free: see wino_nt_kernel
       ra[i] = *reinterpret_cast<const f32x4*>(aptr[i] + kc);
@@ -745,7 +775,7 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
   const int colbase = n0 + wn * 32;
   const bool colok = col < p.N;
   float bv = 0.f;
-  if constexpr (EPI == W_EPI_POOL) bv = (colok && p.bias) ? p.bias[col] : 0.f;
+  if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_LRELU) bv = (colok && p.bias) ? p.bias[col] : 0.f;
   uint32_t wbits = 0, wsign = 0;
   (void)wbits; (void)wsign;
   // MASK: the 64 sign words this lane group needs (rows 4 (Q0 + qo) + h), one per lane, fetched up front
@@ -784,12 +814,12 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
   c1w_acc ca;
   ca.clear();
   c1w_cursor cur;                                          // time index of the quad without per-row divisions
-  if constexpr (EPI != W_EPI_MASK) cur.init(p, 4 * Q0, colbase);
+  if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_C1W) cur.init(p, 4 * Q0, colbase);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int qo = (e & 3) + 8 * (e >> 2);
     const long long Q = Q0 + qo;
-    if constexpr (EPI != W_EPI_MASK)
+    if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_C1W)
       if (e > 0) cur.advance(p, (e & 3) ? 4 : 20);           // quad offsets 0,1,2,3, 8,.. -> row steps 4,4,4,20
     const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
     const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
@@ -815,6 +845,12 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
           wbits = (uint32_t)(m >> (32 * lh));
           wsign = (uint32_t)(ms >> (32 * lh));
         }
+      }
+    } else if constexpr (EPI == W_EPI_LRELU) {
+      const long long R = 4 * Q;
+      if (R < p.M && colok) {                               // M % 4 == 0: the quad shares validity
+#pragma unroll
+        for (int h = 0; h < 4; ++h) p.out[(R + h) * (long long)p.ldo + col] = lrelu(y[h] + bv, p.slope);
       }
     } else if constexpr (EPI == W_EPI_C1W) {
       {
@@ -1209,6 +1245,37 @@ extern "C" int tl_conv3_wino43_nt(const tl_nt_params* pp, void* stream) {
     return TL_EINVAL;
   }
   return check_launch("wino43_nt");
+}
+
+extern "C" int tl_wino43_weights7(const float* w, float* fwd, int O, int I, int taps, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(w != nullptr && fwd != nullptr, "wino43_weights7: null pointer");
+  TL_REQUIRE(O > 0 && I > 0 && taps >= 4 && taps <= 9, "wino43_weights7: bad sizes (4..9 taps)");
+  const int nseg = (taps + 2) / 3;
+  const long long n = (long long)O * nseg * I;
+  TL_REQUIRE(n < (1LL << 31), "wino43_weights7: too large");
+  hipLaunchKernelGGL(wino43_weights7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, fwd,
+                     O, I, taps, nseg);
+  return check_launch("wino43_weights7");
+}
+
+extern "C" int tl_conv7_wino43_nt(const tl_nt_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "conv7_wino43: null params");
+  const tl_nt_params& p = *pp;
+  TL_REQUIRE(p.A && p.Bw && p.out, "conv7_wino43: null A/Bw/out");
+  TL_REQUIRE(p.J >= 7 && p.J <= 9, "conv7_wino43: 7..9 taps (three segments)");
+  TL_REQUIRE(p.M >= 0 && p.M % 4 == 0 && p.N > 0 && p.K > 0, "conv7_wino43: bad M/N/K %lld/%d/%d", (long long)p.M, p.N, p.K);
+  TL_REQUIRE(p.K % 32 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "conv7_wino43: K %% 32, lda %% 4, ldb %% 4 must be 0");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= 3 * p.K, "conv7_wino43: lda < K or ldb < 3 K");
+  TL_REQUIRE(p.loader == W_LOAD_DIRECT && p.epilogue == W_EPI_LRELU && p.row_shift == 0 && p.splitk <= 1,
+             "conv7_wino43: DIRECT loader, LRELU epilogue, row_shift 0, no split-K");
+  const long long nwg = ((p.M + 4 * W4_BQ - 1) / (4 * W4_BQ)) * ((p.N + W4_BN - 1) / W4_BN);
+  if (nwg <= 0) return TL_OK;
+  TL_REQUIRE(nwg < (1LL << 31), "conv7_wino43: grid too large");
+  hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_DIRECT, W_EPI_LRELU, 3>), dim3((unsigned)nwg), dim3(512), 0,
+                     (hipStream_t)stream, p);
+  return check_launch("conv7_wino43");
 }
 
 extern "C" int tl_conv3_wino_tn(const tl_tn_params* pp, void* stream) {

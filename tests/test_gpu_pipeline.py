@@ -69,6 +69,56 @@ def test_deep_classifiers_hip_forward_matches_reference_golden(dev):
             assert rel(h1.cpu().numpy(), g[f"cnnrnn{i}.h1"]) < 1e-4
 
 
+@pytest.mark.parametrize("nseq,Tp,cin,cout,taps", [(3, 20, 64, 96, 7), (2, 516, 32, 40, 7), (1, 8, 96, 64, 8), (5, 12, 32, 33, 9)])
+def test_segmented_winograd_conv7_against_float64(dev, nseq, Tp, cin, cout, taps):
+    """tl_conv7_wino43_nt (three F(4,3) segments) vs a float64 sliding-window convolution + LeakyReLU over
+    every row of the buffer, seams between sequences included (the classifier reads only the valid rows
+    but the kernel computes all of them): ragged column tile (cout not a multiple of 64), partial row
+    tile, 7 / 8 / 9 taps."""
+    import ctypes as C
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._lib import NtParams, LOAD_DIRECT, EPI_LRELU, check, ptr
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(100 * nseq + taps)
+    rows = nseq * Tp
+    x = torch.zeros(rows + 8, cin)
+    x[:rows] = torch.randn(rows, cin, generator=gen)
+    x[rows:] = torch.randn(8, cin, generator=gen)         # readable slack rows: must only reach rows >= rows - taps + 1
+    w = torch.randn(cout, cin, taps, generator=gen) / np.sqrt(cin * taps)
+    b = torch.randn(cout, generator=gen)
+    xd, wd, bd = x.to(dev), w.to(dev).contiguous(), b.to(dev)
+    wp = torch.empty(6, cout, 3 * cin, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.tl_wino43_weights7(ptr(wd), ptr(wp), cout, cin, taps, st), "tl_wino43_weights7")
+    out = torch.full((rows, cout), float("nan"), device=dev)
+    p = NtParams()
+    p.A, p.Bw, p.bias, p.out = ptr(xd), ptr(wp), ptr(bd), ptr(out)
+    p.M, p.A_rows, p.N, p.K, p.lda, p.ldb, p.ldo = rows, rows + 2, cout, cin, cin, 3 * cin, cout
+    p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = taps, 0, Tp, Tp, 0.3
+    p.loader, p.epilogue, p.splitk, p.bm = LOAD_DIRECT, EPI_LRELU, 1, 128
+    check(lib.tl_conv7_wino43_nt(C.byref(p), st), "tl_conv7_wino43_nt")
+    torch.cuda.synchronize()
+    x64 = x.double()
+    ref = torch.zeros(rows, cout, dtype=torch.float64)
+    for j in range(taps):
+        xs = torch.zeros(rows, cin, dtype=torch.float64)
+        n = min(rows, rows + 8 - j)
+        xs[:n] = x64[j:j + n]
+        # the kernel reads input row r only while its segment-local row < A_rows = rows + 2
+        seg_local = torch.arange(rows) + (j % 3)
+        xs[seg_local >= rows + 2] = 0
+        ref += xs @ w[:, :, j].double().T
+    ref = torch.nn.functional.leaky_relu(ref + b.double(), 0.3)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    # bad arguments are refused
+    p.ldb = 2 * cin
+    assert lib.tl_conv7_wino43_nt(C.byref(p), st) != 0 and b"ldb" in lib.tl_last_error()
+    p.ldb, p.J = 3 * cin, 3
+    assert lib.tl_conv7_wino43_nt(C.byref(p), st) != 0
+
+
 def _chain_steps():
     return deepcopy(gi.CHAIN_STEPS)
 
