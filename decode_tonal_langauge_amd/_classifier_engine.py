@@ -230,10 +230,12 @@ class CnnRnnConvEngine:
         if self.tq < 1:
             raise ValueError("input_length too small for the CNN-RNN convolution stack")
         self.Tp = (self.t1 + 3) // 4 * 4
-        # 7-tap stack: three F(4,3) segments per convolution (default) or the direct 7-tap window GEMM
-        self.conv7_form = os.environ.get("TONAL_CONV7", "wino43")
-        if self.conv7_form not in ("wino43", "direct"):
-            raise ValueError("TONAL_CONV7 must be wino43 or direct")
+        # 7-tap stack: "wino43+1" (default) two F(4,3) segments (taps 0..5) plus tap 6 as a one-tap GEMM
+        # added in the epilogue; "wino43" three segments; "direct" the 7-tap window GEMM.  CNN-RNN forward at
+        # C5 (batch 64): 57.0 / 60.3 / 72.8 ms
+        self.conv7_form = os.environ.get("TONAL_CONV7", "wino43+1")
+        if self.conv7_form not in ("wino43", "wino43+1", "direct"):
+            raise ValueError("TONAL_CONV7 must be wino43, wino43+1 or direct")
         self._packed: Dict[str, Tuple[tuple, torch.Tensor]] = {}
         self._B = None
 
@@ -255,22 +257,29 @@ class CnnRnnConvEngine:
         rows = B * self.W * self.Tp
         # + 8 rows: the segmented convolution reads up to 6 rows past the last row it is asked about
         self.P, self.Y1, self.Y2 = z(rows + 8, 1024), z(rows + 8, 512), z(rows, 256)
+        self.Tap = z(rows, 512) if self.conv7_form == "wino43+1" else None
 
     def _conv7(self, src, w, b, dst, cin, cout, key, rows):
         """dst[r] = lrelu(sum_j w[:, :, j] src[r + j] + b) for r < rows; src holds rows + 8 rows."""
         from ._lib import NtParams
         import ctypes as C
         st_ = torch.cuda.current_stream().cuda_stream
-        wino = self.conv7_form == "wino43" and cin % 32 == 0
+        wino = self.conv7_form != "direct" and cin % 32 == 0
+        nseg = 2 if self.conv7_form == "wino43+1" else 3
 
         def pack():
             if not wino:
                 return w.detach().reshape(cout, cin, self.K).permute(2, 0, 1).contiguous()   # [J][O][I]
-            wp = torch.empty(6, cout, 3 * cin, dtype=torch.float32, device=w.device)
+            wp = torch.empty(6, cout, nseg * cin, dtype=torch.float32, device=w.device)
             check(self.lib.tl_wino43_weights7(ptr(w.detach().reshape(cout, cin, self.K).contiguous()), ptr(wp), cout, cin,
-                                              self.K, st_), "tl_wino43_weights7")
+                                              self.K, nseg, st_), "tl_wino43_weights7")
             return wp
         wp = self._cached(key + self.conv7_form, w, pack)
+        if wino and nseg == 2:
+            w6 = self._cached(key + "tap6", w, lambda: w.detach().reshape(cout, cin, self.K)[:, :, 6].contiguous())
+            tap = self.Tap[:, :cout]
+            _launch_nt(self.lib, A=src.data_ptr() + 4 * 6 * cin, Bw=ptr(w6), out=ptr(tap), M=rows, A_rows=rows + 2, N=cout,
+                       K=cin, lda=cin, ldb=cin, ldo=tap.stride(0), loader=LOAD_DIRECT, epilogue=EPI_STORE)
         p = NtParams()
         p.A, p.Bw, p.bias, p.out = ptr(src), ptr(wp), ptr(b.detach()), ptr(dst)
         p.M, p.A_rows = rows, rows + 2
@@ -278,7 +287,9 @@ class CnnRnnConvEngine:
         p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = self.K, 0, self.Tp, self.Tp, self.slope
         p.loader, p.epilogue, p.splitk, p.bm = LOAD_DIRECT, EPI_LRELU, 1, 128
         if wino:
-            p.ldb = 3 * cin
+            p.ldb = nseg * cin
+            if nseg == 2:
+                p.J, p.aux, p.ldaux = 6, ptr(self.Tap), self.Tap.stride(0)
             check(self.lib.tl_conv7_wino43_nt(C.byref(p), st_), "tl_conv7_wino43_nt")
         else:
             p.ldb, p.A_rows = cin, rows + 8

@@ -850,7 +850,11 @@ __global__ __launch_bounds__(512, 2) void wino43_nt_kernel(const tl_nt_params p)
       const long long R = 4 * Q;
       if (R < p.M && colok) {                               // M % 4 == 0: the quad shares validity
 #pragma unroll
-        for (int h = 0; h < 4; ++h) p.out[(R + h) * (long long)p.ldo + col] = lrelu(y[h] + bv, p.slope);
+        for (int h = 0; h < 4; ++h) {
+          // aux: taps the segments do not cover, accumulated by the caller (pre-activation, no bias)
+          const float extra = p.aux != nullptr ? p.aux[(R + h) * (long long)p.ldaux + col] : 0.f;
+          p.out[(R + h) * (long long)p.ldo + col] = lrelu((y[h] + extra) + bv, p.slope);
+        }
       }
     } else if constexpr (EPI == W_EPI_C1W) {
       {
@@ -1247,11 +1251,11 @@ extern "C" int tl_conv3_wino43_nt(const tl_nt_params* pp, void* stream) {
   return check_launch("wino43_nt");
 }
 
-extern "C" int tl_wino43_weights7(const float* w, float* fwd, int O, int I, int taps, void* stream) {
+extern "C" int tl_wino43_weights7(const float* w, float* fwd, int O, int I, int taps, int nseg, void* stream) {
   using namespace tl;
   TL_REQUIRE(w != nullptr && fwd != nullptr, "wino43_weights7: null pointer");
   TL_REQUIRE(O > 0 && I > 0 && taps >= 4 && taps <= 9, "wino43_weights7: bad sizes (4..9 taps)");
-  const int nseg = (taps + 2) / 3;
+  TL_REQUIRE((nseg == 2 || nseg == 3) && 3 * (nseg - 1) < taps, "wino43_weights7: 2 or 3 segments, each with a tap");
   const long long n = (long long)O * nseg * I;
   TL_REQUIRE(n < (1LL << 31), "wino43_weights7: too large");
   hipLaunchKernelGGL(wino43_weights7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, fwd,
@@ -1264,17 +1268,23 @@ extern "C" int tl_conv7_wino43_nt(const tl_nt_params* pp, void* stream) {
   TL_REQUIRE(pp != nullptr, "conv7_wino43: null params");
   const tl_nt_params& p = *pp;
   TL_REQUIRE(p.A && p.Bw && p.out, "conv7_wino43: null A/Bw/out");
-  TL_REQUIRE(p.J >= 7 && p.J <= 9, "conv7_wino43: 7..9 taps (three segments)");
+  TL_REQUIRE(p.J >= 4 && p.J <= 9, "conv7_wino43: 4..6 taps (two segments) or 7..9 (three)");
+  const int nseg = (p.J + 2) / 3;
   TL_REQUIRE(p.M >= 0 && p.M % 4 == 0 && p.N > 0 && p.K > 0, "conv7_wino43: bad M/N/K %lld/%d/%d", (long long)p.M, p.N, p.K);
   TL_REQUIRE(p.K % 32 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "conv7_wino43: K %% 32, lda %% 4, ldb %% 4 must be 0");
-  TL_REQUIRE(p.lda >= p.K && p.ldb >= 3 * p.K, "conv7_wino43: lda < K or ldb < 3 K");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= nseg * p.K, "conv7_wino43: lda < K or ldb < segments * K");
+  TL_REQUIRE(p.aux == nullptr || p.ldaux >= p.N, "conv7_wino43: ldaux < N");
   TL_REQUIRE(p.loader == W_LOAD_DIRECT && p.epilogue == W_EPI_LRELU && p.row_shift == 0 && p.splitk <= 1,
              "conv7_wino43: DIRECT loader, LRELU epilogue, row_shift 0, no split-K");
   const long long nwg = ((p.M + 4 * W4_BQ - 1) / (4 * W4_BQ)) * ((p.N + W4_BN - 1) / W4_BN);
   if (nwg <= 0) return TL_OK;
   TL_REQUIRE(nwg < (1LL << 31), "conv7_wino43: grid too large");
-  hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_DIRECT, W_EPI_LRELU, 3>), dim3((unsigned)nwg), dim3(512), 0,
-                     (hipStream_t)stream, p);
+  if (nseg == 3)
+    hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_DIRECT, W_EPI_LRELU, 3>), dim3((unsigned)nwg), dim3(512), 0,
+                       (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((wino43_nt_kernel<W_LOAD_DIRECT, W_EPI_LRELU, 2>), dim3((unsigned)nwg), dim3(512), 0,
+                       (hipStream_t)stream, p);
   return check_launch("conv7_wino43");
 }
 

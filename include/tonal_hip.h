@@ -120,9 +120,12 @@ int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
  *                          per 4 conv rows; taps [6][N][ldb]; M and Tp multiples of 4)
  *   tl_wino43_weights7 / tl_conv7_wino43_nt: a 7..9-tap (k,1) convolution + LeakyReLU (the CNN-RNN
  *                          classifier's 1024 -> 512 -> 256 stack, models/deep_classifiers.py:247-256) as
- *                          three F(4,3) segments accumulated in the same six products: w (O, I, taps) ->
- *                          fwd [6][O][3 I]; DIRECT loader, LRELU epilogue, ldb >= 3 K, M % 4 == 0;
- *                          segment s reads input rows shifted by 3 s, so A must hold A_rows + 6 rows
+ *                          nseg = ceil(J / 3) F(4,3) segments accumulated in the same six products:
+ *                          w (O, I, taps) -> fwd [6][O][nseg I] (taps 0 .. 3 nseg - 1); DIRECT loader,
+ *                          LRELU epilogue, ldb >= nseg K, M % 4 == 0; segment s reads input rows shifted
+ *                          by 3 s, so A must hold A_rows + 3 (nseg - 1) rows.  aux (optional, ldaux): a
+ *                          pre-activation term added before bias + LeakyReLU - e.g. J = 6 covers taps
+ *                          0..5 of a 7-tap filter and aux holds tap 6 from a one-tap tl_gemm_nt_window
  *   tl_conv3_wino43_tn / tl_wino43_wgrad_finalize: the F(4,3) form of the weight gradient (6 outer
  *                          products per 4 conv rows; slab[z][6][Mdim][ldc], slab_stride >= 6*Mdim*ldc;
  *                          Krows and Tp multiples of 4); red [6][I][ld] -> dW (O, I, 3, 1)
@@ -130,7 +133,7 @@ int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
 int tl_wino_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
 int tl_wino43_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
 int tl_conv3_wino43_nt(const tl_nt_params* p, void* stream);
-int tl_wino43_weights7(const float* w, float* fwd, int O, int I, int taps, void* stream);
+int tl_wino43_weights7(const float* w, float* fwd, int O, int I, int taps, int nseg, void* stream);
 int tl_conv7_wino43_nt(const tl_nt_params* p, void* stream);
 int tl_conv3_wino_nt(const tl_nt_params* p, void* stream);
 int tl_conv3_wino_tn(const tl_tn_params* p, void* stream);

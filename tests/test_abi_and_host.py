@@ -42,8 +42,9 @@ def test_abi_argument_validation_without_gpu():
     assert lib.tl_nadam_lowrank(16, 16, 16, 16, 16, 65, 8, 8, 8, 8, 0., 0., .9, .999, 1., 1e-8, 0., 1., None) == -1
     assert b"rank" in lib.tl_last_error()
     assert lib.tl_conv3_wino43_nt(None, None) == -1 and lib.tl_conv3_wino_tn(None, None) == -1
-    assert lib.tl_conv7_wino43_nt(None, None) == -1 and lib.tl_wino43_weights7(None, None, 8, 8, 7, None) == -1
-    assert lib.tl_wino43_weights7(16, 16, 8, 8, 3, None) == -1 and b"taps" in lib.tl_last_error()
+    assert lib.tl_conv7_wino43_nt(None, None) == -1 and lib.tl_wino43_weights7(None, None, 8, 8, 7, 3, None) == -1
+    assert lib.tl_wino43_weights7(16, 16, 8, 8, 3, 2, None) == -1 and b"taps" in lib.tl_last_error()
+    assert lib.tl_wino43_weights7(16, 16, 8, 8, 6, 3, None) == -1 and b"segments" in lib.tl_last_error()
     assert lib.tl_filtfilt_f64(16, 1, 16, 16, 16, 16, 16, 2, 20, 9, None) == -1
     assert b"padlen" in lib.tl_last_error()
     assert lib.tl_gauss_envelope(16, 1, 16, 16, 2, 100, 8, 200, 0, 1, None) == -1

@@ -69,12 +69,14 @@ def test_deep_classifiers_hip_forward_matches_reference_golden(dev):
             assert rel(h1.cpu().numpy(), g[f"cnnrnn{i}.h1"]) < 1e-4
 
 
-@pytest.mark.parametrize("nseq,Tp,cin,cout,taps", [(3, 20, 64, 96, 7), (2, 516, 32, 40, 7), (1, 8, 96, 64, 8), (5, 12, 32, 33, 9)])
-def test_segmented_winograd_conv7_against_float64(dev, nseq, Tp, cin, cout, taps):
+@pytest.mark.parametrize("nseq,Tp,cin,cout,taps,nseg", [(3, 20, 64, 96, 7, 3), (2, 516, 32, 40, 7, 3), (1, 8, 96, 64, 8, 3),
+                                                        (5, 12, 32, 33, 9, 3), (2, 516, 32, 40, 7, 2), (3, 20, 64, 96, 5, 2)])
+def test_segmented_winograd_conv7_against_float64(dev, nseq, Tp, cin, cout, taps, nseg):
     """tl_conv7_wino43_nt (three F(4,3) segments) vs a float64 sliding-window convolution + LeakyReLU over
     every row of the buffer, seams between sequences included (the classifier reads only the valid rows
     but the kernel computes all of them): ragged column tile (cout not a multiple of 64), partial row
-    tile, 7 / 8 / 9 taps."""
+    tile, 7 / 8 / 9 taps in three segments, and two segments with the remaining tap (if any) supplied
+    through ``aux`` by a one-tap window GEMM - the form the CNN-RNN classifier engine uses."""
     import ctypes as C
     from decode_tonal_langauge_amd import _lib
     from decode_tonal_langauge_amd._lib import NtParams, LOAD_DIRECT, EPI_LRELU, check, ptr
@@ -87,15 +89,26 @@ def test_segmented_winograd_conv7_against_float64(dev, nseq, Tp, cin, cout, taps
     w = torch.randn(cout, cin, taps, generator=gen) / np.sqrt(cin * taps)
     b = torch.randn(cout, generator=gen)
     xd, wd, bd = x.to(dev), w.to(dev).contiguous(), b.to(dev)
-    wp = torch.empty(6, cout, 3 * cin, device=dev)
+    wp = torch.empty(6, cout, nseg * cin, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    check(lib.tl_wino43_weights7(ptr(wd), ptr(wp), cout, cin, taps, st), "tl_wino43_weights7")
+    check(lib.tl_wino43_weights7(ptr(wd), ptr(wp), cout, cin, taps, nseg, st), "tl_wino43_weights7")
     out = torch.full((rows, cout), float("nan"), device=dev)
     p = NtParams()
     p.A, p.Bw, p.bias, p.out = ptr(xd), ptr(wp), ptr(bd), ptr(out)
-    p.M, p.A_rows, p.N, p.K, p.lda, p.ldb, p.ldo = rows, rows + 2, cout, cin, cin, 3 * cin, cout
-    p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = taps, 0, Tp, Tp, 0.3
+    p.M, p.A_rows, p.N, p.K, p.lda, p.ldb, p.ldo = rows, rows + 2, cout, cin, cin, nseg * cin, cout
+    p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = min(taps, 3 * nseg), 0, Tp, Tp, 0.3
     p.loader, p.epilogue, p.splitk, p.bm = LOAD_DIRECT, EPI_LRELU, 1, 128
+    if taps > 3 * nseg:                                    # tap 6 of 7 by a one-tap GEMM on the rows shifted by 6
+        assert taps == 3 * nseg + 1
+        from decode_tonal_langauge_amd._lib import EPI_STORE
+        w_last = wd[:, :, taps - 1].contiguous()
+        tap = torch.full((rows, cout + 4), float("nan"), device=dev)
+        q = NtParams()
+        q.A, q.Bw, q.out = xd.data_ptr() + 4 * (taps - 1) * cin, ptr(w_last), ptr(tap)
+        q.M, q.A_rows, q.N, q.K, q.lda, q.ldb, q.ldo = rows, rows + 2, cout, cin, cin, cin, cout + 4
+        q.J, q.Tp, q.Tvalid, q.loader, q.epilogue, q.splitk, q.bm = 1, 1, 1, LOAD_DIRECT, EPI_STORE, 1, 128
+        check(lib.tl_gemm_nt_window(C.byref(q), st), "tl_gemm_nt_window")
+        p.aux, p.ldaux = ptr(tap), cout + 4
     check(lib.tl_conv7_wino43_nt(C.byref(p), st), "tl_conv7_wino43_nt")
     torch.cuda.synchronize()
     x64 = x.double()
@@ -113,9 +126,9 @@ def test_segmented_winograd_conv7_against_float64(dev, nseq, Tp, cin, cout, taps
     assert torch.isfinite(got).all()
     assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
     # bad arguments are refused
-    p.ldb = 2 * cin
+    p.ldb = (nseg - 1) * cin
     assert lib.tl_conv7_wino43_nt(C.byref(p), st) != 0 and b"ldb" in lib.tl_last_error()
-    p.ldb, p.J = 3 * cin, 3
+    p.ldb, p.J = nseg * cin, 3
     assert lib.tl_conv7_wino43_nt(C.byref(p), st) != 0
 
 
