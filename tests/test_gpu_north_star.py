@@ -219,7 +219,7 @@ def test_train_mode_dropout_mask_forward_and_gradients_against_oracle(dev):
     ref_loss = so.l1_loss(ref, tg[0].long())
     ref_grads = dict(zip(leaves, torch.autograd.grad(ref_loss, list(leaves.values()))))
     assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
-    assert abs(float(loss) - float(ref_loss)) < 1e-5 * float(ref_loss)
+    assert abs(float(loss.detach()) - float(ref_loss)) < 1e-5 * float(ref_loss)
     for k, p in model.named_parameters():
         assert rel_l2(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 5e-3, k
 
