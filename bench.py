@@ -237,7 +237,7 @@ def lite_subresult(dev, steps: int = 200, warm: int = 20):
     flop = 13.85e6 * B                               # 13.85 MFLOP per window per train step
     return {"workload": "SynthesisLite 32ch x 200t -> 80 mel, batch 64, dropout 0.3, NAdam, 919,312 params (C2)",
             "value": round(B / (ms * 1e-3), 1), "unit": "mel-frames/s", "ms_per_step": round(ms, 4), "steps": steps,
-            "warmup": warm, "bound": "launch latency (~66 small kernels per step; tensors are KB-MB)",
+            "warmup": warm, "bound": "launch latency (~50 small kernels per step; tensors are KB-MB)",
             "algorithmic_gflops": round(flop / (ms * 1e-3) / 1e9, 1),
             "cpu_reference_ms_per_step": 19.0, "cpu_reference_note": "SURVEY section 6: reference trainer on 8 host cores"}
 

@@ -87,6 +87,8 @@ SIGNATURES = {
                                   C.c_uint64, _L, _P]),
     "tl_l1_mcd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "tl_nadam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "tl_nadam_multi": (_I, [_P, _I, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "tl_nadam_multi_chunk": (_I, []),
     "tl_nadam_lowrank": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_tone_dynamics": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "tl_lite_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

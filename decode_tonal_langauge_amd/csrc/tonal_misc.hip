@@ -570,12 +570,14 @@ __global__ __launch_bounds__(256) void l1_mcd_kernel(const float* __restrict__ o
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void nadam_one(float& p, float g, float& m, float& v, float cg, float cm, float b1,
                                           float b2, float bc2, float eps, float wd, float gscale) {
+  // every multiply-add is an explicit fma: the three kernels that inline this (per tensor, tensor list,
+  // low rank) then round identically whatever the compiler would have contracted in their loops
   g = fmaf(wd, p, g * gscale);
-  m = m + (g - m) * (1.f - b1);
+  m = fmaf(g - m, 1.f - b1, m);
   v = fmaf(v, b2, (1.f - b2) * g * g);
   const float denom = sqrtf(v / bc2) + eps;
-  p = p - cg * (g / denom);
-  p = p - cm * (m / denom);
+  p = fmaf(-cg, g / denom, p);
+  p = fmaf(-cm, m / denom, p);
 }
 __global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n, float cg,
@@ -602,6 +604,47 @@ __global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ p, const
   }
   for (long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride)
     nadam_one(p[i], g[i], m[i], v[i], cg, cm, b1, b2, bc2, eps, wd, gscale);
+}
+
+// The same update for a whole list of tensors in one launch (a model's many small tensors cost a
+// launch each otherwise: 16 of the 66 launches of a SynthesisLite step).  A block owns one
+// NM_CHUNK-element chunk of one tensor; entries[e].block0 = first block of tensor e (ascending).
+constexpr int NM_CHUNK = 256 * 16;
+__global__ __launch_bounds__(256) void nadam_multi_kernel(const tl_nadam_entry* __restrict__ entries, int count, float cg,
+                                                          float cm, float b1, float b2, float bc2, float eps, float wd,
+                                                          float gscale) {
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = count - 1;                         // last entry with block0 <= blk
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (entries[mid].block0 <= blk) lo = mid; else hi = mid - 1;
+  }
+  const tl_nadam_entry e = entries[lo];
+  const long long base = (blk - e.block0) * NM_CHUNK;
+  const long long end = (base + NM_CHUNK < e.n) ? base + NM_CHUNK : e.n;
+  float* __restrict__ p = e.p;
+  const float* __restrict__ g = e.g;
+  float* __restrict__ m = e.m;
+  float* __restrict__ v = e.v;
+  const long long end4 = base + ((end - base) & ~3LL);
+  for (long long i = base + 4 * threadIdx.x; i < end4; i += 4 * 256) {
+    f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+    f32x4 mv = *reinterpret_cast<f32x4*>(m + i);
+    f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float pq = pv[q], mq = mv[q], vq = vv[q];
+      nadam_one(pq, gv[q], mq, vq, cg, cm, b1, b2, bc2, eps, wd, gscale);
+      pv[q] = pq;
+      mv[q] = mq;
+      vv[q] = vq;
+    }
+    *reinterpret_cast<f32x4*>(p + i) = pv;
+    *reinterpret_cast<f32x4*>(m + i) = mv;
+    *reinterpret_cast<f32x4*>(v + i) = vv;
+  }
+  for (long long i = end4 + threadIdx.x; i < end; i += 256) nadam_one(p[i], g[i], m[i], v[i], cg, cm, b1, b2, bc2, eps, wd, gscale);
 }
 
 // NAdam on a parameter whose gradient is low rank: g = fa^T . fb (fa: kr x rows, fb: kr x cols),
@@ -889,6 +932,18 @@ extern "C" int tl_nadam(float* p, const float* g, float* m, float* v, int64_t n,
                      m, v, (long long)n, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps, weight_decay, grad_scale);
   return check_launch("nadam");
 }
+
+extern "C" int tl_nadam_multi(const tl_nadam_entry* entries_dev, int count, int64_t total_blocks, float coef_grad,
+                              float coef_mom, float beta1, float beta2, float bias_corr2, float eps, float weight_decay,
+                              float grad_scale, void* stream) {
+  TL_REQUIRE(entries_dev != nullptr && count > 0, "nadam_multi: empty table");
+  TL_REQUIRE(total_blocks > 0 && total_blocks < (1LL << 31), "nadam_multi: bad block count %lld", (long long)total_blocks);
+  hipLaunchKernelGGL(nadam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, entries_dev, count,
+                     coef_grad, coef_mom, beta1, beta2, bias_corr2, eps, weight_decay, grad_scale);
+  return check_launch("nadam_multi");
+}
+
+extern "C" int tl_nadam_multi_chunk(void) { return NM_CHUNK; }
 
 extern "C" int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
                                 int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,

@@ -6,6 +6,7 @@ Same update rule and defaults as ``torch.optim.NAdam`` built by the reference tr
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, Optional
 
 import torch
@@ -35,6 +36,8 @@ class FusedNAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       momentum_decay=momentum_decay))
         self._lib = _lib.load()
+        self._tables = {}
+        self.multi_tensor = os.environ.get("TONAL_NADAM_MULTI", "1") != "0"
 
     def _state_for(self, p, shard_rows=None):
         """``shard_rows`` = (row0, rows): this rank owns (and keeps moments for) only those rows of ``p``."""
@@ -62,6 +65,7 @@ class FusedNAdam(torch.optim.Optimizer):
         [row0, row0 + n) of the parameter (a data-parallel rank that owns a row shard of it)."""
         loss = closure() if closure is not None else None
         stream = torch.cuda.current_stream().cuda_stream
+        dense = {}
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -98,9 +102,40 @@ class FusedNAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedNAdam needs contiguous parameters and gradients")
                 st = self._state_for(p)
                 st["step"] += 1
-                cg, cm, bc2, st["mu_product"] = nadam_scalars(st["step"], st["mu_product"], group["lr"], b1, b2,
-                                                              group["momentum_decay"])
-                check(self._lib.tl_nadam(ptr(p), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel(), cg, cm,
-                                         b1, b2, bc2, group["eps"], group["weight_decay"], grad_scale, stream),
-                      "tl_nadam")
+                dense.setdefault((st["step"], st["mu_product"]), []).append((p, g, st))
+            # tensors at the same point of the schedule (normally all of them) share one launch
+            for (step_no, mu_prod), items in dense.items():
+                cg, cm, bc2, mu_prod = nadam_scalars(step_no, mu_prod, group["lr"], b1, b2, group["momentum_decay"])
+                for _, _, st in items:
+                    st["mu_product"] = mu_prod
+                if len(items) == 1 or not self.multi_tensor:
+                    for p, g, st in items:
+                        check(self._lib.tl_nadam(ptr(p), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel(), cg,
+                                                 cm, b1, b2, bc2, group["eps"], group["weight_decay"], grad_scale, stream),
+                              "tl_nadam")
+                    continue
+                table, blocks = self._table(items)
+                check(self._lib.tl_nadam_multi(ptr(table), len(items), blocks, cg, cm, b1, b2, bc2, group["eps"],
+                                               group["weight_decay"], grad_scale, stream), "tl_nadam_multi")
+            dense.clear()
         return loss
+
+    def _table(self, items):
+        """Device table of ``tl_nadam_entry`` rows for ``items`` = [(param, grad, state)], cached while the
+        pointers stay the same (the fused trainer keeps its gradient buffers)."""
+        key = tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                    for p, g, st in items)
+        hit = self._tables.get(key)
+        if hit is None:
+            if len(self._tables) > 8:
+                self._tables.clear()
+            chunk = self._lib.tl_nadam_multi_chunk()
+            rows, block0 = [], 0
+            for pp, gp, mp, vp, n in key:
+                if (pp | gp | mp | vp) & 15:
+                    raise RuntimeError("FusedNAdam: parameter / gradient storage must be 16-byte aligned")
+                rows.append((pp, gp, mp, vp, n, block0))
+                block0 += (n + chunk - 1) // chunk
+            dev = items[0][0].device
+            hit = self._tables[key] = (torch.tensor(rows, dtype=torch.int64).to(dev), block0)
+        return hit

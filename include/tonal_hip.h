@@ -216,6 +216,14 @@ int tl_nadam(float* p, const float* g, float* m, float* v, int64_t n, float coef
 /* the same update for a parameter (rows x cols) whose gradient is low rank, g = fa^T . fb with
  * fa (kr, rows), fb (kr, cols), kr <= 64: the gradient is formed in registers and never stored
  * (label_lstm.weight_hh_l0: 5.4 GB less written and read per step).                              */
+/* One launch for a list of tensors sharing the step's scalars.  entries (DEVICE memory, count of them,
+ * every pointer 16-byte aligned): block0 = first block of the tensor = sum over the tensors before it of
+ * ceil(n / tl_nadam_multi_chunk()); total_blocks = that sum over all.  Same arithmetic as tl_nadam.   */
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; int64_t block0; } tl_nadam_entry;
+int tl_nadam_multi(const tl_nadam_entry* entries_dev, int count, int64_t total_blocks, float coef_grad, float coef_mom,
+                   float beta1, float beta2, float bias_corr2, float eps, float weight_decay, float grad_scale,
+                   void* stream);
+int tl_nadam_multi_chunk(void);
 int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
                      int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
                      float bias_corr2, float eps, float weight_decay, float grad_scale, void* stream);

@@ -39,6 +39,7 @@ def test_abi_argument_validation_without_gpu():
     t = _lib.TnParams()
     assert lib.tl_gemm_tn_window(C.byref(t), None) == -1
     assert lib.tl_nadam(None, None, None, None, 10, 0., 0., .9, .999, 1., 1e-8, 0., 1., None) == -1
+    assert lib.tl_nadam_multi(None, 3, 3, 0., 0., .9, .999, 1., 1e-8, 0., 1., None) == -1 and lib.tl_nadam_multi_chunk() > 0
     assert lib.tl_nadam_lowrank(16, 16, 16, 16, 16, 65, 8, 8, 8, 8, 0., 0., .9, .999, 1., 1e-8, 0., 1., None) == -1
     assert b"rank" in lib.tl_last_error()
     assert lib.tl_conv3_wino43_nt(None, None) == -1 and lib.tl_conv3_wino_tn(None, None) == -1

@@ -575,6 +575,37 @@ def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
             assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-6
 
 
+def test_multi_tensor_nadam_equals_per_tensor_launches_and_torch(dev):
+    """tl_nadam_multi (one launch for a parameter list) is bit-identical to one tl_nadam launch per tensor and
+    follows torch.optim.NAdam (reference models/synthesis_trainer.py:131-137): sizes below / above a chunk,
+    not multiples of 4, a parameter that skips a step (its schedule then differs from the others')."""
+    from decode_tonal_langauge_amd.optim import FusedNAdam
+    sizes = [(80,), (3, 5), (4096,), (4097,), (129, 67), (1, 1), (70000,)]
+    gen = torch.Generator().manual_seed(5)
+    init = [torch.randn(*sz, generator=gen) for sz in sizes]
+    pm = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pt = [torch.nn.Parameter(t.clone().double()) for t in init]
+    om = FusedNAdam(pm, lr=5e-3, weight_decay=0.004)
+    os_ = FusedNAdam(ps, lr=5e-3, weight_decay=0.004)
+    os_.multi_tensor = False
+    ot = torch.optim.NAdam(pt, lr=5e-3, weight_decay=0.004)
+    assert om.multi_tensor
+    for step in range(4):
+        grads = [torch.randn(*sz, generator=gen) for sz in sizes]
+        skip = 2 if step == 1 else -1                      # parameter 2 has no gradient in step 1
+        for plist in (pm, ps):
+            for i, (p, g) in enumerate(zip(plist, grads)):
+                p.grad = None if i == skip else g.to(dev)
+        for i, (p, g) in enumerate(zip(pt, grads)):
+            p.grad = None if i == skip else g.double()
+        om.step(); os_.step(); ot.step()
+    for a, b, c in zip(pm, ps, pt):
+        assert torch.equal(a.detach(), b.detach())
+        assert float((a.detach().cpu().double() - c.detach()).abs().max()) < 2e-6
+    assert len(om._tables) >= 2                            # full list, list without the skipped tensor, ...
+
+
 def test_lowrank_nadam_equals_dense_nadam(dev):
     """FusedNAdam with gradient factors (tl_nadam_lowrank) == FusedNAdam on the materialised gradient."""
     from decode_tonal_langauge_amd.optim import FusedNAdam
