@@ -22,9 +22,9 @@ for r in rows[:26]:
     out.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.1f} |")
 out.append("")
 out.append("Kernel names: `wino43_tn_kernel`: conv2 / conv3 weight gradient, Winograd F(4,3), transforms applied at LDS-staging time "
-           "(new this round; finalised by `wino43_wgrad_finalize_kernel`); `wino43_nt_kernel<0, 2>` = <DIRECT loader, POOL epilogue>: conv2 / conv3 "
-           "forward (Winograd F(4,3)) + bias + LeakyReLU + max-pool + arg-max and sign bits; `wino43_nt_kernel<1, 3>` = <UNPOOL, MASK>: conv3 input "
-           "gradient; `wino43_nt_kernel<1, 4>` = <UNPOOL, C1WGRAD>: conv2 input gradient whose epilogue contracts the result with the raw signal into "
+           "(new this round; finalised by `wino43_wgrad_finalize_kernel`); `wino43_nt_kernel<0, 2, 1>` = <DIRECT loader, POOL epilogue>: conv2 / conv3 "
+           "forward (Winograd F(4,3)) + bias + LeakyReLU + max-pool + arg-max and sign bits; `wino43_nt_kernel<1, 3, 1>` = <UNPOOL, MASK>: conv3 input "
+           "gradient; `wino43_nt_kernel<1, 4, 1>` = <UNPOOL, C1WGRAD>: conv2 input gradient whose epilogue contracts the result with the raw signal into "
            "the conv1 weight gradient (G1 is never stored); `nt_window_kernel<128,...>` / `tn_window_kernel<.>`: direct-form MFMA kernels for conv4, "
            "conv5, the 1x1 stack and the Linear layer; `nt_window_kernel<32, 0, 0>` / `tn_skinny_kernel`: the h.W_hh^T / dgates.W_hh passes over the "
            "5.4 GB LSTM weight; `nadam_lowrank_kernel`: NAdam on that weight from its gradient factors.\n")

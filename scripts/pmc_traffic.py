@@ -12,9 +12,9 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 FAMILIES = {
-    "wino43_nt_kernel<1, 4>": "wino43_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd F(4,3))",
-    "wino43_nt_kernel<1, 3>": "wino43_nt_kernel<UNPOOL,MASK> (conv3 input gradient, Winograd F(4,3))",
-    "wino43_nt_kernel<0, 2>": "wino43_nt_kernel<DIRECT,POOL> (conv2/conv3 forward, Winograd F(4,3))",
+    "wino43_nt_kernel<1, 4": "wino43_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd F(4,3))",
+    "wino43_nt_kernel<1, 3": "wino43_nt_kernel<UNPOOL,MASK> (conv3 input gradient, Winograd F(4,3))",
+    "wino43_nt_kernel<0, 2": "wino43_nt_kernel<DIRECT,POOL> (conv2/conv3 forward, Winograd F(4,3))",
     "wino_nt_kernel<1, 3, 1>": "wino_nt_kernel<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd F(2,3))",
     "wino_nt_kernel<0, 2, 1>": "wino_nt_kernel<DIRECT,POOL> (conv2/conv3 forward, Winograd F(2,3))",
     "wino_tn_kernel": "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))",
