@@ -18,6 +18,7 @@ for spec in "$@"; do
   [ -n "$script" ] && sed -i "$script" $d/$FILE
   extra=""
   [ "$FILE" = "tonal_signal.hip" ] && extra="-ffp-contract=off"
+  [ "$FILE" = "tonal_wino43_tn.hip" ] && extra="-Xclang -target-feature -Xclang -packed-fp32-ops"
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $extra $flags -c $d/$FILE -o $d/v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$name.so $d/v.o $others
   rm -rf $d
