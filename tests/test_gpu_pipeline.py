@@ -69,6 +69,27 @@ def test_deep_classifiers_hip_forward_matches_reference_golden(dev):
             assert rel(h1.cpu().numpy(), g[f"cnnrnn{i}.h1"]) < 1e-4
 
 
+@pytest.mark.parametrize("B,T,D,H", [(5, 7, 12, 20), (64, 9, 33, 136), (70, 4, 8, 800), (33, 1, 16, 24)])
+def test_lstm_inference_paths_against_torch_lstm(dev, B, T, D, H, monkeypatch):
+    """Both HIP inference forms of nn.LSTM(batch_first=True)(x)[0][:, -1] (reference models/deep_classifiers.py:294-296,
+    316-318): the fused one-launch-per-step kernel (64- and 32-row tiles, hidden widths padded to 8, ragged row
+    tiles, T = 1 and odd / even T for the ping-pong state) and the split-K GEMM + cell pair, against torch on the CPU."""
+    from decode_tonal_langauge_amd._classifier_engine import LstmInferEngine
+    torch.manual_seed(B * 1000 + H)
+    lstm = torch.nn.LSTM(D, H, batch_first=True)
+    x = torch.randn(B, T, D)
+    with torch.no_grad():
+        ref = lstm(x)[0][:, -1, :].double()
+    w = [getattr(lstm, n).detach().to(dev) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TONAL_LSTM_FUSED", fused)
+        eng = LstmInferEngine(D, H)
+        assert eng.fused == (fused == "1")
+        got = eng.last_hidden(x.to(dev), *w).cpu().double()
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) < 2e-6, fused
+
+
 @pytest.mark.parametrize("nseq,Tp,cin,cout,taps,nseg", [(3, 20, 64, 96, 7, 3), (2, 516, 32, 40, 7, 3), (1, 8, 96, 64, 8, 3),
                                                         (5, 12, 32, 33, 9, 3), (2, 516, 32, 40, 7, 2), (3, 20, 64, 96, 5, 2)])
 def test_segmented_winograd_conv7_against_float64(dev, nseq, Tp, cin, cout, taps, nseg):
