@@ -200,8 +200,7 @@ class LstmInferEngine:
             h2 = torch.empty(B, Hp, **f32)
             in_b = C.c_int(0)
             check(self.lib.tl_lstm_infer_seq_fused(ptr(xp), T * 4 * Hp, ptr(whp), ptr(h), ptr(h2), ptr(c), B, Hp, T,
-                                                   int(os.environ.get("TONAL_LSTM_TILE", "0")), C.byref(in_b),
-                                                   torch.cuda.current_stream().cuda_stream),
+                                                   C.byref(in_b), torch.cuda.current_stream().cuda_stream),
                   "tl_lstm_infer_seq_fused")
             h = h2 if in_b.value else h
             return h[:, :H] if Hp != H else h

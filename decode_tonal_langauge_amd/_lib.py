@@ -79,7 +79,7 @@ SIGNATURES = {
     "tl_colsum": (_I, [_P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_lstm_cell_infer": (_I, [_P, _I, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
-    "tl_lstm_infer_seq_fused": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(C.c_int), _P]),
+    "tl_lstm_infer_seq_fused": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, C.POINTER(C.c_int), _P]),
     "tl_lstm_infer_seq": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "tl_lstm_ih_grad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

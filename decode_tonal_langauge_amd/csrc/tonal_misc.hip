@@ -458,15 +458,15 @@ __global__ __launch_bounds__(256) void lstm_cell_infer_kernel(const float* __res
   h[i] = og * tanhf(cn);
 }
 
-// One inference step of the LSTM in ONE launch (instead of split-K GEMM + cell): a workgroup owns NRB x 32
+// One inference step of the LSTM in ONE launch (instead of split-K GEMM + cell): a workgroup owns 32
 // batch rows and 8 hidden units = 32 gate columns (the recurrent weight is packed unit-major, row 4 u + g,
 // so a tile holds whole cells); gates = h_prev . Wp^T + xp[t], then the cell update.  8 interleaved K slices
 // per row block, one wave each; operand fragments come straight from L2 (each value feeds one wave, nothing
 // to share through LDS), the eight partial tiles are summed through LDS by the cell epilogue.
 // h is double buffered by the caller: every workgroup reads all of h_in while others write h_out.
 constexpr int LF_NKS = 8;
-template <int NRB>
-__global__ __launch_bounds__(512 * NRB) void lstm_step_fused_kernel(const float* __restrict__ xp, long long xp_row_stride,
+constexpr int NRB = 1;      // row blocks per workgroup (64-row tiles measured slower: 6.3 vs 4.2 ms on 400 steps)
+__global__ __launch_bounds__(512, 2) void lstm_step_fused_kernel(const float* __restrict__ xp, long long xp_row_stride,
                                                                     const float* __restrict__ wp,
                                                                     const float* __restrict__ h_in,
                                                                     float* __restrict__ h_out, float* __restrict__ c,
@@ -477,6 +477,16 @@ __global__ __launch_bounds__(512 * NRB) void lstm_step_fused_kernel(const float*
   const int lr = lane & 31, kh = lane >> 5;
   const int row0 = blockIdx.y * (NRB * 32);
   const int u0 = blockIdx.x * 8;
+  // the cell inputs of this thread's (row, unit): fetched up front, used after the product
+  const int rloc = tid >> 3, ucell = tid & 7;
+  const bool cell = tid < NRB * 256 && row0 + rloc < B;
+  float xg[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+  if (cell) {
+    const float* x = xp + (long long)(row0 + rloc) * xp_row_stride + (u0 + ucell);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xg[g] = x[(long long)g * H];
+    if (!first) cprev = c[(long long)(row0 + rloc) * H + u0 + ucell];
+  }
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -486,7 +496,10 @@ __global__ __launch_bounds__(512 * NRB) void lstm_step_fused_kernel(const float*
     const float* ap = h_in + (long long)row * H + 4 * kh;
     const float* bp = wp + (long long)(4 * u0 + lr) * H + 4 * kh;
     const int nchunk = H >> 3;                           // host-checked: H % 8 == 0
-#pragma unroll 4
+    // two chunks per trip: deeper prefetch measured SLOWER (400 steps, hidden 800, batch 64: 2 -> 4.2 ms, 4 -> 4.5,
+    // 8 -> 5.1, 16 = the whole slice in flight -> 5.4): the step is bound by the 52 fp32 MFMAs per wave (two waves
+    // per SIMD: 3 us) running behind the first loads, and a long burst only delays those
+#pragma unroll 2
     for (int kc = ks; kc < nchunk; kc += LF_NKS) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 8);
       const f32x4 b = *reinterpret_cast<const f32x4*>(bp + kc * 8);
@@ -498,24 +511,19 @@ __global__ __launch_bounds__(512 * NRB) void lstm_step_fused_kernel(const float*
 #pragma unroll
   for (int e = 0; e < 16; ++e) mine[((e & 3) + 8 * (e >> 2) + 4 * kh) * 32 + lr] = acc[e];
   __syncthreads();
-  if (tid < NRB * 256) {                                 // one (row, unit) cell per thread
-    const int rloc = tid >> 3, u = tid & 7;
-    const int row = row0 + rloc;
-    if (row < B) {
-      f32x4 pre = {0.f, 0.f, 0.f, 0.f};
-      if (!first) {
+  if (cell) {                                            // one (row, unit) cell per thread
+    f32x4 pre = {0.f, 0.f, 0.f, 0.f};
+    if (!first) {
 #pragma unroll
-        for (int z = 0; z < LF_NKS; ++z)
-          pre += *reinterpret_cast<const f32x4*>(red + (z * NRB + (rloc >> 5)) * 1024 + (rloc & 31) * 32 + 4 * u);
-      }
-      const float* x = xp + (long long)row * xp_row_stride + (u0 + u);
-      const float ig = sigmoidf_(pre[0] + x[0]), fg = sigmoidf_(pre[1] + x[H]), gg = tanhf(pre[2] + x[2 * (long long)H]),
-                  og = sigmoidf_(pre[3] + x[3 * (long long)H]);
-      const long long i = (long long)row * H + u0 + u;
-      const float cn = (first ? 0.f : fg * c[i]) + ig * gg;
-      c[i] = cn;
-      h_out[i] = og * tanhf(cn);
+      for (int z = 0; z < LF_NKS; ++z)
+        pre += *reinterpret_cast<const f32x4*>(red + (z * NRB + (rloc >> 5)) * 1024 + (rloc & 31) * 32 + 4 * ucell);
     }
+    const float ig = sigmoidf_(pre[0] + xg[0]), fg = sigmoidf_(pre[1] + xg[1]), gg = tanhf(pre[2] + xg[2]),
+                og = sigmoidf_(pre[3] + xg[3]);
+    const long long i = (long long)(row0 + rloc) * H + u0 + ucell;
+    const float cn = fg * cprev + ig * gg;               // cprev = 0 on the first step
+    c[i] = cn;
+    h_out[i] = og * tanhf(cn);
   }
 }
 
@@ -927,24 +935,17 @@ extern "C" int tl_lstm_infer_seq(const float* xp, int64_t xp_row_stride, const f
 // unit-major, row 4 u + g = W_hh row g H + u; xp keeps the torch gate-major columns.  h_a / h_b: ping-pong
 // buffers; the final state is in h_a when T is odd, h_b when T is even (returned through *last_in_b).
 extern "C" int tl_lstm_infer_seq_fused(const float* xp, int64_t xp_row_stride, const float* wp, float* h_a, float* h_b,
-                                       float* c, int B, int H, int T, int tile_rows, int* last_in_b, void* stream) {
+                                       float* c, int B, int H, int T, int* last_in_b, void* stream) {
   TL_REQUIRE(xp && wp && h_a && h_b && c && last_in_b && B > 0 && H > 0 && T > 0, "lstm_infer_seq_fused: bad arguments");
   TL_REQUIRE(H % 8 == 0, "lstm_infer_seq_fused: hidden width must be a multiple of 8 (pad the packed weights)");
   TL_REQUIRE(xp_row_stride >= (int64_t)T * 4 * H, "lstm_infer_seq_fused: xp rows are (b, t): row stride must cover T steps");
-  TL_REQUIRE(tile_rows == 0 || tile_rows == 32 || tile_rows == 64, "lstm_infer_seq_fused: tile_rows must be 0 (auto), 32 or 64");
-  // auto: 64-row tiles only when they still give about a workgroup per CU
-  const int two = tile_rows ? (tile_rows == 64) : (((long long)(H / 8) * ((B + 63) / 64) >= 192) ? 1 : 0);
-  const dim3 grid((unsigned)(H / 8), (unsigned)(two ? (B + 63) / 64 : (B + 31) / 32));
+  const dim3 grid((unsigned)(H / 8), (unsigned)((B + 31) / 32));
   TL_REQUIRE(grid.y <= 65535u, "lstm_infer_seq_fused: batch too large");
   for (int t = 0; t < T; ++t) {
     const float* hin = (t & 1) ? h_a : h_b;
     float* hout = (t & 1) ? h_b : h_a;
-    if (two)
-      hipLaunchKernelGGL(lstm_step_fused_kernel<2>, grid, dim3(1024), 0, (hipStream_t)stream, xp + (long long)t * 4 * H,
-                         (long long)xp_row_stride, wp, hin, hout, c, B, H, t == 0 ? 1 : 0);
-    else
-      hipLaunchKernelGGL(lstm_step_fused_kernel<1>, grid, dim3(512), 0, (hipStream_t)stream, xp + (long long)t * 4 * H,
-                         (long long)xp_row_stride, wp, hin, hout, c, B, H, t == 0 ? 1 : 0);
+    hipLaunchKernelGGL(lstm_step_fused_kernel, grid, dim3(512), 0, (hipStream_t)stream, xp + (long long)t * 4 * H,
+                       (long long)xp_row_stride, wp, hin, hout, c, B, H, t == 0 ? 1 : 0);
   }
   *last_in_b = (T & 1) ? 0 : 1;
   return check_launch("lstm_infer_seq_fused");

@@ -183,7 +183,7 @@ int tl_lstm_infer_seq(const float* xp, int64_t xp_row_stride, const float* w_hh,
  * packed unit-major (row 4 u + g = W_hh row g H + u), H % 8 == 0, h_a / h_b ping-pong state buffers (the
  * first step ignores both); *last_in_b tells which one holds h_T.                                        */
 int tl_lstm_infer_seq_fused(const float* xp, int64_t xp_row_stride, const float* wp, float* h_a, float* h_b, float* c,
-                            int B, int H, int T, int tile_rows /* 0 auto, 32, 64 */, int* last_in_b, void* stream);
+                            int B, int H, int T, int* last_in_b, void* stream);
 /* backward of the same step: dh, dc_next -> dgates (U,4H) row-major and transposed (4H,ldt),
  * dc_prev.  c_prev may be null (t = 0).                                                     */
 int tl_lstm_cell_bwd(const float* dh, const float* dh_rec, const float* dc_next, const float* act,

@@ -65,9 +65,9 @@ def test_abi_argument_validation_without_gpu():
     assert lib.tl_lstm_infer_seq(16, 10, 16, 16, 16, 16, 1, 4, 8, 3, None) == -1 and b"row stride" in lib.tl_last_error()
     import ctypes as C2
     flag = C2.c_int(0)
-    assert lib.tl_lstm_infer_seq_fused(16, 100, 16, 16, 16, 16, 4, 12, 3, 0, C2.byref(flag), None) == -1
+    assert lib.tl_lstm_infer_seq_fused(16, 100, 16, 16, 16, 16, 4, 12, 3, C2.byref(flag), None) == -1
     assert b"multiple of 8" in lib.tl_last_error()
-    assert lib.tl_lstm_infer_seq_fused(16, 10, 16, 16, 16, 16, 4, 8, 3, 0, C2.byref(flag), None) == -1
+    assert lib.tl_lstm_infer_seq_fused(16, 10, 16, 16, 16, 16, 4, 8, 3, C2.byref(flag), None) == -1
     assert b"row stride" in lib.tl_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(-1, "x")
