@@ -264,11 +264,15 @@ class CnnRnnConvEngine:
         self._B, self._dev = B, dev
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
-        self.Pa, self.bits_a = z(B * self.C * self.Tp, 1024), zi(B * self.C * self.Tp, 32)
-        self.Pb, self.bits_b = z(B * self.w1 * self.Tp, 1024), zi(B * self.w1 * self.Tp, 32)
         rows = B * self.W * self.Tp
         # + 8 rows: the segmented convolution reads up to 6 rows past the last row it is asked about
         self.P, self.Y1, self.Y2 = z(rows + 8, 1024), z(rows + 8, 512), z(rows, 256)
+        # sequences are stored branch-major - all LSTM-branch columns of all batch elements, then all electrode
+        # columns - so both first-stage convolutions write straight into P (the stack is per sequence; only the
+        # final feature map needs the reference's (batch, width) order)
+        nb = B * self.w1 * self.Tp
+        self.Pb, self.Pa = self.P[:nb], self.P[nb:rows]
+        self.bits_a, self.bits_b = zi(B * self.C * self.Tp, 32), zi(B * self.w1 * self.Tp, 32)
         self.Tap = z(rows, 512) if self.conv7_form == "wino43+1" else None
 
     def _conv7(self, src, w, b, dst, cin, cout, key, rows):
@@ -336,13 +340,12 @@ class CnnRnnConvEngine:
             check(lib.tl_conv1_fwd(ptr(seqs), ptr(w.detach().reshape(1024, self.K).contiguous()), ptr(b.detach()), ptr(P),
                                    ptr(bits), None, n, self.T, self.K, 1024, self.Tp, self.t1, self.slope, st_),
                   "tl_conv1_fwd")
-        row = self.Tp * 1024
         rows = B * self.W * self.Tp
-        torch.cat((self.Pb.view(B, self.w1, row), self.Pa.view(B, self.C, row)), dim=1,
-                  out=self.P[:rows].view(B, self.W, row))
         self._conv7(self.P, conv3a[0], conv3a[1], self.Y1, 1024, 512, "conv3a", rows)
         self._conv7(self.Y1, conv3b[0], conv3b[1], self.Y2, 512, 256, "conv3b", rows)
-        y = self.Y2.view(B, self.W, self.Tp, 256)[:, :, :3 * self.tq]
-        y = y.reshape(B, self.W, self.tq, 3, 256).amax(dim=3)                          # MaxPool (3,1)
+        y = self.Y2.view(B * self.W, self.Tp, 256)[:, :3 * self.tq]
+        y = y.reshape(B * self.W, self.tq, 3, 256).amax(dim=2)                         # MaxPool (3,1), per sequence
+        nb = B * self.w1
+        y = torch.cat((y[:nb].view(B, self.w1, self.tq, 256), y[nb:].view(B, self.C, self.tq, 256)), dim=1)
         f = y.permute(0, 3, 2, 1).contiguous()                                         # (B, 256, t', W)
         return f.view(B, self.tq, -1)
