@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_POOL, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, NtParams, TnParams,
+from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_POOL, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, LOAD_V, NtParams, TnParams,
                    check, ptr)
 
 
@@ -107,6 +107,9 @@ class CnnEngine:
         # weight gradient: F(4,3) with the transforms applied at LDS-staging time (tonal_wino43_tn.hip; half
         # the direct-form MFMA work) under TONAL_WINO=4 unless TONAL_WINO_TN=2 asks for the F(2,3) kernel
         self.wino43_tn = self.wino43 and os.environ.get("TONAL_WINO_TN", "4") == "4"
+        # round 3: the F(4,3) input transform V = B^T d is written once by the producer of an activation and the
+        # forward / weight-gradient GEMMs read it by LDS-DMA (tonal_wino43v.hip).  TONAL_WINO_V: 0 off, 1 on
+        self.wino_v = self.wino43 and os.environ.get("TONAL_WINO_V", "1") != "0"
         # fold the first stage's weight gradient into the stage-2 input-gradient epilogue (Winograd kernels)
         self.fuse_c1 = os.environ.get("TONAL_FUSE_C1", "1") != "0"
         self._B = None
@@ -123,6 +126,7 @@ class CnnEngine:
         f32 = dict(dtype=torch.float32, device=dev)
         z = lambda *s: torch.zeros(*s, **f32)
         zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        self._v_ready = {}     # V tensors already written by the producing kernel in this forward
         self.P = {1: z(S * self.tp1, self.c1)}
         self.bits = {1: zi(S * self.tp1, self.c1 // 32)}
         self.sbits = {1: zi(S * self.tp1, self.c1 // 32)}      # "pooled output > 0": the LeakyReLU' mask of backward
@@ -138,6 +142,7 @@ class CnnEngine:
         self.Xc = z(rows5, self.ldx)
         self.Y = [z(rows5, d[3]) for d in self.concat_dims]
         self.out_slab = None
+        self.V = {}            # F(4,3) input transforms of P[idx] (quads, 6, channels) for the stages that read them
         self.G = None          # gradient workspaces are allocated lazily on the first backward
 
     def _alloc_bwd(self):
@@ -261,6 +266,30 @@ class CnnEngine:
     def _use_wino43_tn(self, st) -> bool:
         return self.wino43_tn and self._use_wino43(st)
 
+    def _use_wino_v(self, st) -> bool:
+        return self.wino_v and self._use_wino43(st) and st.cin % 16 == 0
+
+    def _v_buffer(self, idx, rows, cin):
+        """V of P[idx]: rows / 4 quads, padded with zero quads to whole 128-quad tiles (the weight-gradient kernel
+        reads whole 8-quad K-steps, the forward kernel 128-quad tiles)."""
+        nq = rows // 4
+        nq_pad = (nq + 127) // 128 * 128
+        V = self.V.get(idx)
+        if V is None or V.shape[0] != nq_pad or V.shape[2] != cin:
+            V = self.V[idx] = torch.zeros(nq_pad, 6, cin, dtype=torch.float32, device=self._dev)
+        return V
+
+    def _input_transform(self, st):
+        """V of the stage's input P[idx-1] (stand-alone transform kernel; stage 2 gets it from tl_conv1_fwd)."""
+        src = self.P[st.idx - 1]
+        V = self._v_buffer(st.idx - 1, src.shape[0], st.cin)
+        ev = self._tick(f"conv{st.idx}_xform")
+        check(self.lib.tl_wino43_input_transform(ptr(src), ptr(V), src.shape[0], st.tp_in, st.cin, src.shape[1], st.cin,
+                                                 self._stream()), "tl_wino43_input_transform")
+        if ev:
+            ev[1].record()
+        return V
+
     def wgrad_issue_factor(self, st) -> float:
         """MFMA FLOPs the weight-gradient kernel of a stage issues per direct-convolution FLOP."""
         if self._use_wino43_tn(st):
@@ -319,6 +348,13 @@ class CnnEngine:
                       ld_obits=st.cout // 32, Tvalid=2 * st.tout)
         else:
             kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
+        if self._use_wino_v(st):
+            V = self._v_ready.get(st.idx - 1)
+            if V is None:
+                V = self._v_ready[st.idx - 1] = self._input_transform(st)
+            kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], loader=LOAD_V)
+            self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino43v_nt", **kw)
+            return
         self._nt(tag=f"conv{st.idx}_fwd", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino
                  else "tl_gemm_nt_window", **kw)
 
@@ -349,11 +385,18 @@ class CnnEngine:
             sk = self._splitk(tiles, (rows_in + 31) // 32, int(os.environ.get("TONAL_TN_TARGET", "8192")))
             slab = torch.empty(sk, 6 * st.cin, ldg, **f32)
             bias_part = torch.empty(sk, nd, **f32)     # the kernel's Y1 = sum of the quad's dZ rows doubles as the bias gradient
-            self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino43_tn", A=ptr(Xin), B=ptr(Gs), slab=ptr(slab),
-                     Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=st.cin,
-                     ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk, slab_stride=6 * st.cin * ldg,
-                     loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout,
-                     colsum=ptr(bias_part))
+            kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0],
+                      Mdim=st.cin, Ndim=nd, lda=st.cin, ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk,
+                      slab_stride=6 * st.cin * ldg, loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]),
+                      ld_bbits=st.cout // 32, Tvalid=2 * st.tout, colsum=ptr(bias_part))
+            fn = "tl_conv3_wino43_tn"
+            if self._use_wino_v(st) and st.cin % 64 == 0:
+                V = self._v_ready.get(st.idx - 1)      # normally written in the forward pass
+                if V is None:
+                    V = self._v_ready[st.idx - 1] = self._input_transform(st)
+                kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2])
+                fn = "tl_conv3_wino43v_tn"
+            self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, **kw)
             if sk > 1:
                 red = torch.empty(6 * st.cin, ldg, **f32)
                 n = 6 * st.cin * ldg
@@ -469,6 +512,7 @@ class CnnEngine:
         self._p_drop_used, self._seed_used = p_drop, seed
         self._drop_row0 = int(row0) * self.C * self.tp5
         self._x = x
+        self._v_ready = {}
         # ---- stage 1 (C_in = 1) ----
         w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
         check(lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]), ptr(self.P[1]), ptr(self.bits[1]),

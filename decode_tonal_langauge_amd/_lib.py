@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TONAL_HIP_LIB", os.path.join(_HERE, "libtonal_hip.so"))   # env override: A/B builds
 
 # epilogue / loader codes of tl_gemm_nt_window (include/tonal_hip.h)
-LOAD_DIRECT, LOAD_UNPOOL = 0, 1
+LOAD_DIRECT, LOAD_UNPOOL, LOAD_V = 0, 1, 2
 EPI_STORE, EPI_LRELU, EPI_POOL, EPI_MASK, EPI_C1WGRAD = 0, 1, 2, 3, 4
 
 
@@ -71,6 +71,9 @@ SIGNATURES = {
     "tl_wino_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_conv3_wino43_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino43_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
+    "tl_wino43_input_transform": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "tl_conv3_wino43v_nt": (_I, [C.POINTER(NtParams), _P]),
+    "tl_conv3_wino43v_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_sizeof_nt_params": (_I, []),
     "tl_sizeof_tn_params": (_I, []),
     "tl_conv1_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),

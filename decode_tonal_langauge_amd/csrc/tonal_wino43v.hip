@@ -1,0 +1,619 @@
+// Winograd F(4,3) with the INPUT TRANSFORM HOISTED OUT of the GEMM kernels (round 3).
+//
+// conv2 / conv3 of the ECoG stack (models/synthesis_models.py:91-97) are 79 % of the train step's FLOPs.
+// The F(4,3) kernels of tonal_wino.hip / tonal_wino43_tn.hip stage raw activation rows and apply
+// V = B^T d (six transforms of the rows 4Q..4Q+5 of a quad Q) next to the MFMAs - and on gfx950 the fp32
+// MFMA runs at the fp32 VECTOR rate: every VALU instruction, every register-staged global load and every
+// ds_write of the two waves of a SIMD displaces matrix-pipe time one for one
+// (profiles/r02_kernel_notes.md section 3a: 2.9 cycles per VALU, 23 per global load, 13 per ds_write_b64).
+// V depends on the activations only, and both the forward pass and the weight gradient consume exactly
+// the same V.  So the producer of an activation writes V once (1.5 x the bytes of the raw rows - HBM is
+// at 8 % of its roof in these kernels), and the two GEMM kernels below become transform-free:
+//
+//   tl_wino43_input_transform   P (rows, channels-last)  ->  V[quad][6][ldv]         (stand-alone form;
+//                               tl_conv1_fwd writes V directly for the first stage)
+//   wino43v_nt_kernel           forward: M_i[quad][n] = sum_k V_i[quad][k] U_i[n][k], i < 6, a batched
+//                               NT GEMM whose two operands go global -> LDS by `buffer_load_dwordx4 ..
+//                               offen lds` (LDS-DMA: no staging VGPRs, no ds_write, no vector address
+//                               arithmetic: SGPR resource + a per-lane offset that is fixed for the whole
+//                               kernel + a scalar K offset), followed by the pool epilogue of
+//                               tonal_wino.hip (y = A^T M, bias, LeakyReLU, max-pool, arg-max bits)
+//   wino43v_tn_kernel           weight gradient: slab_i[c_in][c_out] = sum_quads V_i (x) Y_i, V by
+//                               LDS-DMA, Y = A dy built from the pooled gradient + arg-max bits at
+//                               staging time as before
+//
+// LDS images written by LDS-DMA are lane-linear (1 KiB per wave-instruction), so rows cannot be padded;
+// bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte chunk
+// index that is applied to the per-lane SOURCE address and to the fragment read.
+#include "tonal_common.h"
+#include <type_traits>
+
+namespace tl {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// P -> V.  Thread = (quad, 4 channels).  Rows of a quad that lie beyond its sequence (t >= Tp) are
+// taken as zero: they only ever reach conv rows the epilogues mask (the Winograd identity holds for
+// any finite value there; zero keeps the cancellation error of the last valid row smallest).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino43_xform_kernel(const float* __restrict__ P, float* __restrict__ V,
+                                                            long long nq, int Tp, int C, int ldp, int ldv) {
+  const int c4n = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nq * c4n) return;
+  const long long q = idx / c4n;
+  const int c = (int)(idx - q * c4n) * 4;
+  const int tq = Tp >> 2;
+  const long long seq = q / tq;
+  const int t0 = (int)(q - seq * tq) * 4;
+  const float* src = P + (seq * Tp + t0) * (long long)ldp + c;
+  f32x4 d[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    if (t0 + j < Tp) d[j] = *reinterpret_cast<const f32x4*>(src + (long long)j * ldp);
+    else d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4 s1 = d[4] - 4.f * d[2], s2 = d[3] - 4.f * d[1], s3 = d[4] - d[2], t = d[3] - d[1];
+  float* dst = V + q * 6 * (long long)ldv + c;
+  *reinterpret_cast<f32x4*>(dst) = 4.f * d[0] + (d[4] - 5.f * d[2]);
+  *reinterpret_cast<f32x4*>(dst + ldv) = s1 + s2;
+  *reinterpret_cast<f32x4*>(dst + 2LL * ldv) = s1 - s2;
+  *reinterpret_cast<f32x4*>(dst + 3LL * ldv) = s3 + 2.f * t;
+  *reinterpret_cast<f32x4*>(dst + 4LL * ldv) = s3 - 2.f * t;
+  *reinterpret_cast<f32x4*>(dst + 5LL * ldv) = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward NT kernel on V.  Workgroup: 8 waves as 4 (quads) x 2 (columns); block tile 128 quads (512 conv
+// rows) x 64 columns; wave tile 32 quads x 32 columns x 6 transforms = 96 accumulator registers.  A K-step
+// is 16 channels: A stage [6][128 quads][64 B] = 48 KB, B stage [6][64 columns][64 B] = 24 KB, two stages
+// = 144 KB (one workgroup per CU, two waves per SIMD).  A stage is filled by 72 LDS-DMA pieces (16 rows x
+// 64 B each), 9 per wave, issued right after the barrier that opens the previous step; one counted wait +
+// one barrier closes a step.  The MFMA loop is 24 ds_read_b128 + 48 MFMAs per wave and K-step and nothing
+// else; the last k-group of a step is carried in registers across the barrier.
+// ------------------------------------------------------------------------------------------
+constexpr int V4_BQ = 128, V4_BN = 64, V4_BK = 16;
+constexpr int V4_ROWB = V4_BK * 4;                       // bytes per LDS row (64)
+constexpr int V4_A_BYTES = 6 * V4_BQ * V4_ROWB;          // 49152
+constexpr int V4_B_BYTES = 6 * V4_BN * V4_ROWB;          // 24576
+constexpr int V4_STAGE = V4_A_BYTES + V4_B_BYTES;        // 73728
+constexpr int V4_APIECES = 6 * V4_BQ / 16;               // 48
+constexpr int V4_BPIECES = 6 * V4_BN / 16;               // 24
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+#ifndef V4_SCHED
+#define V4_SCHED 1        // 1: hand-specified issue order of a K-step (see kstep)
+#endif
+#ifndef V4_ABL
+#define V4_ABL 0          // timing-only build variants (scripts/build_v_variants.sh): 1 no steady-state DMA, 2 no epilogue,
+#endif                    // 4 no barrier, 8 order pinned at the top of a K-step, 16 no fragment reads
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p) {
+  __shared__ __attribute__((aligned(1024))) char lds[2 * V4_STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int ntn = (p.N + V4_BN - 1) / V4_BN;
+  const long long ntm = (p.M + 4 * V4_BQ - 1) / (4 * V4_BQ);
+  const long long nwg = ntm * ntn;
+  long long bid = blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const long long tm = bid / ntn;
+  const int tn = (int)(bid % ntn);
+  const long long R0 = tm * (4 * V4_BQ);
+  const long long Qt = tm * V4_BQ;                         // first quad of the tile
+  const int n0 = tn * V4_BN;
+  const int nsteps = p.K / V4_BK;                          // host-checked: K % 16 == 0, K >= 16
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // ---- LDS-DMA plan.  Piece = 16 rows x 64 B; lane -> (row = lane >> 2, physical chunk = lane & 3); the
+  // source chunk is the swizzled one, chunk ^ ((row >> 2) & 3) with row % 16 == lane >> 2.
+  const int prow = lane >> 2;
+  const int src_chunk = (lane & 3) ^ ((lane >> 4) & 3);
+  // A pieces of this wave: pa = 6 wave + t -> (transform i = pa >> 3, 16-quad block j = pa & 7).  Quads past the
+  // end of V are clamped (they only feed rows the epilogue masks).
+  const long long q_left = p.A_rows - Qt;                  // quads addressable from the tile start (> 0)
+  const long long a_span = q_left * 6 * (long long)p.lda * 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + Qt * 6 * (long long)p.lda), 0, (int)(a_span < 0x7fffffffLL ? a_span : 0x7fffffffLL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.Bw, 0, (int)(6LL * p.N * p.ldb * 4), 0x00020000);
+  unsigned avoff[6], bvoff[3];
+  unsigned adst[6], bdst[3];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    const int pa = wave * 6 + t;
+    const int i = pa >> 3, j = pa & 7;
+    long long ql = j * 16 + prow;
+    if (ql > q_left - 1) ql = q_left - 1;
+    avoff[t] = (unsigned)(((ql * 6 + i) * p.lda + src_chunk * 4) * 4);
+    adst[t] = (unsigned)((i * V4_BQ + j * 16) * V4_ROWB);
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int pb = wave * 3 + t;
+    const int i = pb >> 2, j = pb & 3;
+    int n = n0 + j * 16 + prow;
+    if (n > p.N - 1) n = p.N - 1;                          // clamped columns are masked by the epilogue
+    bvoff[t] = (unsigned)((((long long)i * p.N + n) * p.ldb + src_chunk * 4) * 4);
+    bdst[t] = (unsigned)(V4_A_BYTES + (i * V4_BN + j * 16) * V4_ROWB);
+  }
+  auto issue = [&](int step) {
+    char* base = lds + (step & 1) * V4_STAGE;
+    const unsigned soff = (unsigned)step * (V4_BK * 4);
+    if (!(V4_ABL & 64) || step < 2) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) dma16(rsA, base + adst[t], avoff[t], soff);
+    }
+    if (!(V4_ABL & 128) || step < 2) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) dma16(rsB, base + bdst[t], bvoff[t], soff);
+    }
+  };
+
+  // ---- fragment reads: row r of a tile, logical chunk c = 2 g + lh -> r * 64 + ((c ^ ((r >> 2) & 3)) << 4)
+  const int sw = (lr >> 2) & 3;
+  const int a_row = (wm * 32 + lr) * V4_ROWB, b_row = V4_A_BYTES + (wn * 32 + lr) * V4_ROWB;
+  const int c_g0 = ((lh) ^ sw) << 4, c_g1 = ((2 + lh) ^ sw) << 4;
+  f32x4 fa0[6], fb0[6], fa1[6], fb1[6];
+  auto load_frag = [&](f32x4 (&fa)[6], f32x4 (&fb)[6], int stage, int cg) {
+    const char* a_s = lds + stage * V4_STAGE + a_row + cg;
+    const char* b_s = lds + stage * V4_STAGE + b_row + cg;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * (V4_BQ * V4_ROWB));
+      fb[i] = *reinterpret_cast<const f32x4*>(b_s + i * (V4_BN * V4_ROWB));
+    }
+  };
+  auto mfma_group = [&](const f32x4 (&fa)[6], const f32x4 (&fb)[6]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[i][q], acc[i], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // carried k-group of step -1: adds nothing
+
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  auto kstep = [&](auto LAST, int s) {
+    const int stage = s & 1;
+    if (!(V4_ABL & 16) || s == 0) load_frag(fa0, fb0, stage, c_g0);
+    if constexpr (!decltype(LAST)::value)
+      if (!(V4_ABL & 1) || s == 0) issue(s + 1);            // the other stage was released at the last barrier
+    mfma_group(fa1, fb1);                                   // k-group 1 of the previous step (registers)
+    if (!(V4_ABL & 16) || s == 0) load_frag(fa1, fb1, stage, c_g1);
+    mfma_group(fa0, fb0);
+#if V4_SCHED
+    // Issue order of the step (sched_group_barrier: 0x008 MFMA, 0x010 vector memory, 0x100 LDS read).  An LDS-DMA
+    // piece costs the issuing wave ~60 cycles; issued as a clump after the barrier by both waves of a SIMD at once it
+    // idles the matrix pipe (ablation: 6.4 of 45.4 ms), one piece per two MFMAs hides behind the partner's MFMAs.
+    // The reads of k-group 1 are spread over the MFMAs of k-group 0 so none of their latency is left at the barrier.
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+    if constexpr (!decltype(LAST)::value) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#endif
+    if constexpr (!decltype(LAST)::value) {
+      // the builtin (not inline asm) so that the compiler's own wait-count bookkeeping sees the drained counters: after
+      // an asm wait it re-waits lgkmcnt(0) behind the first reads of the next step, in front of the carried MFMAs
+#if V4_ABL & 32
+      __builtin_amdgcn_s_waitcnt(0x3f7f & ~0x0f00);         // lgkmcnt(0)
+#else
+      __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0) lgkmcnt(0)
+#endif
+#if !(V4_ABL & 4)
+      __builtin_amdgcn_s_barrier();
+#endif
+      asm volatile("" ::: "memory");
+    }
+  };
+  for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, s);
+  kstep(std::true_type{}, nsteps - 1);
+  mfma_group(fa1, fb1);
+
+#if V4_ABL & 2
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) t += acc[i][e];
+    if (t == 12345.678f) p.out[tid] = t;
+    return;
+  }
+#endif
+  // ---- epilogue (pool): the four conv rows of a quad from its six products, bias, LeakyReLU, max-pool (2,1),
+  // arg-max and sign bits - the arithmetic of wino43_nt_kernel<DIRECT, POOL> in tonal_wino.hip ----
+  const long long Q0 = (R0 >> 2) + wm * 32 + 4 * lh;       // quad of accumulator element e = 0
+  const int col = n0 + wn * 32 + lr;
+  const int colbase = n0 + wn * 32;
+  const bool colok = col < p.N;
+  const float bv = (colok && p.bias) ? p.bias[col] : 0.f;
+  uint32_t wbits = 0, wsign = 0;
+  int tcur = (int)((4 * Q0) % p.Tp);                        // time index of the quad's first conv row
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int qo = (e & 3) + 8 * (e >> 2);
+    const long long Q = Q0 + qo;
+    if (e > 0) {
+      tcur += (e & 3) ? 4 : 20;                             // quad offsets 0,1,2,3, 8,.. -> row steps 4,4,4,20
+      while (tcur >= p.Tp) tcur -= p.Tp;
+    }
+    const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
+    const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
+    float y[4];
+    y[0] = (acc[0][e] + a12) + a34;
+    y[1] = s12 + 2.f * s34;
+    y[2] = a12 + 4.f * a34;
+    y[3] = (s12 + 8.f * s34) + acc[5][e];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long P = 2 * Q + h;                        // pooled row
+      const float y0 = lrelu(y[2 * h] + bv, p.slope), y1 = lrelu(y[2 * h + 1] + bv, p.slope);
+      const bool rowok = 2 * P < p.M;
+      const bool valid = rowok && (tcur + 2 * h) < p.Tvalid;       // Tp % 4 == 0: a quad never wraps
+      const bool sel = valid && colok && (y1 > y0);
+      const float o = valid ? (sel ? y1 : y0) : 0.f;
+      if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
+      const unsigned long long m = __ballot(sel);
+      const unsigned long long ms = __ballot(o > 0.f);
+      if (lr == 2 * e + h) {
+        wbits = (uint32_t)(m >> (32 * lh));
+        wsign = (uint32_t)(ms >> (32 * lh));
+      }
+    }
+  }
+  {
+    const int e = lr >> 1, h = lr & 1;
+    const long long P = 2 * (Q0 + (e & 3) + 8 * (e >> 2)) + h;
+    if (2 * P < p.M && colbase < p.N) {
+      p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = wbits;
+      if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = wsign;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient on V.  The kernel of tonal_wino43_tn.hip with its A side replaced: V tiles
+// [6][8 quads][64 channels] arrive by LDS-DMA (3 pieces of 4 rows x 256 B per wave and K-step) into a
+// 4-slot ring, three K-steps ahead of their use; the Y side (un-pooled dZ -> A dy, needs the arg-max bits)
+// is staged through registers exactly as before.  Per thread and K-step this removes six 8-byte row
+// loads, 26 transform VALU instructions and six ds_write_b64.  Rows of odd quads keep the two
+// 32-channel halves swapped (conflict-free fragment reads without padding): applied on the SOURCE chunk.
+// ------------------------------------------------------------------------------------------
+constexpr int T4_BM = 64, T4_BN = 64, T4_Q = 8;          // C_in tile, C_out tile, quads per K-step
+constexpr int T4_PLANE = T4_Q * 64;                       // floats per transform plane
+constexpr int T4_TILE = 6 * T4_PLANE;                     // floats per operand tile (12 KB)
+constexpr int T4V_NA = 4;                                 // V ring slots
+
+__global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p) {
+  __shared__ __attribute__((aligned(1024))) float lds[(T4V_NA + 2) * T4_TILE];
+  float* As = lds;                               // [4][6][8][64]  V ring
+  float* Bs = lds + T4V_NA * T4_TILE;            // [2][6][8][64]  Y
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int ntm = (p.Mdim + T4_BM - 1) / T4_BM, ntn = (p.Ndim + T4_BN - 1) / T4_BN;
+  const long long tiles = (long long)ntm * ntn;
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int z = (int)(bid / tiles);
+  const int tt = (int)(bid % tiles);
+  const int m0 = (tt / ntn) * T4_BM, n0 = (tt % ntn) * T4_BN;
+
+  const long long quads_all = p.Krows >> 2;
+  const long long ksteps_all = (quads_all + T4_Q - 1) / T4_Q;
+  const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const int nsteps = ks_end > ks_begin ? (int)(ks_end - ks_begin) : 0;
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // ---- V by LDS-DMA: piece pc = 3 wave + t -> (transform i = pc >> 1, quads 4 (pc & 1) .. + 3); lane -> (quad
+  // offset lane >> 4, physical 16-byte chunk lane & 15); odd quads: halves swapped = source chunk ^ 8
+  const long long v_q0 = ks_begin * T4_Q;                           // first quad of this split
+  const long long v_left = (p.A_rows - v_q0) * 6 * (long long)p.lda * 4 - (long long)m0 * 4;
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + v_q0 * 6 * (long long)p.lda + m0), 0, (int)(v_left < 0x7fffffffLL ? (v_left > 0 ? v_left : 0) : 0x7fffffffLL),
+      0x00020000);
+  unsigned vvoff[3], vdst[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int pc = wave * 3 + t;
+    const int i = pc >> 1, ql = (pc & 1) * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ ((ql & 1) << 3);
+    vvoff[t] = (unsigned)((((long long)ql * 6 + i) * p.lda + chunk * 4) * 4);
+    vdst[t] = (unsigned)((i * T4_PLANE + (pc & 1) * 4 * 64) * 4);
+  }
+  const unsigned v_step = (unsigned)(T4_Q * 6 * p.lda * 4);        // bytes per K-step (host-checked to fit)
+  auto issue_v = [&](int step) {
+    char* base = reinterpret_cast<char*>(As) + (step & (T4V_NA - 1)) * (T4_TILE * 4);
+    const unsigned soff = (unsigned)step * v_step;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dma16(rsV, base + vdst[t], vvoff[t], soff);
+  };
+
+  // ---- Y staging (registers), as in wino43_tn_kernel ----
+  const int qi = tid >> 5, c2 = tid & 31;                   // quad of the K-step, channel pair
+  const int sw = ((c2 * 2) ^ ((qi & 1) << 5));              // swizzled channel position inside the 64-wide row
+  const long long b_last = p.B_rows - 1;
+  const int ncol = n0 + c2 * 2;
+  const bool bnok = ncol < p.Ndim;
+  const int ncolc = bnok ? ncol : n0;
+  long long quad = ks_begin * T4_Q + qi;                    // quad the NEXT load fetches for this thread
+  int tq = (int)((4 * quad) % p.Tp);                        // time index of its first conv row
+  const int dstep = (4 * T4_Q) % p.Tp;
+  long long ld_q0 = ks_begin * T4_Q;
+  const unsigned b_toff = (unsigned)(qi * 2 * p.ldb + (ncolc - n0));
+  const unsigned w_toff = (unsigned)(qi * 2 * p.ld_bbits + (ncolc >> 5));
+
+  struct stage_regs {
+    f32x2 g[2];
+    uint32_t wa, wb;  // arg-max words of the two pooled rows
+    uint32_t ok;      // bit 0 / 1: pair a / b holds a valid gradient
+  };
+  stage_regs rP, rQ, rR;
+  f32x2 bsum = {0.f, 0.f};
+
+  auto load_regs = [&](auto FAST, stage_regs& r) {
+    constexpr bool fast = decltype(FAST)::value;
+    long long pa = 2 * quad, pb = 2 * quad + 1;
+    bool va = bnok && tq < p.Tvalid, vb = bnok && tq + 2 < p.Tvalid;
+    if constexpr (fast) {
+      const float* bu = p.B + (ld_q0 * 2) * (long long)p.ldb + n0;
+      const uint32_t* wu = p.bbits + (ld_q0 * 2) * (long long)p.ld_bbits;
+      r.g[0] = *reinterpret_cast<const f32x2*>(bu + b_toff);
+      r.g[1] = *reinterpret_cast<const f32x2*>(bu + p.ldb + b_toff);
+      r.wa = wu[w_toff];
+      r.wb = wu[p.ld_bbits + w_toff];
+    } else {
+      va = va && 4 * quad < p.Krows && pa <= b_last;
+      vb = vb && 4 * quad + 2 < p.Krows && pb <= b_last;
+      pa = pa < b_last ? pa : b_last;
+      pb = pb < b_last ? pb : b_last;
+      r.g[0] = *reinterpret_cast<const f32x2*>(p.B + pa * (long long)p.ldb + ncolc);
+      r.g[1] = *reinterpret_cast<const f32x2*>(p.B + pb * (long long)p.ldb + ncolc);
+      r.wa = p.bbits[pa * (long long)p.ld_bbits + (ncolc >> 5)];
+      r.wb = p.bbits[pb * (long long)p.ld_bbits + (ncolc >> 5)];
+    }
+    r.ok = (va ? 1u : 0u) | (vb ? 2u : 0u);
+    ld_q0 += T4_Q;
+    quad += T4_Q;
+    tq += dstep;
+    if (tq >= p.Tp) tq -= p.Tp;
+  };
+  auto store_b = [&](const stage_regs& r, int buf) {
+    const int sh = ncolc & 31;
+    f32x2 o[6];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t ma = (uint32_t)__builtin_amdgcn_sbfe((int)r.wa, sh + c, 1);      // all ones if the odd row won
+      const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)r.wb, sh + c, 1);
+      const uint32_t ua = (r.ok & 1u) ? __float_as_uint(r.g[0][c]) : 0u, ub = (r.ok & 2u) ? __float_as_uint(r.g[1][c]) : 0u;
+      const float e_a = __uint_as_float(ua & ~ma), o_a = __uint_as_float(ua & ma);
+      const float e_b = __uint_as_float(ub & ~mb), o_b = __uint_as_float(ub & mb);
+      o[0][c] = e_a;
+      o[1][c] = (e_a + o_a) + (e_b + o_b);
+      o[2][c] = (e_a - o_a) + (e_b - o_b);
+      o[3][c] = fmaf(4.f, fmaf(2.f, o_b, e_b), fmaf(2.f, o_a, e_a));
+      o[4][c] = fmaf(4.f, fmaf(-2.f, o_b, e_b), fmaf(-2.f, o_a, e_a));
+      o[5][c] = o_b;
+    }
+    bsum += o[1];
+    float* dst = Bs + buf * T4_TILE + qi * 64 + sw;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(dst + i * T4_PLANE) = o[i];
+  };
+
+  // ---- MFMA side: k-slice sl of a K-step = quads 2 sl (lanes 0-31) and 2 sl + 1 (lanes 32-63) ----
+  const int a_off = lh * 64 + ((wm * 32 + lr) ^ (lh << 5));
+  const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
+  float fa0[6], fb0[6], fa1[6], fb1[6];
+  auto load_frag = [&](float (&fa)[6], float (&fb)[6], int abuf, int bbuf, int sl) {
+    const float* a_s = As + abuf * T4_TILE + sl * 128 + a_off;
+    const float* b_s = Bs + bbuf * T4_TILE + sl * 128 + b_off;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      fa[i] = a_s[i * T4_PLANE];
+      fb[i] = b_s[i * T4_PLANE];
+    }
+  };
+  auto mfma6 = [&](const float (&fa)[6], const float (&fb)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[i], 0, 0, 0);
+  };
+
+  // One K-step: V(s + 3) and the Y registers of step s + 3 are requested at the top; Y(s + 1) is transformed and
+  // written mid-step.  Closing wait: everything up to V(s + 1) must have landed - the younger operations of this
+  // wave are the 4 Y loads + 3 pieces of steps s + 2 and s + 3 = 14 (tail steps drain completely).
+  auto kstep = [&](auto TAIL, int s, stage_regs& r_ld, const stage_regs& r_st) {
+    constexpr bool tail = decltype(TAIL)::value;
+    const int abuf = s & (T4V_NA - 1), bbuf = s & 1;
+    load_frag(fa0, fb0, abuf, bbuf, 0);
+    if constexpr (!tail) {
+      load_regs(std::true_type{}, r_ld);
+      issue_v(s + 3);
+    } else if (s + 3 < nsteps) {
+      load_regs(std::false_type{}, r_ld);
+      issue_v(s + 3);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(fa1, fb1);                                        // slice 3 of the previous step
+    load_frag(fa1, fb1, abuf, bbuf, 1);
+    mfma6(fa0, fb0);
+    load_frag(fa0, fb0, abuf, bbuf, 2);
+    mfma6(fa1, fb1);
+    if (!tail || s + 1 < nsteps) store_b(r_st, bbuf ^ 1);
+    load_frag(fa1, fb1, abuf, bbuf, 3);
+    mfma6(fa0, fb0);
+    if constexpr (!tail) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  using Y = std::true_type;
+  using N = std::false_type;
+
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = 0.f;
+
+  if (nsteps > 0) {
+    issue_v(0);
+    load_regs(N{}, rP);
+    store_b(rP, 0);
+    if (nsteps > 1) {
+      issue_v(1);
+      load_regs(N{}, rQ);
+    }
+    if (nsteps > 2) {
+      issue_v(2);
+      load_regs(N{}, rR);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  int s = 0;
+  const bool whole = 2 * p.B_rows >= p.Krows;
+  // kstep(s, ld, st): loads step s + 3 into ld (the set that held step s, already in LDS), stores st = step s + 1
+  if (whole)
+    for (; s + 8 < nsteps; s += 3) {
+      kstep(N{}, s, rP, rQ);
+      kstep(N{}, s + 1, rQ, rR);
+      kstep(N{}, s + 2, rR, rP);
+    }
+  for (; s < nsteps; s += 3) {
+    kstep(Y{}, s, rP, rQ);
+    if (s + 1 < nsteps) kstep(Y{}, s + 1, rQ, rR);
+    if (s + 2 < nsteps) kstep(Y{}, s + 2, rR, rP);
+  }
+  mfma6(fa1, fb1);
+
+  if (p.colsum != nullptr && m0 == 0) {
+    __syncthreads();
+    float* red = lds;
+    *reinterpret_cast<f32x2*>(red + qi * 64 + c2 * 2) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < T4_Q; ++q) t += red[q * 64 + tid];
+      if (n0 + tid < p.Ndim) p.colsum[(long long)z * p.Ndim + n0 + tid] = t;
+    }
+  }
+  float* out = p.slab + (long long)z * p.slab_stride;
+  const int col = n0 + wn * 32 + lr;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (m < p.Mdim && col < p.Ndim) out[((long long)i * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
+    }
+}
+
+}  // namespace tl
+
+extern "C" int tl_wino43_input_transform(const float* P, float* V, int64_t rows, int Tp, int C, int ldp, int ldv,
+                                         void* stream) {
+  using namespace tl;
+  TL_REQUIRE(P && V, "wino43_input_transform: null pointer");
+  TL_REQUIRE(rows > 0 && Tp > 0 && Tp % 4 == 0 && rows % Tp == 0, "wino43_input_transform: rows must be whole sequences of Tp %% 4 == 0 rows");
+  TL_REQUIRE(C > 0 && C % 4 == 0 && ldp >= C && ldv >= C && ldp % 4 == 0 && ldv % 4 == 0, "wino43_input_transform: C/ldp/ldv must be multiples of 4");
+  const long long nq = rows / 4;
+  const long long n = nq * (C / 4);
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino43_input_transform: grid too large");
+  hipLaunchKernelGGL(wino43_xform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, V, nq, Tp,
+                     C, ldp, ldv);
+  return check_launch("wino43_input_transform");
+}
+
+// forward pass on V (loader 2): A = V[quad][6][lda], A_rows = quads in V, M = conv rows (4 per quad)
+extern "C" int tl_conv3_wino43v_nt(const tl_nt_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "wino43v_nt: null params");
+  const tl_nt_params& p = *pp;
+  TL_REQUIRE(p.A && p.Bw && p.out && p.obits, "wino43v_nt: null V/Bw/out/obits");
+  TL_REQUIRE(p.loader == 2 && p.epilogue == 2, "wino43v_nt: loader 2 (V) with the POOL epilogue only");
+  TL_REQUIRE(p.J == 3 && p.row_shift == 0 && p.splitk <= 1, "wino43v_nt: 3 taps, forward, no split-K");
+  TL_REQUIRE(p.M > 0 && p.M % 4 == 0 && p.N > 0 && p.K >= 16 && p.K % 16 == 0, "wino43v_nt: M %% 4, K %% 16 needed");
+  TL_REQUIRE(p.A_rows >= p.M / 4, "wino43v_nt: V holds fewer quads than M / 4");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K && p.lda % 4 == 0 && p.ldb % 4 == 0 && p.ldo >= p.N, "wino43v_nt: bad leading dimensions");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 4 == 0 && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino43v_nt: Tp %% 4 == 0 and an even Tvalid needed");
+  TL_REQUIRE(p.ld_obits * 32 >= p.N, "wino43v_nt: obits row too short");
+  TL_REQUIRE(6LL * p.N * p.ldb * 4 < (1LL << 31), "wino43v_nt: tap set larger than a buffer resource");
+  TL_REQUIRE(128LL * 6 * p.lda * 4 + 4LL * p.K < (1LL << 31), "wino43v_nt: tile span too large");
+  const long long nwg = ((p.M + 4 * V4_BQ - 1) / (4 * V4_BQ)) * ((p.N + V4_BN - 1) / V4_BN);
+  TL_REQUIRE(nwg < (1LL << 31), "wino43v_nt: grid too large");
+  hipLaunchKernelGGL(wino43v_nt_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+  return check_launch("wino43v_nt");
+}
+
+// weight gradient on V (a_form 1): A = V[quad][6][lda], A_rows = quads held by V (a whole number of 8-quad K-steps)
+extern "C" int tl_conv3_wino43v_tn(const tl_tn_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "wino43v_tn: null params");
+  tl_tn_params p = *pp;
+  if (p.splitk < 1) p.splitk = 1;
+  TL_REQUIRE(p.A && p.B && p.slab && p.bbits, "wino43v_tn: null V/B/bbits/slab");
+  TL_REQUIRE(p.J == 3 && p.loader == 1, "wino43v_tn: 3 taps, UNPOOL loader only");
+  TL_REQUIRE(p.Krows > 0 && p.Krows % 4 == 0 && p.Mdim > 0 && p.Ndim > 0, "wino43v_tn: bad sizes (Krows %% 4 must be 0)");
+  TL_REQUIRE(p.Krows + 64 < (1LL << 31), "wino43v_tn: more than 2^31 reduction rows");
+  TL_REQUIRE(p.B_rows > 0, "wino43v_tn: empty operand");
+  TL_REQUIRE(p.Mdim % 64 == 0 && p.Ndim % 4 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino43v_tn: Mdim %% 64, Ndim/ld %% 4 needed");
+  TL_REQUIRE(p.lda >= p.Mdim && p.ldb >= p.Ndim && p.ldc >= p.Ndim, "wino43v_tn: leading dimension too small");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 4 == 0 && p.Tvalid % 2 == 0, "wino43v_tn: Tp %% 4 == 0 and an even Tvalid needed");
+  TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim, "wino43v_tn: bbits row too short");
+  TL_REQUIRE(p.splitk <= 65535, "wino43v_tn: splitk too large");
+  TL_REQUIRE(p.splitk == 1 || p.slab_stride >= 6LL * p.Mdim * p.ldc, "wino43v_tn: slab_stride smaller than 6*Mdim*ldc");
+  const long long ksteps_all = ((p.Krows >> 2) + T4_Q - 1) / T4_Q;
+  TL_REQUIRE(p.A_rows >= ksteps_all * T4_Q, "wino43v_tn: V must hold whole 8-quad K-steps (pad it with zero quads)");
+  const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
+  TL_REQUIRE((per + 4) * (long long)T4_Q * 6 * p.lda * 4 < (1LL << 31), "wino43v_tn: a reduction split spans more than 2 GB of V: raise splitk");
+  const long long t = (long long)((p.Mdim + T4_BM - 1) / T4_BM) * ((p.Ndim + T4_BN - 1) / T4_BN);
+  TL_REQUIRE(t < (1LL << 31), "wino43v_tn: grid too large");
+  hipLaunchKernelGGL(wino43v_tn_kernel, dim3((unsigned)t, (unsigned)p.splitk, 1), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("wino43v_tn");
+}

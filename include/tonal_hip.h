@@ -129,6 +129,20 @@ int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
  *   tl_conv3_wino43_tn / tl_wino43_wgrad_finalize: the F(4,3) form of the weight gradient (6 outer
  *                          products per 4 conv rows; slab[z][6][Mdim][ldc], slab_stride >= 6*Mdim*ldc;
  *                          Krows and Tp multiples of 4); red [6][I][ld] -> dW (O, I, 3, 1)
+ *
+ * Round 3 - the F(4,3) INPUT TRANSFORM HOISTED INTO THE PRODUCER of an activation.  Both the forward
+ * pass and the weight gradient of a stage consume the same V = B^T d of its input rows; on gfx950 the
+ * fp32 MFMA shares the vector ALU's rate, so transform / staging instructions inside the GEMM kernels
+ * displace matrix work one for one.  V[quad][6][ldv] (quad Q = input rows 4Q..4Q+5 of one sequence,
+ * rows past the sequence taken as zero) is written once and the GEMM kernels become transform-free:
+ *   tl_wino43_input_transform  P (rows, C; whole sequences of Tp rows, Tp % 4 == 0) -> V (rows / 4 quads)
+ *   tl_conv3_wino43v_nt        forward pass of tl_conv3_wino43_nt with loader = 2: A = V, lda = ldv,
+ *                              A_rows = quads held by V (>= M / 4); POOL epilogue; K % 16 == 0; both
+ *                              operands reach LDS by buffer_load .. lds (no staging registers)
+ *   tl_conv3_wino43v_tn        weight gradient of tl_conv3_wino43_tn with A = V (lda = ldv, A_rows = quads
+ *                              held by V, a whole number of 8-quad K-steps: pad with zero quads); V by
+ *                              LDS-DMA into a 4-slot ring, Y = A dy staged as before; Mdim % 64 == 0
+ * tl_conv1_fwd writes V of its own output directly when `V` is not null (P may then be null).
  * ------------------------------------------------------------------------------------------ */
 int tl_wino_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
 int tl_wino43_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
@@ -140,6 +154,9 @@ int tl_conv3_wino_tn(const tl_tn_params* p, void* stream);
 int tl_wino_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
 int tl_conv3_wino43_tn(const tl_tn_params* p, void* stream);
 int tl_wino43_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
+int tl_wino43_input_transform(const float* P, float* V, int64_t rows, int Tp, int C, int ldp, int ldv, void* stream);
+int tl_conv3_wino43v_nt(const tl_nt_params* p, void* stream);
+int tl_conv3_wino43v_tn(const tl_tn_params* p, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
 int tl_sizeof_nt_params(void);
 int tl_sizeof_tn_params(void);
