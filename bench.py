@@ -441,8 +441,9 @@ def main():
                                      "frac": round(v["tflops"] * issued_of[k] / PEAK_FP32_MFMA_TFLOPS, 4),
                                      "algorithmic_tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms_per_step"], 2)}
                                  for k, v in stats.items()},
-                    "per_launch": {t: {"ms": round(tsum[t][1], 3),
-                                       "algorithmic_tflops": round(conv_flops(eng, int(t[4]), B) / (tsum[t][1] * 1e-3) / 1e12, 2)}
+                    "per_launch": {t: ({"ms": round(tsum[t][1], 3),
+                                        "algorithmic_tflops": round(conv_flops(eng, int(t[4]), B) / (tsum[t][1] * 1e-3) / 1e12, 2)}
+                                       if t.rsplit("_", 1)[-1] in ("fwd", "dgrad", "wgrad") else {"ms": round(tsum[t][1], 3)})
                                    for t in sorted(tsum)}}
         extras = {}
         if world == 1 and args.model == "full" and not args.no_extras:

@@ -110,6 +110,9 @@ class CnnEngine:
         # round 3: the F(4,3) input transform V = B^T d is written once by the producer of an activation and the
         # forward / weight-gradient GEMMs read it by LDS-DMA (tonal_wino43v.hip).  TONAL_WINO_V: 0 off, 1 on
         self.wino_v = self.wino43 and os.environ.get("TONAL_WINO_V", "1") != "0"
+        # with V written by the first stage the raw pooled rows P1 (13.4 GB at the north-star shape) have no reader
+        # left (the LeakyReLU' mask of the backward pass comes from the 1-bit sign array); store_p1 keeps them anyway
+        self.store_p1 = os.environ.get("TONAL_STORE_P1", "0") == "1"
         # fold the first stage's weight gradient into the stage-2 input-gradient epilogue (Winograd kernels)
         self.fuse_c1 = os.environ.get("TONAL_FUSE_C1", "1") != "0"
         self._B = None
@@ -127,7 +130,9 @@ class CnnEngine:
         z = lambda *s: torch.zeros(*s, **f32)
         zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
         self._v_ready = {}     # V tensors already written by the producing kernel in this forward
-        self.P = {1: z(S * self.tp1, self.c1)}
+        self.P = {}
+        if not self._conv1_writes_v() or self.store_p1:
+            self.P[1] = z(S * self.tp1, self.c1)
         self.bits = {1: zi(S * self.tp1, self.c1 // 32)}
         self.sbits = {1: zi(S * self.tp1, self.c1 // 32)}      # "pooled output > 0": the LeakyReLU' mask of backward
         for st in self.stages:
@@ -267,7 +272,16 @@ class CnnEngine:
         return self.wino43_tn and self._use_wino43(st)
 
     def _use_wino_v(self, st) -> bool:
-        return self.wino_v and self._use_wino43(st) and st.cin % 16 == 0
+        return self.wino_v and self._use_wino43(st) and st.cin % 64 == 0
+
+    def _conv1_writes_v(self) -> bool:
+        """The first stage hands its output to stage 2 as V (tl_conv1_fwd_v) - nothing else reads P1 then."""
+        return (self._use_wino_v(self.stages[0]) and self._use_wino43_tn(self.stages[0]) and self.tp1 % 4 == 0
+                and self.c1 in (128, 256, 512, 1024) and (self.fuse_c1 and self._c1_fusable()))
+
+    def _pin(self, st):
+        """Input activation of a stage, or None when only its V form exists (stage 2 behind tl_conv1_fwd_v)."""
+        return self.P.get(st.idx - 1)
 
     def _v_buffer(self, idx, rows, cin):
         """V of P[idx]: rows / 4 quads, padded with zero quads to whole 128-quad tiles (the weight-gradient kernel
@@ -308,7 +322,12 @@ class CnnEngine:
         fused = self.fuse_c1 and self._c1_fusable()
         tn = "wino43_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3))" if self.wino43_tn else \
             "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))"
-        fams = {f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {form})": ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}
+        fwd = f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {form})"
+        if self.wino_v and all(self._use_wino_v(st) for st in self.stages[:2]):
+            fwd = "wino43v_nt_kernel (conv2/conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)"
+            if self.wino43_tn:
+                tn = "wino43v_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA)"
+        fams = {fwd: ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}
         if fused:       # the stage-2 launch carries the fused conv1 weight-gradient epilogue: its own kernel name
             fams[f"{nt}<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd {form})"] = ["conv2_dgrad"]
             fams[f"{nt}<UNPOOL,MASK> (conv3 input gradient, Winograd {form})"] = ["conv3_dgrad"]
@@ -338,9 +357,9 @@ class CnnEngine:
         wino = self._use_wino(st)
         f43 = self._use_wino43(st)
         wp = self._pack_wino(w, True, f43) if wino else self._pack_conv(w, st.cin, False)
-        src = self.P[st.idx - 1]
+        src = self._pin(st)
         kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(self.P[st.idx]), M=S * st.tp_in,
-                  A_rows=src.shape[0], N=st.cout, K=st.cin, lda=src.shape[1], ldb=st.cin,
+                  A_rows=S * st.tp_in, N=st.cout, K=st.cin, lda=st.cin, ldb=st.cin,
                   ldo=self.P[st.idx].shape[1], J=st.k, row_shift=0, Tp=st.tp_in, slope=self.slope,
                   loader=LOAD_DIRECT)
         if st.pool:
@@ -370,7 +389,7 @@ class CnnEngine:
         """dW, db of one stage from its input P[idx-1] and G[idx] (pooled gradient + arg-max bits)."""
         S = self.S
         f32 = dict(dtype=torch.float32, device=self._dev)
-        Xin = self.P[st.idx - 1]
+        Xin = self._pin(st)
         Gs = self.G[st.idx]
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
@@ -385,7 +404,7 @@ class CnnEngine:
             sk = self._splitk(tiles, (rows_in + 31) // 32, int(os.environ.get("TONAL_TN_TARGET", "8192")))
             slab = torch.empty(sk, 6 * st.cin, ldg, **f32)
             bias_part = torch.empty(sk, nd, **f32)     # the kernel's Y1 = sum of the quad's dZ rows doubles as the bias gradient
-            kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0],
+            kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=rows_in, B_rows=Gs.shape[0],
                       Mdim=st.cin, Ndim=nd, lda=st.cin, ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk,
                       slab_stride=6 * st.cin * ldg, loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]),
                       ld_bbits=st.cout // 32, Tvalid=2 * st.tout, colsum=ptr(bias_part))
@@ -457,7 +476,7 @@ class CnnEngine:
         signal into per-row-tile partial sums of the first stage's weight / bias gradient, which are
         returned (shape (tiles, (k1 + 1) * c1), layout of ``tl_conv1_wgrad``'s partials)."""
         S = self.S
-        Xin = self.P[st.idx - 1]
+        Xin = self._pin(st)
         Gs = self.G[st.idx]
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
@@ -515,8 +534,17 @@ class CnnEngine:
         self._v_ready = {}
         # ---- stage 1 (C_in = 1) ----
         w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
-        check(lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]), ptr(self.P[1]), ptr(self.bits[1]),
-                               ptr(self.sbits[1]), S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd")
+        if self._conv1_writes_v():
+            if self.store_p1 and 1 not in self.P:
+                self.P[1] = torch.zeros(S * self.tp1, self.c1, dtype=torch.float32, device=dev)
+            V1 = self._v_buffer(1, S * self.tp1, self.c1)
+            check(lib.tl_conv1_fwd_v(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]),
+                                     ptr(self.P[1]) if self.store_p1 else None, ptr(V1), ptr(self.bits[1]), ptr(self.sbits[1]),
+                                     S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd_v")
+            self._v_ready[1] = V1
+        else:
+            check(lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]), ptr(self.P[1]), ptr(self.bits[1]),
+                                   ptr(self.sbits[1]), S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd")
         # ---- stages 2..5: windowed implicit GEMM on fp32 MFMA ----
         for st in self.stages:
             self.stage_forward(st, prm[self.STAGE_NAMES[st.idx] + ".weight"], prm[self.STAGE_NAMES[st.idx] + ".bias"])

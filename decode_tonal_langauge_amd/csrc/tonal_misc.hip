@@ -140,6 +140,94 @@ __global__ __launch_bounds__(256) void conv1_fwd_v4_kernel(const float* __restri
   }
 }
 
+// Same stage, writing the F(4,3) INPUT TRANSFORM of its pooled output for the next stage (tonal_wino43v.hip):
+// V[(seq * Tp/4 + q)][6][C1] from the pooled rows 4q..4q+5 (rows past Tout, and past the sequence, are zero), so the
+// next stage's forward / weight-gradient GEMMs read V by LDS-DMA and the 13 GB of P1 need not exist at all (P is
+// optional: tests and the direct-form kernels want it).  Thread = 4 channels x one quad; the two halo rows of a quad
+// are recomputed (3 MACs per element from the LDS-resident signal) rather than exchanged.  HBM-write bound.
+__global__ __launch_bounds__(256) void conv1_fwd_vq_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ P,
+                                                           float* __restrict__ V, uint32_t* __restrict__ bits,
+                                                           uint32_t* __restrict__ sign, long long S, int T, int kt, int C1,
+                                                           int Tp, int Tout, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const long long seq = blockIdx.x;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
+  __syncthreads();
+  const int groups = C1 >> 2;                    // threads per quad (<= 256, a multiple of 32)
+  const int qpp = 256 / groups;                  // quads per pass
+  const int g = threadIdx.x % groups, qsub = threadIdx.x / groups;
+  const int o = 4 * g;
+  float wv[4][MAXKT], bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bv[c] = b[o + c];
+#pragma unroll
+    for (int j = 0; j < MAXKT; ++j) wv[c][j] = j < kt ? w[(o + c) * kt + j] : 0.f;
+  }
+  const int sh = 4 * (threadIdx.x & 7);
+  const int Tq = Tp >> 2;
+  for (int q0 = 0; q0 < Tq; q0 += qpp) {
+    const int q = q0 + qsub;                     // Tq % qpp may be non-zero: guard the stores, keep the shuffles uniform
+    f32x4 d[6];
+    uint32_t wb[4], ws[4];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int p = 4 * q + j;
+      f32x4 out = {0.f, 0.f, 0.f, 0.f};
+      uint32_t nib = 0, nsg = 0;
+      if (q < Tq && p < Tout) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < MAXKT; ++jj)
+            if (jj < kt) {
+              z0 = fmaf(wv[c][jj], xs[2 * p + jj], z0);
+              z1 = fmaf(wv[c][jj], xs[2 * p + 1 + jj], z1);
+            }
+          const float y0 = lrelu(z0 + bv[c], slope), y1 = lrelu(z1 + bv[c], slope);
+          const bool sel = y1 > y0;
+          const float v = sel ? y1 : y0;
+          out[c] = v;
+          nib |= (sel ? 1u : 0u) << c;
+          nsg |= (v > 0.f ? 1u : 0u) << c;
+        }
+      }
+      d[j] = out;
+      if (j < 4) {
+        uint32_t a = nib << sh, e = nsg << sh;
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+          a |= __shfl_xor(a, m);
+          e |= __shfl_xor(e, m);
+        }
+        wb[j] = a;
+        ws[j] = e;
+      }
+    }
+    if (q < Tq) {
+      const long long row0 = seq * Tp + 4 * q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (P != nullptr) *reinterpret_cast<f32x4*>(P + (row0 + j) * C1 + o) = d[j];
+        if ((threadIdx.x & 7) == 0) {
+          bits[(row0 + j) * (C1 >> 5) + (o >> 5)] = wb[j];
+          if (sign != nullptr) sign[(row0 + j) * (C1 >> 5) + (o >> 5)] = ws[j];
+        }
+      }
+      const f32x4 s1 = d[4] - 4.f * d[2], s2 = d[3] - 4.f * d[1], s3 = d[4] - d[2], t = d[3] - d[1];
+      float* dst = V + (seq * Tq + q) * 6LL * C1 + o;
+      *reinterpret_cast<f32x4*>(dst) = 4.f * d[0] + (d[4] - 5.f * d[2]);
+      *reinterpret_cast<f32x4*>(dst + C1) = s1 + s2;
+      *reinterpret_cast<f32x4*>(dst + 2LL * C1) = s1 - s2;
+      *reinterpret_cast<f32x4*>(dst + 3LL * C1) = s3 + 2.f * t;
+      *reinterpret_cast<f32x4*>(dst + 4LL * C1) = s3 - 2.f * t;
+      *reinterpret_cast<f32x4*>(dst + 5LL * C1) = (4.f * d[1] - 5.f * d[3]) + d[5];
+    }
+  }
+}
+
 // conv1 weight/bias gradient partials: block handles a contiguous range of sequences;
 // thread owns channels tid and tid + 256 (C1 <= 512), barriers are outside every guard.
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ G,
@@ -832,6 +920,21 @@ extern "C" int tl_conv1_fwd(const float* x, const float* w, const float* b, floa
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,
                        bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
   return check_launch("conv1_fwd");
+}
+
+extern "C" int tl_conv1_fwd_v(const float* x, const float* w, const float* b, float* P, float* V, uint32_t* bits,
+                              uint32_t* sign, int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope,
+                              void* stream) {
+  TL_REQUIRE(x && w && b && V && bits, "conv1_fwd_v: null pointer");
+  TL_REQUIRE(S > 0 && S < (1LL << 31), "conv1_fwd_v: bad S");
+  TL_REQUIRE(ktaps >= 1 && ktaps <= MAXKT, "conv1_fwd_v: ktaps must be 1..%d", MAXKT);
+  TL_REQUIRE(C1 % 128 == 0 && C1 <= 1024 && (C1 & (C1 - 1)) == 0, "conv1_fwd_v: C1 must be 128, 256, 512 or 1024");
+  TL_REQUIRE(Tp > 0 && Tp % 4 == 0, "conv1_fwd_v: Tp must be a multiple of 4");
+  TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_fwd_v: Tout/Tp/T inconsistent (%d,%d,%d)", Tout, Tp, T);
+  TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_fwd_v: T too large for the LDS window");
+  hipLaunchKernelGGL(conv1_fwd_vq_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P, V,
+                     bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+  return check_launch("conv1_fwd_v");
 }
 
 extern "C" int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial, int nblk,

@@ -142,7 +142,7 @@ int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
  *   tl_conv3_wino43v_tn        weight gradient of tl_conv3_wino43_tn with A = V (lda = ldv, A_rows = quads
  *                              held by V, a whole number of 8-quad K-steps: pad with zero quads); V by
  *                              LDS-DMA into a 4-slot ring, Y = A dy staged as before; Mdim % 64 == 0
- * tl_conv1_fwd writes V of its own output directly when `V` is not null (P may then be null).
+ * tl_conv1_fwd_v (below) writes V of the first stage's output directly.
  * ------------------------------------------------------------------------------------------ */
 int tl_wino_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
 int tl_wino43_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
@@ -165,6 +165,10 @@ int tl_sizeof_tn_params(void);
  * x (S, T) -> P1 rows (S*Tp, C1) + arg-max bits (+ sign bits "P1 > 0", may be null); w (C1,3) b (C1). */
 int tl_conv1_fwd(const float* x, const float* w, const float* b, float* P, uint32_t* bits, uint32_t* sign,
                  int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream);
+/* the same stage writing V = the F(4,3) input transform of its pooled output (V[S * Tp / 4][6][C1], Tp % 4 == 0)
+ * for tl_conv3_wino43v_nt / _tn of the next stage; P is optional (null: the raw pooled rows are never stored)     */
+int tl_conv1_fwd_v(const float* x, const float* w, const float* b, float* P, float* V, uint32_t* bits, uint32_t* sign,
+                   int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream);
 /* its weight/bias gradient from G1 = dL/dZ at the arg-max: partial[nblk][(ktaps+1)*C1]      */
 int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial,
                    int nblk, int64_t S, int T, int ktaps, int C1, int Tp, int Tout, void* stream);

@@ -83,6 +83,20 @@ def test_c3_shape_train_step_matches_reference_golden(dev, c3):
     assert rel(out.cpu().numpy(), g["out"]) < 1e-4
     S = B * Cn
     acts = {}
+    # the first stage hands its output to stage 2 as V (the F(4,3) input transform, tl_conv1_fwd_v) and the raw pooled
+    # rows are not stored by default: a second forward with store_p1 yields them, and V must be their transform
+    assert eng._conv1_writes_v() and 1 not in eng.P
+    V1 = eng._v_ready[1].clone()
+    eng.store_p1 = True
+    with torch.no_grad():
+        out2 = model(x.to(dev), lab.to(dev))
+    eng.store_p1 = False
+    assert torch.equal(out2, out)
+    from decode_tonal_langauge_amd._lib import check, ptr
+    Vref = torch.zeros_like(V1)
+    check(eng.lib.tl_wino43_input_transform(ptr(eng.P[1]), ptr(Vref), eng.P[1].shape[0], eng.tp1, eng.c1, eng.c1, eng.c1,
+                                            torch.cuda.current_stream().cuda_stream), "tl_wino43_input_transform")
+    assert torch.allclose(V1, Vref, rtol=1e-6, atol=1e-6)
     for i in (1, 2, 3, 4):
         st_tp = eng.tp1 if i == 1 else eng.stages[i - 2].tp_out
         tout = eng.tout1 if i == 1 else eng.stages[i - 2].tout

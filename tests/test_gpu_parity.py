@@ -528,7 +528,7 @@ def test_cnnrnn_classifier_hip_trunk_matches_module_graph(dev):
         assert float((hip - ref.detach()).abs().max()) < 1e-4
 
 
-@pytest.mark.parametrize("widths", [(64, 96, 32), (32, 160, 64), (96, 32, 96)])
+@pytest.mark.parametrize("widths", [(64, 96, 32), (32, 160, 64), (96, 32, 96), (128, 64, 64)])
 def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
     """Stage kernels at the C-ABI level on channel counts that are not multiples of the column tiles
     (tile tails in N, one- and two-chunk K loops): all three Winograd forms against the direct kernels."""
