@@ -317,6 +317,9 @@ constexpr int T4_BM = 64, T4_BN = 64, T4_Q = 8;          // C_in tile, C_out til
 constexpr int T4_PLANE = T4_Q * 64;                       // floats per transform plane
 constexpr int T4_TILE = 6 * T4_PLANE;                     // floats per operand tile (12 KB)
 constexpr int T4V_NA = 4;                                 // V ring slots
+#ifndef T4V_SCHED
+#define T4V_SCHED 0        // > 0: hand-specified issue order of a K-step with this many VALU per MFMA slot
+#endif
 
 __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p) {
   __shared__ __attribute__((aligned(1024))) float lds[(T4V_NA + 2) * T4_TILE];
@@ -479,7 +482,9 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
       load_regs(std::false_type{}, r_ld);
       issue_v(s + 3);
     }
+#if !T4V_SCHED
     __builtin_amdgcn_sched_barrier(0);
+#endif
     mfma6(fa1, fb1);                                        // slice 3 of the previous step
     load_frag(fa1, fb1, abuf, bbuf, 1);
     mfma6(fa0, fb0);
@@ -488,6 +493,22 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
     if (!tail || s + 1 < nsteps) store_b(r_st, bbuf ^ 1);
     load_frag(fa1, fb1, abuf, bbuf, 3);
     mfma6(fa0, fb0);
+#if T4V_SCHED
+    // issue order of the step: the first fragment reads, then one vector-memory operation (4 Y loads, 3 V pieces),
+    // two transform VALU and one fragment read per MFMA slot, the three Y stores late (0x008 MFMA, 0x002 VALU,
+    // 0x010 vector memory, 0x100 / 0x200 LDS read / write)
+    if constexpr (!tail) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int t = 0; t < 24; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (t < 7) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, T4V_SCHED, 0);
+        if (t < 18) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (t >= 18 && t < 21) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+#endif
     if constexpr (!tail) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
