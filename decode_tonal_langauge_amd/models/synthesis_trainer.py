@@ -91,10 +91,15 @@ class SynthesisTrainer:
         # the batch gathers from them by id = tone * n_syllables + syllable (no torch.unique, no host sync per step)
         n_syl = getattr(self.syllable_model, "n_classes", None)
         self._pair_table = None
-        if not self._need_check and n_syl is not None and n_syl >= 1 and self._n_rows * n_syl <= 16:
-            syl_col = torch.arange(n_syl, dtype=torch.float32).view(1, n_syl, 1).expand(self._n_rows, n_syl, self._L)
-            dyn = table[:self._n_rows].view(self._n_rows, 1, self._L).expand(self._n_rows, n_syl, self._L)
-            self._pair_table = torch.stack([syl_col, dyn], dim=2).reshape(self._n_rows * n_syl, 2, self._L).contiguous() \
+        # Only the tone classes the classifier can predict (rows 0 .. n_classes - 1, all present when _need_check is
+        # False) enter the table: a mapping with extra keys above them (say "5" beside a 4-class model) would otherwise
+        # contribute NaN rows for the keys in between - no batch element gathers them, but the LSTM unrolls over every
+        # table row and 0 * NaN in its backward pass would poison all of W_hh, W_ih and the biases.
+        if not self._need_check and n_syl is not None and n_syl >= 1 and n_cls * n_syl <= 16:
+            syl_col = torch.arange(n_syl, dtype=torch.float32).view(1, n_syl, 1).expand(n_cls, n_syl, self._L)
+            dyn = table[:n_cls].view(n_cls, 1, self._L).expand(n_cls, n_syl, self._L)
+            assert not torch.isnan(dyn).any()
+            self._pair_table = torch.stack([syl_col, dyn], dim=2).reshape(n_cls * n_syl, 2, self._L).contiguous() \
                 .to(self.device)
             self._n_syl = int(n_syl)
         self._pair_ids = None
@@ -209,6 +214,7 @@ class SynthesisTrainer:
         out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True, seed=model._next_seed(),
                           row0=getattr(self, "_row0", 0), **kw)
         B, D = out.shape
+        self._last_out = out             # the step's outputs (pre-update), for callers that track them (tests)
         dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)
         self._loss_stats(out, targets, dout, eng.ldd, 1)
         gather = self._timed(parallel.gather_lowrank) if self.dp else None

@@ -632,3 +632,63 @@ def test_lowrank_nadam_equals_dense_nadam(dev):
         assert float((sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max()) < 1e-4 * float(sa["exp_avg_sq"].abs().max())
     with pytest.raises(RuntimeError, match="rank"):
         ob.step(grads={}, lowrank={pb: (torch.zeros(65, 33, device=dev), torch.zeros(65, 4, device=dev))})
+
+
+def test_sparse_tone_mapping_keeps_the_label_lstm_finite(dev):
+    """A tone mapping with a key gap above the classifier's classes (keys 0..3 and "5" beside a 4-class tone model): the
+    (tone, syllable) pair table must hold the predictable classes only.  Rows for the missing key 4 would be NaN; no
+    batch element gathers them, but the label LSTM unrolls over every table row and 0 * NaN in its backward pass would
+    turn W_hh, W_ih and the biases NaN after one step.  The update must equal the one under the dense mapping."""
+    from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
+    B, C, T = 6, 4, 100
+    xs, _t, _s, _labs, tg = gi.train_batches(2, B, C, T, seed=3)
+    gen = torch.Generator().manual_seed(9)
+    xt = [torch.randn(B, 8, T, generator=gen) for _ in range(2)]
+    xsyl = [torch.randn(B, 8, T, generator=gen) for _ in range(2)]
+    finals = []
+    for mapping in (gi.TONE_MAP, dict(gi.TONE_MAP, **{"5": [2, 2, 2, 2, 2]})):
+        torch.manual_seed(0)
+        model = SynthesisModelCNN(80, C, T, dropout=0.0)
+        torch.manual_seed(1)
+        tone, syl = LogisticRegressionClassifier(8 * T, 4), LogisticRegressionClassifier(8 * T, 2)
+        tr = SynthesisTrainer(model, tone, syl, mapping, device=dev, verbose=False)
+        assert tr._pair_table is not None and tr._pair_table.shape[0] == 8 and not torch.isnan(tr._pair_table).any()
+        for i in range(2):
+            tr.train_step(xs[i], xsyl[i], xt[i], tg[i])
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    for k, v in finals[1].items():
+        assert torch.isfinite(v).all(), k
+        assert torch.equal(v, finals[0][k]), k
+
+
+@pytest.mark.parametrize("wino", ["4", "1", "0"])
+def test_cnn_training_trajectory_matches_reference_golden(dev, monkeypatch, wino):
+    """G14: 30 NAdam steps of the reference's SynthesisModelCNN(80, 16, 200, dropout=0) on 30 seeded batches - the HIP
+    path's L1 loss, MCD and mel MSE mean((out - target)^2) stay within 1e-3 of the reference at EVERY step (the bound
+    BASELINE.json's north_star states), for the default kernels (F(4,3) on V), F(2,3) and the direct MFMA form."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    g = np.load(os.path.join(GOLD, "g14_cnn_trajectory.npz"))
+    D, C, T, B, N = (int(v) for v in g["dims"])
+    xs, _t, _s, labs, tg = gi.train_batches(N, B, C, T, seed=int(g["data_seed"]))
+    assert abs(gi.checksum(*xs, *labs, *tg) - float(g["in_checksum"])) < 1e-6 * float(g["in_checksum"])
+    monkeypatch.setenv("TONAL_WINO", wino)
+    torch.manual_seed(int(g["seed"]))
+    model = SynthesisModelCNN(D, C, T, dropout=0.0)
+    tr = _trainer(model, dev, T)
+    assert model._engine.wino == (wino != "0") and model._engine.wino43 == (wino == "4")
+    model.train()
+    worst = 0.0
+    for s in range(N):
+        tr._fused_step(xs[s].to(dev), labs[s].to(dev), tg[s].to(dev))
+        st = tr._stats.cpu().numpy()
+        out = tr._last_out.double().cpu() if hasattr(tr, "_last_out") else None
+        assert abs(st[2] - g["losses"][s]) < 1e-3 * g["losses"][s], (s, st[2], g["losses"][s])
+        assert abs(st[3] - g["mcds"][s]) < 1e-3 * g["mcds"][s], (s, st[3], g["mcds"][s])
+        assert out is not None
+        mse = float(((out - tg[s].double()) ** 2).mean())
+        worst = max(worst, abs(mse - g["mses"][s]) / g["mses"][s])
+        assert abs(mse - g["mses"][s]) < 1e-3 * g["mses"][s], (s, mse, g["mses"][s])
+        assert rel(out.numpy(), g["outs"][s]) < 5e-3, s          # element-wise, late in the trajectory
+    print(f"TONAL_WINO={wino}: worst relative mel-MSE deviation over {N} steps {worst:.2e}")

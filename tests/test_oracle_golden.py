@@ -255,3 +255,31 @@ def test_g13_preprocess_chain_oracle():
     d = sg.run(d, Namespace(signal_freq=f, bands=gi.CHAIN_STEPS[2]["params"]["bands"]))
     d = sg.channel_zscore(d)
     assert f == int(g["freq"]) and rel(d, g["out"]) < 1e-10
+
+
+def test_g14_trajectory_oracle_follows_the_reference():
+    """G14: 30 NAdam steps of the reference's SynthesisModelCNN(80, 16, 200) - the oracle's loss and mel MSE stay
+    within 1e-4 of the reference at every step (observed 1.1e-6)."""
+    g = np.load(os.path.join(GOLD, "g14_cnn_trajectory.npz"))
+    D, C, T, B, N = (int(v) for v in g["dims"])
+    xs, _t, _s, labs, tg = gi.train_batches(N, B, C, T, seed=int(g["data_seed"]))
+    assert abs(gi.checksum(*xs, *labs, *tg) - float(g["in_checksum"])) < 1e-6 * float(g["in_checksum"])
+    torch.manual_seed(int(g["seed"]))
+    p = so.init_cnn_params(D, C, T)
+    st = so.NAdamState(p)
+    for s in range(N):
+        loss, mcd, _g, out = so.train_step("cnn", p, None, st, xs[s], labs[s], tg[s], return_grads=True)
+        mse = float(((out.double() - tg[s].double()) ** 2).mean())
+        assert abs(loss - g["losses"][s]) < 1e-4 * g["losses"][s], s
+        assert abs(mcd - g["mcds"][s]) < 1e-4 * g["mcds"][s], s
+        assert abs(mse - g["mses"][s]) < 1e-4 * g["mses"][s], s
+
+
+def test_g15_hilbert_low_band_at_raw_rate():
+    """G15: the reference's hilbert_filter for a 1-4 Hz band and the high-gamma band at 3 kHz."""
+    g = np.load(os.path.join(GOLD, "g15_hilbert_low_band.npz"))
+    fs = int(g["fs"])
+    x = np.random.default_rng(15).standard_normal((2, 9000))
+    assert abs(float(np.abs(x).sum()) - float(g["x_checksum"])) < 1e-9
+    for name, fr, env in (("low_env", [1.0, 4.0], True), ("low_real", [1.0, 4.0], False), ("hg_env", [70.0, 150.0], True)):
+        assert rel(sg.hilbert_filter(x, fs, fr, envelope=env), g[name]) < 1e-12, name
