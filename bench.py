@@ -79,12 +79,18 @@ def parse_args(argv=None):
 # launcher: python bench.py --gpus N without torchrun
 # ------------------------------------------------------------------------------------------------
 def spawn_ranks(args) -> int:
-    """Start one child process per GPU BEFORE this process makes any GPU call (the parent never
-    initialises HIP; it only counts devices, which does not).  Children get RANK / LOCAL_RANK /
-    WORLD_SIZE / MASTER_* and run this file; rank 0 prints the JSON line on the inherited stdout."""
-    import torch
+    """Start one child process per GPU.  The parent never touches the GPU runtime: the devices are counted in a
+    short-lived child (torch.cuda.device_count() may fall back to hipGetDeviceCount, which initialises the runtime in
+    the calling process).  Children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and run this file; rank 0 prints
+    the JSON line on the inherited stdout.  The rendezvous port is picked by bind-and-release (a race with other
+    processes on the box is possible in principle; a failed rendezvous ends the run non-zero, it cannot hang it:
+    the first rank to fail takes its peers down)."""
     n = args.gpus
-    have = torch.cuda.device_count()
+    try:
+        have = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                  capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError, subprocess.SubprocessError):
+        have = 0
     share = os.environ.get("TONAL_BENCH_SHARE_GPU") == "1"      # rehearsal: all ranks on device 0 over gloo
     if have < n and not share:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
@@ -353,6 +359,10 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
+    if os.environ.get("TONAL_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        # test hook (tests/test_gpu_dp.py): a rank that dies must end the whole run non-zero, not hang its peers
+        print(f"bench.py: rank {rank} exits on request (TONAL_BENCH_FAIL_RANK)", file=sys.stderr)
+        os._exit(3)
     C, T, D = args.channels, args.timepoints, 80
     if args.scaling == "strong":
         GB = args.batch

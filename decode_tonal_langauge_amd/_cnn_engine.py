@@ -551,7 +551,8 @@ class CnnEngine:
         # ---- label LSTM on the distinct label sequences ----
         L = labels.shape[2]
         flat = labels.reshape(B, 2 * L)
-        if label_ids is not None and label_table is not None:
+        self._table_labels = label_ids is not None and label_table is not None
+        if self._table_labels:
             uniq, inv = label_table.reshape(label_table.shape[0], 2 * L).float(), label_ids
         else:
             uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
@@ -642,7 +643,7 @@ class CnnEngine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, prm: Dict[str, torch.Tensor], dout: torch.Tensor, grads: Dict[str, torch.Tensor],
-                 gather_whh=None, whh_factors: bool = False) -> None:
+                 gather_whh=None, whh_factors: bool = False, reduce_rows=None) -> None:
         """dout: (B, ldd) gradient of the loss w.r.t. the output (pad columns zero).
         Fills ``grads[name]`` (torch layouts) for every parameter.  ``gather_whh(dg, h)`` may
         return the low-rank factors of every data-parallel rank (parallel.gather_lowrank): the
@@ -763,7 +764,14 @@ class CnnEngine:
                     raise RuntimeError("the row-sharded label LSTM needs the factored W_hh update (whh_factors=True)")
                 self.whh_factors = (fa[:, sh[0]:sh[0] + sh[1]], fb.contiguous(), sh[0], sh[1])
                 fa = fb = None
+            elif gather_whh is not None and self._table_labels and reduce_rows is not None:
+                # the label table is the same on every rank: row (t, u) of the factors means the same (step, label
+                # sequence) everywhere and carries bit-identical h, so the factor of the GLOBAL gradient is simply the sum
+                # of the ranks' dgates rows - one small all-reduce ((L-1) U x 4H floats), no gather, no host sync
+                fa = fa.clone()                  # dg itself stays local: the W_ih / bias gradients are reduced with the buckets
+                reduce_rows(fa)
             elif gather_whh is not None:
+                # arbitrary label tensors: the distinct rows differ per rank (torch.unique above already synchronised)
                 # key of row (t, u): the step and the label sequence h_t was unrolled from
                 steps = torch.arange(L - 1, device=dev, dtype=torch.float32).repeat_interleave(U).unsqueeze(1)
                 keys = torch.cat([steps, self._xu.permute(1, 0, 2).reshape(U, 2 * L).repeat(L - 1, 1)], dim=1)

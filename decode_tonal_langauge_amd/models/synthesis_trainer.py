@@ -18,6 +18,8 @@ optimizer, :131-137) - ``train_classifiers`` only toggles ``.train()``.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -110,7 +112,8 @@ class SynthesisTrainer:
         self.dp = parallel.active()
         self._whh_dirty = False
         eng = getattr(self.model, "_engine", None)
-        if self.dp and eng is not None and hasattr(eng, "lstm_shard") and self._pair_table is not None:
+        if (self.dp and eng is not None and hasattr(eng, "lstm_shard") and self._pair_table is not None
+                and os.environ.get("TONAL_LSTM_SHARD", "1") != "0"):
             eng.lstm_shard = (self.rank, self.world)        # row-sharded label LSTM (parallel.py docstring)
 
     # ------------------------------------------------------------------ helpers
@@ -218,7 +221,8 @@ class SynthesisTrainer:
         dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)
         self._loss_stats(out, targets, dout, eng.ldd, 1)
         gather = self._timed(parallel.gather_lowrank) if self.dp else None
-        eng.backward(prm, dout, self._grads, gather_whh=gather, whh_factors=skip is not None)
+        reduce_rows = self._timed(parallel.all_reduce_) if self.dp else None
+        eng.backward(prm, dout, self._grads, gather_whh=gather, whh_factors=skip is not None, reduce_rows=reduce_rows)
         scale = 1.0          # the 1/N of the global mean is already in dout (weight of this rank's rows)
         if self.dp:
             sharded = getattr(eng, "_sh", None) is not None

@@ -27,9 +27,9 @@ def _build(dev, sizes=(8, 8), dropout=0.0):
     return model, tr, batches
 
 
-def _worker(rank, world, port, q, sizes=(8, 8), dropout=0.0):
+def _worker(rank, world, port, q, sizes=(8, 8), dropout=0.0, shard="1"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK="0", TONAL_LSTM_SHARD=shard)
     from decode_tonal_langauge_amd import parallel
     parallel.init_from_env(backend="gloo")
     dev = torch.device("cuda:0")
@@ -163,3 +163,74 @@ def test_exchange_step_over_rccl_single_rank():
         err = float((torch.from_numpy(params[k]).double() - ref[k].double()).norm() / max(float(upd.norm()), 1e-30))
         assert err < 2e-2, (k, err)
     assert abs(float(stats[0]) - float(tr._stats[0])) < 1e-3 * abs(float(tr._stats[0]))
+
+
+def test_two_rank_training_unsharded_lstm_reduces_the_factor_rows():
+    """TONAL_LSTM_SHARD=0: every rank keeps the whole label LSTM.  The trainer still knows the label table, so row
+    (step, table row) of the W_hh gradient factors means the same thing on every rank and the global factor is one
+    small all-reduce of the dgates rows (no gather, no torch.unique, no host synchronisation) - the two ranks must
+    again end on the single-process parameters."""
+    dev = torch.device("cuda:0")
+    model, tr, batches = _build(dev)
+    model.train()
+    for b in batches:
+        tr.train_step(*b)
+    ref = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, (8, 8), 0.0, "0")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    from decode_tonal_langauge_amd.models import SynthesisModelCNN
+    init = {k: v.detach().clone() for k, v in SynthesisModelCNN(80, 8, 100, dropout=0.0).named_parameters()}
+    for rank, params, stats, sharded in res:
+        assert not sharded
+        for k in ref:
+            upd = (ref[k] - init[k]).double()
+            err = float((torch.from_numpy(params[k]).double() - ref[k].double()).norm() / max(float(upd.norm()), 1e-30))
+            assert err < 2e-2, (rank, k, err)
+    for k in ref:
+        assert (res[0][1][k] == res[1][1][k]).all(), k
+
+
+def _bench(extra_env, *flags, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_two_rank_launch_at_the_headline_shape():
+    """`python bench.py --gpus 2` at the north-star shape (C4's first point), both ranks on the test GPU over gloo
+    (TONAL_BENCH_SHARE_GPU=1; RCCL refuses two ranks per device): the launcher starts the ranks, the global batch of
+    256 is sharded 128 + 128, the exchange step is timed, and rank 0 prints the one JSON line of the contract."""
+    import math
+    r, line = _bench({"TONAL_BENCH_SHARE_GPU": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                     "--no-extras")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    cfg = line["config"]
+    assert cfg["backend"] == "gloo" and cfg["per_gpu_batch"] == 128 and cfg["global_batch"] == 256
+    assert cfg["parallelism"] == "dp2" and line["scaling"] == "strong"
+    assert math.isfinite(cfg["exchange_ms_per_step"]) and cfg["exchange_ms_per_step"] > 0
+    assert line["value"] > 0 and abs(line["value"] - 256 / (line["ms_per_step"] * 1e-3)) < 1e-2 * line["value"]
+
+
+def test_bench_ends_non_zero_when_a_rank_dies():
+    r, line = _bench({"TONAL_BENCH_SHARE_GPU": "1", "TONAL_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "1",
+                     "--warmup", "0", "--batch", "8", "--channels", "8", "--timepoints", "100", "--no-cpu-baseline",
+                     "--no-extras", timeout=600)
+    assert r.returncode != 0 and line is None
+    assert "exits on request" in r.stderr
