@@ -280,7 +280,15 @@ def signal_subresult(dev, with_cpu: bool):
     x_np = np.random.default_rng(0).standard_normal((C, T)).astype(np.float32)
     x = torch.from_numpy(x_np).to(dev)
     out = {"shape": [C, T], "fs": FS, "dtype_in": "f32", "dtype_out": "f64"}
+    def hilbert_dft():
+        os.environ["TONAL_HILBERT"] = "fft"
+        try:
+            return ff.hilbert_filter(x, FS, [70., 150.])
+        finally:
+            os.environ.pop("TONAL_HILBERT", None)
+
     cases = [("hilbert", lambda: ff.hilbert_filter(x, FS, [70., 150.]), 8),
+             ("hilbert_dft_domain_path", hilbert_dft, 8),       # the path long (low-band / raw-rate) kernels take
              ("butter_filtfilt", lambda: ff.butter_filter(x, [0.3, 100], FS), 8),
              ("fir390", lambda: ff.fir_bandpass_filter(x, FS, 390, [100.]), 4)]
     for name, fn, s_out in cases:
@@ -300,6 +308,9 @@ def signal_subresult(dev, with_cpu: bool):
             rec.update({"bound": "fp64 VALU (time-domain 8-band complex Gabor bank, 557 FLOP/B: far right of the ridge)",
                         "fp64_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "fp64_peak_tflops": PEAK_FP64_VALU_TFLOPS,
                         "frac_of_fp64_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 4)})
+        elif name == "hilbert_dft_domain_path":
+            rec["bound"] = ("HBM / L2 (Bluestein chirp-z over radix-2 Stockham passes in fp64: 18 FFTs of 65 536 points per "
+                            "channel, one pass over a 1 MB buffer per radix-2 stage); not the default for this band")
         elif name == "butter_filtfilt":
             rec["bound"] = "latency (fp64 IIR recurrence, sequential in time)"
         else:

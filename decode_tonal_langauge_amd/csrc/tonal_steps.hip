@@ -205,6 +205,51 @@ __global__ __launch_bounds__(256) void rs_out_kernel(const c64* __restrict__ c2,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// DFT-domain Gaussian Hilbert bank (frequency_filter.py:155-184 taken literally): X = DFT(x); per band
+// z_b = IDFT(X . K_b), K_b = H_b x analytic multiplier (real, host coefficient data); y = mean_b |z_b| or Re z_b.
+// Arbitrary recording length through Bluestein on the Stockham passes above.  This is the path for bands whose
+// time-domain kernels are too long for tl_gauss_envelope's LDS window (low bands at a raw recording rate).
+// ------------------------------------------------------------------------------------------
+// X[c][k] = conj(w[k]) c1[c][k] / m2, k < n   (c1 = chirp-convolved forward transform, un-normalised)
+__global__ __launch_bounds__(256) void hb_spec_kernel(const c64* __restrict__ c1, const c64* __restrict__ w, c64* __restrict__ X,
+                                                      long long total, int n, int m2) {
+  const double inv = 1.0 / (double)m2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % n);
+    const long long c = i / n;
+    c64 v = cmul(cconj(w[k]), c1[c * m2 + k]);
+    X[i] = {v.re * inv, v.im * inv};
+  }
+}
+// a[c][k] = conj(X[c][k] K[k]) conj(w[k]) for k < n, 0 up to m2: Bluestein input of DFT(conj(Z)), Z = X K
+__global__ __launch_bounds__(256) void hb_band_prep_kernel(const c64* __restrict__ X, const double* __restrict__ K,
+                                                           const c64* __restrict__ w, c64* __restrict__ a, long long total,
+                                                           int n, int m2) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % m2);
+    const long long c = i / m2;
+    c64 v = {0.0, 0.0};
+    if (k < n) {
+      const c64 x = X[c * n + k];
+      const double kk = K[k];
+      v = cmul(c64{x.re * kk, -x.im * kk}, cconj(w[k]));
+    }
+    a[i] = v;
+  }
+}
+// d = conj(w[t]) c2[c][t] / m2 = DFT(conj Z)[t]; z[t] = conj(d) / n.  y (+)= (|d| or Re d) * scale
+__global__ __launch_bounds__(256) void hb_accum_kernel(const c64* __restrict__ c2, const c64* __restrict__ w, double* __restrict__ y,
+                                                       long long total, int n, int m2, double scale, int envelope, int first) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % n);
+    const long long c = i / n;
+    const c64 d = cmul(cconj(w[t]), c2[c * m2 + t]);
+    const double v = (envelope ? sqrt(d.re * d.re + d.im * d.im) : d.re) * scale;
+    y[i] = first ? v : y[i] + v;
+  }
+}
+
 static inline unsigned sgrid(long long total) {
   long long g = (total + 255) / 256;
   if (g < 1) g = 1;
@@ -309,4 +354,43 @@ extern "C" int tl_fft_resample(const void* x, int is_f64, void* y, int C, int64_
   else
     hipLaunchKernelGGL((tl::rs_out_kernel<float>), dim3(sgrid(to)), dim3(256), 0, st, A2, W2, (float*)y, to, (int)num, m2b, scale);
   return check_launch("fft_resample");
+}
+
+extern "C" int tl_hilbert_fft(const void* x, int is_f64, double* y, int C, int64_t T, const double* kernels, int nb,
+                              const double* w, const double* bf, const double* tw, int m2, int envelope, double* work,
+                              void* stream) {
+  TL_REQUIRE(x && y && kernels && w && bf && tw && work, "hilbert_fft: null pointer");
+  TL_REQUIRE(C > 0 && T > 1 && nb > 0, "hilbert_fft: bad sizes");
+  TL_REQUIRE(m2 >= 2 * T - 1 && (m2 & (m2 - 1)) == 0, "hilbert_fft: m2 must be a power of two >= 2T-1");
+  TL_REQUIRE(T < (1LL << 30), "hilbert_fft: recording too long");
+  hipStream_t st = (hipStream_t)stream;
+  tl::c64* A = reinterpret_cast<tl::c64*>(work);                 // (C, m2)
+  tl::c64* Tm = A + (size_t)C * m2;                              // scratch (C, m2)
+  tl::c64* X = Tm + (size_t)C * m2;                              // (C, T) spectrum
+  const tl::c64* W = reinterpret_cast<const tl::c64*>(w);
+  const tl::c64* BF = reinterpret_cast<const tl::c64*>(bf);
+  const tl::c64* TW = reinterpret_cast<const tl::c64*>(tw);
+  const long long ta = (long long)C * m2, tx = (long long)C * T;
+  const int n = (int)T;
+  if (is_f64)
+    hipLaunchKernelGGL((tl::rs_prep_kernel<double>), dim3(sgrid(ta)), dim3(256), 0, st, x, W, A, ta, n, m2);
+  else
+    hipLaunchKernelGGL((tl::rs_prep_kernel<float>), dim3(sgrid(ta)), dim3(256), 0, st, x, W, A, ta, n, m2);
+  int rc = fft_pow2(A, Tm, TW, C, m2, 0, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(tl::rs_cmul_kernel, dim3(sgrid(ta)), dim3(256), 0, st, A, BF, ta, m2);
+  rc = fft_pow2(A, Tm, TW, C, m2, 1, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(tl::hb_spec_kernel, dim3(sgrid(tx)), dim3(256), 0, st, A, W, X, tx, n, m2);
+  const double scale = 1.0 / ((double)m2 * (double)T * (double)nb);
+  for (int b = 0; b < nb; ++b) {
+    hipLaunchKernelGGL(tl::hb_band_prep_kernel, dim3(sgrid(ta)), dim3(256), 0, st, X, kernels + (size_t)b * T, W, A, ta, n, m2);
+    rc = fft_pow2(A, Tm, TW, C, m2, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tl::rs_cmul_kernel, dim3(sgrid(ta)), dim3(256), 0, st, A, BF, ta, m2);
+    rc = fft_pow2(A, Tm, TW, C, m2, 1, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tl::hb_accum_kernel, dim3(sgrid(tx)), dim3(256), 0, st, A, W, y, tx, n, m2, scale, envelope, b == 0 ? 1 : 0);
+  }
+  return check_launch("hilbert_fft");
 }

@@ -5,11 +5,16 @@ Same plugin ABI: ``run(data (C,T), params) -> (C', T)`` with ``params.bands`` / 
 ``hilbert_filter`` (:80-184), ``butter_filter`` (:187-229), ``fir_bandpass_filter`` (:232-274).
 
 The arithmetic runs in HIP kernels (``csrc/tonal_signal.hip``):
- * the Gaussian-bank analytic signal is evaluated as an *exact* circular convolution: the host
+ * the Gaussian-bank analytic signal is evaluated - when its band kernels are short, as for high gamma on the
+   400 Hz recordings of the pipeline - as an *exact* circular convolution: the host
    takes the inverse DFT of the reference's frequency-domain kernel ``H_b * hilbert_mult``
    (including its ``H[0] = 0`` and the one-sided multiplier) and keeps every tap above the fp64
    round-off floor of that inverse DFT (1e-13 of the kernel peak); the kernel then computes |sum_n h_b[n] x[(t-n) mod T]| per band and the mean
-   over bands in one pass over the recording (the reference loops n_bands x C Python-level iFFTs);
+   over bands in one pass over the recording (the reference loops n_bands x C Python-level iFFTs); bands whose
+   kernels are longer than that kernel's LDS window (low bands at a raw recording rate: sigma_t of hundreds to
+   thousands of samples) go through the DFT domain exactly as the reference writes it - forward DFT, per-band
+   multiplier, inverse DFT - with the arbitrary-length DFT as a Bluestein chirp-z over power-of-two Stockham
+   passes (``tl_hilbert_fft``; ``TONAL_HILBERT=fft`` forces that path, ``=taps`` forbids it);
  * ``filtfilt`` / ``sosfilt`` are fp64 direct-form-II-transposed recurrences, one lane per channel;
  * the FIR bank is a causal convolution with zero initial state.
 Filter *design* (``butter``, ``lfilter_zi``, ``firwin``) stays on scipy: coefficient generation,
@@ -21,6 +26,7 @@ tensors (stay resident; a CUDA tensor is returned).
 from __future__ import annotations
 
 import math
+import os
 from argparse import Namespace
 from typing import List, Tuple, Union
 
@@ -90,6 +96,25 @@ def gaussian_bank(freq_ranges, sampling_rate, f0=0.018, octspace=1 / 7, filterba
     return np.array(cfs), np.array(sds) * np.sqrt(2)
 
 
+def band_multipliers(T: int, sampling_rate: float, cfs: np.ndarray, sds: np.ndarray) -> np.ndarray:
+    """(nb, T) real DFT-domain kernels H_b x analytic multiplier of the reference (:155-175)."""
+    freqs = np.fft.fftfreq(T, d=1.0 / sampling_rate)
+    mult = np.zeros(T)
+    if T % 2 == 0:
+        mult[0] = 1
+        mult[1:T // 2] = 2
+        mult[T // 2] = 1
+    else:
+        mult[0] = 1
+        mult[1:(T + 1) // 2] = 2
+    ker = np.empty((len(cfs), T))
+    for i, (fc, sf) in enumerate(zip(cfs, sds)):
+        H = np.exp(-0.5 * ((freqs - fc) / sf) ** 2)
+        H[0] = 0
+        ker[i] = H * mult
+    return ker
+
+
 def analytic_taps(T: int, sampling_rate: float, cfs: np.ndarray, sds: np.ndarray, tol: float = 1e-13):
     """Time-domain kernels of the reference's per-band DFT multiplier (:155-175).
 
@@ -138,6 +163,34 @@ def _device_taps(T, sampling_rate, cfs, sds, dev):
     return hit
 
 
+_MULT_CACHE = {}
+
+
+def _hilbert_dft(x: torch.Tensor, sampling_rate, cfs, sds, envelope: bool) -> torch.Tensor:
+    """The bank in the DFT domain (``tl_hilbert_fft``), channels in chunks that bound the workspace to ~4 GB."""
+    from .downsample import _bluestein_coeffs
+    C, T = x.shape
+    dev = x.device
+    w, bf, tw, m2 = _bluestein_coeffs(T, dev)
+    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev))
+    kd = _MULT_CACHE.get(key)
+    if kd is None:
+        if len(_MULT_CACHE) > 8:
+            _MULT_CACHE.clear()
+        kd = _MULT_CACHE[key] = torch.from_numpy(band_multipliers(T, sampling_rate, cfs, sds)).to(dev)
+    y = torch.empty(C, T, dtype=torch.float64, device=dev)
+    per_ch = (2 * m2 + T) * 16
+    chunk = int(max(1, min(C, (4 << 30) // per_ch)))
+    work = torch.empty(chunk * (2 * m2 + T), 2, dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    for c0 in range(0, C, chunk):
+        n = min(chunk, C - c0)
+        check(lib.tl_hilbert_fft(ptr(x[c0:c0 + n]), int(x.dtype == torch.float64), ptr(y[c0:c0 + n]), n, T, ptr(kd),
+                                 len(cfs), ptr(w), ptr(bf), ptr(tw), m2, int(envelope), ptr(work), _stream()),
+              "tl_hilbert_fft")
+    return y
+
+
 def hilbert_filter(data, sampling_rate: int, freq_ranges: Union[List[Tuple[float, float]], Tuple[float, float]],
                    f0: float = 0.018, octspace: float = 1 / 7, filterbank_bias: float = math.log10(0.39),
                    filterbank_slope: float = 0.5, envelope: bool = True):
@@ -148,10 +201,13 @@ def hilbert_filter(data, sampling_rate: int, freq_ranges: Union[List[Tuple[float
     if len(cfs) == 0:
         # the reference's mean over an empty band axis yields NaN
         return _ret(torch.full((C, T), float("nan"), dtype=torch.float64, device=x.device), was_np)
-    tp, ntap, half = _device_taps(T, sampling_rate, cfs, sds, x.device)
-    if ntap > _MAX_TAPS_LDS:
-        raise ValueError(f"hilbert_filter: the band kernels need {ntap} taps at this sampling rate; "
-                         f"the MI355X kernel supports up to {_MAX_TAPS_LDS}")
+    mode = os.environ.get("TONAL_HILBERT", "auto")
+    tp, ntap, half = (None, 0, 0) if mode == "fft" else _device_taps(T, sampling_rate, cfs, sds, x.device)
+    if mode == "fft" or ntap > _MAX_TAPS_LDS:
+        if mode == "taps":
+            raise ValueError(f"hilbert_filter: the band kernels need {ntap} taps at this sampling rate; the time-domain "
+                             f"kernel supports up to {_MAX_TAPS_LDS} (TONAL_HILBERT=taps forbids the DFT-domain path)")
+        return _ret(_hilbert_dft(x, sampling_rate, cfs, sds, bool(envelope)), was_np)
     y = torch.empty(C, T, dtype=torch.float64, device=x.device)
     check(_lib.load().tl_gauss_envelope(ptr(x), int(x.dtype == torch.float64), ptr(tp), ptr(y), C, T, len(cfs), ntap,
                                         half, int(bool(envelope)), _stream()), "tl_gauss_envelope")

@@ -297,6 +297,14 @@ int tl_lite_uncat(const float* dfeat, float* dy2, float* dh, int B, int F, int H
  * mean_b |sum_n h_b[n] x[(t-n) mod T]| (envelope != 0) or the mean of the real parts.        */
 int tl_gauss_envelope(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T,
                       int nb, int ntap, int half, int envelope, void* stream);
+/* The same bank evaluated in the DFT domain exactly as the reference writes it (frequency_filter.py:155-184):
+ * X = DFT(x), z_b = IDFT(X . K_b), y = mean_b |z_b| (envelope) or mean_b Re z_b.  Arbitrary T (Bluestein chirp-z
+ * over radix-2 Stockham passes, fp64).  kernels (nb, T) real = H_b x analytic multiplier; w (T,2) chirp, bf (m2,2) FFT
+ * of the chirp filter, tw (m2/2,2) twiddles, m2 >= 2T-1 a power of two: coefficient data from the host, as for
+ * tl_fft_resample.  work: (2 C m2 + C T) complex128.  No limit on the kernel length: used when the time-domain
+ * taps exceed tl_gauss_envelope's LDS window (low bands at a raw recording rate).                              */
+int tl_hilbert_fft(const void* x, int x_is_f64, double* y, int C, int64_t T, const double* kernels, int nb,
+                   const double* w, const double* bf, const double* tw, int m2, int envelope, double* work, void* stream);
 /* zero-phase IIR (scipy filtfilt, odd padding, lfilter_zi), fp64 (frequency_filter.py:226-227);
  * work holds 2*C*(T + 6*ntaps) doubles                                                        */
 int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, const double* a, const double* zi,

@@ -692,3 +692,30 @@ def test_cnn_training_trajectory_matches_reference_golden(dev, monkeypatch, wino
         assert abs(mse - g["mses"][s]) < 1e-3 * g["mses"][s], (s, mse, g["mses"][s])
         assert rel(out.numpy(), g["outs"][s]) < 5e-3, s          # element-wise, late in the trajectory
     print(f"TONAL_WINO={wino}: worst relative mel-MSE deviation over {N} steps {worst:.2e}")
+
+
+def test_hilbert_low_band_at_raw_rate_matches_reference_golden(dev, monkeypatch):
+    """G15: the reference's hilbert_filter for a 1-4 Hz band at 3 kHz - Gaussian kernels thousands of samples long, more
+    than the time-domain kernel's LDS window: the DFT-domain path (tl_hilbert_fft, Bluestein over Stockham passes) -
+    and the high-gamma band at that rate on both paths; G6 (400 Hz) through the DFT-domain path as well."""
+    from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
+    g = np.load(os.path.join(GOLD, "g15_hilbert_low_band.npz"))
+    fs = int(g["fs"])
+    x = np.random.default_rng(15).standard_normal((2, 9000))
+    assert abs(float(np.abs(x).sum()) - float(g["x_checksum"])) < 1e-9
+    assert rel(ff.hilbert_filter(x, fs, [1.0, 4.0]), g["low_env"]) < 1e-9
+    assert rel(ff.hilbert_filter(x, fs, [1.0, 4.0], envelope=False), g["low_real"]) < 1e-9
+    assert rel(ff.hilbert_filter(x.astype(np.float32), fs, [1.0, 4.0]), g["low_env_f32"]) < 1e-5     # reference: complex64
+    assert rel(ff.hilbert_filter(x, fs, [70.0, 150.0]), g["hg_env"]) < 1e-9                          # time-domain taps
+    with monkeypatch.context() as m:
+        m.setenv("TONAL_HILBERT", "taps")
+        with pytest.raises(ValueError, match="taps"):
+            ff.hilbert_filter(x, fs, [1.0, 4.0])
+    monkeypatch.setenv("TONAL_HILBERT", "fft")
+    assert rel(ff.hilbert_filter(x, fs, [70.0, 150.0]), g["hg_env"]) < 1e-9                          # DFT domain
+    g6 = np.load(os.path.join(GOLD, "g6_signal.npz"))
+    x6, _x2 = gi.g6_inputs()
+    assert rel(ff.hilbert_filter(x6, 400, freq_ranges=[70., 150.]), g6["hilbert"]) < 1e-9
+    assert rel(ff.hilbert_filter(x6, 400, freq_ranges=[70., 150.], envelope=False), g6["hilbert_real"]) < 1e-9
+    xt = torch.from_numpy(x).to(dev)                                                                 # resident input
+    assert rel(ff.hilbert_filter(xt, fs, [1.0, 4.0]).cpu().numpy(), g["low_env"]) < 1e-9
