@@ -56,7 +56,10 @@ class CnnClassifierEngine(CnnEngine):
             hit = self._packed[key] = (ver, build())
         return hit[1]
 
-    def forward_scores(self, convs: List[Tuple[torch.Tensor, torch.Tensor]], fc1, fc2, x: torch.Tensor) -> torch.Tensor:
+    def forward_scores(self, convs: List[Tuple[torch.Tensor, torch.Tensor]], fc1, fc2, x: torch.Tensor,
+                       p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+        """``p_drop`` > 0: the module's ``nn.Dropout`` after the last pool (reference :81) is active - applied in place on
+        the feature map by ``tl_dropout_scale`` (counter-hash stream, ``seed``), so train-mode classifiers stay on HIP."""
         B, Cn, T = x.shape
         if Cn != self.C or T != self.T:
             raise ValueError(f"expected input (B, {self.C}, {self.T}), got {tuple(x.shape)}")
@@ -87,6 +90,8 @@ class CnnClassifierEngine(CnnEngine):
                 kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
             self._nt(fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino else "tl_gemm_nt_window", **kw)
         feat = self.P[self.stages[-1].idx]                       # [S*tp_last][ld_last] == [B][kflat_cls]
+        if p_drop > 0.0:
+            check(lib.tl_dropout_scale(ptr(feat), feat.numel(), float(p_drop), int(seed), st_), "tl_dropout_scale")
         w_fc1, b_fc1 = fc1
         lat, latC = self.lat, self.lat * self.C
 
@@ -325,7 +330,8 @@ class CnnRnnConvEngine:
         return out
 
     @torch.no_grad()
-    def features(self, x: torch.Tensor, h1: torch.Tensor, block1, block2, conv3a, conv3b) -> torch.Tensor:
+    def features(self, x: torch.Tensor, h1: torch.Tensor, block1, block2, conv3a, conv3b, p_drop: float = 0.0,
+                 seed: int = 0) -> torch.Tensor:
         """x (B, C, T), h1 (B, lstm_dim); blockN / conv3x = (weight, bias).  Returns the tensor the
         reference feeds to its second LSTM: (B, t', 256 * W) - a raw view of the contiguous
         (B, 256, t', W) activation (reference :315)."""
@@ -344,7 +350,9 @@ class CnnRnnConvEngine:
         self._conv7(self.P, conv3a[0], conv3a[1], self.Y1, 1024, 512, "conv3a", rows)
         self._conv7(self.Y1, conv3b[0], conv3b[1], self.Y2, 512, 256, "conv3b", rows)
         y = self.Y2.view(B * self.W, self.Tp, 256)[:, :3 * self.tq]
-        y = y.reshape(B * self.W, self.tq, 3, 256).amax(dim=2)                         # MaxPool (3,1), per sequence
+        y = y.reshape(B * self.W, self.tq, 3, 256).amax(dim=2).contiguous()            # MaxPool (3,1), per sequence
+        if p_drop > 0.0:                   # the block's nn.Dropout (reference :258), train mode: in place on (seq, t', 256)
+            check(lib.tl_dropout_scale(ptr(y), y.numel(), float(p_drop), int(seed), st_), "tl_dropout_scale")
         nb = B * self.w1
         y = torch.cat((y[:nb].view(B, self.w1, self.tq, 256), y[nb:].view(B, self.C, self.tq, 256)), dim=1)
         f = y.permute(0, 3, 2, 1).contiguous()                                         # (B, 256, t', W)

@@ -78,6 +78,7 @@ SIGNATURES = {
     "tl_sizeof_tn_params": (_I, []),
     "tl_conv1_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
     "tl_conv1_fwd_v": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
+    "tl_dropout_scale": (_I, [_P, _L, _F, C.c_uint64, _P]),
     "tl_conv1_wgrad": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P]),
     "tl_permute_reduce": (_I, [_P, _P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _L, _P, _P]),
     "tl_colsum": (_I, [_P, _P, _I, _L, _I, _I, _I, _I, _P]),

@@ -228,6 +228,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_vq_kernel(const float* __restri
   }
 }
 
+// Inverted dropout in place on a flat buffer (nn.Dropout of the deep classifiers, reference
+// models/deep_classifiers.py:81,258, active when the synthesis trainer runs them in train mode): keep with
+// probability 1 - p, scale by 1 / (1 - p); the counter-hash stream of the synthesis model's dropout (u01 above),
+// indexed by the element's position in the buffer.
+__global__ __launch_bounds__(256) void dropout_scale_kernel(float* __restrict__ x, long long n, float p, float inv_keep,
+                                                            uint64_t seed) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    x[i] = u01(seed, (uint64_t)i) >= p ? x[i] * inv_keep : 0.f;
+}
+
 // conv1 weight/bias gradient partials: block handles a contiguous range of sequences;
 // thread owns channels tid and tid + 256 (C1 <= 512), barriers are outside every guard.
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ G,
@@ -935,6 +945,17 @@ extern "C" int tl_conv1_fwd_v(const float* x, const float* w, const float* b, fl
   hipLaunchKernelGGL(conv1_fwd_vq_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P, V,
                      bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
   return check_launch("conv1_fwd_v");
+}
+
+extern "C" int tl_dropout_scale(float* x, int64_t n, float p, uint64_t seed, void* stream) {
+  TL_REQUIRE(x && n > 0, "dropout_scale: bad arguments");
+  TL_REQUIRE(p >= 0.f && p < 1.f, "dropout_scale: p must be in [0, 1)");
+  if (p == 0.f) return TL_OK;
+  long long g = (n + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(dropout_scale_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long long)n, p,
+                     1.0f / (1.0f - p), seed);
+  return check_launch("dropout_scale");
 }
 
 extern "C" int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial, int nblk,

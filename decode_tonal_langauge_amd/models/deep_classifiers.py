@@ -4,8 +4,10 @@ They run forward-only inside every synthesis train step (reference models/synthe
 Their kernels are a "next" row of the hot-path scope: this module keeps the
 reference's constructor arguments, sub-module names (hence ``state_dict`` keys, so pre-trained
 ``.pt`` files load) and forward semantics - including the raw ``view`` that re-interprets the
-(B, 256, t', w) feature map as (B, t', 256*w) in ``CNNRNNClassifier`` (:315) - and executes on stock
-PyTorch-ROCm until HIP versions exist.
+(B, 256, t', w) feature map as (B, t', 256*w) in ``CNNRNNClassifier`` (:315).  Called without autograd on CUDA tensors
+(how the trainer calls them) they run on the HIP kernels (``_classifier_engine``) - in eval mode and, with their
+``nn.Dropout`` drawn from the package's counter-hash stream, in train mode (the reference CLI's default,
+train_synthesizer.py:275-284); only a call that needs autograd THROUGH the classifier uses the module graph.
 """
 from __future__ import annotations
 
@@ -57,6 +59,11 @@ class CNNClassifier(ClassifierModel):
 
         self._hip = None
         self._hip_cfg = (input_channels, input_length, negative_slope)
+        self._drop_calls = 0
+
+    def _next_seed(self) -> int:
+        self._drop_calls += 1
+        return (torch.initial_seed() * 0x9E3779B1 + 0x51ED27 + self._drop_calls) & 0xFFFFFFFFFFFFFFFF
 
     def _hip_engine(self):
         if self._hip is None:
@@ -77,12 +84,13 @@ class CNNClassifier(ClassifierModel):
         # that needs autograd through the classifier (its own training is outside the hot-path
         # scope) uses the module graph on stock PyTorch-ROCm.
         needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        dropout_active = self.training and self.feature_extractor[-1].p > 0
-        if x.is_cuda and not needs_graph and not dropout_active and self._hip_cfg[2] >= 0:
+        p_drop = float(self.feature_extractor[-1].p) if self.training else 0.0
+        if x.is_cuda and not needs_graph and p_drop < 1.0 and self._hip_cfg[2] >= 0:
             convs = [(m.weight.detach(), m.bias.detach()) for m in self.feature_extractor if isinstance(m, nn.Conv2d)]
             fc1, fc2 = self.classifier[1], self.classifier[3]
+            self._last_seed = self._next_seed() if p_drop > 0 else 0
             return self._hip_engine().forward_scores(convs, (fc1.weight.detach(), fc1.bias.detach()),
-                                                     (fc2.weight.detach(), fc2.bias.detach()), x)
+                                                     (fc2.weight.detach(), fc2.bias.detach()), x, p_drop, self._last_seed)
         x = x.unsqueeze(1).permute(0, 1, 3, 2)            # (B, 1, T, C)
         return self.classifier(self.feature_extractor(x))
 
@@ -113,6 +121,11 @@ class CNNRNNClassifier(ClassifierModel):
         self.lstm2 = nn.LSTM(input_size=256 * w, hidden_size=512, batch_first=True)
         self.output = nn.Linear(512, n_classes)
         self._hip = None
+        self._drop_calls = 0
+
+    def _next_seed(self) -> int:
+        self._drop_calls += 1
+        return (torch.initial_seed() * 0x9E3779B1 + 0x7A3C11 + self._drop_calls) & 0xFFFFFFFFFFFFFFFF
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, C, T = x.shape
@@ -123,7 +136,8 @@ class CNNRNNClassifier(ClassifierModel):
         xt = x.permute(0, 2, 1)                            # (B, T, C)
         needs_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         slope = self.conv_pool_block1[1].negative_slope
-        if x.is_cuda and not needs_graph and not (self.training and self.conv_block3[5].p > 0) and slope >= 0:
+        p_drop = float(self.conv_block3[5].p) if self.training else 0.0
+        if x.is_cuda and not needs_graph and p_drop < 1.0 and slope >= 0:
             # inference on CUDA (how the synthesis trainer calls the classifiers): everything on the HIP
             # kernels - both LSTMs (LstmInferEngine), the convolutional trunk, the output layer
             if self._hip is None:
@@ -135,8 +149,9 @@ class CNNRNNClassifier(ClassifierModel):
             lw = lambda m: (m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0)
             h1 = self._hip_lstm1.last_hidden(xt, *lw(self.lstm1))
             self._hip.last_h1 = h1
+            self._last_seed = self._next_seed() if p_drop > 0 else 0
             f = self._hip.features(x, h1, wb(self.conv_pool_block1[0]), wb(self.conv_pool_block2[0]),
-                                   wb(self.conv_block3[0]), wb(self.conv_block3[2]))
+                                   wb(self.conv_block3[0]), wb(self.conv_block3[2]), p_drop, self._last_seed)
             h2 = self._hip_lstm2.last_hidden(f, *lw(self.lstm2))
             return torch.sigmoid(self._hip.linear(h2, self.output.weight.detach(), self.output.bias.detach()))
         h1 = self.lstm1(xt)[0][:, -1, :]                   # (B, lstm_dim)

@@ -173,6 +173,10 @@ int tl_conv1_fwd_v(const float* x, const float* w, const float* b, float* P, flo
 int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial,
                    int nblk, int64_t S, int T, int ktaps, int C1, int Tp, int Tout, void* stream);
 
+/* nn.Dropout of the deep classifiers (models/deep_classifiers.py:81,258) in train mode, in place on a flat buffer:
+ * x[i] = keep(seed, i) ? x[i] / (1 - p) : 0 with the counter-hash stream of tl_concat_pack (index = position i)   */
+int tl_dropout_scale(float* x, int64_t n, float p, uint64_t seed, void* stream);
+
 /* ---- small strided helpers --------------------------------------------------------------- */
 /* dst[i0][i1][i2][i3] (contiguous) = sum_{z<nz} src[z*zs + i0*s0 + i1*s1 + i2*s2 + i3*s3];
  * elements whose i_d >= lim_d (source extents) read as 0. Used to pack torch-layout weights

@@ -359,6 +359,14 @@ def test_trainer_with_deep_classifiers(dev):
     assert len(hist) == 2 and all(np.isfinite(v) for h in hist for v in h)
     mcd, recon, origin = tr.evaluate(torch.utils.data.DataLoader(ds, batch_size=6))
     assert np.isfinite(mcd) and recon.shape == (12, 80) and origin.shape == (12, 80)
+    # the reference CLI's default: train_classifiers=True puts the classifiers in train mode (dropout active) - they
+    # must still run on the HIP engines, with a fresh dropout seed per call
+    tr2 = SynthesisTrainer(model, tone, syl, gi.TONE_MAP, device=dev, verbose=False, train_classifiers=True)
+    tone._hip = syl._hip = None
+    s0, t0 = syl._drop_calls, tone._drop_calls
+    hist = tr2.train(torch.utils.data.DataLoader(ds, batch_size=6), 1, verbose=False)
+    assert tone.training and syl.training and tone._hip is not None and syl._hip is not None
+    assert syl._drop_calls == s0 + 2 and tone._drop_calls == t0 + 2 and all(np.isfinite(v) for h in hist for v in h)
 
 
 @pytest.mark.parametrize("cfg", [
@@ -719,3 +727,64 @@ def test_hilbert_low_band_at_raw_rate_matches_reference_golden(dev, monkeypatch)
     assert rel(ff.hilbert_filter(x6, 400, freq_ranges=[70., 150.], envelope=False), g6["hilbert_real"]) < 1e-9
     xt = torch.from_numpy(x).to(dev)                                                                 # resident input
     assert rel(ff.hilbert_filter(xt, fs, [1.0, 4.0]).cpu().numpy(), g["low_env"]) < 1e-9
+
+
+def _hip_dropout_mask(dev, numel, p, seed):
+    """The keep mask tl_dropout_scale draws for a buffer of ``numel`` elements: the kernel applied to ones."""
+    from decode_tonal_langauge_amd import _lib
+    m = torch.ones(numel, dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().tl_dropout_scale(m.data_ptr(), numel, float(p), int(seed), torch.cuda.current_stream().cuda_stream),
+               "tl_dropout_scale")
+    return m
+
+
+def test_deep_classifiers_train_mode_dropout_stays_on_hip(dev):
+    """The reference CLI trains with ``train_classifiers=True`` by default (train_synthesizer.py:275-284), i.e. the deep
+    classifiers run in train mode with their Dropout active (models/deep_classifiers.py:81,258; synthesis_trainer.py:
+    193-195).  They must stay on the HIP kernels then.  torch's Philox draws cannot be replayed, so - as for the
+    synthesis model's dropout - the HIP keep mask is read back (values {0, 1/(1-p)}, keep rate, a fresh mask per call)
+    and fed to the module's own graph with nn.Dropout replaced by that mask: outputs must agree."""
+    from decode_tonal_langauge_amd.models import CNNClassifier, CNNRNNClassifier
+    torch.manual_seed(0)
+    # ---- CNNClassifier: Dropout on the (B, 256, lat, C) feature map ----
+    C, T, B, p = 4, 160, 6, 0.5
+    clf = CNNClassifier(input_channels=C, input_length=T, n_classes=3, dropout_rate=p).to(dev).train()
+    x = torch.randn(B, C, T, device=dev)
+    with torch.no_grad():
+        hip = clf(x)
+        hip2 = clf(x)
+    eng = clf._hip
+    assert eng is not None and clf._last_seed != 0
+    assert float((hip - hip2).abs().max()) > 0                       # a new mask per forward
+    feat = eng.P[eng.stages[-1].idx]
+    m = _hip_dropout_mask(dev, feat.numel(), p, clf._last_seed).view(B, C, eng.tp_last, eng.ld_last)
+    vals = torch.unique(m)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-6
+    keep = float((m > 0).float().mean())
+    assert abs(keep - (1 - p)) < 4 * (p * (1 - p) / m.numel()) ** 0.5
+    mask_t = m[:, :, :eng.lat, :256].permute(0, 3, 2, 1)            # -> (B, 256, lat, C)
+    with torch.no_grad():
+        f = clf.feature_extractor[:-1](x.unsqueeze(1).permute(0, 1, 3, 2))
+        ref = clf.classifier(f * mask_t)
+    assert float((hip2 - ref).abs().max()) < 1e-5
+    # ---- CNNRNNClassifier: Dropout on the (B, 256, t', W) map behind the (3,1) pool ----
+    C, T, B, lstm_dim = 4, 100, 3, 200
+    rnn = CNNRNNClassifier(input_channels=C, input_length=T, n_classes=4, lstm_dim=lstm_dim, dropout=p).to(dev).train()
+    x = torch.randn(B, C, T, device=dev)
+    with torch.no_grad():
+        hip = rnn(x)
+    e2 = rnn._hip
+    assert e2 is not None and rnn._last_seed != 0
+    W, w1, tq = e2.W, e2.w1, e2.tq
+    m = _hip_dropout_mask(dev, B * W * tq * 256, p, rnn._last_seed).view(B * W, tq, 256)
+    nb = B * w1
+    mask_t = torch.cat((m[:nb].view(B, w1, tq, 256), m[nb:].view(B, C, tq, 256)), dim=1).permute(0, 3, 2, 1)   # (B, 256, t', W)
+    with torch.no_grad():
+        xt = x.permute(0, 2, 1)
+        h1 = rnn.lstm1(xt)[0][:, -1, :]
+        a = rnn.conv_pool_block1(xt.unsqueeze(1))
+        b = rnn.conv_pool_block2(h1.reshape(B, 1, T, -1))
+        f = rnn.conv_block3[:-1](torch.cat((b, a), dim=3)) * mask_t
+        f = f.contiguous().view(B, f.shape[2], -1)
+        ref = torch.sigmoid(rnn.output(rnn.lstm2(f)[0][:, -1, :]))
+    assert float((hip - ref).abs().max()) < 1e-4
