@@ -115,6 +115,12 @@ class CnnEngine:
         self.store_p1 = os.environ.get("TONAL_STORE_P1", "0") == "1"
         # fold the first stage's weight gradient into the stage-2 input-gradient epilogue (Winograd kernels)
         self.fuse_c1 = os.environ.get("TONAL_FUSE_C1", "1") != "0"
+        # TONAL_OVERLAP=1: run the label LSTM (forward and BPTT: HBM-bound streams of the 5.4 GB W_hh) and the W_hh update
+        # on a side stream beside the MFMA-bound convolution stack they do not depend on.  Measured equal to one stream
+        # (251.1 vs 250.7 ms): a conv workgroup holds 144 KB of LDS and both waves' worth of registers of every SIMD, so
+        # the streaming kernels (which stage through LDS too) find no free CU and the two streams serialise.  Off.
+        self.overlap = os.environ.get("TONAL_OVERLAP", "0") == "1"
+        self._side = None
         self._B = None
         self.generation = 0
         self._saved_generation = -1
@@ -164,6 +170,11 @@ class CnnEngine:
             self.G[st.idx] = z(S * st.tp_out, st.cout if st.pool else self.ld5)
         self.GY = [z(self.rows5, d[3]) for d in self.concat_dims]
         self.dXc = z(self.rows5, self.ldx)
+
+    def _side_stream(self, dev):
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     # ------------------------------------------------------------------ ABI helpers
     def _stream(self):
@@ -506,62 +517,11 @@ class CnnEngine:
                  else "tl_gemm_nt_window", **kw)
         return part
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,
-                save: bool, seed: int = 0, row0: int = 0, label_ids: Optional[torch.Tensor] = None,
-                label_table: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``row0``: index of this shard's first window in the global batch (data parallel): the dropout
-        hash is indexed by the global element, so N ranks draw the masks of one process.
-        ``label_ids`` (B,) int32 + ``label_table`` (U, 2, L): the caller already knows the distinct label
-        sequences (the trainer builds them from (tone, syllable) class pairs) - ``labels[b] == label_table[ids[b]]``;
-        the LSTM then runs on the table rows and no ``torch.unique`` (a host synchronisation) is needed."""
-        B, Cn, T = x.shape
-        if Cn != self.C or T != self.T:
-            raise ValueError(f"expected ECoG input (B, {self.C}, {self.T}), got {tuple(x.shape)}")
-        if labels.dim() != 3 or labels.shape[0] != B or labels.shape[1] != 2:
-            raise ValueError(f"expected labels (B, 2, L), got {tuple(labels.shape)}")
-        x = x.contiguous().float()
-        labels = labels.contiguous().float()
-        dev = x.device
-        self._alloc(B, dev)
+    def _lstm_forward(self, prm, xu, U, L, dev, training, label_table) -> None:
+        """The label LSTM on the U distinct label rows (torch's current stream: the forward runs it on a side stream beside
+        the convolution stack, which it does not depend on - four 5.4 GB streams of W_hh next to MFMA-bound kernels)."""
         lib, st_ = self.lib, self._stream()
-        S = self.S
-        self.generation += 1
-        p_drop = self.p_drop if training else 0.0
-        self._p_drop_used, self._seed_used = p_drop, seed
-        self._drop_row0 = int(row0) * self.C * self.tp5
-        self._x = x
-        self._v_ready = {}
-        # ---- stage 1 (C_in = 1) ----
-        w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
-        if self._conv1_writes_v():
-            if self.store_p1 and 1 not in self.P:
-                self.P[1] = torch.zeros(S * self.tp1, self.c1, dtype=torch.float32, device=dev)
-            V1 = self._v_buffer(1, S * self.tp1, self.c1)
-            check(lib.tl_conv1_fwd_v(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]),
-                                     ptr(self.P[1]) if self.store_p1 else None, ptr(V1), ptr(self.bits[1]), ptr(self.sbits[1]),
-                                     S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd_v")
-            self._v_ready[1] = V1
-        else:
-            check(lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]), ptr(self.P[1]), ptr(self.bits[1]),
-                                   ptr(self.sbits[1]), S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd")
-        # ---- stages 2..5: windowed implicit GEMM on fp32 MFMA ----
-        for st in self.stages:
-            self.stage_forward(st, prm[self.STAGE_NAMES[st.idx] + ".weight"], prm[self.STAGE_NAMES[st.idx] + ".bias"])
-        # ---- label LSTM on the distinct label sequences ----
-        L = labels.shape[2]
-        flat = labels.reshape(B, 2 * L)
-        self._table_labels = label_ids is not None and label_table is not None
-        if self._table_labels:
-            uniq, inv = label_table.reshape(label_table.shape[0], 2 * L).float(), label_ids
-        else:
-            uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
-        U = uniq.shape[0]
-        self._U, self._L = U, L
-        self._uid = inv.to(torch.int32).contiguous()
         H = self.H
-        xu = uniq.reshape(U, 2, L).permute(2, 0, 1).contiguous()          # (L, U, 2) time-major
-        self._xu = xu
         f32 = dict(dtype=torch.float32, device=dev)
         self._act = torch.empty(L, U, 4 * H, **f32)
         self._c = torch.empty(L, U, H, **f32)
@@ -605,6 +565,75 @@ class CnnEngine:
             check(lib.tl_lstm_cell_fwd(ptr(hh) if t > 0 else None, ptr(xu[t]), ptr(w_ih), ptr(b_ih), ptr(b_hh),
                                        ptr(self._c[t - 1]) if t > 0 else None, ptr(self._act[t]), ptr(self._c[t]),
                                        ptr(self._h[t]), U, H, 2, 4 * H, st_), "tl_lstm_cell_fwd")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, prm: Dict[str, torch.Tensor], x: torch.Tensor, labels: torch.Tensor, training: bool,
+                save: bool, seed: int = 0, row0: int = 0, label_ids: Optional[torch.Tensor] = None,
+                label_table: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``row0``: index of this shard's first window in the global batch (data parallel): the dropout
+        hash is indexed by the global element, so N ranks draw the masks of one process.
+        ``label_ids`` (B,) int32 + ``label_table`` (U, 2, L): the caller already knows the distinct label
+        sequences (the trainer builds them from (tone, syllable) class pairs) - ``labels[b] == label_table[ids[b]]``;
+        the LSTM then runs on the table rows and no ``torch.unique`` (a host synchronisation) is needed."""
+        B, Cn, T = x.shape
+        if Cn != self.C or T != self.T:
+            raise ValueError(f"expected ECoG input (B, {self.C}, {self.T}), got {tuple(x.shape)}")
+        if labels.dim() != 3 or labels.shape[0] != B or labels.shape[1] != 2:
+            raise ValueError(f"expected labels (B, 2, L), got {tuple(labels.shape)}")
+        x = x.contiguous().float()
+        labels = labels.contiguous().float()
+        dev = x.device
+        self._alloc(B, dev)
+        lib, st_ = self.lib, self._stream()
+        S = self.S
+        self.generation += 1
+        p_drop = self.p_drop if training else 0.0
+        self._p_drop_used, self._seed_used = p_drop, seed
+        self._drop_row0 = int(row0) * self.C * self.tp5
+        self._x = x
+        self._v_ready = {}
+        # ---- stage 1 (C_in = 1) ----
+        w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
+        if self._conv1_writes_v():
+            if self.store_p1 and 1 not in self.P:
+                self.P[1] = torch.zeros(S * self.tp1, self.c1, dtype=torch.float32, device=dev)
+            V1 = self._v_buffer(1, S * self.tp1, self.c1)
+            check(lib.tl_conv1_fwd_v(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]),
+                                     ptr(self.P[1]) if self.store_p1 else None, ptr(V1), ptr(self.bits[1]), ptr(self.sbits[1]),
+                                     S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd_v")
+            self._v_ready[1] = V1
+        else:
+            check(lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]), ptr(self.P[1]), ptr(self.bits[1]),
+                                   ptr(self.sbits[1]), S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd")
+        # ---- label LSTM on the distinct label sequences ----
+        L = labels.shape[2]
+        flat = labels.reshape(B, 2 * L)
+        self._table_labels = label_ids is not None and label_table is not None
+        if self._table_labels:
+            uniq, inv = label_table.reshape(label_table.shape[0], 2 * L).float(), label_ids
+        else:
+            uniq, inv = torch.unique(flat, dim=0, return_inverse=True)
+        U = uniq.shape[0]
+        self._U, self._L = U, L
+        self._uid = inv.to(torch.int32).contiguous()
+        H = self.H
+        xu = uniq.reshape(U, 2, L).permute(2, 0, 1).contiguous()          # (L, U, 2) time-major
+        self._xu = xu
+        f32 = dict(dtype=torch.float32, device=dev)
+        # the LSTM does not depend on the convolution stack: it runs on a side stream beside it (HBM-bound next to
+        # MFMA-bound), joined in front of the concat kernel.  Not under the row-sharded data-parallel LSTM (collectives).
+        side = self._side_stream(dev) if (self.overlap and self.lstm_shard is None) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._lstm_forward(prm, xu, U, L, dev, training, label_table)
+        # ---- stages 2..5: windowed implicit GEMM on fp32 MFMA ----
+        for st in self.stages:
+            self.stage_forward(st, prm[self.STAGE_NAMES[st.idx] + ".weight"], prm[self.STAGE_NAMES[st.idx] + ".bias"])
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            self._lstm_forward(prm, xu, U, L, dev, training, label_table)
         # ---- dropout + concat ----
         check(lib.tl_concat_pack(ptr(self.P[5]), ptr(self._h[L - 1]), ptr(self._uid), ptr(self.Xc), B, self.C,
                                  self.tp5, self.lat, self.Cc, self.Lc, self.ld5, H, self.ldx, p_drop, seed,
@@ -641,80 +670,14 @@ class CnnEngine:
             self._saved_generation = self.generation
         return out
 
-    # ------------------------------------------------------------------ backward
-    def backward(self, prm: Dict[str, torch.Tensor], dout: torch.Tensor, grads: Dict[str, torch.Tensor],
-                 gather_whh=None, whh_factors: bool = False, reduce_rows=None) -> None:
-        """dout: (B, ldd) gradient of the loss w.r.t. the output (pad columns zero).
-        Fills ``grads[name]`` (torch layouts) for every parameter.  ``gather_whh(dg, h)`` may
-        return the low-rank factors of every data-parallel rank (parallel.gather_lowrank): the
-        W_hh gradient written is then already the sum over ranks.  With ``whh_factors`` the W_hh
-        gradient is not written at all: ``self.whh_factors = (fa, fb)`` (gradient = fa^T . fb) is left for
-        ``FusedNAdam.step(lowrank=...)``; ``None`` afterwards means the dense gradient was written instead
-        (rank above 64)."""
-        self.whh_factors = None
-        if self._saved_generation != self.generation:
-            raise RuntimeError("SynthesisModelCNN backward: the forward intermediates were overwritten by a later "
-                               "forward pass (one forward/backward pair at a time per model)")
-        self._alloc_bwd()
+    def _lstm_backward(self, prm, grads, dh_ext, gather_whh, whh_factors, reduce_rows, on_factors) -> None:
+        """BPTT of the label LSTM on the distinct rows, its W_ih / bias gradients and the W_hh gradient (dense, or left as
+        factors in ``self.whh_factors``) - on torch's current stream.  ``on_factors()`` is called at the end (the trainer
+        updates W_hh there, on the same stream)."""
         lib, st_ = self.lib, self._stream()
-        B, S, dev = self._B, self.S, self._dev
+        dev = self._dev
         f32 = dict(dtype=torch.float32, device=dev)
         H, U, L = self.H, self._U, self._L
-        rows5 = self.rows5
-
-        colsum = self._colsum
-
-        # ---- output layer ----
-        gw = grads["output_layer.weight"]
-        slab = torch.empty(self.ldd, self.kflat, **f32)
-        self._tn(A=ptr(dout), B=ptr(self.Y[-1]), slab=ptr(slab), Krows=B, A_rows=B, B_rows=B, Mdim=self.ldd,
-                 Ndim=self.kflat, lda=self.ldd, ldb=self.kflat, ldc=self.kflat, loader=LOAD_DIRECT)
-        latC = self.lat * self.C
-        self._permute(slab, gw, (self.out_dim, self.Cc, self.lat, self.C),
-                      (self.kflat, 1, self.ldy5, self.tp5 * self.ldy5))
-        colsum(dout, B, self.out_dim, self.ldd, 1, 1, grads["output_layer.bias"])
-        # dY5 = dout . Wp_out, masked by lrelu'(Y5)
-        wpt = torch.empty(self.kflat, self.ldd, **f32)
-        self._permute(prm["output_layer.weight"], wpt, (self.C, self.tp5, self.ldy5, self.ldd),
-                      (1, self.C, latC, self.Cc * latC), (self.C, self.lat, self.Cc, self.out_dim))
-        self._nt(A=ptr(dout), Bw=ptr(wpt), aux=ptr(self.Y[-1]), out=ptr(self.GY[-1]), M=B, A_rows=B, N=self.kflat,
-                 K=self.ldd, lda=self.ldd, ldb=self.ldd, ldo=self.kflat, ldaux=self.kflat, loader=LOAD_DIRECT,
-                 epilogue=EPI_MASK, slope=self.cslope)
-        del wpt
-        # ---- concat 1x1 stack, last to first ----
-        for i in range(len(self.concat_dims) - 1, -1, -1):
-            cin_t, cin_ld, cout_t, cout_ld = self.concat_dims[i]
-            src = self.Xc if i == 0 else self.Y[i - 1]
-            Gi = self.GY[i]
-            name = f"concat_conv_block.{2 * i}"
-            tiles = ((cin_ld + 127) // 128) * ((cout_ld + 127) // 128)
-            sk = self._splitk(tiles, (rows5 + 31) // 32)
-            slab = torch.empty(sk, cin_ld, cout_ld, **f32)
-            self._tn(A=ptr(src), B=ptr(Gi), slab=ptr(slab), Krows=rows5, A_rows=rows5, B_rows=rows5, Mdim=cin_ld,
-                     Ndim=cout_ld, lda=cin_ld, ldb=cout_ld, ldc=cout_ld, loader=LOAD_DIRECT, Tp=self.tp5,
-                     Tvalid=self.lat, splitk=sk, slab_stride=cin_ld * cout_ld)
-            self._permute(slab, grads[name + ".weight"], (1, 1, cout_t, cin_t), (0, 0, 1, cout_ld), nz=sk,
-                          zs=cin_ld * cout_ld)
-            colsum(Gi, rows5, cout_t, cout_ld, self.tp5, self.lat, grads[name + ".bias"])
-            wd = self._pack_conv(prm[name + ".weight"], cin_ld, True)          # [1][cin_ld][cout_ld]
-            if i > 0:
-                self._nt(A=ptr(Gi), Bw=ptr(wd), aux=ptr(src), out=ptr(self.GY[i - 1]), M=rows5, A_rows=rows5,
-                         N=cin_ld, K=cout_ld, lda=cout_ld, ldb=cout_ld, ldo=cin_ld, ldaux=cin_ld, loader=LOAD_DIRECT,
-                         epilogue=EPI_MASK, slope=self.cslope)
-            else:
-                self._nt(A=ptr(Gi), Bw=ptr(wd), out=ptr(self.dXc), M=rows5, A_rows=rows5, N=cin_ld, K=cout_ld,
-                         lda=cout_ld, ldb=cout_ld, ldo=cin_ld, loader=LOAD_DIRECT, epilogue=EPI_STORE)
-        # ---- un-concat: G5 (dropout + lrelu') and dh summed over duplicates ----
-        order = torch.argsort(self._uid, stable=True).to(torch.int32)
-        counts = torch.zeros(U, dtype=torch.int32, device=dev)           # (torch.bincount synchronises)
-        counts.scatter_add_(0, self._uid.long(), torch.ones_like(self._uid))
-        offsets = torch.zeros(U + 1, dtype=torch.int32, device=dev)
-        offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
-        dh_ext = torch.empty(U, H, **f32)
-        check(lib.tl_concat_unpack_bwd(ptr(self.dXc), ptr(self.P[5]), ptr(order), ptr(offsets), ptr(self.G[5]),
-                                       ptr(dh_ext), B, U, self.C, self.tp5, self.lat, self.Cc, self.Lc, self.ld5, H,
-                                       self.ldx, self.slope, self._p_drop_used, self._seed_used, self._drop_row0,
-                                       st_), "tl_concat_unpack_bwd")
         # ---- LSTM BPTT on the distinct rows ----
         sh = self._sh
         if sh:      # every rank runs the same BPTT on the gradient of the GLOBAL batch
@@ -795,6 +758,90 @@ class CnnEngine:
                                   st_), "tl_lstm_ih_grad")
         grads["label_lstm.bias_hh_l0"].copy_(gb)
         del dg, dgt
+        if on_factors is not None:
+            on_factors()
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, prm: Dict[str, torch.Tensor], dout: torch.Tensor, grads: Dict[str, torch.Tensor],
+                 gather_whh=None, whh_factors: bool = False, reduce_rows=None, on_factors=None) -> None:
+        """dout: (B, ldd) gradient of the loss w.r.t. the output (pad columns zero).
+        Fills ``grads[name]`` (torch layouts) for every parameter.  ``gather_whh(dg, h)`` may
+        return the low-rank factors of every data-parallel rank (parallel.gather_lowrank): the
+        W_hh gradient written is then already the sum over ranks.  With ``whh_factors`` the W_hh
+        gradient is not written at all: ``self.whh_factors = (fa, fb)`` (gradient = fa^T . fb) is left for
+        ``FusedNAdam.step(lowrank=...)``; ``None`` afterwards means the dense gradient was written instead
+        (rank above 64)."""
+        self.whh_factors = None
+        if self._saved_generation != self.generation:
+            raise RuntimeError("SynthesisModelCNN backward: the forward intermediates were overwritten by a later "
+                               "forward pass (one forward/backward pair at a time per model)")
+        self._alloc_bwd()
+        lib, st_ = self.lib, self._stream()
+        B, S, dev = self._B, self.S, self._dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        H, U, L = self.H, self._U, self._L
+        rows5 = self.rows5
+
+        colsum = self._colsum
+
+        # ---- output layer ----
+        gw = grads["output_layer.weight"]
+        slab = torch.empty(self.ldd, self.kflat, **f32)
+        self._tn(A=ptr(dout), B=ptr(self.Y[-1]), slab=ptr(slab), Krows=B, A_rows=B, B_rows=B, Mdim=self.ldd,
+                 Ndim=self.kflat, lda=self.ldd, ldb=self.kflat, ldc=self.kflat, loader=LOAD_DIRECT)
+        latC = self.lat * self.C
+        self._permute(slab, gw, (self.out_dim, self.Cc, self.lat, self.C),
+                      (self.kflat, 1, self.ldy5, self.tp5 * self.ldy5))
+        colsum(dout, B, self.out_dim, self.ldd, 1, 1, grads["output_layer.bias"])
+        # dY5 = dout . Wp_out, masked by lrelu'(Y5)
+        wpt = torch.empty(self.kflat, self.ldd, **f32)
+        self._permute(prm["output_layer.weight"], wpt, (self.C, self.tp5, self.ldy5, self.ldd),
+                      (1, self.C, latC, self.Cc * latC), (self.C, self.lat, self.Cc, self.out_dim))
+        self._nt(A=ptr(dout), Bw=ptr(wpt), aux=ptr(self.Y[-1]), out=ptr(self.GY[-1]), M=B, A_rows=B, N=self.kflat,
+                 K=self.ldd, lda=self.ldd, ldb=self.ldd, ldo=self.kflat, ldaux=self.kflat, loader=LOAD_DIRECT,
+                 epilogue=EPI_MASK, slope=self.cslope)
+        del wpt
+        # ---- concat 1x1 stack, last to first ----
+        for i in range(len(self.concat_dims) - 1, -1, -1):
+            cin_t, cin_ld, cout_t, cout_ld = self.concat_dims[i]
+            src = self.Xc if i == 0 else self.Y[i - 1]
+            Gi = self.GY[i]
+            name = f"concat_conv_block.{2 * i}"
+            tiles = ((cin_ld + 127) // 128) * ((cout_ld + 127) // 128)
+            sk = self._splitk(tiles, (rows5 + 31) // 32)
+            slab = torch.empty(sk, cin_ld, cout_ld, **f32)
+            self._tn(A=ptr(src), B=ptr(Gi), slab=ptr(slab), Krows=rows5, A_rows=rows5, B_rows=rows5, Mdim=cin_ld,
+                     Ndim=cout_ld, lda=cin_ld, ldb=cout_ld, ldc=cout_ld, loader=LOAD_DIRECT, Tp=self.tp5,
+                     Tvalid=self.lat, splitk=sk, slab_stride=cin_ld * cout_ld)
+            self._permute(slab, grads[name + ".weight"], (1, 1, cout_t, cin_t), (0, 0, 1, cout_ld), nz=sk,
+                          zs=cin_ld * cout_ld)
+            colsum(Gi, rows5, cout_t, cout_ld, self.tp5, self.lat, grads[name + ".bias"])
+            wd = self._pack_conv(prm[name + ".weight"], cin_ld, True)          # [1][cin_ld][cout_ld]
+            if i > 0:
+                self._nt(A=ptr(Gi), Bw=ptr(wd), aux=ptr(src), out=ptr(self.GY[i - 1]), M=rows5, A_rows=rows5,
+                         N=cin_ld, K=cout_ld, lda=cout_ld, ldb=cout_ld, ldo=cin_ld, ldaux=cin_ld, loader=LOAD_DIRECT,
+                         epilogue=EPI_MASK, slope=self.cslope)
+            else:
+                self._nt(A=ptr(Gi), Bw=ptr(wd), out=ptr(self.dXc), M=rows5, A_rows=rows5, N=cin_ld, K=cout_ld,
+                         lda=cout_ld, ldb=cout_ld, ldo=cin_ld, loader=LOAD_DIRECT, epilogue=EPI_STORE)
+        # ---- un-concat: G5 (dropout + lrelu') and dh summed over duplicates ----
+        # duplicates of a label sequence: the kernel scans the batch's label ids in batch order (what a stable argsort
+        # would list) - no argsort / scatter_add_ / cumsum in front of it
+        dh_ext = torch.empty(U, H, **f32)
+        check(lib.tl_concat_unpack_bwd(ptr(self.dXc), ptr(self.P[5]), None, ptr(self._uid), ptr(self.G[5]),
+                                       ptr(dh_ext), B, U, self.C, self.tp5, self.lat, self.Cc, self.Lc, self.ld5, H,
+                                       self.ldx, self.slope, self._p_drop_used, self._seed_used, self._drop_row0,
+                                       st_), "tl_concat_unpack_bwd")
+        # ---- LSTM BPTT on the distinct rows: independent of the convolution backward below - on the side stream beside it
+        # when nothing in it is a collective (single process); the trainer's W_hh update rides along (on_factors) ----
+        side = self._side_stream(self._dev) if (self.overlap and gather_whh is None and self._sh is None) else None
+        if side is not None:
+            dh_ext.record_stream(side)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._lstm_backward(prm, grads, dh_ext, gather_whh, whh_factors, reduce_rows, on_factors)
+        else:
+            self._lstm_backward(prm, grads, dh_ext, gather_whh, whh_factors, reduce_rows, on_factors)
         # ---- ecog stages 5..2 ----
         for st in reversed(self.stages):
             name = self.STAGE_NAMES[st.idx]
@@ -812,3 +859,5 @@ class CnnEngine:
                       zs=zs)
         self._permute(part, grads["ecog_conv_block.0.bias"], (1, 1, 1, self.c1), (0, 0, 0, 1), nz=nblk, zs=zs,
                       src_off=self.k1 * self.c1)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)

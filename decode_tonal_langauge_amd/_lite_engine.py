@@ -157,7 +157,7 @@ class LiteEngine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, t: Dict[str, torch.Tensor], dout: torch.Tensor, grads: Dict[str, torch.Tensor],
-                 gather_whh=None, whh_factors: bool = False, reduce_rows=None) -> None:
+                 gather_whh=None, whh_factors: bool = False, reduce_rows=None, on_factors=None) -> None:
         if self._saved_generation != self.generation:
             raise RuntimeError("SynthesisLite backward: the forward intermediates were overwritten by a later forward")
         lib, st = self.lib, self._stream()

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void concat_g5_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void concat_dh_kernel(const float* __restrict__ dXc, const int32_t* __restrict__ members,
                                                         const int32_t* __restrict__ offsets, float* __restrict__ dh, int U,
-                                                        int C, int Tp, int lat, int Cc, int Lc, int ldh, int ldx) {
+                                                        int C, int Tp, int lat, int Cc, int Lc, int ldh, int ldx, int Bn) {
   const long long per_u = (long long)Lc * lat * C;
   const long long total = (long long)U * per_u;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -684,9 +684,16 @@ __global__ __launch_bounds__(256) void concat_dh_kernel(const float* __restrict_
     const int t = (int)(r % lat);
     const int lc = (int)(r / lat);
     float acc = 0.f;
-    for (int q = offsets[u]; q < offsets[u + 1]; ++q) {
-      const int b = members[q];
-      acc += dXc[(((long long)b * C + cch) * Tp + t) * ldx + Cc + lc];
+    if (members != nullptr) {
+      for (int q = offsets[u]; q < offsets[u + 1]; ++q) {
+        const int b = members[q];
+        acc += dXc[(((long long)b * C + cch) * Tp + t) * ldx + Cc + lc];
+      }
+    } else {
+      // no member lists: `offsets` holds the batch's label ids (B entries) - scan them in batch order, which is the
+      // order a stable sort of the ids would list the members in (same sum, no argsort / cumsum in front of this kernel)
+      for (int b = 0; b < Bn; ++b)
+        if (offsets[b] == u) acc += dXc[(((long long)b * C + cch) * Tp + t) * ldx + Cc + lc];
     }
     dh[(long long)u * ldh + ((long long)lc * lat + t) * C + cch] = acc;
   }
@@ -1115,7 +1122,7 @@ extern "C" int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int
                                     float* G5, float* dh, int B, int U, int C, int Tp, int lat, int Cc, int Lc, int ld5,
                                     int ldh, int ldx, float slope, float p_drop, uint64_t seed, int64_t drop_row0,
                                     void* stream) {
-  TL_REQUIRE(dXc && O5 && members && offsets && G5 && dh, "concat_unpack_bwd: null pointer");
+  TL_REQUIRE(dXc && O5 && offsets && G5 && dh, "concat_unpack_bwd: null pointer");
   TL_REQUIRE(ldx >= Cc + Lc && ld5 >= Cc && lat <= Tp && p_drop >= 0.f && p_drop < 1.f, "concat_unpack_bwd: bad arguments");
   const long long rows = (long long)B * C * Tp;
   hipLaunchKernelGGL(concat_g5_kernel, dim3(grid_for(rows * Cc)), dim3(256), 0, (hipStream_t)stream, dXc, O5, G5, rows,
@@ -1124,7 +1131,7 @@ extern "C" int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int
   if (rc) return rc;
   const long long total = (long long)U * Lc * lat * C;
   hipLaunchKernelGGL(concat_dh_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dXc, members, offsets,
-                     dh, U, C, Tp, lat, Cc, Lc, ldh, ldx);
+                     dh, U, C, Tp, lat, Cc, Lc, ldh, ldx, B);
   return check_launch("concat_dh");
 }
 

@@ -222,8 +222,18 @@ class SynthesisTrainer:
         self._loss_stats(out, targets, dout, eng.ldd, 1)
         gather = self._timed(parallel.gather_lowrank) if self.dp else None
         reduce_rows = self._timed(parallel.all_reduce_) if self.dp else None
-        eng.backward(prm, dout, self._grads, gather_whh=gather, whh_factors=skip is not None, reduce_rows=reduce_rows)
         scale = 1.0          # the 1/N of the global mean is already in dout (weight of this rank's rows)
+        early = []
+
+        def on_factors():
+            # single process: the W_hh update (33 GB of HBM traffic) is issued as soon as its gradient factors exist, on the
+            # stream the LSTM backward runs on - beside the convolution backward instead of behind it
+            factors = getattr(eng, "whh_factors", None)
+            if factors is not None and not self.dp:
+                self.optimizer.step_lowrank({params[skip]: factors}, grad_scale=scale)
+                early.append(params[skip])
+        eng.backward(prm, dout, self._grads, gather_whh=gather, whh_factors=skip is not None, reduce_rows=reduce_rows,
+                     on_factors=on_factors if skip is not None else None)
         if self.dp:
             sharded = getattr(eng, "_sh", None) is not None
             # with the row-sharded LSTM its dgates - hence the W_ih / bias gradients - already belong to the global
@@ -233,7 +243,9 @@ class SynthesisTrainer:
                                                       if k != skip and k not in local_only])
             self._whh_dirty = self._whh_dirty or sharded
         factors = getattr(eng, "whh_factors", None)
-        if factors is not None:          # the optimiser forms that gradient from its factors on the fly
+        if early:            # W_hh is already updated
+            self.optimizer.step(grads={params[k]: self._grads[k] for k in names if k != skip}, grad_scale=scale, skip=set(early))
+        elif factors is not None:          # the optimiser forms that gradient from its factors on the fly
             self.optimizer.step(grads={params[k]: self._grads[k] for k in names if k != skip}, grad_scale=scale,
                                 lowrank={params[skip]: factors})
         else:

@@ -56,13 +56,50 @@ class FusedNAdam(torch.optim.Optimizer):
     LOWRANK_MAX = 64          # largest factor rank tl_nadam_lowrank takes
 
     @torch.no_grad()
+    def step_lowrank(self, lowrank: Dict[torch.nn.Parameter, tuple], grad_scale: float = 1.0) -> None:
+        """The low-rank part of ``step`` alone, on torch's current stream: lets the caller update such a parameter as soon
+        as its factors exist (the trainer runs it on a side stream beside the convolution backward) and hand the same
+        parameters to ``step(..., skip=...)`` afterwards."""
+        stream = torch.cuda.current_stream().cuda_stream
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p in lowrank:
+                    self._step_lowrank(p, group, lowrank[p], grad_scale, stream)
+
+    def _step_lowrank(self, p, group, spec, grad_scale, stream) -> None:
+        b1, b2 = group["betas"]
+        fa, fb = spec[0], spec[1]
+        shard = (int(spec[2]), int(spec[3])) if len(spec) > 2 else None
+        kr = 0 if fa is None else fa.shape[0]
+        if p.dim() != 2 or not p.is_contiguous() or kr > self.LOWRANK_MAX:
+            raise RuntimeError("FusedNAdam: low-rank update needs a contiguous 2-D parameter and rank <= 64")
+        row0, rows = shard if shard is not None else (0, p.shape[0])
+        if row0 < 0 or rows < 1 or row0 + rows > p.shape[0]:
+            raise RuntimeError("FusedNAdam: row shard outside the parameter")
+        if kr and (fa.shape[1] != rows or fb.shape[1] != p.shape[1] or fb.shape[0] != kr
+                   or fa.stride(1) != 1 or fb.stride(1) != 1):
+            raise RuntimeError("FusedNAdam: low-rank factors do not match the parameter")
+        _lib.require_gpu(p, "FusedNAdam.step")
+        st = self._state_for(p, shard)
+        st["step"] += 1
+        cg, cm, bc2, st["mu_product"] = nadam_scalars(st["step"], st["mu_product"], group["lr"], b1, b2,
+                                                      group["momentum_decay"])
+        check(self._lib.tl_nadam_lowrank(p.data_ptr() + 4 * row0 * p.shape[1], ptr(st["exp_avg"]),
+                                         ptr(st["exp_avg_sq"]), ptr(fa), ptr(fb),
+                                         kr, rows, p.shape[1], fa.stride(0) if kr else rows,
+                                         fb.stride(0) if kr else p.shape[1], cg, cm, b1, b2, bc2,
+                                         group["eps"], group["weight_decay"], grad_scale, stream),
+              "tl_nadam_lowrank")
+
+    @torch.no_grad()
     def step(self, closure=None, grads: Optional[Dict[torch.nn.Parameter, torch.Tensor]] = None,
-             grad_scale: float = 1.0, lowrank: Optional[Dict[torch.nn.Parameter, tuple]] = None):
+             grad_scale: float = 1.0, lowrank: Optional[Dict[torch.nn.Parameter, tuple]] = None, skip=None):
         """``grads`` optionally maps parameter -> gradient tensor (fused trainer path, no ``.grad``).
         ``lowrank`` maps a 2-D parameter (rows, cols) to factors ``(fa (k, rows), fb (k, cols))`` of its
         gradient ``fa^T . fb``, k <= LOWRANK_MAX (or ``(None, None)`` for a zero gradient): the update is
         applied without materialising the gradient.  ``(fa (k, n), fb, row0, n)`` updates only rows
-        [row0, row0 + n) of the parameter (a data-parallel rank that owns a row shard of it)."""
+        [row0, row0 + n) of the parameter (a data-parallel rank that owns a row shard of it).
+        ``skip``: parameters already updated this step through ``step_lowrank``."""
         loss = closure() if closure is not None else None
         stream = torch.cuda.current_stream().cuda_stream
         dense = {}
@@ -70,29 +107,9 @@ class FusedNAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             for p in group["params"]:
                 if lowrank is not None and p in lowrank:
-                    spec = lowrank[p]
-                    fa, fb = spec[0], spec[1]
-                    shard = (int(spec[2]), int(spec[3])) if len(spec) > 2 else None
-                    kr = 0 if fa is None else fa.shape[0]
-                    if p.dim() != 2 or not p.is_contiguous() or kr > self.LOWRANK_MAX:
-                        raise RuntimeError("FusedNAdam: low-rank update needs a contiguous 2-D parameter and rank <= 64")
-                    row0, rows = shard if shard is not None else (0, p.shape[0])
-                    if row0 < 0 or rows < 1 or row0 + rows > p.shape[0]:
-                        raise RuntimeError("FusedNAdam: row shard outside the parameter")
-                    if kr and (fa.shape[1] != rows or fb.shape[1] != p.shape[1] or fb.shape[0] != kr
-                               or fa.stride(1) != 1 or fb.stride(1) != 1):
-                        raise RuntimeError("FusedNAdam: low-rank factors do not match the parameter")
-                    _lib.require_gpu(p, "FusedNAdam.step")
-                    st = self._state_for(p, shard)
-                    st["step"] += 1
-                    cg, cm, bc2, st["mu_product"] = nadam_scalars(st["step"], st["mu_product"], group["lr"], b1, b2,
-                                                                  group["momentum_decay"])
-                    check(self._lib.tl_nadam_lowrank(p.data_ptr() + 4 * row0 * p.shape[1], ptr(st["exp_avg"]),
-                                                     ptr(st["exp_avg_sq"]), ptr(fa), ptr(fb),
-                                                     kr, rows, p.shape[1], fa.stride(0) if kr else rows,
-                                                     fb.stride(0) if kr else p.shape[1], cg, cm, b1, b2, bc2,
-                                                     group["eps"], group["weight_decay"], grad_scale, stream),
-                          "tl_nadam_lowrank")
+                    self._step_lowrank(p, group, lowrank[p], grad_scale, stream)
+                    continue
+                if skip is not None and p in skip:
                     continue
                 g = grads.get(p) if grads is not None else p.grad
                 if g is None:

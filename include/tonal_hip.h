@@ -226,7 +226,9 @@ int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih, float* db
 int tl_concat_pack(const float* O5, const float* h, const int32_t* uid, float* Xc,
                    int B, int C, int Tp, int lat, int Cc, int Lc, int ld5, int ldh, int ldx,
                    float p_drop, uint64_t seed, int64_t drop_row0, void* stream);
-/* backward: G5[row][ch] = dXc[row][ch]*keep*lrelu'(O5); dh[u][..] = sum_{b in u} dXc[..][Cc+lc] */
+/* backward: G5[row][ch] = dXc[row][ch]*keep*lrelu'(O5); dh[u][..] = sum_{b in u} dXc[..][Cc+lc], the members of u
+ * taken from members[offsets[u] .. offsets[u+1]) - or, with members == NULL, by scanning offsets = the batch's label
+ * ids (B entries) in batch order (the order a stable sort would give: same sums, nothing to prepare)              */
 int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int32_t* members, const int32_t* offsets,
                          float* G5, float* dh, int B, int U, int C, int Tp, int lat, int Cc, int Lc,
                          int ld5, int ldh, int ldx, float slope, float p_drop, uint64_t seed, int64_t drop_row0,
