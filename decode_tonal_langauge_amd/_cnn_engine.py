@@ -120,6 +120,7 @@ class CnnEngine:
         # (251.1 vs 250.7 ms): a conv workgroup holds 144 KB of LDS and both waves' worth of registers of every SIMD, so
         # the streaming kernels (which stage through LDS too) find no free CU and the two streams serialise.  Off.
         self.overlap = os.environ.get("TONAL_OVERLAP", "0") == "1"
+        self.vd_mode = os.environ.get("TONAL_WINO_VD", "tn")
         self._side = None
         self._B = None
         self.generation = 0
@@ -154,6 +155,8 @@ class CnnEngine:
         self.Y = [z(rows5, d[3]) for d in self.concat_dims]
         self.out_slab = None
         self.V = {}            # F(4,3) input transforms of P[idx] (quads, 6, channels) for the stages that read them
+        self.Vd = {}           # ... and of the un-pooled dZ of stage idx (the operand of its input-gradient pass)
+        self._vd_ready = {}
         self.G = None          # gradient workspaces are allocated lazily on the first backward
 
     def _alloc_bwd(self):
@@ -285,6 +288,14 @@ class CnnEngine:
     def _use_wino_v(self, st) -> bool:
         return self.wino_v and self._use_wino43(st) and st.cin % 64 == 0
 
+    def _use_wino_vd(self, st) -> bool:
+        """The stage's input gradient runs on the transform-free V-form kernel, reading Vd = the F(4,3) input transform of
+        the un-pooled dZ.  TONAL_WINO_VD: "tn" (default) - the first C_in tile of the stage's weight-gradient kernel writes
+        Vd (it already holds those dZ rows for its own transform); "side" - Vd comes from the stand-alone, LDS-free
+        ``tl_wino43_unpool_transform`` launched on a side stream beside the weight-gradient kernel (measured: the two share
+        the CUs but the sum of their times stays the serial one - 249.9 vs 245.4 ms per step); "0" - off."""
+        return (self._use_wino_v(st) and self._use_wino43_tn(st) and _r4(st.cout) % 16 == 0 and self.vd_mode != "0")
+
     def _conv1_writes_v(self) -> bool:
         """The first stage hands its output to stage 2 as V (tl_conv1_fwd_v) - nothing else reads P1 then."""
         return (self._use_wino_v(self.stages[0]) and self._use_wino43_tn(self.stages[0]) and self.tp1 % 4 == 0
@@ -339,6 +350,9 @@ class CnnEngine:
             if self.wino43_tn:
                 tn = "wino43v_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA)"
         fams = {fwd: ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}
+        if all(self._use_wino_vd(st) for st in self.stages[:2]):
+            nt = "wino43v_nt_kernel"
+            form = "F(4,3) on the pre-transformed dZ, LDS-DMA"
         if fused:       # the stage-2 launch carries the fused conv1 weight-gradient epilogue: its own kernel name
             fams[f"{nt}<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd {form})"] = ["conv2_dgrad"]
             fams[f"{nt}<UNPOOL,MASK> (conv3 input gradient, Winograd {form})"] = ["conv3_dgrad"]
@@ -426,6 +440,28 @@ class CnnEngine:
                     V = self._v_ready[st.idx - 1] = self._input_transform(st)
                 kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2])
                 fn = "tl_conv3_wino43v_tn"
+                if self._use_wino_vd(st):
+                    nq_pad = (rows_in // 4 + 127) // 128 * 128
+                    Vd = self.Vd.get(st.idx)
+                    if Vd is None or Vd.shape[0] != nq_pad or Vd.shape[2] != nd:
+                        Vd = self.Vd[st.idx] = torch.zeros(nq_pad, 6, nd, **f32)
+                    if self.vd_mode == "tn":
+                        kw.update(vd=ptr(Vd), ld_vd=nd)
+                    else:
+                        # HBM-bound (26 GB at conv2) and LDS-free: on the side stream it shares the CUs with the
+                        # weight-gradient kernel launched below (two 4-wave workgroups per CU leave every SIMD the
+                        # registers for one more light wave)
+                        side = self._side_stream(self._dev)
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            ev = self._tick(f"conv{st.idx}_vdxform")
+                            check(self.lib.tl_wino43_unpool_transform(ptr(Gs), ptr(self.bits[st.idx]), ptr(Vd), rows_in,
+                                                                      Gs.shape[0], st.tp_in, 2 * st.tout, nd, ldg,
+                                                                      st.cout // 32, nd, self._stream()),
+                                  "tl_wino43_unpool_transform")
+                            if ev:
+                                ev[1].record()
+                    self._vd_ready[st.idx] = self.generation
             self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, **kw)
             if sk > 1:
                 red = torch.empty(6 * st.cin, ldg, **f32)
@@ -513,6 +549,15 @@ class CnnEngine:
             part = torch.empty(ntm, (self.k1 + 1) * self.c1, dtype=torch.float32, device=self._dev)
             kw.update(epilogue=EPI_C1WGRAD, out=None, c1x=ptr(self._x), c1bits=ptr(self.bits[1]), c1partial=ptr(part),
                       c1T=self.T, c1kt=self.k1, Tvalid=self.tout1)
+        if self._use_wino_vd(st) and self._vd_ready.get(st.idx) == self.generation and st.idx in self.Vd:
+            # the weight-gradient kernel of this stage (run just before) left Vd = B^T (un-pooled dZ rows 4q-2 .. 4q+3)
+            Vd = self.Vd[st.idx]
+            if self.vd_mode != "tn":
+                torch.cuda.current_stream().wait_stream(self._side_stream(self._dev))
+            kw.update(A=ptr(Vd), A_rows=Vd.shape[0], lda=Vd.shape[2], loader=LOAD_V)
+            self._vd_ready[st.idx] = -1
+            self._nt(tag=f"conv{st.idx}_dgrad", fn="tl_conv3_wino43v_nt", **kw)
+            return part
         self._nt(tag=f"conv{st.idx}_dgrad", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino
                  else "tl_gemm_nt_window", **kw)
         return part

@@ -46,6 +46,7 @@ class TnParams(C.Structure):
         ("J", C.c_int), ("Tp", C.c_int), ("Tvalid", C.c_int), ("loader", C.c_int),
         ("splitk", C.c_int), ("slab_stride", C.c_int64),
         ("colsum", C.c_void_p),
+        ("vd", C.c_void_p), ("ld_vd", C.c_int),
     ]
 
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "tl_wino43_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_wino43_input_transform": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "tl_conv3_wino43v_nt": (_I, [C.POINTER(NtParams), _P]),
+    "tl_wino43_unpool_transform": (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
     "tl_conv3_wino43v_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_sizeof_nt_params": (_I, []),
     "tl_sizeof_tn_params": (_I, []),

@@ -26,6 +26,7 @@
 // bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte chunk
 // index that is applied to the per-lane SOURCE address and to the fragment read.
 #include "tonal_common.h"
+#include "tonal_wino43_epi.h"
 #include <type_traits>
 
 namespace tl {
@@ -37,7 +38,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // taken as zero: they only ever reach conv rows the epilogues mask (the Winograd identity holds for
 // any finite value there; zero keeps the cancellation error of the last valid row smallest).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino43_xform_kernel(const float* __restrict__ P, float* __restrict__ V,
+__global__ __launch_bounds__(256, 4) void wino43_xform_kernel(const float* __restrict__ P, float* __restrict__ V,
                                                             long long nq, int Tp, int C, int ldp, int ldv) {
   const int c4n = C >> 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,6 +54,51 @@ __global__ __launch_bounds__(256) void wino43_xform_kernel(const float* __restri
   for (int j = 0; j < 6; ++j) {
     if (t0 + j < Tp) d[j] = *reinterpret_cast<const f32x4*>(src + (long long)j * ldp);
     else d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4 s1 = d[4] - 4.f * d[2], s2 = d[3] - 4.f * d[1], s3 = d[4] - d[2], t = d[3] - d[1];
+  float* dst = V + q * 6 * (long long)ldv + c;
+  *reinterpret_cast<f32x4*>(dst) = 4.f * d[0] + (d[4] - 5.f * d[2]);
+  *reinterpret_cast<f32x4*>(dst + ldv) = s1 + s2;
+  *reinterpret_cast<f32x4*>(dst + 2LL * ldv) = s1 - s2;
+  *reinterpret_cast<f32x4*>(dst + 3LL * ldv) = s3 + 2.f * t;
+  *reinterpret_cast<f32x4*>(dst + 4LL * ldv) = s3 - 2.f * t;
+  *reinterpret_cast<f32x4*>(dst + 5LL * ldv) = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+
+// ------------------------------------------------------------------------------------------
+// (G, arg-max bits) -> Vd: the input-gradient operand of a pooled 3-tap stage.  Vd[quad q][6][ldv] = B^T of the
+// un-pooled dZ rows 4q-2 .. 4q+3 (row Rz of dZ = G[Rz / 2] where the arg-max bit equals Rz & 1 and (Rz % Tp) < Tvalid,
+// else 0).  Thread = (quad, 4 channels): three pooled rows + three bit words in, six 16-byte stores out; no LDS and few
+// registers on purpose - the kernel is HBM-bound and is launched on a side stream BESIDE the MFMA-bound weight-gradient
+// kernel of the same stage, whose two workgroups per CU leave the register file room for one such wave per SIMD.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void wino43_unpool_xform_kernel(const float* __restrict__ G, const uint32_t* __restrict__ bits,
+                                                                     float* __restrict__ V, long long nq, long long g_rows,
+                                                                     int Tp, int Tvalid, int C, int ldg, int ld_bits, int ldv) {
+  const int c4n = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nq * c4n) return;
+  const long long q = idx / c4n;
+  const int c = (int)(idx - q * c4n) * 4;
+  const int tq = (int)((4 * q) % Tp);                       // time index of conv row 4q
+  f32x4 d[6];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const long long pr = 2 * q - 1 + j;                     // pooled row; its conv rows have time tq - 2 + 2j, + 1
+    const int t = tq - 2 + 2 * j;
+    const bool ok = pr >= 0 && pr < g_rows && t >= 0 && t < Tvalid;      // t < 0: the previous sequence's pad rows
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    uint32_t w = 0;
+    if (ok) {
+      g = *reinterpret_cast<const f32x4*>(G + pr * (long long)ldg + c);
+      w = bits[pr * (long long)ld_bits + (c >> 5)] >> (c & 31);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool odd = (w >> k) & 1u;
+      d[2 * j][k] = odd ? 0.f : g[k];
+      d[2 * j + 1][k] = odd ? g[k] : 0.f;
+    }
   }
   const f32x4 s1 = d[4] - 4.f * d[2], s2 = d[3] - 4.f * d[1], s3 = d[4] - d[2], t = d[3] - d[1];
   float* dst = V + q * 6 * (long long)ldv + c;
@@ -93,6 +139,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_dst, 16, voff, soff, 0, 0);
 }
 
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p) {
   __shared__ __attribute__((aligned(1024))) char lds[2 * V4_STAGE];
   const int tid = threadIdx.x;
@@ -253,57 +300,11 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
     return;
   }
 #endif
-  // ---- epilogue (pool): the four conv rows of a quad from its six products, bias, LeakyReLU, max-pool (2,1),
-  // arg-max and sign bits - the arithmetic of wino43_nt_kernel<DIRECT, POOL> in tonal_wino.hip ----
-  const long long Q0 = (R0 >> 2) + wm * 32 + 4 * lh;       // quad of accumulator element e = 0
-  const int col = n0 + wn * 32 + lr;
-  const int colbase = n0 + wn * 32;
-  const bool colok = col < p.N;
-  const float bv = (colok && p.bias) ? p.bias[col] : 0.f;
-  uint32_t wbits = 0, wsign = 0;
-  int tcur = (int)((4 * Q0) % p.Tp);                        // time index of the quad's first conv row
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int qo = (e & 3) + 8 * (e >> 2);
-    const long long Q = Q0 + qo;
-    if (e > 0) {
-      tcur += (e & 3) ? 4 : 20;                             // quad offsets 0,1,2,3, 8,.. -> row steps 4,4,4,20
-      while (tcur >= p.Tp) tcur -= p.Tp;
-    }
-    const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e];
-    const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4;
-    float y[4];
-    y[0] = (acc[0][e] + a12) + a34;
-    y[1] = s12 + 2.f * s34;
-    y[2] = a12 + 4.f * a34;
-    y[3] = (s12 + 8.f * s34) + acc[5][e];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const long long P = 2 * Q + h;                        // pooled row
-      const float y0 = lrelu(y[2 * h] + bv, p.slope), y1 = lrelu(y[2 * h + 1] + bv, p.slope);
-      const bool rowok = 2 * P < p.M;
-      const bool valid = rowok && (tcur + 2 * h) < p.Tvalid;       // Tp % 4 == 0: a quad never wraps
-      const bool sel = valid && colok && (y1 > y0);
-      const float o = valid ? (sel ? y1 : y0) : 0.f;
-      if (rowok && colok) p.out[P * (long long)p.ldo + col] = o;
-      const unsigned long long m = __ballot(sel);
-      const unsigned long long ms = __ballot(o > 0.f);
-      if (lr == 2 * e + h) {
-        wbits = (uint32_t)(m >> (32 * lh));
-        wsign = (uint32_t)(ms >> (32 * lh));
-      }
-    }
-  }
-  {
-    const int e = lr >> 1, h = lr & 1;
-    const long long P = 2 * (Q0 + (e & 3) + 8 * (e >> 2)) + h;
-    if (2 * P < p.M && colbase < p.N) {
-      p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = wbits;
-      if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = wsign;
-    }
-  }
+  // ---- epilogue (shared with the in-loop-transform kernels, tonal_wino43_epi.h): the four conv rows of a quad from its
+  // six products, then pool / mask / fused first-stage weight gradient ----
+  if constexpr (EPI == W_EPI_C1W) __syncthreads();        // its reduction reuses the LDS other waves may still be reading
+  wino43_epilogue<EPI>(p, acc, reinterpret_cast<float*>(lds), R0, n0, wm, wn, lr, lh, tm);
 }
-
 
 // ------------------------------------------------------------------------------------------
 // Weight gradient on V.  The kernel of tonal_wino43_tn.hip with its A side replaced: V tiles
@@ -321,15 +322,19 @@ constexpr int T4V_NA = 4;                                 // V ring slots
 #define T4V_SCHED 0        // > 0: hand-specified issue order of a K-step with this many VALU per MFMA slot
 #endif
 
-__global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p) {
+// WVD: this launch covers the first C_in tile only and also writes Vd (see write_vd below); the other C_in tiles run in
+// a second launch of the plain instantiation (a run-time branch around the Vd code splits the K-step into basic blocks
+// the scheduler cannot interleave across: 43.6 -> 46.3 ms for every workgroup).  mt0 / mtn: first C_in tile, tile count.
+template <bool WVD>
+__global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p, int mt0, int mtn) {
   __shared__ __attribute__((aligned(1024))) float lds[(T4V_NA + 2) * T4_TILE];
   float* As = lds;                               // [4][6][8][64]  V ring
   float* Bs = lds + T4V_NA * T4_TILE;            // [2][6][8][64]  Y
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
-  const int ntm = (p.Mdim + T4_BM - 1) / T4_BM, ntn = (p.Ndim + T4_BN - 1) / T4_BN;
-  const long long tiles = (long long)ntm * ntn;
+  const int ntn = (p.Ndim + T4_BN - 1) / T4_BN;
+  const long long tiles = (long long)mtn * ntn;
   const long long nwg = tiles * p.splitk;
   long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
   {
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   }
   const int z = (int)(bid / tiles);
   const int tt = (int)(bid % tiles);
-  const int m0 = (tt / ntn) * T4_BM, n0 = (tt % ntn) * T4_BN;
+  const int m0 = (mt0 + tt / ntn) * T4_BM, n0 = (tt % ntn) * T4_BN;
 
   const long long quads_all = p.Krows >> 2;
   const long long ksteps_all = (quads_all + T4_Q - 1) / T4_Q;
@@ -395,22 +400,56 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   struct stage_regs {
     f32x2 g[2];
     uint32_t wa, wb;  // arg-max words of the two pooled rows
-    uint32_t ok;      // bit 0 / 1: pair a / b holds a valid gradient
+    uint32_t ok;      // bit 0 / 1: pair a / b holds a valid gradient (bit 2: the pooled row in front of the quad)
+    f32x2 gp;         // write_vd only: pooled row 2 q - 1 (conv rows 4 q - 2, 4 q - 1), its arg-max word, the quad index
+    uint32_t wp;
+    int q;
   };
   stage_regs rP, rQ, rR;
+  // The workgroups of the first C_in tile also WRITE the input-gradient operand of this stage: Vd[quad][6][C_out] = the
+  // F(4,3) input transform of the un-pooled dZ rows 4 q - 2 .. 4 q + 3 (the rows the input gradient of conv rows
+  // 4 q .. 4 q + 3 contracts with the flipped taps).  They already hold dZ rows 4 q .. 4 q + 3 for the Y transform; one more
+  // pooled row and six 8-byte stores per thread and K-step turn the input-gradient pass into the transform-free V-form
+  // kernel (wino43v_nt_kernel) without a pass of its own over G (19.7 GB written beside MFMA-bound work).
+  constexpr bool write_vd = WVD;
   f32x2 bsum = {0.f, 0.f};
 
   auto load_regs = [&](auto FAST, stage_regs& r) {
     constexpr bool fast = decltype(FAST)::value;
     long long pa = 2 * quad, pb = 2 * quad + 1;
     bool va = bnok && tq < p.Tvalid, vb = bnok && tq + 2 < p.Tvalid;
+    uint32_t okp = 0;
+    if constexpr (write_vd) {
+      long long pr = 2 * quad - 1;
+      const bool vp = bnok && quad > 0 && tq >= 2 && tq - 2 < p.Tvalid && 4 * quad - 2 < p.Krows && pr <= b_last;
+      pr = pr < 0 ? 0 : (pr < b_last ? pr : b_last);
+      if constexpr (fast) {
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.gp) : "v"(p.B + pr * (long long)p.ldb + ncolc) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.wp) : "v"(p.bbits + pr * (long long)p.ld_bbits + (ncolc >> 5)) : "memory");
+      } else {
+        r.gp = *reinterpret_cast<const f32x2*>(p.B + pr * (long long)p.ldb + ncolc);
+        r.wp = p.bbits[pr * (long long)p.ld_bbits + (ncolc >> 5)];
+      }
+      r.q = (int)quad;
+      okp = vp ? 4u : 0u;
+    }
     if constexpr (fast) {
       const float* bu = p.B + (ld_q0 * 2) * (long long)p.ldb + n0;
       const uint32_t* wu = p.bbits + (ld_q0 * 2) * (long long)p.ld_bbits;
-      r.g[0] = *reinterpret_cast<const f32x2*>(bu + b_toff);
-      r.g[1] = *reinterpret_cast<const f32x2*>(bu + p.ldb + b_toff);
-      r.wa = wu[w_toff];
-      r.wb = wu[p.ld_bbits + w_toff];
+      if constexpr (write_vd) {
+        // Loads the compiler does not count (inline asm): with the Vd stores in the same vmcnt stream its own wait in
+        // front of the transform comes out as vmcnt(9..10) - a drain of the three-step prefetch every K-step (the
+        // launch ran at 45 % of the plain kernel's rate).  The counted wait is placed by hand in kstep.
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.g[0]) : "v"(bu + b_toff) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.g[1]) : "v"(bu + p.ldb + b_toff) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.wa) : "v"(wu + w_toff) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.wb) : "v"(wu + p.ld_bbits + w_toff) : "memory");
+      } else {
+        r.g[0] = *reinterpret_cast<const f32x2*>(bu + b_toff);
+        r.g[1] = *reinterpret_cast<const f32x2*>(bu + p.ldb + b_toff);
+        r.wa = wu[w_toff];
+        r.wb = wu[p.ld_bbits + w_toff];
+      }
     } else {
       va = va && 4 * quad < p.Krows && pa <= b_last;
       vb = vb && 4 * quad + 2 < p.Krows && pb <= b_last;
@@ -421,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
       r.wa = p.bbits[pa * (long long)p.ld_bbits + (ncolc >> 5)];
       r.wb = p.bbits[pb * (long long)p.ld_bbits + (ncolc >> 5)];
     }
-    r.ok = (va ? 1u : 0u) | (vb ? 2u : 0u);
+    r.ok = (va ? 1u : 0u) | (vb ? 2u : 0u) | okp;
     ld_q0 += T4_Q;
     quad += T4_Q;
     tq += dstep;
@@ -429,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   };
   auto store_b = [&](const stage_regs& r, int buf) {
     const int sh = ncolc & 31;
-    f32x2 o[6];
+    f32x2 o[6], vd[6];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const uint32_t ma = (uint32_t)__builtin_amdgcn_sbfe((int)r.wa, sh + c, 1);      // all ones if the odd row won
@@ -443,11 +482,29 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
       o[3][c] = fmaf(4.f, fmaf(2.f, o_b, e_b), fmaf(2.f, o_a, e_a));
       o[4][c] = fmaf(4.f, fmaf(-2.f, o_b, e_b), fmaf(-2.f, o_a, e_a));
       o[5][c] = o_b;
+      if constexpr (write_vd) {
+        // d0..d5 = dZ rows 4 q - 2 .. 4 q + 3 = (e_p, o_p, e_a, o_a, e_b, o_b); B^T d as in wino43_xform_kernel
+        const uint32_t mp = (uint32_t)__builtin_amdgcn_sbfe((int)r.wp, sh + c, 1);
+        const uint32_t up = (r.ok & 4u) ? __float_as_uint(r.gp[c]) : 0u;
+        const float d0 = __uint_as_float(up & ~mp), d1 = __uint_as_float(up & mp);
+        const float s1 = e_b - 4.f * e_a, s2 = o_a - 4.f * d1, s3 = e_b - e_a, t = o_a - d1;
+        vd[0][c] = 4.f * d0 + (e_b - 5.f * e_a);
+        vd[1][c] = s1 + s2;
+        vd[2][c] = s1 - s2;
+        vd[3][c] = s3 + 2.f * t;
+        vd[4][c] = s3 - 2.f * t;
+        vd[5][c] = (4.f * d1 - 5.f * o_a) + o_b;
+      }
     }
     bsum += o[1];
     float* dst = Bs + buf * T4_TILE + qi * 64 + sw;
 #pragma unroll
     for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(dst + i * T4_PLANE) = o[i];
+    if (write_vd && bnok && r.q < (int)quads_all) {   // (write_vd is a compile-time constant)
+      float* g = p.vd + (long long)r.q * 6 * p.ld_vd + ncolc;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(g + (long long)i * p.ld_vd) = vd[i];
+    }
   };
 
   // ---- MFMA side: k-slice sl of a K-step = quads 2 sl (lanes 0-31) and 2 sl + 1 (lanes 32-63) ----
@@ -490,6 +547,16 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
     mfma6(fa0, fb0);
     load_frag(fa0, fb0, abuf, bbuf, 2);
     mfma6(fa1, fb1);
+    if constexpr (write_vd) {
+      // r_st was loaded (asm) two steps ago: 6 loads, then 3 pieces + 6 stores of that step, 15 operations of the last
+      // step and the 9 loads / pieces issued at the top of this one = 33 younger operations may stay in flight.  Tail
+      // steps drain completely (their own loads are compiler-counted, but r_st may still come from the asm loads).
+      stage_regs& w = const_cast<stage_regs&>(r_st);
+      if constexpr (!tail)
+        asm volatile("s_waitcnt vmcnt(33)" : "+v"(w.g[0]), "+v"(w.g[1]), "+v"(w.gp), "+v"(w.wa), "+v"(w.wb), "+v"(w.wp));
+      else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w.g[0]), "+v"(w.g[1]), "+v"(w.gp), "+v"(w.wa), "+v"(w.wb), "+v"(w.wp));
+    }
     if (!tail || s + 1 < nsteps) store_b(r_st, bbuf ^ 1);
     load_frag(fa1, fb1, abuf, bbuf, 3);
     mfma6(fa0, fb0);
@@ -509,8 +576,14 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
       }
     }
 #endif
-    if constexpr (!tail) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (a workgroup that also writes Vd issues 2 more loads and 6 stores per step - stores count in vmcnt too: the
+    // younger operations are then the 6 stores of step s - 2 and 15 + 15 of steps s - 1 and s = 36)
+    if constexpr (!tail) {
+      if constexpr (write_vd) asm volatile("s_waitcnt vmcnt(36) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -591,24 +664,43 @@ extern "C" int tl_wino43_input_transform(const float* P, float* V, int64_t rows,
   return check_launch("wino43_input_transform");
 }
 
-// forward pass on V (loader 2): A = V[quad][6][lda], A_rows = quads in V, M = conv rows (4 per quad)
+// NT passes on a pre-transformed operand (loader 2): A = V[quad][6][lda], A_rows = quads in V, M = output rows (4 per
+// quad).  Forward: V of the stage input, POOL epilogue.  Input gradient: V of the un-pooled dZ rows 4q-2 .. 4q+3 (written
+// by tl_conv3_wino43v_tn), taps = the flipped / transposed set, MASK or fused-conv1-weight-gradient epilogue.
 extern "C" int tl_conv3_wino43v_nt(const tl_nt_params* pp, void* stream) {
   using namespace tl;
   TL_REQUIRE(pp != nullptr, "wino43v_nt: null params");
   const tl_nt_params& p = *pp;
-  TL_REQUIRE(p.A && p.Bw && p.out && p.obits, "wino43v_nt: null V/Bw/out/obits");
-  TL_REQUIRE(p.loader == 2 && p.epilogue == 2, "wino43v_nt: loader 2 (V) with the POOL epilogue only");
-  TL_REQUIRE(p.J == 3 && p.row_shift == 0 && p.splitk <= 1, "wino43v_nt: 3 taps, forward, no split-K");
+  TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W), "wino43v_nt: null V/Bw/out");
+  TL_REQUIRE(p.loader == W_LOAD_V, "wino43v_nt: loader 2 (pre-transformed operand) only");
+  TL_REQUIRE(p.J == 3 && p.splitk <= 1, "wino43v_nt: 3 taps, no split-K");
   TL_REQUIRE(p.M > 0 && p.M % 4 == 0 && p.N > 0 && p.K >= 16 && p.K % 16 == 0, "wino43v_nt: M %% 4, K %% 16 needed");
   TL_REQUIRE(p.A_rows >= p.M / 4, "wino43v_nt: V holds fewer quads than M / 4");
-  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K && p.lda % 4 == 0 && p.ldb % 4 == 0 && p.ldo >= p.N, "wino43v_nt: bad leading dimensions");
-  TL_REQUIRE(p.Tp > 0 && p.Tp % 4 == 0 && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino43v_nt: Tp %% 4 == 0 and an even Tvalid needed");
-  TL_REQUIRE(p.ld_obits * 32 >= p.N, "wino43v_nt: obits row too short");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino43v_nt: bad leading dimensions");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 4 == 0, "wino43v_nt: Tp must be a positive multiple of 4");
   TL_REQUIRE(6LL * p.N * p.ldb * 4 < (1LL << 31), "wino43v_nt: tap set larger than a buffer resource");
   TL_REQUIRE(128LL * 6 * p.lda * 4 + 4LL * p.K < (1LL << 31), "wino43v_nt: tile span too large");
   const long long nwg = ((p.M + 4 * V4_BQ - 1) / (4 * V4_BQ)) * ((p.N + V4_BN - 1) / V4_BN);
   TL_REQUIRE(nwg < (1LL << 31), "wino43v_nt: grid too large");
-  hipLaunchKernelGGL(wino43v_nt_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (p.epilogue == W_EPI_POOL) {
+    TL_REQUIRE(p.row_shift == 0 && p.out && p.ldo >= p.N, "wino43v_nt: forward needs row_shift 0 and an output");
+    TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino43v_nt: POOL needs obits and an even Tvalid");
+    TL_REQUIRE(p.N % 32 == 0 && p.ld_obits * 32 >= p.N, "wino43v_nt: POOL needs N %% 32 == 0");
+    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_POOL>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+  } else if (p.epilogue == W_EPI_MASK) {
+    TL_REQUIRE(p.row_shift == -2 && p.ldo >= p.N, "wino43v_nt: input gradient needs row_shift -2");
+    TL_REQUIRE(p.aux != nullptr || p.auxbits != nullptr, "wino43v_nt: MASK needs aux or auxbits");
+    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_MASK>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+  } else if (p.epilogue == W_EPI_C1W) {
+    TL_REQUIRE(p.row_shift == -2, "wino43v_nt: input gradient needs row_shift -2");
+    TL_REQUIRE(p.auxbits && p.c1x && p.c1bits && p.c1partial, "wino43v_nt: epilogue 4 needs auxbits, c1x, c1bits, c1partial");
+    TL_REQUIRE(p.c1kt >= 1 && p.c1kt <= 3 && p.c1T >= 2 * p.Tvalid + 2, "wino43v_nt: epilogue 4: 1..3 taps, c1T >= 2*Tvalid + 2");
+    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_C1W>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+  } else {
+    set_error("wino43v_nt: unsupported epilogue %d", p.epilogue);
+    return TL_EINVAL;
+  }
   return check_launch("wino43v_nt");
 }
 
@@ -633,8 +725,38 @@ extern "C" int tl_conv3_wino43v_tn(const tl_tn_params* pp, void* stream) {
   TL_REQUIRE(p.A_rows >= ksteps_all * T4_Q, "wino43v_tn: V must hold whole 8-quad K-steps (pad it with zero quads)");
   const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
   TL_REQUIRE((per + 4) * (long long)T4_Q * 6 * p.lda * 4 < (1LL << 31), "wino43v_tn: a reduction split spans more than 2 GB of V: raise splitk");
-  const long long t = (long long)((p.Mdim + T4_BM - 1) / T4_BM) * ((p.Ndim + T4_BN - 1) / T4_BN);
-  TL_REQUIRE(t < (1LL << 31), "wino43v_tn: grid too large");
-  hipLaunchKernelGGL(wino43v_tn_kernel, dim3((unsigned)t, (unsigned)p.splitk, 1), dim3(256), 0, (hipStream_t)stream, p);
+  TL_REQUIRE(p.vd == nullptr || (p.ld_vd >= p.Ndim && p.ld_vd % 2 == 0), "wino43v_tn: ld_vd must cover Ndim");
+  const int ntm = (p.Mdim + T4_BM - 1) / T4_BM, ntn = (p.Ndim + T4_BN - 1) / T4_BN;
+  TL_REQUIRE((long long)ntm * ntn < (1LL << 31), "wino43v_tn: grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (p.vd != nullptr) {
+    // first C_in tile: the instantiation that also writes Vd; the other tiles: the plain one
+    hipLaunchKernelGGL((wino43v_tn_kernel<true>), dim3((unsigned)ntn, (unsigned)p.splitk, 1), dim3(256), 0, st, p, 0, 1);
+    int rc = check_launch("wino43v_tn (Vd)");
+    if (rc) return rc;
+    if (ntm > 1)
+      hipLaunchKernelGGL((wino43v_tn_kernel<false>), dim3((unsigned)((ntm - 1) * ntn), (unsigned)p.splitk, 1), dim3(256), 0, st,
+                         p, 1, ntm - 1);
+  } else {
+    hipLaunchKernelGGL((wino43v_tn_kernel<false>), dim3((unsigned)(ntm * ntn), (unsigned)p.splitk, 1), dim3(256), 0, st, p, 0,
+                       ntm);
+  }
   return check_launch("wino43v_tn");
+}
+
+// Vd of a stage from its pooled output gradient G (g_rows rows = conv_rows / 2) and arg-max bits: conv_rows / 4 quads
+extern "C" int tl_wino43_unpool_transform(const float* G, const uint32_t* bits, float* V, int64_t conv_rows, int64_t g_rows,
+                                          int Tp, int Tvalid, int C, int ldg, int ld_bits, int ldv, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(G && bits && V, "wino43_unpool_transform: null pointer");
+  TL_REQUIRE(conv_rows > 0 && conv_rows % 4 == 0 && g_rows > 0 && Tp > 0 && Tp % 4 == 0 && Tvalid % 2 == 0 && Tvalid <= Tp,
+             "wino43_unpool_transform: conv_rows %% 4, Tp %% 4, even Tvalid <= Tp needed");
+  TL_REQUIRE(C > 0 && C % 4 == 0 && ldg >= C && ldv >= C && ldg % 4 == 0 && ldv % 4 == 0 && ld_bits * 32 >= C,
+             "wino43_unpool_transform: C/ldg/ldv must be multiples of 4, bits row must cover C");
+  const long long nq = conv_rows / 4;
+  const long long n = nq * (C / 4);
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino43_unpool_transform: grid too large");
+  hipLaunchKernelGGL(wino43_unpool_xform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, bits, V,
+                     nq, (long long)g_rows, Tp, Tvalid, C, ldg, ld_bits, ldv);
+  return check_launch("wino43_unpool_transform");
 }

@@ -100,6 +100,9 @@ typedef struct {
   int splitk; int64_t slab_stride;
   float* colsum;      /* optional (tl_conv3_wino43_tn): colsum[z][n] = sum over split z of the un-pooled
                          dZ column n (the bias gradient partial sums; Ndim floats per split), or null */
+  float* vd; int ld_vd; /* optional (tl_conv3_wino43v_tn): also write Vd[quad][6][ld_vd] = the F(4,3) input transform of
+                         the un-pooled dZ rows 4q-2 .. 4q+3 - the operand of the stage's input-gradient pass
+                         (tl_conv3_wino43v_nt, MASK / conv1-weight-gradient epilogue); Krows / 4 quads, or null    */
 } tl_tn_params;
 int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
 
@@ -156,6 +159,12 @@ int tl_conv3_wino43_tn(const tl_tn_params* p, void* stream);
 int tl_wino43_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
 int tl_wino43_input_transform(const float* P, float* V, int64_t rows, int Tp, int C, int ldp, int ldv, void* stream);
 int tl_conv3_wino43v_nt(const tl_nt_params* p, void* stream);
+/* Vd[conv_rows / 4][6][ldv] of a pooled 3-tap stage from its output gradient G (g_rows pooled rows, ldg) and arg-max bits:
+ * the F(4,3) input transform of the un-pooled dZ rows 4q-2 .. 4q+3 = the operand of tl_conv3_wino43v_nt with the MASK /
+ * conv1-weight-gradient epilogue.  LDS-free and register-light: meant to run on a side stream beside the stage's
+ * MFMA-bound weight-gradient kernel.                                                                                    */
+int tl_wino43_unpool_transform(const float* G, const uint32_t* bits, float* V, int64_t conv_rows, int64_t g_rows, int Tp,
+                               int Tvalid, int C, int ldg, int ld_bits, int ldv, void* stream);
 int tl_conv3_wino43v_tn(const tl_tn_params* p, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
 int tl_sizeof_nt_params(void);

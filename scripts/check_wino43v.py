@@ -14,7 +14,7 @@ ap.add_argument("--channels", type=int, default=16)
 ap.add_argument("--timepoints", type=int, default=400)
 ap.add_argument("--iters", type=int, default=0)
 ap.add_argument("--stages", default="2,3")
-ap.add_argument("--passes", default="fwd,wgrad")
+ap.add_argument("--passes", default="fwd,wgrad,dgrad")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
@@ -57,6 +57,13 @@ for si in [int(s) for s in args.stages.split(",")]:
                 eng._v_ready = {}
             eng.stage_wgrad(st, gw, gb)
             out["gw"], out["gb"] = gw.clone(), gb.clone()
+        if "dgrad" in passes:
+            if mode:                       # the V-form input gradient reads the Vd its weight-gradient kernel wrote
+                gw2, gb2 = torch.zeros_like(w), torch.zeros_like(b)
+                eng.stage_wgrad(st, gw2, gb2)
+            eng.G[si - 1].zero_()
+            eng.stage_dgrad(st, w)
+            out["dg"] = eng.G[si - 1].clone()
         if "fwd" in passes:
             eng.P[si].zero_()
             eng.stage_forward(st, w, b)
@@ -73,6 +80,10 @@ for si in [int(s) for s in args.stages.split(",")]:
         r = rel(v["P"], d["P"])
         msg += f" fwd rel {r:.3e} max {float((v['P'] - d['P']).abs().max()):.3e} argmax flips {nflip} sign flips {nsf} of {d['bits'].numel() * 32}"
         bad |= not (r < 5e-6)
+    if "dgrad" in passes:
+        r3 = rel(v["dg"], d["dg"])
+        msg += f"  dgrad rel {r3:.3e} max {float((v['dg'] - d['dg']).abs().max()):.3e}"
+        bad |= not (r3 < 5e-6)
     if "wgrad" in passes:
         r1, r2 = rel(v["gw"], d["gw"]), rel(v["gb"], d["gb"])
         msg += f"  wgrad rel {r1:.3e} bias {r2:.3e}"
@@ -95,7 +106,12 @@ if args.iters:
                     eng._input_transform(st)
                 ts = eng.timer_summary(); eng.enable_timers(False)
                 print(f"V-form conv{si}_xform  {ts[f'conv{si}_xform'][1]:8.3f} ms (stand-alone input transform)", flush=True)
-            for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("wgrad", lambda: eng.stage_wgrad(st, gw, gb))):
+            def dgrad():
+                if mode:
+                    eng.stage_wgrad(st, gw, gb)
+                eng.stage_dgrad(st, w)
+            for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("wgrad", lambda: eng.stage_wgrad(st, gw, gb)),
+                             ("dgrad", dgrad)):
                 if name not in passes:
                     continue
                 fn(); torch.cuda.synchronize()
