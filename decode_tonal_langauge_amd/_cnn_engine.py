@@ -462,6 +462,8 @@ class CnnEngine:
                             if ev:
                                 ev[1].record()
                     self._vd_ready[st.idx] = self.generation
+            # (measured and not kept: the Vd-writing launch on a side stream beside the launch of the other seven C_in tiles
+            # - tl_tn_params.part - 249.4 vs 244.9 ms per step)
             self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, **kw)
             if sk > 1:
                 red = torch.empty(6 * st.cin, ldg, **f32)

@@ -730,11 +730,14 @@ extern "C" int tl_conv3_wino43v_tn(const tl_tn_params* pp, void* stream) {
   TL_REQUIRE((long long)ntm * ntn < (1LL << 31), "wino43v_tn: grid too large");
   hipStream_t st = (hipStream_t)stream;
   if (p.vd != nullptr) {
-    // first C_in tile: the instantiation that also writes Vd; the other tiles: the plain one
-    hipLaunchKernelGGL((wino43v_tn_kernel<true>), dim3((unsigned)ntn, (unsigned)p.splitk, 1), dim3(256), 0, st, p, 0, 1);
-    int rc = check_launch("wino43v_tn (Vd)");
-    if (rc) return rc;
-    if (ntm > 1)
+    // first C_in tile: the instantiation that also writes Vd; the other tiles: the plain one.  p.part selects one of the
+    // two launches (1: the Vd tile, 2: the rest) so a caller can put them on different streams; 0: both, in order
+    if (p.part != 2) {
+      hipLaunchKernelGGL((wino43v_tn_kernel<true>), dim3((unsigned)ntn, (unsigned)p.splitk, 1), dim3(256), 0, st, p, 0, 1);
+      int rc = check_launch("wino43v_tn (Vd)");
+      if (rc) return rc;
+    }
+    if (ntm > 1 && p.part != 1)
       hipLaunchKernelGGL((wino43v_tn_kernel<false>), dim3((unsigned)((ntm - 1) * ntn), (unsigned)p.splitk, 1), dim3(256), 0, st,
                          p, 1, ntm - 1);
   } else {

@@ -103,6 +103,8 @@ typedef struct {
   float* vd; int ld_vd; /* optional (tl_conv3_wino43v_tn): also write Vd[quad][6][ld_vd] = the F(4,3) input transform of
                          the un-pooled dZ rows 4q-2 .. 4q+3 - the operand of the stage's input-gradient pass
                          (tl_conv3_wino43v_nt, MASK / conv1-weight-gradient epilogue); Krows / 4 quads, or null    */
+  int part;           /* with vd: 0 both launches (the Vd-writing first C_in tile, then the other tiles), 1 / 2 only the
+                         first / second of them (to put them on different streams)                                  */
 } tl_tn_params;
 int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
 
