@@ -175,8 +175,9 @@ class LiteEngine:
         w2t = torch.empty(hid, ldd, **f32)
         self._permute(t["fc.3.weight"], w2t, (1, 1, hid, ldd), (0, 0, 1, hid), (1, 1, hid, self.out_dim))
         g1 = torch.empty(B, hid, **f32)
+        bm = 32 if B <= 64 else 128            # small batches: 32-row tiles, the grid comes from columns / split-K
         self._nt(A=ptr(dout), Bw=ptr(w2t), aux=ptr(self.a1), out=ptr(g1), M=B, A_rows=B, N=hid, K=ldd, lda=ldd, ldb=ldd,
-                 ldo=hid, ldaux=hid, loader=LOAD_DIRECT, epilogue=EPI_MASK, slope=self.slope)
+                 ldo=hid, ldaux=hid, loader=LOAD_DIRECT, epilogue=EPI_MASK, slope=self.slope, bm=bm)
         # fc.1
         slab1 = torch.empty(hid, ldf, **f32)
         self._tn(A=ptr(g1), B=ptr(self.feat), slab=ptr(slab1), Krows=B, A_rows=B, B_rows=B, Mdim=hid, Ndim=ldf, lda=hid,
@@ -186,8 +187,16 @@ class LiteEngine:
         w1t = torch.empty(ldf, hid, **f32)
         self._permute(t["fc.1.weight"], w1t, (1, 1, ldf, hid), (0, 0, 1, fh), (1, 1, fh, hid))
         dfeat = torch.empty(B, ldf, **f32)
-        self._nt(A=ptr(g1), Bw=ptr(w1t), out=ptr(dfeat), M=B, A_rows=B, N=ldf, K=hid, lda=hid, ldb=hid, ldo=ldf,
-                 loader=LOAD_DIRECT, epilogue=EPI_STORE)
+        tiles = ((B + bm - 1) // bm) * ((ldf + 127) // 128)
+        sk = int(max(1, min((hid + 31) // 32, 256 // tiles)))
+        if sk > 1:
+            slab_d = torch.empty(sk, B, ldf, **f32)
+            self._nt(A=ptr(g1), Bw=ptr(w1t), out=ptr(slab_d), M=B, A_rows=B, N=ldf, K=hid, lda=hid, ldb=hid, ldo=ldf,
+                     loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm, splitk=sk, slab_stride=B * ldf)
+            self._permute(slab_d, dfeat, (1, 1, 1, B * ldf), (0, 0, 0, 1), nz=sk, zs=B * ldf)
+        else:
+            self._nt(A=ptr(g1), Bw=ptr(w1t), out=ptr(dfeat), M=B, A_rows=B, N=ldf, K=hid, lda=hid, ldb=hid, ldo=ldf,
+                     loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm)
         dy2 = torch.empty(B, CC, T2, **f32)
         dh = torch.empty(B, H, **f32)
         check(lib.tl_lite_uncat(ptr(dfeat), ptr(dy2), ptr(dh), B, self.F, H, ldf, self._p_used, self._seed, st),

@@ -26,12 +26,8 @@ __global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restr
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = t0 + lane;
-  for (int o = wave; o < Cout; o += 4) {
-    float acc = bias[o];
-    const float* wo = w + (long long)o * Cin * k;
-    for (int ci = 0; ci < Cin; ++ci)
-      for (int j = 0; j < k; ++j) acc = fmaf(wo[ci * k + j], xs[ci * W + lane + j], acc);
-    const bool ok = t < T;
+  const bool ok = t < T;
+  auto finish = [&](int o, float acc) {
     if (ok) z[((long long)b * Cout + o) * T + t] = acc;
     float s1 = ok ? acc : 0.f, s2 = ok ? acc * acc : 0.f;
 #pragma unroll
@@ -43,6 +39,36 @@ __global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restr
       float* pp = part + (((long long)b * gridDim.x + tile) * Cout + o) * 2;
       pp[0] = s1;
       pp[1] = s2;
+    }
+  };
+  constexpr int OB = 8;        // output channels a lane accumulates at once: one LDS read feeds OB FMAs
+  if (Cout % (4 * OB) == 0 && k <= 8) {
+    for (int o0 = wave * OB; o0 < Cout; o0 += 4 * OB) {
+      float acc[OB];
+#pragma unroll
+      for (int u = 0; u < OB; ++u) acc[u] = bias[o0 + u];
+      for (int ci = 0; ci < Cin; ++ci) {
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = j < k ? xs[ci * W + lane + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < OB; ++u) {
+          const float* wo = w + ((long long)(o0 + u) * Cin + ci) * k;       // wave-uniform: scalar loads
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < k) acc[u] = fmaf(wo[j], xv[j], acc[u]);                 // same (ci, j) order as the scalar loop below
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < OB; ++u) finish(o0 + u, acc[u]);
+    }
+  } else {
+    for (int o = wave; o < Cout; o += 4) {
+      float acc = bias[o];
+      const float* wo = w + (long long)o * Cin * k;
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int j = 0; j < k; ++j) acc = fmaf(wo[ci * k + j], xs[ci * W + lane + j], acc);
+      finish(o, acc);
     }
   }
 }
@@ -194,12 +220,37 @@ __global__ __launch_bounds__(256) void lite_conv_dx_kernel(const float* __restri
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = t0 + lane;
-  for (int ci = wave; ci < Cin; ci += 4) {
-    float acc = 0.f;
-    for (int o = 0; o < Cout; ++o)
-      for (int j = 0; j < k; ++j)      // dz index t - j + pad = t0 + lane + (k-1-j) - (k-1-pad)
-        acc = fmaf(w[((long long)o * Cin + ci) * k + j], ds[o * W + lane + (k - 1 - j)], acc);
-    if (t < T) dx[((long long)b * Cin + ci) * T + t] = acc;
+  constexpr int CB = 8;        // input channels a lane accumulates at once
+  if (Cin % (4 * CB) == 0 && k <= 8) {
+    for (int c0 = wave * CB; c0 < Cin; c0 += 4 * CB) {
+      float acc[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) acc[u] = 0.f;
+      for (int o = 0; o < Cout; ++o) {
+        float dv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] = j < k ? ds[o * W + lane + (k - 1 - j)] : 0.f;
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+          const float* wr = w + ((long long)o * Cin + c0 + u) * k;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < k) acc[u] = fmaf(wr[j], dv[j], acc[u]);
+        }
+      }
+      if (t < T) {
+#pragma unroll
+        for (int u = 0; u < CB; ++u) dx[((long long)b * Cin + c0 + u) * T + t] = acc[u];
+      }
+    }
+  } else {
+    for (int ci = wave; ci < Cin; ci += 4) {
+      float acc = 0.f;
+      for (int o = 0; o < Cout; ++o)
+        for (int j = 0; j < k; ++j)      // dz index t - j + pad = t0 + lane + (k-1-j) - (k-1-pad)
+          acc = fmaf(w[((long long)o * Cin + ci) * k + j], ds[o * W + lane + (k - 1 - j)], acc);
+      if (t < T) dx[((long long)b * Cin + ci) * T + t] = acc;
+    }
   }
 }
 // dwpart[b][o][i][j] = sum_t dz[b][o][t] x[b][i][t + j - pad];  dbpart[b][o] = sum_t dz[b][o][t]
@@ -250,13 +301,27 @@ __global__ __launch_bounds__(256) void lite_lstm_fwd_kernel(const float* __restr
   const int b = blockIdx.x;
   for (int i = threadIdx.x; i < H; i += blockDim.x) h[i] = c[i] = 0.f;
   __syncthreads();
+  // H == 64 (the reference's default, models/synthesis_models.py:211): thread r keeps row r of W_hh in registers for the
+  // whole sequence (4H = 256 threads x 64 floats), so a step is 64 FMAs on broadcast LDS reads of h with no memory
+  // traffic - the generic loop below re-reads its 16 KB row set from L2 every step (43 -> ~10 us at batch 64)
+  const bool regw = (H == 64) && (blockDim.x == 256);
+  float wreg[64];
+  if (regw) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q) wreg[q] = w_hh[(long long)threadIdx.x * 64 + q];
+  }
   for (int t = 0; t < L; ++t) {
     for (int r = threadIdx.x; r < 4 * H; r += blockDim.x) {
       float acc = b_ih[r];
       for (int d = 0; d < in_dim; ++d) acc = fmaf(xl[((long long)b * L + t) * in_dim + d], w_ih[r * in_dim + d], acc);
       float hh = b_hh[r];
-      const float* wr = w_hh + (long long)r * H;
-      for (int q = 0; q < H; ++q) hh = fmaf(h[q], wr[q], hh);
+      if (regw) {
+#pragma unroll
+        for (int q = 0; q < 64; ++q) hh = fmaf(h[q], wreg[q], hh);
+      } else {
+        const float* wr = w_hh + (long long)r * H;
+        for (int q = 0; q < H; ++q) hh = fmaf(h[q], wr[q], hh);
+      }
       const float pre = acc + hh;
       gt[r] = (r >= 2 * H && r < 3 * H) ? tanhf(pre) : sigm(pre);
     }
@@ -281,7 +346,15 @@ __global__ __launch_bounds__(256) void lite_lstm_bwd_kernel(const float* __restr
   float* dh = sm;
   float* dc = sm + H;
   float* dg = sm + 2 * H;
+  float* part4 = sm + 6 * H;          // [4][64] partial sums (H == 64 path)
   const int b = blockIdx.x;
+  const bool regw = (H == 64) && (blockDim.x == 256);
+  float wreg[64];
+  if (regw) {
+    const int pw = threadIdx.x >> 6, q = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) wreg[j] = w_hh[(long long)(pw * 64 + j) * 64 + q];      // coalesced over q
+  }
   for (int q = threadIdx.x; q < H; q += blockDim.x) {
     dh[q] = dh_last[(long long)b * ld_dh + q];
     dc[q] = 0.f;
@@ -303,10 +376,22 @@ __global__ __launch_bounds__(256) void lite_lstm_bwd_kernel(const float* __restr
     }
     __syncthreads();
     for (int r = threadIdx.x; r < 4 * H; r += blockDim.x) dgates[((long long)b * L + t) * 4 * H + r] = dg[r];
-    for (int q = threadIdx.x; q < H; q += blockDim.x) {
+    if (regw) {
+      // wave p contracts gate rows [64 p, 64 p + 64) with its register-resident slice of W_hh (broadcast reads of dg),
+      // the four partial sums meet in LDS: all 256 threads work instead of 64 (152 -> ~40 us at batch 64)
+      const int pw = threadIdx.x >> 6, q = threadIdx.x & 63;
       float acc = 0.f;
-      for (int r = 0; r < 4 * H; ++r) acc = fmaf(dg[r], w_hh[(long long)r * H + q], acc);
-      dh[q] = acc;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) acc = fmaf(dg[pw * 64 + j], wreg[j], acc);
+      part4[pw * 64 + q] = acc;
+      __syncthreads();
+      if (threadIdx.x < 64) dh[q] = (part4[q] + part4[64 + q]) + (part4[128 + q] + part4[192 + q]);
+    } else {
+      for (int q = threadIdx.x; q < H; q += blockDim.x) {
+        float acc = 0.f;
+        for (int r = 0; r < 4 * H; ++r) acc = fmaf(dg[r], w_hh[(long long)r * H + q], acc);
+        dh[q] = acc;
+      }
     }
     __syncthreads();
   }
@@ -431,7 +516,7 @@ extern "C" int tl_lite_lstm_fwd(const float* xl, const float* w_ih, const float*
 extern "C" int tl_lite_lstm_bwd(const float* dh_last, const float* w_hh, const float* act, const float* cs,
                                 float* dgates, int B, int L, int H, int ld_dh, void* stream) {
   TL_REQUIRE(dh_last && w_hh && act && cs && dgates && B > 0 && L > 0 && H > 0, "lite_lstm_bwd: bad arguments");
-  const size_t lds = (size_t)6 * H * 4;
+  const size_t lds = (size_t)(6 * H + 256) * 4;
   TL_REQUIRE(lds <= 64 * 1024, "lite_lstm_bwd: hidden size too large");
   hipLaunchKernelGGL(lite_lstm_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, dh_last, w_hh, act, cs, dgates, L,
                      H, ld_dh);
