@@ -148,9 +148,19 @@ class LiteEngine:
         self._permute(slab, pre, (1, 1, B, self.hid), (0, 0, self.hid, 1), nz=sk, zs=B * self.hid, bias=t["fc.1.bias"])
         self.a1 = torch.nn.functional.leaky_relu(pre, self.slope)
         out = torch.empty(B, self.out_dim, **f32)
-        self._nt(A=ptr(self.a1), Bw=ptr(t["fc.3.weight"]), bias=ptr(t["fc.3.bias"]), out=ptr(out), M=B, A_rows=B,
-                 N=self.out_dim, K=self.hid, lda=self.hid, ldb=self.hid, ldo=self.out_dim, loader=LOAD_DIRECT,
-                 epilogue=EPI_STORE)
+        tiles3 = ((B + bm - 1) // bm) * ((self.out_dim + 127) // 128)
+        sk3 = int(max(1, min((self.hid + 31) // 32, 64 // tiles3)))
+        if sk3 > 1:           # one or two tiles of a 16-step K loop are latency-bound (48 us): split K, reduce + bias after
+            slab3 = torch.empty(sk3, B, self.out_dim, **f32)
+            self._nt(A=ptr(self.a1), Bw=ptr(t["fc.3.weight"]), out=ptr(slab3), M=B, A_rows=B, N=self.out_dim, K=self.hid,
+                     lda=self.hid, ldb=self.hid, ldo=self.out_dim, loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm,
+                     splitk=sk3, slab_stride=B * self.out_dim)
+            self._permute(slab3, out, (1, 1, B, self.out_dim), (0, 0, self.out_dim, 1), nz=sk3, zs=B * self.out_dim,
+                          bias=t["fc.3.bias"])
+        else:
+            self._nt(A=ptr(self.a1), Bw=ptr(t["fc.3.weight"]), bias=ptr(t["fc.3.bias"]), out=ptr(out), M=B, A_rows=B,
+                     N=self.out_dim, K=self.hid, lda=self.hid, ldb=self.hid, ldo=self.out_dim, loader=LOAD_DIRECT,
+                     epilogue=EPI_STORE, bm=bm)
         if save:
             self._saved_generation = self.generation
         return out

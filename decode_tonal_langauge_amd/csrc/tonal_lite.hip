@@ -5,6 +5,7 @@
 // each kernel does a whole layer stage per launch and no kernel needs more than one pass.
 #include "tonal_common.h"
 #include <math.h>
+#include <type_traits>
 
 namespace tl {
 
@@ -24,7 +25,8 @@ __global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restr
     xs[i] = (tt >= 0 && tt < T) ? x[((long long)b * Cin + ci) * T + tt] : 0.f;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: weight addresses become scalar
   const int t = t0 + lane;
   const bool ok = t < T;
   auto finish = [&](int o, float acc) {
@@ -42,26 +44,31 @@ __global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restr
     }
   };
   constexpr int OB = 8;        // output channels a lane accumulates at once: one LDS read feeds OB FMAs
-  if (Cout % (4 * OB) == 0 && k <= 8) {
+  auto blocked = [&](auto KC) {
+    constexpr int K = decltype(KC)::value;            // compile-time tap count: the j loops unroll without branches
     for (int o0 = wave * OB; o0 < Cout; o0 += 4 * OB) {
       float acc[OB];
 #pragma unroll
       for (int u = 0; u < OB; ++u) acc[u] = bias[o0 + u];
       for (int ci = 0; ci < Cin; ++ci) {
-        float xv[8];
+        float xv[K];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xv[j] = j < k ? xs[ci * W + lane + j] : 0.f;
+        for (int j = 0; j < K; ++j) xv[j] = xs[ci * W + lane + j];
 #pragma unroll
         for (int u = 0; u < OB; ++u) {
-          const float* wo = w + ((long long)(o0 + u) * Cin + ci) * k;       // wave-uniform: scalar loads
+          const float* wo = w + ((long long)(o0 + u) * Cin + ci) * K;       // wave-uniform: scalar loads
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j < k) acc[u] = fmaf(wo[j], xv[j], acc[u]);                 // same (ci, j) order as the scalar loop below
+          for (int j = 0; j < K; ++j) acc[u] = fmaf(wo[j], xv[j], acc[u]);  // same (ci, j) order as the scalar loop below
         }
       }
 #pragma unroll
       for (int u = 0; u < OB; ++u) finish(o0 + u, acc[u]);
     }
+  };
+  if (Cout % (4 * OB) == 0 && k == 5) {
+    blocked(std::integral_constant<int, 5>{});
+  } else if (Cout % (4 * OB) == 0 && k == 3) {
+    blocked(std::integral_constant<int, 3>{});
   } else {
     for (int o = wave; o < Cout; o += 4) {
       float acc = bias[o];
@@ -218,24 +225,25 @@ __global__ __launch_bounds__(256) void lite_conv_dx_kernel(const float* __restri
     ds[i] = (tt >= 0 && tt < T) ? dz[((long long)b * Cout + o) * T + tt] : 0.f;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = t0 + lane;
   constexpr int CB = 8;        // input channels a lane accumulates at once
-  if (Cin % (4 * CB) == 0 && k <= 8) {
+  auto blocked = [&](auto KC) {
+    constexpr int K = decltype(KC)::value;
     for (int c0 = wave * CB; c0 < Cin; c0 += 4 * CB) {
       float acc[CB];
 #pragma unroll
       for (int u = 0; u < CB; ++u) acc[u] = 0.f;
       for (int o = 0; o < Cout; ++o) {
-        float dv[8];
+        float dv[K];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dv[j] = j < k ? ds[o * W + lane + (k - 1 - j)] : 0.f;
+        for (int j = 0; j < K; ++j) dv[j] = ds[o * W + lane + (K - 1 - j)];
 #pragma unroll
         for (int u = 0; u < CB; ++u) {
-          const float* wr = w + ((long long)o * Cin + c0 + u) * k;
+          const float* wr = w + ((long long)o * Cin + c0 + u) * K;
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j < k) acc[u] = fmaf(wr[j], dv[j], acc[u]);
+          for (int j = 0; j < K; ++j) acc[u] = fmaf(wr[j], dv[j], acc[u]);
         }
       }
       if (t < T) {
@@ -243,6 +251,11 @@ __global__ __launch_bounds__(256) void lite_conv_dx_kernel(const float* __restri
         for (int u = 0; u < CB; ++u) dx[((long long)b * Cin + c0 + u) * T + t] = acc[u];
       }
     }
+  };
+  if (Cin % (4 * CB) == 0 && k == 5) {
+    blocked(std::integral_constant<int, 5>{});
+  } else if (Cin % (4 * CB) == 0 && k == 3) {
+    blocked(std::integral_constant<int, 3>{});
   } else {
     for (int ci = wave; ci < Cin; ci += 4) {
       float acc = 0.f;
@@ -254,14 +267,44 @@ __global__ __launch_bounds__(256) void lite_conv_dx_kernel(const float* __restri
   }
 }
 // dwpart[b][o][i][j] = sum_t dz[b][o][t] x[b][i][t + j - pad];  dbpart[b][o] = sum_t dz[b][o][t]
+// One weight element per thread; the block's rows of x[b] (all input channels) and dz[b] (the output channels its 256
+// elements touch) are staged in LDS once, so the T-long dot products read LDS instead of 2 T global loads per thread.
 __global__ __launch_bounds__(256) void lite_conv_dw_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                            float* __restrict__ dwpart, float* __restrict__ dbpart, int Cin,
-                                                           int Cout, int T, int k, int pad) {
+                                                           int Cout, int T, int k, int pad, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // xs[Cin][T], dzs[no][T]
   const int b = blockIdx.x;
   const int n = Cout * Cin * k;
-  const int e = blockIdx.y * blockDim.x + threadIdx.x;       // one weight element per thread
-  if (e < n) {
-    const int j = e % k, ci = (e / k) % Cin, o = e / (k * Cin);
+  const int e0 = blockIdx.y * blockDim.x;
+  const int e = e0 + threadIdx.x;       // one weight element per thread
+  const int per_o = Cin * k;
+  const int o_lo = e0 / per_o;
+  const int e_hi = min(n, e0 + (int)blockDim.x) - 1;
+  const int no = e_hi / per_o - o_lo + 1;
+  if (use_lds) {
+    float* xs = sm;
+    float* dzs = sm + (long long)Cin * T;
+    for (int i = threadIdx.x; i < Cin * T; i += blockDim.x) xs[i] = x[(long long)b * Cin * T + i];
+    for (int i = threadIdx.x; i < no * T; i += blockDim.x) dzs[i] = dz[((long long)b * Cout + o_lo) * T + i];
+    __syncthreads();
+    if (e < n) {
+      const int j = e % k, ci = (e / k) % Cin, o = e / per_o;
+      const float* dzr = dzs + (o - o_lo) * T;
+      const float* xr = xs + ci * T;
+      const int lo = max(0, pad - j), hi = min(T, T + pad - j);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int t = lo;
+      for (; t + 4 <= hi; t += 4) {
+        a0 = fmaf(dzr[t], xr[t + j - pad], a0);
+        a1 = fmaf(dzr[t + 1], xr[t + 1 + j - pad], a1);
+        a2 = fmaf(dzr[t + 2], xr[t + 2 + j - pad], a2);
+        a3 = fmaf(dzr[t + 3], xr[t + 3 + j - pad], a3);
+      }
+      for (; t < hi; ++t) a0 = fmaf(dzr[t], xr[t + j - pad], a0);
+      dwpart[(long long)b * n + e] = (a0 + a1) + (a2 + a3);
+    }
+  } else if (e < n) {
+    const int j = e % k, ci = (e / k) % Cin, o = e / per_o;
     const float* dzr = dz + ((long long)b * Cout + o) * T;
     const float* xr = x + ((long long)b * Cin + ci) * T;
     const int lo = max(0, pad - j), hi = min(T, T + pad - j);
@@ -277,11 +320,15 @@ __global__ __launch_bounds__(256) void lite_conv_dw_kernel(const float* __restri
     dwpart[(long long)b * n + e] = (a0 + a1) + (a2 + a3);
   }
   if (blockIdx.y == 0) {
-    for (int o = threadIdx.x; o < Cout; o += blockDim.x) {
+    // bias partials: a wave per output channel, lanes across time
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = wave; o < Cout; o += 4) {
       const float* dzr = dz + ((long long)b * Cout + o) * T;
       float acc = 0.f;
-      for (int t = 0; t < T; ++t) acc += dzr[t];
-      dbpart[(long long)b * Cout + o] = acc;
+      for (int t = lane; t < T; t += 64) acc += dzr[t];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+      if (lane == 0) dbpart[(long long)b * Cout + o] = acc;
     }
   }
 }
@@ -499,8 +546,11 @@ extern "C" int tl_lite_conv_bwd(const float* dz, const float* x, const float* w,
     TL_REQUIRE(lds <= 64 * 1024, "lite_conv_bwd: Cout too large for the LDS tile");
     hipLaunchKernelGGL(lite_conv_dx_kernel, dim3((T + LT - 1) / LT, B), dim3(256), lds, st, dz, w, dx, Cin, Cout, T, k, pad);
   }
-  hipLaunchKernelGGL(lite_conv_dw_kernel, dim3(B, (Cout * Cin * k + 255) / 256), dim3(256), 0, st, dz, x, dwpart, dbpart, Cin,
-                     Cout, T, k, pad);
+  const int max_o = (255 + Cin * k - 1) / (Cin * k) + 1;              // output channels a block of 256 elements can touch
+  const size_t lds_dw = ((size_t)Cin * T + (size_t)max_o * T) * 4;
+  const int use_lds = lds_dw <= 64 * 1024;
+  hipLaunchKernelGGL(lite_conv_dw_kernel, dim3(B, (Cout * Cin * k + 255) / 256), dim3(256), use_lds ? lds_dw : 0, st, dz, x,
+                     dwpart, dbpart, Cin, Cout, T, k, pad, use_lds);
   return check_launch("lite_conv_bwd");
 }
 extern "C" int tl_lite_lstm_fwd(const float* xl, const float* w_ih, const float* w_hh, const float* b_ih,
