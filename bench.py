@@ -450,7 +450,8 @@ def main():
                 tags = [t for t in tags if t in tsum]
                 if not tags:
                     continue
-                fl = [conv_flops(eng, int(t[4]), B) for t in tags]
+                share = getattr(eng, "_fam_share", {}).get(fam, 1.0)     # a family may compute only part of its stages' FLOPs
+                fl = [conv_flops(eng, int(t[4]), B) * share for t in tags]
                 ms = [tsum[t][1] for t in tags]
                 stats[fam] = {"ms_per_step": sum(ms), "launches_per_step": len(tags),
                               "flops_per_launch": sum(fl) / len(tags), "avg_launch_ms": sum(ms) / len(tags),

@@ -345,11 +345,22 @@ class CnnEngine:
         tn = "wino43_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3))" if self.wino43_tn else \
             "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))"
         fwd = f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {form})"
+        extra = {}
+        self._fam_share = {}         # family -> share of its stages' algorithmic FLOPs it computes (default 1)
         if self.wino_v and all(self._use_wino_v(st) for st in self.stages[:2]):
-            fwd = "wino43v_nt_kernel (conv2/conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)"
+            fwd = "wino43v_nt_kernel<POOL> (conv2/conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)"
             if self.wino43_tn:
                 tn = "wino43v_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA)"
+                if self.vd_mode == "tn" and all(self._use_wino_vd(st) for st in self.stages[:2]):
+                    # the op is two launches, named apart by rocprofv3: the first C_in tile (1 / ntm of the MFMA work) also
+                    # writes Vd, the operand of the input gradient; the plain instantiation does the other tiles
+                    ntm = (self.stages[0].cin + 63) // 64
+                    tn = f"wino43v_tn_kernel<false> (conv2/conv3 weight gradient, C_in tiles 1..{ntm - 1} of {ntm}, Winograd F(4,3) on V, LDS-DMA)"
+                    vdn = f"wino43v_tn_kernel<true> (conv2/conv3 weight gradient, C_in tile 0 of {ntm}, + writes Vd for the input gradient)"
+                    extra[vdn] = ["conv2_wgrad_vd", "conv3_wgrad_vd"]
+                    self._fam_share = {tn: (ntm - 1) / ntm, vdn: 1.0 / ntm}
         fams = {fwd: ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}
+        fams.update(extra)
         if all(self._use_wino_vd(st) for st in self.stages[:2]):
             nt = "wino43v_nt_kernel"
             form = "F(4,3) on the pre-transformed dZ, LDS-DMA"
@@ -464,7 +475,12 @@ class CnnEngine:
                     self._vd_ready[st.idx] = self.generation
             # (measured and not kept: the Vd-writing launch on a side stream beside the launch of the other seven C_in tiles
             # - tl_tn_params.part - 249.4 vs 244.9 ms per step)
-            self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, **kw)
+            if kw.get("vd") and self.timers is not None:
+                # two calls so that the two launches of the op get their own HIP-event timers (rocprofv3 names them apart too)
+                self._tn(tag=f"conv{st.idx}_wgrad_vd", fn=fn, part=1, **kw)
+                self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, part=2, **kw)
+            else:
+                self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, **kw)
             if sk > 1:
                 red = torch.empty(6 * st.cin, ldg, **f32)
                 n = 6 * st.cin * ldg

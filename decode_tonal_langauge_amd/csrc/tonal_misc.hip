@@ -167,46 +167,52 @@ __global__ __launch_bounds__(256) void conv1_fwd_vq_kernel(const float* __restri
   }
   const int sh = 4 * (threadIdx.x & 7);
   const int Tq = Tp >> 2;
-  for (int q0 = 0; q0 < Tq; q0 += qpp) {
-    const int q = q0 + qsub;                     // Tq % qpp may be non-zero: guard the stores, keep the shuffles uniform
-    f32x4 d[6];
-    uint32_t wb[4], ws[4];
+  // one pooled row (4 channels of this thread) + its arg-max / sign bit words assembled over the 8 lanes of a 32-channel group
+  auto row = [&](int p, bool live, f32x4& out, uint32_t& wb, uint32_t& ws) {
+    out = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint32_t nib = 0, nsg = 0;
+    if (live && p < Tout) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int p = 4 * q + j;
-      f32x4 out = {0.f, 0.f, 0.f, 0.f};
-      uint32_t nib = 0, nsg = 0;
-      if (q < Tq && p < Tout) {
+      for (int c = 0; c < 4; ++c) {
+        float z0 = 0.f, z1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float z0 = 0.f, z1 = 0.f;
-#pragma unroll
-          for (int jj = 0; jj < MAXKT; ++jj)
-            if (jj < kt) {
-              z0 = fmaf(wv[c][jj], xs[2 * p + jj], z0);
-              z1 = fmaf(wv[c][jj], xs[2 * p + 1 + jj], z1);
-            }
-          const float y0 = lrelu(z0 + bv[c], slope), y1 = lrelu(z1 + bv[c], slope);
-          const bool sel = y1 > y0;
-          const float v = sel ? y1 : y0;
-          out[c] = v;
-          nib |= (sel ? 1u : 0u) << c;
-          nsg |= (v > 0.f ? 1u : 0u) << c;
-        }
-      }
-      d[j] = out;
-      if (j < 4) {
-        uint32_t a = nib << sh, e = nsg << sh;
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-          a |= __shfl_xor(a, m);
-          e |= __shfl_xor(e, m);
-        }
-        wb[j] = a;
-        ws[j] = e;
+        for (int jj = 0; jj < MAXKT; ++jj)
+          if (jj < kt) {
+            z0 = fmaf(wv[c][jj], xs[2 * p + jj], z0);
+            z1 = fmaf(wv[c][jj], xs[2 * p + 1 + jj], z1);
+          }
+        const float y0 = lrelu(z0 + bv[c], slope), y1 = lrelu(z1 + bv[c], slope);
+        const bool sel = y1 > y0;
+        const float v = sel ? y1 : y0;
+        out[c] = v;
+        nib |= (sel ? 1u : 0u) << c;
+        nsg |= (v > 0.f ? 1u : 0u) << c;
       }
     }
-    if (q < Tq) {
+    uint32_t a = nib << sh, e = nsg << sh;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      a |= __shfl_xor(a, m);
+      e |= __shfl_xor(e, m);
+    }
+    wb = a;
+    ws = e;
+  };
+  // a thread walks CONSECUTIVE quads (its row group takes quads [qsub * per, (qsub + 1) * per)): rows 4, 5 of a quad are
+  // rows 0, 1 of the next, so four new pooled rows per quad instead of six (the shuffles stay uniform: every thread of a
+  // wave runs the same trip count)
+  const int per = (Tq + qpp - 1) / qpp;
+  const int qb = qsub * per;
+  f32x4 d[6];
+  uint32_t wb[6], ws[6];
+  row(4 * qb, qb < Tq, d[0], wb[0], ws[0]);
+  row(4 * qb + 1, qb < Tq, d[1], wb[1], ws[1]);
+  for (int i = 0; i < per; ++i) {
+    const int q = qb + i;
+    const bool live = q < Tq;
+#pragma unroll
+    for (int j = 2; j < 6; ++j) row(4 * q + j, live, d[j], wb[j], ws[j]);
+    if (live) {
       const long long row0 = seq * Tp + 4 * q;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -225,6 +231,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_vq_kernel(const float* __restri
       *reinterpret_cast<f32x4*>(dst + 4LL * C1) = s3 - 2.f * t;
       *reinterpret_cast<f32x4*>(dst + 5LL * C1) = (4.f * d[1] - 5.f * d[3]) + d[5];
     }
+    d[0] = d[4]; d[1] = d[5];
+    wb[0] = wb[4]; wb[1] = wb[5];
+    ws[0] = ws[4]; ws[1] = ws[5];
   }
 }
 

@@ -13,6 +13,8 @@ from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--train-classifiers", action="store_true",
+                help="the reference CLI default (train_synthesizer.py:275-284): classifiers in train mode, dropout active")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 TONE_MAP = {"0": [3, 3, 3, 3, 3], "1": [1, 2, 3, 4, 5], "2": [3, 2, 1, 2, 4], "3": [5, 4, 3, 2, 1]}
@@ -30,7 +32,7 @@ torch.manual_seed(0)
 model = SynthesisModelCNN(80, 128, T)
 syl = CNNClassifier(input_channels=64, input_length=T, n_classes=2)
 tone = CNNRNNClassifier(input_channels=64, input_length=T, n_classes=4, lstm_dim=800)
-tr = SynthesisTrainer(model, tone, syl, TONE_MAP, device=dev, verbose=False)
+tr = SynthesisTrainer(model, tone, syl, TONE_MAP, device=dev, verbose=False, train_classifiers=args.train_classifiers)
 model.train()
 tr.train_step(x_non, x_syl, x_tone, tgt); torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -40,7 +42,7 @@ torch.cuda.synchronize()
 t_step = (time.perf_counter() - t0) / args.steps
 with torch.no_grad():
     t0 = time.perf_counter(); tr._labels(x_tone, x_syl); torch.cuda.synchronize(); t_cls = time.perf_counter() - t0
-print(json.dumps({"config": "C5 rehearsal, 1 GPU", "per_gpu_batch": B, "signal_ms_256x24000": round(t_sig * 1e3, 3),
+print(json.dumps({"config": "C5 rehearsal, 1 GPU", "per_gpu_batch": B, "train_classifiers": bool(args.train_classifiers), "signal_ms_256x24000": round(t_sig * 1e3, 3),
                   "train_step_ms": round(t_step * 1e3, 2), "of_which_classifier_forwards_ms": round(t_cls * 1e3, 2),
                   "mel_frames_per_s": round(B / t_step, 1), "loss": float(tr._stats[2])}))
 # per-classifier split (HIP-event timed, 3 repetitions each)

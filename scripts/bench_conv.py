@@ -34,7 +34,11 @@ for si in [int(s) for s in args.stages.split(",")]:
     b = torch.randn(st.cout, device=dev, generator=g) * 0.1
     gw, gb = torch.empty_like(w), torch.empty_like(b)
     fl = 2.0 * B * eng.C * st.tc * st.k * st.cin * st.cout
-    for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("dgrad", lambda: eng.stage_dgrad(st, w)),
+    def dgrad():
+        if eng._use_wino_vd(st):          # the V-form input gradient reads the Vd its weight-gradient kernel leaves
+            eng.stage_wgrad(st, gw, gb)
+        eng.stage_dgrad(st, w)
+    for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("dgrad", dgrad),
                      ("wgrad", lambda: eng.stage_wgrad(st, gw, gb))):
         if name not in args.passes.split(","):
             continue

@@ -11,7 +11,14 @@ in KiB; FETCH_SIZE tallies the 128-B requests of 16-B/lane streaming reads at 64
 import csv, glob, json, os, sys
 from collections import defaultdict
 
+# round 3: the V-form kernels (tonal_wino43v.hip); names as Engine.kernel_families() / rocprofv3 give them.  A weight-
+# gradient op is two launches (the Vd-writing first C_in tile, then the other tiles), listed apart.
 FAMILIES = {
+    "wino43v_nt_kernel<2>": "wino43v_nt_kernel<POOL> (conv2/conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)",
+    "wino43v_nt_kernel<4>": "wino43v_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd F(4,3) on the pre-transformed dZ, LDS-DMA)",
+    "wino43v_nt_kernel<3>": "wino43v_nt_kernel<UNPOOL,MASK> (conv3 input gradient, Winograd F(4,3) on the pre-transformed dZ, LDS-DMA)",
+    "wino43v_tn_kernel<false>": "wino43v_tn_kernel<false> (conv2/conv3 weight gradient, C_in tiles 1..7 of 8, Winograd F(4,3) on V, LDS-DMA)",
+    "wino43v_tn_kernel<true>": "wino43v_tn_kernel<true> (conv2/conv3 weight gradient, C_in tile 0 of 8, + writes Vd for the input gradient)",
     "wino43_nt_kernel<1, 4": "wino43_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd F(4,3))",
     "wino43_nt_kernel<1, 3": "wino43_nt_kernel<UNPOOL,MASK> (conv3 input gradient, Winograd F(4,3))",
     "wino43_nt_kernel<0, 2": "wino43_nt_kernel<DIRECT,POOL> (conv2/conv3 forward, Winograd F(4,3))",
@@ -38,7 +45,7 @@ def collect(d, counter):
 fetch, nf = collect(sys.argv[1], "FETCH_SIZE")
 write, nw = collect(sys.argv[2], "WRITE_SIZE")
 out = {}
-for fam in FAMILIES.values():
+for fam in dict.fromkeys(FAMILIES.values()):
     if fam not in fetch or fam not in write:
         continue
     rd = fetch[fam] / nf[fam] * 1024 * 2
