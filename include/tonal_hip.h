@@ -256,9 +256,6 @@ int tl_l1_mcd(const float* out, const float* targets, float* dout, float* stats,
 int tl_nadam(float* p, const float* g, float* m, float* v, int64_t n, float coef_grad, float coef_mom,
              float beta1, float beta2, float bias_corr2, float eps, float weight_decay, float grad_scale,
              void* stream);
-/* the same update for a parameter (rows x cols) whose gradient is low rank, g = fa^T . fb with
- * fa (kr, rows), fb (kr, cols), kr <= 64: the gradient is formed in registers and never stored
- * (label_lstm.weight_hh_l0: 5.4 GB less written and read per step).                              */
 /* One launch for a list of tensors sharing the step's scalars.  entries (DEVICE memory, count of them,
  * every pointer 16-byte aligned): block0 = first block of the tensor = sum over the tensors before it of
  * ceil(n / tl_nadam_multi_chunk()); total_blocks = that sum over all.  Same arithmetic as tl_nadam.   */
@@ -267,6 +264,9 @@ int tl_nadam_multi(const tl_nadam_entry* entries_dev, int count, int64_t total_b
                    float beta1, float beta2, float bias_corr2, float eps, float weight_decay, float grad_scale,
                    void* stream);
 int tl_nadam_multi_chunk(void);
+/* the same update for a parameter (rows x cols) whose gradient is low rank, g = fa^T . fb with
+ * fa (kr, rows), fb (kr, cols), kr <= 64: the gradient is formed in registers and never stored
+ * (label_lstm.weight_hh_l0: 5.4 GB less written and read per step).                              */
 int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
                      int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
                      float bias_corr2, float eps, float weight_decay, float grad_scale, void* stream);
