@@ -287,6 +287,9 @@ class CnnRnnConvEngine:
         st_ = torch.cuda.current_stream().cuda_stream
         wino = self.conv7_form != "direct" and cin % 32 == 0
         nseg = 2 if self.conv7_form == "wino43+1" else 3
+        # the segmented kernel reads A rows up to A_rows + 3 (nseg - 1) = rows + 2 + 3 (nseg - 1); the direct form rows + 8
+        if src.shape[0] < rows + max(8, 2 + 3 * (nseg - 1)):
+            raise RuntimeError("conv7: the input buffer is shorter than the rows the segmented convolution reads")
 
         def pack():
             if not wino:

@@ -115,6 +115,11 @@ class SynthesisTrainer:
         if (self.dp and eng is not None and hasattr(eng, "lstm_shard") and self._pair_table is not None
                 and os.environ.get("TONAL_LSTM_SHARD", "1") != "0"):
             eng.lstm_shard = (self.rank, self.world)        # row-sharded label LSTM (parallel.py docstring)
+            # Between steps each rank holds current values only for its own rows of weight_hh_l0.  `train` / `evaluate`
+            # re-assemble it, but `train_step` is public: anything that reads the whole model (state_dict -> checkpoints)
+            # first runs the collective, on every rank (a collective: all ranks must call state_dict together).  The
+            # NAdam moments of that parameter stay per-rank shards: optimizer state under data parallelism is per rank.
+            self.model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.sync_parameters())
 
     # ------------------------------------------------------------------ helpers
     def _labels(self, inputs_tone, inputs_syllable) -> torch.Tensor:
