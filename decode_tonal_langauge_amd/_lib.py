@@ -97,6 +97,8 @@ SIGNATURES = {
     "tl_nadam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_multi": (_I, [_P, _I, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_multi_chunk": (_I, []),
+    "tl_set_step_scalars": (_I, [_P, _P, _F, _F, _F, C.c_uint64, _P]),
+    "tl_nadam_multi_dev": (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_lowrank": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_tone_dynamics": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "tl_lite_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -108,6 +110,8 @@ SIGNATURES = {
     "tl_lite_lstm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_lite_cat": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, C.c_uint64, _P]),
     "tl_lite_uncat": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, C.c_uint64, _P]),
+    "tl_lite_cat_dev": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "tl_lite_uncat_dev": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
     "tl_row_zscore": (_I, [_P, _I, _P, _P, _I, _L, _L, _L, _I, _P]),
     "tl_car": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),
     "tl_rolling_zscore": (_I, [_P, _I, _P, _I, _L, _I, _I, _P]),

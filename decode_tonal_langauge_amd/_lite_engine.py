@@ -24,6 +24,7 @@ class LiteEngine:
             raise ValueError("the MI355X path needs negative_slope >= 0")
         if label_dim > 8:
             raise ValueError("label_dim > 8 is not supported by the LSTM input-gradient kernel")
+        self.seed_dev = None          # set by the trainer's HIP-graph mode: dropout seed (int64 tensor) in device memory
         self.lib = _lib.load()
         self.out_dim, self.C, self.T, self.in_dim = output_dim, n_channels, n_timepoints, label_dim
         self.CC, self.H = conv_channels, lstm_hidden
@@ -128,8 +129,12 @@ class LiteEngine:
                                    ptr(self.cs), ptr(self.hs), B, L, H, self.in_dim, st), "tl_lite_lstm_fwd")
         # concat + dropout, fc.1 + LeakyReLU, fc.3
         self.feat = torch.empty(B, self.ldf, **f32)
-        check(lib.tl_lite_cat(ptr(y2), ptr(self.hs), ptr(self.feat), B, self.F, H, L, self.ldf, p_drop, seed, st),
-              "tl_lite_cat")
+        if getattr(self, "seed_dev", None) is not None and p_drop > 0:     # HIP-graph mode: the seed lives in device memory
+            check(lib.tl_lite_cat_dev(ptr(y2), ptr(self.hs), ptr(self.feat), B, self.F, H, L, self.ldf, p_drop,
+                                      ptr(self.seed_dev), st), "tl_lite_cat_dev")
+        else:
+            check(lib.tl_lite_cat(ptr(y2), ptr(self.hs), ptr(self.feat), B, self.F, H, L, self.ldf, p_drop, seed, st),
+                  "tl_lite_cat")
         fh = self.F + H
         w1 = t["fc.1.weight"]
         if self.ldf != fh:
@@ -209,8 +214,12 @@ class LiteEngine:
                      loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm)
         dy2 = torch.empty(B, CC, T2, **f32)
         dh = torch.empty(B, H, **f32)
-        check(lib.tl_lite_uncat(ptr(dfeat), ptr(dy2), ptr(dh), B, self.F, H, ldf, self._p_used, self._seed, st),
-              "tl_lite_uncat")
+        if getattr(self, "seed_dev", None) is not None and self._p_used > 0:
+            check(lib.tl_lite_uncat_dev(ptr(dfeat), ptr(dy2), ptr(dh), B, self.F, H, ldf, self._p_used, ptr(self.seed_dev), st),
+                  "tl_lite_uncat_dev")
+        else:
+            check(lib.tl_lite_uncat(ptr(dfeat), ptr(dy2), ptr(dh), B, self.F, H, ldf, self._p_used, self._seed, st),
+                  "tl_lite_uncat")
         # LSTM
         dg = torch.empty(B, L, 4 * H, **f32)
         check(lib.tl_lite_lstm_bwd(ptr(dh), ptr(t["label_lstm.weight_hh_l0"]), ptr(self.act), ptr(self.cs), ptr(dg), B, L,

@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256) void lite_lstm_bwd_kernel(const float* __restr
 // feat[b][0:F] = y2[b][:] (flattened conv features), feat[b][F:F+H] = h_L[b]; dropout (fc.0) on all
 __global__ __launch_bounds__(256) void lite_cat_kernel(const float* __restrict__ y2, const float* __restrict__ hs,
                                                        float* __restrict__ feat, int B, int F, int H, int L, int ldf,
-                                                       float p_drop, uint64_t seed) {
+                                                       float p_drop, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed = *seed_dev;      // dropout seed in device memory (HIP-graph replays draw new masks)
   const long long total = (long long)B * ldf;
   const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(256) void lite_cat_kernel(const float* __restrict__
 }
 __global__ __launch_bounds__(256) void lite_uncat_kernel(const float* __restrict__ dfeat, float* __restrict__ dy2,
                                                          float* __restrict__ dh, int B, int F, int H, int ldf, float p_drop,
-                                                         uint64_t seed) {
+                                                         uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev != nullptr) seed = *seed_dev;
   const long long total = (long long)B * (F + H);
   const float ks = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -576,13 +578,29 @@ extern "C" int tl_lite_cat(const float* y2, const float* hs, float* feat, int B,
                            float p_drop, uint64_t seed, void* stream) {
   TL_REQUIRE(y2 && hs && feat && ldf >= F + H && p_drop >= 0.f && p_drop < 1.f, "lite_cat: bad arguments");
   hipLaunchKernelGGL(lite_cat_kernel, dim3(lgrid((long long)B * ldf)), dim3(256), 0, (hipStream_t)stream, y2, hs, feat, B, F,
-                     H, L, ldf, p_drop, seed);
+                     H, L, ldf, p_drop, seed, (const uint64_t*)nullptr);
   return check_launch("lite_cat");
 }
 extern "C" int tl_lite_uncat(const float* dfeat, float* dy2, float* dh, int B, int F, int H, int ldf, float p_drop,
                              uint64_t seed, void* stream) {
   TL_REQUIRE(dfeat && dy2 && dh && ldf >= F + H && p_drop >= 0.f && p_drop < 1.f, "lite_uncat: bad arguments");
   hipLaunchKernelGGL(lite_uncat_kernel, dim3(lgrid((long long)B * (F + H))), dim3(256), 0, (hipStream_t)stream, dfeat, dy2,
-                     dh, B, F, H, ldf, p_drop, seed);
+                     dh, B, F, H, ldf, p_drop, seed, (const uint64_t*)nullptr);
   return check_launch("lite_uncat");
+}
+// the same two with the dropout seed read from device memory (one uint64): the launches can sit in a HIP graph whose
+// replays draw a fresh mask each, the caller updating *seed_dev between replays
+extern "C" int tl_lite_cat_dev(const float* y2, const float* hs, float* feat, int B, int F, int H, int L, int ldf,
+                               float p_drop, const uint64_t* seed_dev, void* stream) {
+  TL_REQUIRE(y2 && hs && feat && seed_dev && ldf >= F + H && p_drop >= 0.f && p_drop < 1.f, "lite_cat_dev: bad arguments");
+  hipLaunchKernelGGL(lite_cat_kernel, dim3(lgrid((long long)B * ldf)), dim3(256), 0, (hipStream_t)stream, y2, hs, feat, B, F,
+                     H, L, ldf, p_drop, (uint64_t)0, seed_dev);
+  return check_launch("lite_cat_dev");
+}
+extern "C" int tl_lite_uncat_dev(const float* dfeat, float* dy2, float* dh, int B, int F, int H, int ldf, float p_drop,
+                                 const uint64_t* seed_dev, void* stream) {
+  TL_REQUIRE(dfeat && dy2 && dh && seed_dev && ldf >= F + H && p_drop >= 0.f && p_drop < 1.f, "lite_uncat_dev: bad arguments");
+  hipLaunchKernelGGL(lite_uncat_kernel, dim3(lgrid((long long)B * (F + H))), dim3(256), 0, (hipStream_t)stream, dfeat, dy2,
+                     dh, B, F, H, ldf, p_drop, (uint64_t)0, seed_dev);
+  return check_launch("lite_uncat_dev");
 }

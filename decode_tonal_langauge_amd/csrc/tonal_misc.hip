@@ -247,6 +247,21 @@ __global__ __launch_bounds__(256) void dropout_scale_kernel(float* __restrict__ 
     x[i] = u01(seed, (uint64_t)i) >= p ? x[i] * inv_keep : 0.f;
 }
 
+// The per-step scalars of a HIP-graph-replayed train step (tl_nadam_multi_dev, tl_lite_cat_dev / tl_lite_uncat_dev) are
+// written by a one-thread launch whose ARGUMENTS carry the values: stream-ordered in front of the replay with no host
+// buffer that a later step could overwrite before an asynchronous copy has read it.
+__global__ void set_step_scalars_kernel(float* __restrict__ sc, uint64_t* __restrict__ seed, float cg, float cm, float bc2,
+                                        uint64_t seedval) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (sc != nullptr) {
+      sc[0] = cg;
+      sc[1] = cm;
+      sc[2] = bc2;
+    }
+    if (seed != nullptr) *seed = seedval;
+  }
+}
+
 // conv1 weight/bias gradient partials: block handles a contiguous range of sequences;
 // thread owns channels tid and tid + 256 (C1 <= 512), barriers are outside every guard.
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ G,
@@ -805,7 +820,12 @@ __global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ p, const
 constexpr int NM_CHUNK = 256 * 16;
 __global__ __launch_bounds__(256) void nadam_multi_kernel(const tl_nadam_entry* __restrict__ entries, int count, float cg,
                                                           float cm, float b1, float b2, float bc2, float eps, float wd,
-                                                          float gscale) {
+                                                          float gscale, const float* __restrict__ sc) {
+  if (sc != nullptr) {      // step scalars in device memory (a HIP graph replays the launch with new values): cg, cm, bc2
+    cg = sc[0];
+    cm = sc[1];
+    bc2 = sc[2];
+  }
   const long long blk = blockIdx.x;
   int lo = 0, hi = count - 1;                         // last entry with block0 <= blk
   while (lo < hi) {
@@ -982,6 +1002,14 @@ extern "C" int tl_dropout_scale(float* x, int64_t n, float p, uint64_t seed, voi
   hipLaunchKernelGGL(dropout_scale_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (long long)n, p,
                      1.0f / (1.0f - p), seed);
   return check_launch("dropout_scale");
+}
+
+extern "C" int tl_set_step_scalars(float* scalars_dev, uint64_t* seed_dev, float coef_grad, float coef_mom, float bias_corr2,
+                                   uint64_t seed, void* stream) {
+  TL_REQUIRE(scalars_dev || seed_dev, "set_step_scalars: nothing to set");
+  hipLaunchKernelGGL(set_step_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scalars_dev, seed_dev, coef_grad, coef_mom,
+                     bias_corr2, seed);
+  return check_launch("set_step_scalars");
 }
 
 extern "C" int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial, int nblk,
@@ -1178,8 +1206,17 @@ extern "C" int tl_nadam_multi(const tl_nadam_entry* entries_dev, int count, int6
   TL_REQUIRE(entries_dev != nullptr && count > 0, "nadam_multi: empty table");
   TL_REQUIRE(total_blocks > 0 && total_blocks < (1LL << 31), "nadam_multi: bad block count %lld", (long long)total_blocks);
   hipLaunchKernelGGL(nadam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, entries_dev, count,
-                     coef_grad, coef_mom, beta1, beta2, bias_corr2, eps, weight_decay, grad_scale);
+                     coef_grad, coef_mom, beta1, beta2, bias_corr2, eps, weight_decay, grad_scale, (const float*)nullptr);
   return check_launch("nadam_multi");
+}
+
+extern "C" int tl_nadam_multi_dev(const tl_nadam_entry* entries_dev, int count, int64_t total_blocks, const float* scalars_dev,
+                                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+  TL_REQUIRE(entries_dev != nullptr && count > 0 && scalars_dev != nullptr, "nadam_multi_dev: empty table / null scalars");
+  TL_REQUIRE(total_blocks > 0 && total_blocks < (1LL << 31), "nadam_multi_dev: bad block count %lld", (long long)total_blocks);
+  hipLaunchKernelGGL(nadam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, entries_dev, count,
+                     0.f, 0.f, beta1, beta2, 1.f, eps, weight_decay, grad_scale, scalars_dev);
+  return check_launch("nadam_multi_dev");
 }
 
 extern "C" int tl_nadam_multi_chunk(void) { return NM_CHUNK; }

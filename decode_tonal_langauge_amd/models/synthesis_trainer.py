@@ -111,6 +111,8 @@ class SynthesisTrainer:
         self.rank, self.world = parallel.world()
         self.dp = parallel.active()
         self._whh_dirty = False
+        self._graph_enabled = os.environ.get("TONAL_GRAPH", "1") != "0"
+        self._graphs, self._g_scal = {}, None
         eng = getattr(self.model, "_engine", None)
         if (self.dp and eng is not None and hasattr(eng, "lstm_shard") and self._pair_table is not None
                 and os.environ.get("TONAL_LSTM_SHARD", "1") != "0"):
@@ -203,7 +205,7 @@ class SynthesisTrainer:
             return r
         return run
 
-    def _fused_step(self, inputs_non, inputs_label, targets) -> None:
+    def _fused_step(self, inputs_non, inputs_label, targets, graph: bool = False) -> None:
         model = self.model
         eng = model._engine
         names = model._pnames
@@ -219,8 +221,10 @@ class SynthesisTrainer:
         ids = getattr(self, "_pair_ids", None)
         if ids is not None and ids[1] is inputs_label and getattr(eng, "lowrank_param", None) is not None:
             kw = dict(label_ids=ids[0], label_table=self._pair_table)             # CNN engine: skip torch.unique
-        out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True, seed=model._next_seed(),
-                          row0=getattr(self, "_row0", 0), **kw)
+        # (HIP-graph capture: the engine reads the dropout seed from device memory, the host seed counter is advanced by
+        # the caller once per replay)
+        out = eng.forward(prm, inputs_non, inputs_label, training=model.training, save=True,
+                          seed=0 if graph else model._next_seed(), row0=getattr(self, "_row0", 0), **kw)
         B, D = out.shape
         self._last_out = out             # the step's outputs (pre-update), for callers that track them (tests)
         dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)
@@ -248,7 +252,9 @@ class SynthesisTrainer:
                                                       if k != skip and k not in local_only])
             self._whh_dirty = self._whh_dirty or sharded
         factors = getattr(eng, "whh_factors", None)
-        if early:            # W_hh is already updated
+        if graph:            # scalars of the step from device memory (advanced by the caller per replay)
+            self.optimizer.step_graph({params[k]: self._grads[k] for k in names}, self._g_scal, grad_scale=scale)
+        elif early:            # W_hh is already updated
             self.optimizer.step(grads={params[k]: self._grads[k] for k in names if k != skip}, grad_scale=scale, skip=set(early))
         elif factors is not None:          # the optimiser forms that gradient from its factors on the fly
             self.optimizer.step(grads={params[k]: self._grads[k] for k in names if k != skip}, grad_scale=scale,
@@ -294,12 +300,71 @@ class SynthesisTrainer:
         targets = targets.to(dev, non_blocking=True).float().contiguous()
         inputs_non, inputs_syllable, inputs_tone, targets = self._shard(inputs_non, inputs_syllable, inputs_tone,
                                                                         targets)
+        if self._graph_ok() and self._graph_step(inputs_non, inputs_syllable, inputs_tone, targets):
+            return
         with torch.no_grad():
             inputs_label = self._labels(inputs_tone, inputs_syllable)
         if getattr(self.model, "_engine", None) is not None and hasattr(self.model._engine, "backward"):
             self._fused_step(inputs_non.float().contiguous(), inputs_label, targets.contiguous())
         else:
             self._generic_step(inputs_non, inputs_label, targets)
+
+    # ------------------------------------------------------------------ HIP-graph replay of a launch-bound step
+    def _graph_ok(self) -> bool:
+        """The step of a small model (SynthesisLite: ~58 launches of 4-20 us) is bound by launch overhead, not by the GPU:
+        after three eager steps at a batch shape it is captured once into a HIP graph and replayed.  What changes from step
+        to step lives in device memory - the NAdam coefficients (``tl_nadam_multi_dev``) and the dropout seed
+        (``tl_lite_cat_dev`` / ``tl_lite_uncat_dev``) - and is refreshed by two small copies before each replay.  Not under
+        data parallelism (collectives), not with classifiers in train mode (their dropout seed is a launch argument), not
+        for the big model (GPU-bound; its W_hh update takes launch-argument scalars).  TONAL_GRAPH=0 turns it off."""
+        eng = getattr(self.model, "_engine", None)
+        return (self._graph_enabled and eng is not None and hasattr(eng, "seed_dev") and not self.dp
+                and not self.train_classifiers and not self._need_check and self.model.training)
+
+    def _graph_step(self, inputs_non, inputs_syllable, inputs_tone, targets) -> bool:
+        key = (tuple(inputs_non.shape), tuple(inputs_syllable.shape), tuple(inputs_tone.shape), tuple(targets.shape),
+               inputs_non.dtype, inputs_syllable.dtype, inputs_tone.dtype)
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {"warm": 0, "graph": None}
+        if st["graph"] is None:
+            if st["warm"] < 3 or len([v for v in self._graphs.values() if v["graph"] is not None]) >= 2:
+                st["warm"] += 1
+                return False                      # eager warm-up steps (and at most two captured shapes)
+            model, eng = self.model, self.model._engine
+            params = [p for _, p in model.named_parameters()]
+            st["in"] = tuple(torch.empty_like(t) for t in (inputs_non, inputs_syllable, inputs_tone, targets))
+            if self._g_scal is None:
+                self._g_scal = torch.zeros(4, dtype=torch.float32, device=self.device)
+                self._g_seed = torch.zeros(1, dtype=torch.int64, device=self.device)
+            eng.seed_dev = self._g_seed
+            for d, t in zip(st["in"], (inputs_non, inputs_syllable, inputs_tone, targets)):
+                d.copy_(t)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    with torch.no_grad():
+                        lab = self._labels(st["in"][2], st["in"][1])
+                    self._fused_step(st["in"][0].float().contiguous(), lab, st["in"][3].contiguous(), graph=True)
+            except Exception as e:      # noqa: BLE001 - capture refused (e.g. an op that synchronises): stay eager for good
+                import warnings
+                warnings.warn(f"SynthesisTrainer: HIP-graph capture of the train step failed ({e!r}); continuing eagerly")
+                eng.seed_dev = None
+                self._graph_enabled = False
+                return False            # nothing was executed during the failed capture: run this step eagerly
+            eng.seed_dev = None                      # eager steps (other shapes) keep passing the seed by value
+            st["graph"], st["params"] = g, set(params)
+        else:
+            for d, t in zip(st["in"], (inputs_non, inputs_syllable, inputs_tone, targets)):
+                d.copy_(t, non_blocking=True)
+        cg, cm, bc2 = self.optimizer.advance_scalars(st["params"])
+        # the values travel as launch arguments (a pinned host buffer would be overwritten by the next step before an
+        # asynchronous copy of this one has read it: the host runs ahead of the stream)
+        check(self.lib.tl_set_step_scalars(ptr(self._g_scal), ptr(self._g_seed), cg, cm, bc2, self.model._next_seed(),
+                                           torch.cuda.current_stream().cuda_stream), "tl_set_step_scalars")
+        st["graph"].replay()
+        return True
 
     # ------------------------------------------------------------------ public API
     def train(self, train_loader: DataLoader, epochs: int, verbose: bool = True) -> List[Tuple[float, float]]:

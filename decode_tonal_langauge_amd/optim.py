@@ -137,6 +137,49 @@ class FusedNAdam(torch.optim.Optimizer):
             dense.clear()
         return loss
 
+    # ---- HIP-graph support: the step's scalars live in device memory, the host only keeps the schedule ----
+    @torch.no_grad()
+    def step_graph(self, grads: Dict[torch.nn.Parameter, torch.Tensor], scalars_dev: torch.Tensor,
+                   grad_scale: float = 1.0) -> None:
+        """Enqueue the update of every parameter in ``grads`` with coef_grad / coef_mom / bias_corr2 read from
+        ``scalars_dev[0..2]`` (``tl_nadam_multi_dev``): the launch can be captured in a HIP graph.  Does NOT advance the
+        schedule - call ``advance_scalars()`` once per (re)play and copy its result into ``scalars_dev`` first."""
+        stream = torch.cuda.current_stream().cuda_stream
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            items = []
+            for p in group["params"]:
+                g = grads.get(p)
+                if g is None:
+                    continue
+                _lib.require_gpu(p, "FusedNAdam.step_graph")
+                if not (p.is_contiguous() and g.is_contiguous()):
+                    raise RuntimeError("FusedNAdam needs contiguous parameters and gradients")
+                items.append((p, g, self._state_for(p)))
+            if not items:
+                continue
+            table, blocks = self._table(items)
+            check(self._lib.tl_nadam_multi_dev(ptr(table), len(items), blocks, ptr(scalars_dev), b1, b2, group["eps"],
+                                               group["weight_decay"], grad_scale, stream), "tl_nadam_multi_dev")
+
+    def advance_scalars(self, params) -> tuple:
+        """Advance the schedule of ``params`` (all at the same point of it) by one step on the host and return
+        (coef_grad, coef_mom, bias_corr2) of that step - what ``step`` would have passed by value."""
+        out = None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p not in params:
+                    continue
+                st = self._state_for(p)
+                st["step"] += 1
+                cg, cm, bc2, st["mu_product"] = nadam_scalars(st["step"], st["mu_product"], group["lr"], b1, b2,
+                                                              group["momentum_decay"])
+                if out is not None and out != (cg, cm, bc2):
+                    raise RuntimeError("FusedNAdam.advance_scalars: parameters at different points of the schedule")
+                out = (cg, cm, bc2)
+        return out
+
     def _table(self, items):
         """Device table of ``tl_nadam_entry`` rows for ``items`` = [(param, grad, state)], cached while the
         pointers stay the same (the fused trainer keeps its gradient buffers)."""

@@ -264,6 +264,15 @@ int tl_nadam_multi(const tl_nadam_entry* entries_dev, int count, int64_t total_b
                    float beta1, float beta2, float bias_corr2, float eps, float weight_decay, float grad_scale,
                    void* stream);
 int tl_nadam_multi_chunk(void);
+/* tl_nadam_multi with the step's scalars (coef_grad, coef_mom, bias_corr2) read from device memory scalars_dev[0..2]: the
+ * launch can be captured in a HIP graph and replayed with new values (models/synthesis_trainer.py:227, one optimizer.step
+ * per batch)                                                                                                         */
+/* scalars_dev[0..2] = (coef_grad, coef_mom, bias_corr2), *seed_dev = seed (either may be null): the values travel as
+ * launch arguments, stream-ordered in front of a graph replay that reads them                                       */
+int tl_set_step_scalars(float* scalars_dev, uint64_t* seed_dev, float coef_grad, float coef_mom, float bias_corr2,
+                        uint64_t seed, void* stream);
+int tl_nadam_multi_dev(const tl_nadam_entry* entries_dev, int count, int64_t total_blocks, const float* scalars_dev,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 /* the same update for a parameter (rows x cols) whose gradient is low rank, g = fa^T . fb with
  * fa (kr, rows), fb (kr, cols), kr <= 64: the gradient is formed in registers and never stored
  * (label_lstm.weight_hh_l0: 5.4 GB less written and read per step).                              */
@@ -306,6 +315,11 @@ int tl_lite_cat(const float* y2, const float* hs, float* feat, int B, int F, int
                 float p_drop, uint64_t seed, void* stream);
 int tl_lite_uncat(const float* dfeat, float* dy2, float* dh, int B, int F, int H, int ldf, float p_drop,
                   uint64_t seed, void* stream);
+/* the same two with the dropout seed in device memory (*seed_dev): capturable in a HIP graph whose replays draw new masks */
+int tl_lite_cat_dev(const float* y2, const float* hs, float* feat, int B, int F, int H, int L, int ldf,
+                    float p_drop, const uint64_t* seed_dev, void* stream);
+int tl_lite_uncat_dev(const float* dfeat, float* dy2, float* dh, int B, int F, int H, int ldf, float p_drop,
+                      const uint64_t* seed_dev, void* stream);
 
 /* ---- preprocess/signal band extraction (preprocess/signal/frequency_filter.py) ------------ */
 /* Gaussian-bank analytic envelope, circular, exact DFT-domain taps supplied by the host:

@@ -788,3 +788,34 @@ def test_deep_classifiers_train_mode_dropout_stays_on_hip(dev):
         f = f.contiguous().view(B, f.shape[2], -1)
         ref = torch.sigmoid(rnn.output(rnn.lstm2(f)[0][:, -1, :]))
     assert float((hip - ref).abs().max()) < 1e-4
+
+
+def test_lite_hip_graph_replay_equals_eager_steps(dev, monkeypatch):
+    """SynthesisLite's launch-bound train step is captured into a HIP graph after three eager steps (NAdam coefficients and
+    the dropout seed live in device memory and are refreshed per replay).  Ten steps with dropout 0.3 through the graph
+    path must leave exactly the parameters, BatchNorm statistics and loss statistics of ten eager steps (TONAL_GRAPH=0)."""
+    from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisLite
+    from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
+    B, C, T = 16, 32, 200
+    gen = torch.Generator().manual_seed(21)
+    data = [(torch.randn(B, C, T, generator=gen), torch.randn(B, 8, T, generator=gen), torch.randn(B, 8, T, generator=gen),
+             10 * torch.randn(B, 80, generator=gen)) for _ in range(10)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TONAL_GRAPH", mode)
+        torch.manual_seed(0)
+        model = SynthesisLite(80, C, T, dropout=0.3)
+        torch.manual_seed(1)
+        tr = SynthesisTrainer(model, LogisticRegressionClassifier(8 * T, 4), LogisticRegressionClassifier(8 * T, 2), gi.TONE_MAP,
+                              device=dev, verbose=False)
+        model.train()
+        for b in data:
+            tr.train_step(*b)
+        torch.cuda.synchronize()
+        captured = sum(1 for v in tr._graphs.values() if v["graph"] is not None)
+        assert captured == (1 if mode == "1" else 0)
+        res[mode] = ({k: v.detach().clone() for k, v in model.state_dict().items()}, tr._stats.clone(), tr._last_out.clone())
+    for k, v in res["1"][0].items():
+        assert torch.equal(v, res["0"][0][k]), k
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
