@@ -182,10 +182,14 @@ class LiteEngine:
         fh = self.F + H
         hid, ldd, ldf = self.hid, self.ldd, self.ldf
         # fc.3
-        slab = torch.empty(ldd, hid, **f32)
+        # the weight-gradient GEMMs write straight into the gradient tensors when their padded extents equal the true
+        # ones (out_dim and F + H multiples of 4 - the reference's sizes are): no slab, no copy
+        direct3 = ldd == self.out_dim and grads["fc.3.weight"].is_contiguous()
+        slab = grads["fc.3.weight"] if direct3 else torch.empty(ldd, hid, **f32)
         self._tn(A=ptr(dout), B=ptr(self.a1), slab=ptr(slab), Krows=B, A_rows=B, B_rows=B, Mdim=ldd, Ndim=hid, lda=ldd,
                  ldb=hid, ldc=hid, loader=LOAD_DIRECT)
-        grads["fc.3.weight"].copy_(slab[:self.out_dim])
+        if not direct3:
+            grads["fc.3.weight"].copy_(slab[:self.out_dim])
         self._colsum(dout, B, self.out_dim, ldd, grads["fc.3.bias"])
         w2t = torch.empty(hid, ldd, **f32)
         self._permute(t["fc.3.weight"], w2t, (1, 1, hid, ldd), (0, 0, 1, hid), (1, 1, hid, self.out_dim))
@@ -194,10 +198,12 @@ class LiteEngine:
         self._nt(A=ptr(dout), Bw=ptr(w2t), aux=ptr(self.a1), out=ptr(g1), M=B, A_rows=B, N=hid, K=ldd, lda=ldd, ldb=ldd,
                  ldo=hid, ldaux=hid, loader=LOAD_DIRECT, epilogue=EPI_MASK, slope=self.slope, bm=bm)
         # fc.1
-        slab1 = torch.empty(hid, ldf, **f32)
+        direct1 = ldf == fh and grads["fc.1.weight"].is_contiguous()
+        slab1 = grads["fc.1.weight"] if direct1 else torch.empty(hid, ldf, **f32)
         self._tn(A=ptr(g1), B=ptr(self.feat), slab=ptr(slab1), Krows=B, A_rows=B, B_rows=B, Mdim=hid, Ndim=ldf, lda=hid,
                  ldb=ldf, ldc=ldf, loader=LOAD_DIRECT)
-        grads["fc.1.weight"].copy_(slab1[:, :fh])
+        if not direct1:
+            grads["fc.1.weight"].copy_(slab1[:, :fh])
         self._colsum(g1, B, hid, hid, grads["fc.1.bias"])
         w1t = torch.empty(ldf, hid, **f32)
         self._permute(t["fc.1.weight"], w1t, (1, 1, ldf, hid), (0, 0, 1, fh), (1, 1, fh, hid))

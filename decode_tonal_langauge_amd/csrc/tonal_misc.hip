@@ -735,6 +735,7 @@ __global__ __launch_bounds__(256) void l1_mcd_kernel(const float* __restrict__ o
   // a wave per row, lanes across the D outputs (coalesced), a shuffle tree per row: the row sums are formed in a
   // fixed order, lane 0 of each wave carries them (a thread-per-row loop took 22-54 us for 5-20 k elements)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll 8          // rows are independent: let the loads of several rows be in flight together
   for (int b = wave; b < B; b += nw) {
     float a1 = 0.f, a2 = 0.f;
     for (int d = lane; d < D; d += 64) {
