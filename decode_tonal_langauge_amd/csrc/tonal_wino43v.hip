@@ -128,6 +128,9 @@ constexpr int V4_APIECES = 6 * V4_BQ / 16;               // 48
 constexpr int V4_BPIECES = 6 * V4_BN / 16;               // 24
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+#ifndef V4_STAGGER
+#define V4_STAGGER 0      // 1: waves 4-7 issue their LDS-DMA pieces in the second half of a K-step (see kstep)
+#endif
 #ifndef V4_SCHED
 #define V4_SCHED 1        // 1: hand-specified issue order of a K-step (see kstep)
 #endif
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  auto kstep = [&](auto LAST, int s) {
+  auto kstep = [&](auto LAST, auto LATE, int s) {
     const int stage = s & 1;
     if (!(V4_ABL & 16) || s == 0) load_frag(fa0, fb0, stage, c_g0);
     if constexpr (!decltype(LAST)::value)
@@ -254,8 +257,11 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
     // piece costs the issuing wave ~60 cycles; issued as a clump after the barrier by both waves of a SIMD at once it
     // idles the matrix pipe (ablation: 6.4 of 45.4 ms), one piece per two MFMAs hides behind the partner's MFMAs.
     // The reads of k-group 1 are spread over the MFMAs of k-group 0 so none of their latency is left at the barrier.
+    // V4_STAGGER: waves 4-7 (the SIMD partners of waves 0-3) issue their pieces in the SECOND half of the step, so the two
+    // waves of a SIMD are never in their DMA-issue phase together (MI355X_MICROARCH.md, two waves per SIMD, item 9)
+    constexpr bool late = decltype(LATE)::value;
     __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-    if constexpr (!decltype(LAST)::value) {
+    if constexpr (!decltype(LAST)::value && !late) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -269,6 +275,8 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
     for (int t = 0; t < 12; ++t) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if constexpr (!decltype(LAST)::value && late)
+        if (t < 9) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
     }
 #endif
     if constexpr (!decltype(LAST)::value) {
@@ -285,8 +293,15 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
       asm volatile("" ::: "memory");
     }
   };
-  for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, s);
-  kstep(std::true_type{}, nsteps - 1);
+#if V4_STAGGER
+  if (wave >= 4) {
+    for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::true_type{}, s);
+  } else
+#endif
+  {
+    for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::false_type{}, s);
+  }
+  kstep(std::true_type{}, std::false_type{}, nsteps - 1);
   mfma_group(fa1, fb1);
 
 #if V4_ABL & 2

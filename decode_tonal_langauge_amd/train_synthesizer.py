@@ -9,7 +9,8 @@ Two ways in:
    ``params:`` carrying the same names as the CLI flags.
 
 Inputs (reference :161-201): ``sample_path`` .npz with ``ecog (N,C,T)`` and either ``mel (N, n_mels*frames)``
-(pre-computed, what the synthetic generators emit) or ``audio`` (needs librosa, not shipped here);
+(pre-computed, what the synthetic generators emit) or ``audio`` (converted by ``utils.audio.audio_to_mel``, the
+librosa calls of the reference restated with NumPy / SciPy);
 ``channel_file`` JSON {active_channels, tone_discriminative, syllable_discriminative};
 ``config_file`` JSON {mel_kwargs, tone_dynamic_mapping, n_syllables, n_tones[, *_model_kwargs]}.
 Output: one CSV row per run with the reference's columns (:369-385).
@@ -80,18 +81,12 @@ def _build_classifier(name: str, n_channels: int, seq_length: int, n_classes: in
 
 
 def _mels_from_dataset(dataset, params, mel_kwargs) -> np.ndarray:
+    """Mel targets: a pre-computed 'mel' array of the sample file, else the audio of every sample through
+    ``utils.audio.audio_to_mel`` (reference train_synthesizer.py:189-201)."""
     if 'mel' in dataset:
         return np.asarray(dataset['mel'], dtype=np.float32)
-    try:
-        import librosa  # noqa: F401
-    except ImportError as e:
-        raise RuntimeError("the sample file has no pre-computed 'mel' array and librosa is not installed "
-                           "(audio -> mel conversion is out of the hot-path scope)") from e
-    mels = []
-    for audio in dataset['audio']:
-        mel = librosa.feature.melspectrogram(y=audio, sr=params.audio_sampling_rate, **mel_kwargs)
-        mels.append(librosa.power_to_db(mel, ref=np.max).reshape(-1))
-    return np.array(mels)
+    from .utils.audio import audio_to_mel
+    return np.array([audio_to_mel(audio, params.audio_sampling_rate, mel_kwargs=mel_kwargs) for audio in dataset['audio']])
 
 
 def train(params: Namespace) -> dict:
@@ -204,6 +199,17 @@ def train(params: Namespace) -> dict:
         print("Saved training losses figure to ", path)
     if params.audio_dir:
         np.savez(os.path.join(params.audio_dir, 'mels.npz'), origin=origin_mels[:10], recon=recon_mels[:10])
+        # the first samples as audio (reference :408-428): Griffin-Lim inversion of the original / synthesised dB mels
+        from scipy.io.wavfile import write as write_wave
+        from .utils.audio import mel_to_audio
+        stft_kw = {k: mel_kwargs[k] for k in ("n_fft", "hop_length", "win_length", "fmin", "fmax") if k in mel_kwargs}
+        for i in range(min(int(getattr(params, "n_audio_samples", 10)), len(origin_mels))):
+            for tag, mel in (("origin", origin_mels[i]), ("recon", recon_mels[i])):
+                wave = mel_to_audio(np.asarray(mel), mel_kwargs['n_mels'], audio_sampling_rate=params.audio_sampling_rate,
+                                    **stft_kw)
+                path = os.path.join(params.audio_dir, f'{tag}_audio_{i}.wav')
+                write_wave(path, int(params.audio_sampling_rate), wave)
+                print(f"Saved {tag} audio to ", path)
     return results
 
 
