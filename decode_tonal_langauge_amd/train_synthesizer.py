@@ -207,6 +207,8 @@ def train(params: Namespace) -> dict:
             for tag, mel in (("origin", origin_mels[i]), ("recon", recon_mels[i])):
                 wave = mel_to_audio(np.asarray(mel), mel_kwargs['n_mels'], audio_sampling_rate=params.audio_sampling_rate,
                                     **stft_kw)
+                if wave.size == 0:          # a single mel frame inverts to zero samples (centred STFT)
+                    continue
                 path = os.path.join(params.audio_dir, f'{tag}_audio_{i}.wav')
                 write_wave(path, int(params.audio_sampling_rate), wave)
                 print(f"Saved {tag} audio to ", path)

@@ -83,9 +83,10 @@ def test_mel_to_audio_reconstructs_the_spectrum_of_a_tone():
     assert np.allclose(w2, wave, atol=1e-4)
 
 
-def test_mel_to_audio_single_frame_and_default_rate():
-    """The synthetic configurations carry one mel frame per window (output_dim = n_mels = 80): the inversion must still
-    return a finite waveform (what train_synthesizer writes as .wav)."""
-    mel_db = -40.0 + 30.0 * np.random.default_rng(3).random(80)
-    wave = au.mel_to_audio(mel_db, 80, n_fft=512, hop_length=128, n_iter=4)
-    assert wave.ndim == 1 and wave.size > 0 and np.isfinite(wave).all()
+def test_mel_to_audio_single_frame_is_empty_like_a_centred_istft():
+    """One mel frame (the synthetic configurations: output_dim = n_mels = 80) inverts to hop * (frames - 1) = 0 samples
+    with a centred STFT - as in librosa; two frames give one hop.  train_synthesizer skips empty waves."""
+    rng = np.random.default_rng(3)
+    assert au.mel_to_audio(-40.0 + 30.0 * rng.random(80), 80, n_fft=512, hop_length=128, n_iter=2).size == 0
+    two = au.mel_to_audio(-40.0 + 30.0 * rng.random(160), 80, n_fft=512, hop_length=128, n_iter=2)
+    assert two.shape == (128,) and np.isfinite(two).all()
