@@ -456,6 +456,9 @@ def main():
                 stats[fam] = {"ms_per_step": sum(ms), "launches_per_step": len(tags),
                               "flops_per_launch": sum(fl) / len(tags), "avg_launch_ms": sum(ms) / len(tags),
                               "tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12}
+            # timer tag -> share of its stage's algorithmic FLOPs the launch computes (a family may cover part of an op)
+            tag_share = {t: getattr(eng, "_fam_share", {}).get(fam, 1.0) for fam, tags in fams.items() for t in tags
+                         if getattr(eng, "_fam_share", {}).get(fam, 1.0) != 1.0}
             dom = max(stats, key=lambda k: stats[k]["ms_per_step"])
             d = stats[dom]
             issued = issued_of[dom]
@@ -487,8 +490,10 @@ def main():
                                      "algorithmic_tflops": round(v["tflops"], 2), "ms_per_step": round(v["ms_per_step"], 2)}
                                  for k, v in stats.items()},
                     "per_launch": {t: ({"ms": round(tsum[t][1], 3),
-                                        "algorithmic_tflops": round(conv_flops(eng, int(t[4]), B) / (tsum[t][1] * 1e-3) / 1e12, 2)}
-                                       if t.rsplit("_", 1)[-1] in ("fwd", "dgrad", "wgrad") else {"ms": round(tsum[t][1], 3)})
+                                        "algorithmic_tflops": round(conv_flops(eng, int(t[4]), B) * tag_share.get(t, 1.0)
+                                                                    / (tsum[t][1] * 1e-3) / 1e12, 2)}
+                                       if t.rsplit("_", 1)[-1] in ("fwd", "dgrad", "wgrad") or t in tag_share
+                                       else {"ms": round(tsum[t][1], 3)})
                                    for t in sorted(tsum)}}
         extras = {}
         if world == 1 and args.model == "full" and not args.no_extras:

@@ -13,6 +13,7 @@ from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--no-stock-compare", action="store_true", help="skip the stock-PyTorch LSTM comparison at the end (clean kernel trace)")
 ap.add_argument("--train-classifiers", action="store_true",
                 help="the reference CLI default (train_synthesizer.py:275-284): classifiers in train mode, dropout active")
 args = ap.parse_args()
@@ -57,7 +58,7 @@ def _ev(fn, n=3):
 with torch.no_grad():
     lw = lambda m: (m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0)
     parts = {"cnn_classifier_ms": _ev(lambda: tr.syllable_model(x_syl)), "cnnrnn_classifier_ms": _ev(lambda: tr.tone_model(x_tone))}
-    if getattr(tone, "_hip_lstm1", None) is not None:
+    if getattr(tone, "_hip_lstm1", None) is not None and not args.no_stock_compare:
         xt = x_tone.permute(0, 2, 1)
         parts["cnnrnn_lstm1_ms"] = _ev(lambda: tone._hip_lstm1.last_hidden(xt, *lw(tone.lstm1)))
         f = torch.randn(B, tone._hip.tq, tone.lstm2.input_size, device=dev)

@@ -20,7 +20,7 @@ case "$1" in
                --kernel-trace --output-format csv -d $O/sqold_$p -o sq -- python3 $R/scripts/bench_conv.py --stages 2 --passes $p --iters 2 > $O/sqold_$p.log 2>&1
            done ;;
   c2)      rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -o l -- python3 $R/bench.py --model lite --channels 32 --timepoints 200 --batch 64 --steps 200 --warmup 20 --no-extras > $O/c2_run.log 2>&1 ;;
-  c5)      rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -o c5 -- python3 $R/scripts/bench_c5.py --train-classifiers > $O/c5_run.log 2>&1 ;;
+  c5)      rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -o c5 -- python3 $R/scripts/bench_c5.py --train-classifiers --no-stock-compare > $O/c5_run.log 2>&1 ;;
   signal)  rocprofv3 --kernel-trace --stats --output-format csv -d $O/sig -o s -- python3 $R/scripts/bench_signal.py > $O/sig_run.log 2>&1 ;;
   *) echo "unknown section $1"; exit 2 ;;
 esac
