@@ -121,6 +121,9 @@ class CnnEngine:
         # the streaming kernels (which stage through LDS too) find no free CU and the two streams serialise.  Off.
         self.overlap = os.environ.get("TONAL_OVERLAP", "0") == "1"
         self.vd_mode = os.environ.get("TONAL_WINO_VD", "tn")
+        # C_in tile of the V-form weight-gradient kernel: 0 = 128 (8 waves) where C_in % 128 == 0, else 64; 64 forces the
+        # 4-wave kernel (the A/B partner: same results bit for bit)
+        self.tn_bm = int(os.environ.get("TONAL_TN_BM", "0"))
         self._side = None
         self._B = None
         self.generation = 0
@@ -296,6 +299,9 @@ class CnnEngine:
         the CUs but the sum of their times stays the serial one - 249.9 vs 245.4 ms per step); "0" - off."""
         return (self._use_wino_v(st) and self._use_wino43_tn(st) and _r4(st.cout) % 16 == 0 and self.vd_mode != "0")
 
+    def _tn_bm(self, st) -> int:
+        return self.tn_bm if self.tn_bm else (128 if st.cin % 128 == 0 else 64)
+
     def _conv1_writes_v(self) -> bool:
         """The first stage hands its output to stage 2 as V (tl_conv1_fwd_v) - nothing else reads P1 then."""
         return (self._use_wino_v(self.stages[0]) and self._use_wino43_tn(self.stages[0]) and self.tp1 % 4 == 0
@@ -354,7 +360,7 @@ class CnnEngine:
                 if self.vd_mode == "tn" and all(self._use_wino_vd(st) for st in self.stages[:2]):
                     # the op is two launches, named apart by rocprofv3: the first C_in tile (1 / ntm of the MFMA work) also
                     # writes Vd, the operand of the input gradient; the plain instantiation does the other tiles
-                    ntm = (self.stages[0].cin + 63) // 64
+                    ntm = (self.stages[0].cin + self._tn_bm(self.stages[0]) - 1) // self._tn_bm(self.stages[0])
                     tn = f"wino43v_tn_kernel<false> (conv2/conv3 weight gradient, C_in tiles 1..{ntm - 1} of {ntm}, Winograd F(4,3) on V, LDS-DMA)"
                     vdn = f"wino43v_tn_kernel<true> (conv2/conv3 weight gradient, C_in tile 0 of {ntm}, + writes Vd for the input gradient)"
                     extra[vdn] = ["conv2_wgrad_vd", "conv3_wgrad_vd"]
@@ -449,7 +455,7 @@ class CnnEngine:
                 V = self._v_ready.get(st.idx - 1)      # normally written in the forward pass
                 if V is None:
                     V = self._v_ready[st.idx - 1] = self._input_transform(st)
-                kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2])
+                kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], bm=self._tn_bm(st))
                 fn = "tl_conv3_wino43v_tn"
                 if self._use_wino_vd(st):
                     nq_pad = (rows_in // 4 + 127) // 128 * 128

@@ -46,7 +46,7 @@ class TnParams(C.Structure):
         ("J", C.c_int), ("Tp", C.c_int), ("Tvalid", C.c_int), ("loader", C.c_int),
         ("splitk", C.c_int), ("slab_stride", C.c_int64),
         ("colsum", C.c_void_p),
-        ("vd", C.c_void_p), ("ld_vd", C.c_int), ("part", C.c_int),
+        ("vd", C.c_void_p), ("ld_vd", C.c_int), ("part", C.c_int), ("bm", C.c_int),
     ]
 
 

@@ -65,6 +65,19 @@ __global__ __launch_bounds__(256, 4) void wino43_xform_kernel(const float* __res
   *reinterpret_cast<f32x4*>(dst + 5LL * ldv) = (4.f * d[1] - 5.f * d[3]) + d[5];
 }
 
+// B^T d of six un-pooled gradient rows with every product fused (one rounding per fmaf, nothing left for the compiler to
+// contract): the writers of Vd - the stand-alone kernel below and both tilings of the weight-gradient kernel - agree bit
+// for bit whatever vector width they are compiled at.
+__device__ __forceinline__ void vd_transform(float d0, float d1, float d2, float d3, float d4, float d5, float (&v)[6]) {
+  const float s1 = fmaf(-4.f, d2, d4), s2 = fmaf(-4.f, d1, d3), s3 = d4 - d2, t = d3 - d1;
+  v[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+  v[1] = s1 + s2;
+  v[2] = s1 - s2;
+  v[3] = fmaf(2.f, t, s3);
+  v[4] = fmaf(-2.f, t, s3);
+  v[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+}
+
 // ------------------------------------------------------------------------------------------
 // (G, arg-max bits) -> Vd: the input-gradient operand of a pooled 3-tap stage.  Vd[quad q][6][ldv] = B^T of the
 // un-pooled dZ rows 4q-2 .. 4q+3 (row Rz of dZ = G[Rz / 2] where the arg-max bit equals Rz & 1 and (Rz % Tp) < Tvalid,
@@ -100,14 +113,17 @@ __global__ __launch_bounds__(256, 4) void wino43_unpool_xform_kernel(const float
       d[2 * j + 1][k] = odd ? g[k] : 0.f;
     }
   }
-  const f32x4 s1 = d[4] - 4.f * d[2], s2 = d[3] - 4.f * d[1], s3 = d[4] - d[2], t = d[3] - d[1];
+  f32x4 o[6];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v[6];
+    vd_transform(d[0][k], d[1][k], d[2][k], d[3][k], d[4][k], d[5][k], v);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i][k] = v[i];
+  }
   float* dst = V + q * 6 * (long long)ldv + c;
-  *reinterpret_cast<f32x4*>(dst) = 4.f * d[0] + (d[4] - 5.f * d[2]);
-  *reinterpret_cast<f32x4*>(dst + ldv) = s1 + s2;
-  *reinterpret_cast<f32x4*>(dst + 2LL * ldv) = s1 - s2;
-  *reinterpret_cast<f32x4*>(dst + 3LL * ldv) = s3 + 2.f * t;
-  *reinterpret_cast<f32x4*>(dst + 4LL * ldv) = s3 - 2.f * t;
-  *reinterpret_cast<f32x4*>(dst + 5LL * ldv) = (4.f * d[1] - 5.f * d[3]) + d[5];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(dst + (long long)i * ldv) = o[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -329,10 +345,16 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
 // loads, 26 transform VALU instructions and six ds_write_b64.  Rows of odd quads keep the two
 // 32-channel halves swapped (conflict-free fragment reads without padding): applied on the SOURCE chunk.
 // ------------------------------------------------------------------------------------------
-constexpr int T4_BM = 64, T4_BN = 64, T4_Q = 8;          // C_in tile, C_out tile, quads per K-step
+constexpr int T4_BN = 64, T4_Q = 8;                       // C_out tile, quads per K-step (C_in tile: 32 MW)
 constexpr int T4_PLANE = T4_Q * 64;                       // floats per transform plane
 constexpr int T4_TILE = 6 * T4_PLANE;                     // floats per operand tile (12 KB)
 constexpr int T4V_NA = 4;                                 // V ring slots
+#ifndef T4V_NT_STORE
+#define T4V_NT_STORE 1     // Vd is written once and read by a later kernel: stream it past the L2
+#endif
+#ifndef T4V_ABL
+#define T4V_ABL 0          // timing-only ablations (results garbage): 1 no steady-state V pieces, 2 no steady-state Y loads,
+#endif                     // 4 no Vd stores, 8 no Y transform / LDS store in the steady state
 #ifndef T4V_SCHED
 #define T4V_SCHED 0        // > 0: hand-specified issue order of a K-step with this many VALU per MFMA slot
 #endif
@@ -340,11 +362,22 @@ constexpr int T4V_NA = 4;                                 // V ring slots
 // WVD: this launch covers the first C_in tile only and also writes Vd (see write_vd below); the other C_in tiles run in
 // a second launch of the plain instantiation (a run-time branch around the Vd code splits the K-step into basic blocks
 // the scheduler cannot interleave across: 43.6 -> 46.3 ms for every workgroup).  mt0 / mtn: first C_in tile, tile count.
-template <bool WVD>
-__global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p, int mt0, int mtn) {
-  __shared__ __attribute__((aligned(1024))) float lds[(T4V_NA + 2) * T4_TILE];
-  float* As = lds;                               // [4][6][8][64]  V ring
-  float* Bs = lds + T4V_NA * T4_TILE;            // [2][6][8][64]  Y
+//
+// MW: waves along C_in.  MW = 2: 64 x 64 tile, 4 waves, two workgroups per CU, a channel PAIR of one quad per thread
+// on the Y side.  MW = 4 (C_in a multiple of 128): 128 x 64 tile, 8 waves, one workgroup per CU; the Y tile is the same
+// 8 quads x 64 channels but is now built by 512 threads (one channel each) for twice the MFMA work - the transform
+// VALU per MFMA halves, which is what bounds this kernel (fp32 MFMA shares its issue rate with the vector ALU:
+// r03_kernel_notes.md section 3).  The V tile is held as MW / 2 half-tiles of 64 channels in the layout of the 64-wide
+// kernel, so pieces, swizzle and fragment reads are the same code.  Same k order per accumulator: bit-identical results.
+template <bool WVD, int MW>
+__global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void wino43v_tn_kernel(const tl_tn_params p, int mt0, int mtn) {
+  constexpr int NH = MW / 2;                     // 64-channel half-tiles of V per K-step
+  constexpr int CPT = 4 / MW;                    // Y channels per thread
+  constexpr int TPQ = 64 / CPT;                  // threads per quad row of the Y tile
+  constexpr int BM = 32 * MW;
+  __shared__ __attribute__((aligned(1024))) float lds[(T4V_NA * NH + 2) * T4_TILE];
+  float* As = lds;                               // [4][NH][6][8][64]  V ring
+  float* Bs = lds + T4V_NA * NH * T4_TILE;       // [2][6][8][64]      Y
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   }
   const int z = (int)(bid / tiles);
   const int tt = (int)(bid % tiles);
-  const int m0 = (mt0 + tt / ntn) * T4_BM, n0 = (tt % ntn) * T4_BN;
+  const int m0 = (mt0 + tt / ntn) * BM, n0 = (tt % ntn) * T4_BN;
 
   const long long quads_all = p.Krows >> 2;
   const long long ksteps_all = (quads_all + T4_Q - 1) / T4_Q;
@@ -374,8 +407,9 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-  // ---- V by LDS-DMA: piece pc = 3 wave + t -> (transform i = pc >> 1, quads 4 (pc & 1) .. + 3); lane -> (quad
-  // offset lane >> 4, physical 16-byte chunk lane & 15); odd quads: halves swapped = source chunk ^ 8
+  // ---- V by LDS-DMA: piece 3 wave + t -> half-tile pc / 12, then pc % 12 -> (transform i = pc >> 1, quads
+  // 4 (pc & 1) .. + 3); lane -> (quad offset lane >> 4, physical 16-byte chunk lane & 15); odd quads: halves swapped =
+  // source chunk ^ 8
   const long long v_q0 = ks_begin * T4_Q;                           // first quad of this split
   const long long v_left = (p.A_rows - v_q0) * 6 * (long long)p.lda * 4 - (long long)m0 * 4;
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
@@ -384,25 +418,26 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   unsigned vvoff[3], vdst[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
-    const int pc = wave * 3 + t;
+    const int half = (wave * 3 + t) / 12, pc = (wave * 3 + t) % 12;
     const int i = pc >> 1, ql = (pc & 1) * 4 + (lane >> 4);
     const int chunk = (lane & 15) ^ ((ql & 1) << 3);
-    vvoff[t] = (unsigned)((((long long)ql * 6 + i) * p.lda + chunk * 4) * 4);
-    vdst[t] = (unsigned)((i * T4_PLANE + (pc & 1) * 4 * 64) * 4);
+    vvoff[t] = (unsigned)((((long long)ql * 6 + i) * p.lda + half * 64 + chunk * 4) * 4);
+    vdst[t] = (unsigned)((half * T4_TILE + i * T4_PLANE + (pc & 1) * 4 * 64) * 4);
   }
   const unsigned v_step = (unsigned)(T4_Q * 6 * p.lda * 4);        // bytes per K-step (host-checked to fit)
   auto issue_v = [&](int step) {
-    char* base = reinterpret_cast<char*>(As) + (step & (T4V_NA - 1)) * (T4_TILE * 4);
+    char* base = reinterpret_cast<char*>(As) + (step & (T4V_NA - 1)) * (NH * T4_TILE * 4);
     const unsigned soff = (unsigned)step * v_step;
 #pragma unroll
     for (int t = 0; t < 3; ++t) dma16(rsV, base + vdst[t], vvoff[t], soff);
   };
 
   // ---- Y staging (registers), as in wino43_tn_kernel ----
-  const int qi = tid >> 5, c2 = tid & 31;                   // quad of the K-step, channel pair
-  const int sw = ((c2 * 2) ^ ((qi & 1) << 5));              // swizzled channel position inside the 64-wide row
+  using yv = std::conditional_t<CPT == 2, f32x2, float>;    // the CPT channels a thread transforms
+  const int qi = tid / TPQ, c2 = tid % TPQ;                 // quad of the K-step, channel (pair)
+  const int sw = ((c2 * CPT) ^ ((qi & 1) << 5));            // swizzled channel position inside the 64-wide row
   const long long b_last = p.B_rows - 1;
-  const int ncol = n0 + c2 * 2;
+  const int ncol = n0 + c2 * CPT;
   const bool bnok = ncol < p.Ndim;
   const int ncolc = bnok ? ncol : n0;
   long long quad = ks_begin * T4_Q + qi;                    // quad the NEXT load fetches for this thread
@@ -413,10 +448,10 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   const unsigned w_toff = (unsigned)(qi * 2 * p.ld_bbits + (ncolc >> 5));
 
   struct stage_regs {
-    f32x2 g[2];
+    yv g[2];
     uint32_t wa, wb;  // arg-max words of the two pooled rows
     uint32_t ok;      // bit 0 / 1: pair a / b holds a valid gradient (bit 2: the pooled row in front of the quad)
-    f32x2 gp;         // write_vd only: pooled row 2 q - 1 (conv rows 4 q - 2, 4 q - 1), its arg-max word, the quad index
+    yv gp;            // write_vd only: pooled row 2 q - 1 (conv rows 4 q - 2, 4 q - 1), its arg-max word, the quad index
     uint32_t wp;
     int q;
   };
@@ -427,7 +462,13 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   // pooled row and six 8-byte stores per thread and K-step turn the input-gradient pass into the transform-free V-form
   // kernel (wino43v_nt_kernel) without a pass of its own over G (19.7 GB written beside MFMA-bound work).
   constexpr bool write_vd = WVD;
-  f32x2 bsum = {0.f, 0.f};
+  typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+  const unsigned vd_qstride = (unsigned)(6 * p.ld_vd * 4), vd_coff = (unsigned)((ncolc - n0) * 4);
+  long long vd_left = write_vd ? (quads_all - v_q0) * 6 * (long long)p.ld_vd * 4 - (long long)n0 * 4 : 0;
+  vd_left = vd_left < 0 ? 0 : (vd_left < 0x7fffffffLL ? vd_left : 0x7fffffffLL);
+  const __amdgpu_buffer_rsrc_t rsVd = __builtin_amdgcn_make_buffer_rsrc(
+      write_vd ? (void*)(p.vd + v_q0 * 6 * (long long)p.ld_vd + n0) : (void*)p.slab, 0, (int)vd_left, 0x00020000);
+  yv bsum = {};
 
   auto load_regs = [&](auto FAST, stage_regs& r) {
     constexpr bool fast = decltype(FAST)::value;
@@ -439,10 +480,13 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
       const bool vp = bnok && quad > 0 && tq >= 2 && tq - 2 < p.Tvalid && 4 * quad - 2 < p.Krows && pr <= b_last;
       pr = pr < 0 ? 0 : (pr < b_last ? pr : b_last);
       if constexpr (fast) {
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.gp) : "v"(p.B + pr * (long long)p.ldb + ncolc) : "memory");
+        if constexpr (CPT == 2)
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.gp) : "v"(p.B + pr * (long long)p.ldb + ncolc) : "memory");
+        else
+          asm volatile("global_load_dword %0, %1, off" : "=v"(r.gp) : "v"(p.B + pr * (long long)p.ldb + ncolc) : "memory");
         asm volatile("global_load_dword %0, %1, off" : "=v"(r.wp) : "v"(p.bbits + pr * (long long)p.ld_bbits + (ncolc >> 5)) : "memory");
       } else {
-        r.gp = *reinterpret_cast<const f32x2*>(p.B + pr * (long long)p.ldb + ncolc);
+        r.gp = *reinterpret_cast<const yv*>(p.B + pr * (long long)p.ldb + ncolc);
         r.wp = p.bbits[pr * (long long)p.ld_bbits + (ncolc >> 5)];
       }
       r.q = (int)quad;
@@ -455,13 +499,18 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
         // Loads the compiler does not count (inline asm): with the Vd stores in the same vmcnt stream its own wait in
         // front of the transform comes out as vmcnt(9..10) - a drain of the three-step prefetch every K-step (the
         // launch ran at 45 % of the plain kernel's rate).  The counted wait is placed by hand in kstep.
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.g[0]) : "v"(bu + b_toff) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.g[1]) : "v"(bu + p.ldb + b_toff) : "memory");
+        if constexpr (CPT == 2) {
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.g[0]) : "v"(bu + b_toff) : "memory");
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.g[1]) : "v"(bu + p.ldb + b_toff) : "memory");
+        } else {
+          asm volatile("global_load_dword %0, %1, off" : "=v"(r.g[0]) : "v"(bu + b_toff) : "memory");
+          asm volatile("global_load_dword %0, %1, off" : "=v"(r.g[1]) : "v"(bu + p.ldb + b_toff) : "memory");
+        }
         asm volatile("global_load_dword %0, %1, off" : "=v"(r.wa) : "v"(wu + w_toff) : "memory");
         asm volatile("global_load_dword %0, %1, off" : "=v"(r.wb) : "v"(wu + p.ld_bbits + w_toff) : "memory");
       } else {
-        r.g[0] = *reinterpret_cast<const f32x2*>(bu + b_toff);
-        r.g[1] = *reinterpret_cast<const f32x2*>(bu + p.ldb + b_toff);
+        r.g[0] = *reinterpret_cast<const yv*>(bu + b_toff);
+        r.g[1] = *reinterpret_cast<const yv*>(bu + p.ldb + b_toff);
         r.wa = wu[w_toff];
         r.wb = wu[p.ld_bbits + w_toff];
       }
@@ -470,8 +519,8 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
       vb = vb && 4 * quad + 2 < p.Krows && pb <= b_last;
       pa = pa < b_last ? pa : b_last;
       pb = pb < b_last ? pb : b_last;
-      r.g[0] = *reinterpret_cast<const f32x2*>(p.B + pa * (long long)p.ldb + ncolc);
-      r.g[1] = *reinterpret_cast<const f32x2*>(p.B + pb * (long long)p.ldb + ncolc);
+      r.g[0] = *reinterpret_cast<const yv*>(p.B + pa * (long long)p.ldb + ncolc);
+      r.g[1] = *reinterpret_cast<const yv*>(p.B + pb * (long long)p.ldb + ncolc);
       r.wa = p.bbits[pa * (long long)p.ld_bbits + (ncolc >> 5)];
       r.wb = p.bbits[pb * (long long)p.ld_bbits + (ncolc >> 5)];
     }
@@ -483,51 +532,64 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   };
   auto store_b = [&](const stage_regs& r, int buf) {
     const int sh = ncolc & 31;
-    f32x2 o[6], vd[6];
+    yv o[6], vd[6];
+    auto at = [](auto& v, int c) -> float& {
+      if constexpr (CPT == 2) return reinterpret_cast<float*>(&v)[c];
+      else return v;
+    };
+    auto cat = [](const yv& v, int c) -> float {
+      if constexpr (CPT == 2) return v[c];
+      else return v;
+    };
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < CPT; ++c) {
       const uint32_t ma = (uint32_t)__builtin_amdgcn_sbfe((int)r.wa, sh + c, 1);      // all ones if the odd row won
       const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)r.wb, sh + c, 1);
-      const uint32_t ua = (r.ok & 1u) ? __float_as_uint(r.g[0][c]) : 0u, ub = (r.ok & 2u) ? __float_as_uint(r.g[1][c]) : 0u;
+      const uint32_t ua = (r.ok & 1u) ? __float_as_uint(cat(r.g[0], c)) : 0u, ub = (r.ok & 2u) ? __float_as_uint(cat(r.g[1], c)) : 0u;
       const float e_a = __uint_as_float(ua & ~ma), o_a = __uint_as_float(ua & ma);
       const float e_b = __uint_as_float(ub & ~mb), o_b = __uint_as_float(ub & mb);
-      o[0][c] = e_a;
-      o[1][c] = (e_a + o_a) + (e_b + o_b);
-      o[2][c] = (e_a - o_a) + (e_b - o_b);
-      o[3][c] = fmaf(4.f, fmaf(2.f, o_b, e_b), fmaf(2.f, o_a, e_a));
-      o[4][c] = fmaf(4.f, fmaf(-2.f, o_b, e_b), fmaf(-2.f, o_a, e_a));
-      o[5][c] = o_b;
+      at(o[0], c) = e_a;
+      at(o[1], c) = (e_a + o_a) + (e_b + o_b);
+      at(o[2], c) = (e_a - o_a) + (e_b - o_b);
+      at(o[3], c) = fmaf(4.f, fmaf(2.f, o_b, e_b), fmaf(2.f, o_a, e_a));
+      at(o[4], c) = fmaf(4.f, fmaf(-2.f, o_b, e_b), fmaf(-2.f, o_a, e_a));
+      at(o[5], c) = o_b;
       if constexpr (write_vd) {
         // d0..d5 = dZ rows 4 q - 2 .. 4 q + 3 = (e_p, o_p, e_a, o_a, e_b, o_b); B^T d as in wino43_xform_kernel
         const uint32_t mp = (uint32_t)__builtin_amdgcn_sbfe((int)r.wp, sh + c, 1);
-        const uint32_t up = (r.ok & 4u) ? __float_as_uint(r.gp[c]) : 0u;
+        const uint32_t up = (r.ok & 4u) ? __float_as_uint(cat(r.gp, c)) : 0u;
         const float d0 = __uint_as_float(up & ~mp), d1 = __uint_as_float(up & mp);
-        const float s1 = e_b - 4.f * e_a, s2 = o_a - 4.f * d1, s3 = e_b - e_a, t = o_a - d1;
-        vd[0][c] = 4.f * d0 + (e_b - 5.f * e_a);
-        vd[1][c] = s1 + s2;
-        vd[2][c] = s1 - s2;
-        vd[3][c] = s3 + 2.f * t;
-        vd[4][c] = s3 - 2.f * t;
-        vd[5][c] = (4.f * d1 - 5.f * o_a) + o_b;
+        float v[6];
+        vd_transform(d0, d1, e_a, o_a, e_b, o_b, v);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) at(vd[i], c) = v[i];
       }
     }
     bsum += o[1];
     float* dst = Bs + buf * T4_TILE + qi * 64 + sw;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(dst + i * T4_PLANE) = o[i];
-    if (write_vd && bnok && r.q < (int)quads_all) {   // (write_vd is a compile-time constant)
-      float* g = p.vd + (long long)r.q * 6 * p.ld_vd + ncolc;
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<yv*>(dst + i * T4_PLANE) = o[i];
+    if constexpr (write_vd && !(T4V_ABL & 4)) {
+      // buffer stores relative to the first quad of this split: a lane with nothing to write (column past C_out, quad of
+      // the padding) carries an offset past the resource and the hardware drops its store - no branch in the K-step (an
+      // exec-mask branch around the stores splits it into basic blocks the scheduler cannot interleave across)
+      const unsigned off = (bnok && r.q < (int)quads_all) ? (unsigned)(r.q - (int)v_q0) * vd_qstride + vd_coff : 0xfffffff0u;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(g + (long long)i * p.ld_vd) = vd[i];
+      for (int i = 0; i < 6; ++i) {
+        if constexpr (CPT == 2)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, vd[i]), rsVd, off, (unsigned)(i * p.ld_vd * 4), T4V_NT_STORE ? 2 : 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vd[i]), rsVd, off, (unsigned)(i * p.ld_vd * 4), T4V_NT_STORE ? 2 : 0);
+      }
     }
   };
 
   // ---- MFMA side: k-slice sl of a K-step = quads 2 sl (lanes 0-31) and 2 sl + 1 (lanes 32-63) ----
-  const int a_off = lh * 64 + ((wm * 32 + lr) ^ (lh << 5));
+  const int a_off = (wm >> 1) * T4_TILE + lh * 64 + (((wm & 1) * 32 + lr) ^ (lh << 5));
   const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
   float fa0[6], fb0[6], fa1[6], fb1[6];
   auto load_frag = [&](float (&fa)[6], float (&fb)[6], int abuf, int bbuf, int sl) {
-    const float* a_s = As + abuf * T4_TILE + sl * 128 + a_off;
+    const float* a_s = As + abuf * (NH * T4_TILE) + sl * 128 + a_off;
     const float* b_s = Bs + bbuf * T4_TILE + sl * 128 + b_off;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -548,8 +610,8 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
     const int abuf = s & (T4V_NA - 1), bbuf = s & 1;
     load_frag(fa0, fb0, abuf, bbuf, 0);
     if constexpr (!tail) {
-      load_regs(std::true_type{}, r_ld);
-      issue_v(s + 3);
+      if (!(T4V_ABL & 2)) load_regs(std::true_type{}, r_ld);
+      if (!(T4V_ABL & 1)) issue_v(s + 3);
     } else if (s + 3 < nsteps) {
       load_regs(std::false_type{}, r_ld);
       issue_v(s + 3);
@@ -572,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
       else
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(w.g[0]), "+v"(w.g[1]), "+v"(w.gp), "+v"(w.wa), "+v"(w.wb), "+v"(w.wp));
     }
-    if (!tail || s + 1 < nsteps) store_b(r_st, bbuf ^ 1);
+    if ((!tail && !(T4V_ABL & 8)) || (tail && s + 1 < nsteps)) store_b(r_st, bbuf ^ 1);
     load_frag(fa1, fb1, abuf, bbuf, 3);
     mfma6(fa0, fb0);
 #if T4V_SCHED
@@ -643,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
   if (p.colsum != nullptr && m0 == 0) {
     __syncthreads();
     float* red = lds;
-    *reinterpret_cast<f32x2*>(red + qi * 64 + c2 * 2) = bsum;
+    *reinterpret_cast<yv*>(red + qi * 64 + c2 * CPT) = bsum;
     __syncthreads();
     if (tid < 64) {
       float t = 0.f;
@@ -660,6 +722,333 @@ __global__ __launch_bounds__(256, 2) void wino43v_tn_kernel(const tl_tn_params p
     for (int e = 0; e < 16; ++e) {
       const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
       if (m < p.Mdim && col < p.Ndim) out[((long long)i * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient on V, 128 x 64 tile, 8 waves, one workgroup per CU: the product kernel where C_in % 128 == 0 and
+// C_out % 64 == 0.  Against wino43v_tn_kernel<., 4> (same tile, same MFMA side, bit-identical results) the Y side has
+// no vector-memory load that returns into registers left - timing-only ablations priced those at 55 cycles of matrix
+// time each (4 per wave and K-step: 3.6 of 32.3 ms at conv2), more than the whole transform:
+//   * the pooled gradient rows of a K-step (16 rows x 64 channels, 4 KB) arrive RAW by LDS-DMA, four steps ahead, in an
+//     8-slot ring (1 piece per wave and step; waves 4-7 repeat the pieces of waves 0-3, which keeps the step free of
+//     branches); a wave then owns one quad, a lane one channel: two ds_read_b32 fetch its pooled pair;
+//   * the arg-max words of a quad's pooled rows are wave-uniform: scalar loads, and the 64-bit word pair IS the lane
+//     mask of the un-pool select (v_cndmask on an SGPR pair; row validity folds into the mask on the scalar ALU);
+//   * the vector-memory operations that are left - 3 V pieces, 1 G piece and, for the workgroups that also write Vd, the
+//     six stores of the PREVIOUS step's transform (kept in registers across the barrier) - are issued one per MFMA in
+//     the first half of the step (sched_group_barrier), the transform runs in the second half.
+// One K-step body serves every step: prefetches past the end of a split read memory the resource still covers (or
+// zeros), a step past the end is transformed with all-zero masks, so the vmcnt arithmetic of the closing wait never
+// changes: what may stay in flight are the operations of this step and the one before, 2 x (4 or 10).
+// ------------------------------------------------------------------------------------------
+#ifndef T8_SCHED
+#define T8_SCHED 1
+#endif
+#ifndef T8_ABL
+#define T8_ABL 0           // timing-only: 1 no V pieces, 2 no G piece, 4 no Vd stores, 8 no transform, 16 no barrier,
+                           // 32 no vmcnt wait, 64 no scalar loads / row logic (the masks of the first step throughout)
+#endif
+template <bool WVD>
+__global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params p, int mt0, int mtn) {
+  constexpr int NA = T4V_NA, NG = 8, GT = 16 * 64;   // V ring slots; raw-gradient ring slots, floats per raw tile
+  __shared__ __attribute__((aligned(1024))) float lds[(NA * 2 + 2) * T4_TILE + NG * GT];
+  float* As = lds;                               // [4][2][6][8][64]  V ring (two 64-channel half-tiles)
+  float* Bs = lds + NA * 2 * T4_TILE;            // [2][6][8][64]     Y
+  float* Gs = Bs + 2 * T4_TILE;                  // [8][16][64]       raw pooled gradient rows
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int ntn = p.Ndim / T4_BN;
+  const long long tiles = (long long)mtn * ntn;
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  // (integer division runs on the vector ALU: what is derived from its result stays there unless it is moved back)
+  const int z = __builtin_amdgcn_readfirstlane((int)(bid / tiles));
+  const int tt = __builtin_amdgcn_readfirstlane((int)(bid % tiles));
+  const int m0 = __builtin_amdgcn_readfirstlane((mt0 + tt / ntn) * 128), n0 = __builtin_amdgcn_readfirstlane((tt % ntn) * T4_BN);
+
+  const long long quads_all = p.Krows >> 2;
+  const long long ksteps_all = (quads_all + T4_Q - 1) / T4_Q;
+  const long long per = __builtin_amdgcn_readfirstlane((int)((ksteps_all + p.splitk - 1) / p.splitk));
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const int nsteps = ks_end > ks_begin ? (int)(ks_end - ks_begin) : 0;
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  auto clip31 = [](long long v) { return (int)(v < 0 ? 0 : (v < 0x7fffffffLL ? v : 0x7fffffffLL)); };
+  // ---- V by LDS-DMA (as wino43v_tn_kernel<., 4>): piece 3 wave + t -> half-tile, transform, four quads
+  const long long v_q0 = ks_begin * T4_Q;
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + v_q0 * 6 * (long long)p.lda + m0), 0, clip31((p.A_rows - v_q0) * 6 * (long long)p.lda * 4 - (long long)m0 * 4),
+      0x00020000);
+  unsigned vvoff[3], vdst[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int half = (wave * 3 + t) / 12, pc = (wave * 3 + t) % 12;
+    const int i = pc >> 1, ql = (pc & 1) * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ ((ql & 1) << 3);
+    vvoff[t] = (unsigned)((((long long)ql * 6 + i) * p.lda + half * 64 + chunk * 4) * 4);
+    vdst[t] = (unsigned)((half * T4_TILE + i * T4_PLANE + (pc & 1) * 4 * 64) * 4);
+  }
+  const unsigned v_step = (unsigned)(T4_Q * 6 * p.lda * 4);
+  auto issue_v = [&](int step) {
+    char* base = reinterpret_cast<char*>(As) + (step & (NA - 1)) * (2 * T4_TILE * 4);
+    const unsigned soff = (unsigned)step * v_step;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dma16(rsV, base + vdst[t], vvoff[t], soff);
+  };
+  // ---- raw pooled gradient rows by LDS-DMA: piece wave & 3 = rows 4 t .. 4 t + 3 of the step's 16; lane -> (row
+  // lane >> 4, 16-byte chunk lane & 15); the LDS image is row-major [16][64]
+  const long long g_r0 = ks_begin * 2 * T4_Q;
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.B + g_r0 * (long long)p.ldb + n0), 0, clip31((p.B_rows - g_r0) * (long long)p.ldb * 4 - (long long)n0 * 4), 0x00020000);
+  const unsigned gvoff = (unsigned)((((wave & 3) * 4 + (lane >> 4)) * (long long)p.ldb + (lane & 15) * 4) * 4);
+  const unsigned gdst = (unsigned)((wave & 3) * 256 * 4);
+  const unsigned g_step = (unsigned)(2 * T4_Q * p.ldb * 4);
+  auto issue_g = [&](int step) {
+    dma16(rsG, reinterpret_cast<char*>(Gs) + (step & (NG - 1)) * (GT * 4) + gdst, gvoff, (unsigned)step * g_step);
+  };
+
+  // ---- Y side: wave = quad of the K-step, lane = channel ----
+  constexpr bool write_vd = WVD;
+  const int sw = lane ^ ((wave & 1) << 5);                  // swizzled channel position inside the 64-wide row
+  // (integer division runs on the vector ALU: without the readfirstlane everything derived from tq stays there)
+  int tq = __builtin_amdgcn_readfirstlane((int)((4 * (v_q0 + wave)) % p.Tp));   // first conv row of the NEXT quad to transform
+  const int dstep = __builtin_amdgcn_readfirstlane((4 * T4_Q) % p.Tp);
+  // the arg-max words are never written by this kernel: read them through the constant address space, where a load
+  // from a wave-uniform address is a scalar load (through the global one it is a vector load into 64 identical lanes)
+  typedef const __attribute__((address_space(4))) unsigned long long* cmask_ptr;
+  const uint32_t* bits0 = p.bbits + (n0 >> 5);
+  auto bits_of = [&](int row) -> unsigned long long {
+    return *reinterpret_cast<cmask_ptr>(reinterpret_cast<uintptr_t>(bits0 + row * (long long)p.ld_bbits));
+  };
+  float bsum = 0.f;
+  const unsigned vd_qstride = (unsigned)(6 * p.ld_vd * 4);
+  const __amdgpu_buffer_rsrc_t rsVd = __builtin_amdgcn_make_buffer_rsrc(
+      write_vd ? (void*)(p.vd + v_q0 * 6 * (long long)p.ld_vd + n0) : (void*)p.slab, 0,
+      write_vd ? clip31((quads_all - v_q0) * 6 * (long long)p.ld_vd * 4 - (long long)n0 * 4) : 0, 0x00020000);
+  float pend[6];                                            // Vd of the last transform, stored in the next step
+  // (declared below: y_bits wn_ = arg-max words and row flags of the NEXT step to transform)
+  unsigned pend_off = 0xfffffff0u;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) pend[i] = 0.f;
+  auto sel = [](unsigned long long m, float v) -> float {   // lane's bit of m set ? v : 0
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+    return r;
+  };
+  // Y(sd) -> Bs[sd & 1]; with WVD also Vd of the step's quads -> pend.  live = 0: a step past the end of the split.
+  // Three parts.  fetch_bits: the scalar loads of the arg-max words and the row logic, ONE STEP AHEAD of their use and
+  // behind the last counted LDS wait of a step - scalar loads return out of order, so while one is pending every lgkmcnt
+  // wait has to be a full drain, and the first use of its result drains the LDS queue too (measured: 5 of 33 ms at conv2
+  // with the loads next to their use).  fetch_y: masks from those words (scalar ALU) and the LDS reads of the raw rows.
+  // compute_y: the arithmetic.  All row logic is 32-bit scalar arithmetic without short-circuit evaluation (a branch would
+  // split the K-step into basic blocks).
+  const int krows = (int)p.Krows, blast = (int)(p.B_rows - 1), nquads = (int)quads_all, q_first = (int)v_q0;
+  struct y_bits {
+    unsigned long long wa, wb, wp;
+    int va, vb, vp;
+    unsigned off;
+  };
+  struct y_in {
+    float ga, gb, gp;
+    unsigned long long m_oa, m_ea, m_ob, m_eb, m_op, m_ep;
+    unsigned off;
+  };
+  auto fetch_bits = [&](int sd, int live, y_bits& w) {
+    const int q = q_first + sd * T4_Q + wave;
+    const int pa = 2 * q, pb = 2 * q + 1;
+    w.va = live & (tq < p.Tvalid) & (4 * q < krows) & (pa <= blast);
+    w.vb = live & (tq + 2 < p.Tvalid) & (4 * q + 2 < krows) & (pb <= blast);
+    w.wa = bits_of(pa < blast ? pa : blast);
+    w.wb = bits_of(pb < blast ? pb : blast);
+    if constexpr (write_vd) {
+      int pr = 2 * q - 1;
+      w.vp = live & (q > 0) & (tq >= 2) & (tq - 2 < p.Tvalid) & (4 * q - 2 < krows) & (pr <= blast);
+      pr = pr < 0 ? 0 : (pr < blast ? pr : blast);
+      w.wp = bits_of(pr);
+      w.off = (live & (q < nquads)) ? (unsigned)(q - q_first) * vd_qstride + (unsigned)lane * 4u : 0xfffffff0u;
+    }
+    tq += dstep;
+    if (tq >= p.Tp) tq -= p.Tp;
+  };
+  auto fetch_y = [&](int sd, const y_bits& w, y_in& y) {
+    const float* gs = Gs + (sd & (NG - 1)) * GT + wave * 128 + lane;
+    y.ga = gs[0];
+    y.gb = gs[64];
+    y.m_oa = w.va ? w.wa : 0ull;
+    y.m_ea = w.va ? ~w.wa : 0ull;
+    y.m_ob = w.vb ? w.wb : 0ull;
+    y.m_eb = w.vb ? ~w.wb : 0ull;
+    if constexpr (write_vd) {
+      // rows 4 q - 2, 4 q - 1 = pooled row 2 q - 1: the row in front of this wave's pair, for wave 0 the last row of the
+      // previous step's tile (still in the ring; in front of the first step: the piece the prologue fetched)
+      const int poff = wave > 0 ? (sd & (NG - 1)) * GT + wave * 128 - 64 : ((sd - 1) & (NG - 1)) * GT + 15 * 64;
+      y.gp = Gs[poff + lane];
+      y.m_op = w.vp ? w.wp : 0ull;
+      y.m_ep = w.vp ? ~w.wp : 0ull;
+      y.off = w.off;
+    }
+  };
+  y_bits wn_ = {};
+  auto compute_y = [&](int sd, const y_in& y) {
+    const float o_a = sel(y.m_oa, y.ga), e_a = sel(y.m_ea, y.ga);
+    const float o_b = sel(y.m_ob, y.gb), e_b = sel(y.m_eb, y.gb);
+    float o[6];
+    o[0] = e_a;
+    o[1] = (e_a + o_a) + (e_b + o_b);
+    o[2] = (e_a - o_a) + (e_b - o_b);
+    o[3] = fmaf(4.f, fmaf(2.f, o_b, e_b), fmaf(2.f, o_a, e_a));
+    o[4] = fmaf(4.f, fmaf(-2.f, o_b, e_b), fmaf(-2.f, o_a, e_a));
+    o[5] = o_b;
+    bsum += o[1];
+    float* dst = Bs + (sd & 1) * T4_TILE + wave * 64 + sw;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dst[i * T4_PLANE] = o[i];
+    if constexpr (write_vd) {
+      const float d1 = sel(y.m_op, y.gp), d0 = sel(y.m_ep, y.gp);
+      vd_transform(d0, d1, e_a, o_a, e_b, o_b, pend);
+      pend_off = y.off;
+    }
+  };
+  auto flush_vd = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[i]), rsVd, pend_off, (unsigned)(i * p.ld_vd * 4),
+                                            T4V_NT_STORE ? 2 : 0);
+  };
+
+  // ---- MFMA side (as wino43v_tn_kernel<., 4>) ----
+  const int a_off = (wm >> 1) * T4_TILE + lh * 64 + (((wm & 1) * 32 + lr) ^ (lh << 5));
+  const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
+  float fa0[6], fb0[6], fa1[6], fb1[6], fa2[6], fb2[6], fac[6], fbc[6];   // slices 0..2 of a step; slice 3, carried
+  auto load_frag = [&](float (&fa)[6], float (&fb)[6], int abuf, int bbuf, int sl) {
+    const float* a_s = As + abuf * (2 * T4_TILE) + sl * 128 + a_off;
+    const float* b_s = Bs + bbuf * T4_TILE + sl * 128 + b_off;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      fa[i] = a_s[i * T4_PLANE];
+      fb[i] = b_s[i * T4_PLANE];
+    }
+  };
+  auto mfma6 = [&](const float (&fa)[6], const float (&fb)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[i], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fac[i] = fbc[i] = 0.f;
+
+  {   // (also for an empty split: every access is clamped by its resource, the masks are all zero)
+    issue_v(0);
+    issue_v(1);
+    issue_v(2);
+    issue_g(0);
+    issue_g(1);
+    issue_g(2);
+    issue_g(3);
+    if (write_vd && g_r0 > 0) {   // pooled rows g_r0 - 4 .. g_r0 - 1 -> rows 12 .. 15 of ring slot -1
+      const __amdgpu_buffer_rsrc_t rsGm = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.B + (g_r0 - 4) * (long long)p.ldb + n0), 0,
+          clip31((p.B_rows - (g_r0 - 4) < 4 ? p.B_rows - (g_r0 - 4) : 4LL) * p.ldb * 4 - (long long)n0 * 4), 0x00020000);
+      dma16(rsGm, reinterpret_cast<char*>(Gs) + ((NG - 1) * GT + 12 * 64) * 4,
+            (unsigned)(((lane >> 4) * (long long)p.ldb + (lane & 15) * 4) * 4), 0u);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      y_in y0;
+      fetch_bits(0, nsteps > 0 ? 1 : 0, wn_);
+      fetch_y(0, wn_, y0);
+      compute_y(0, y0);
+      fetch_bits(1, 1 < nsteps ? 1 : 0, wn_);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const int abuf = s & (NA - 1), bbuf = s & 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(T8_ABL & 1)) issue_v(s + 3);
+    if (!(T8_ABL & 2)) issue_g(s + 4);
+    if constexpr (write_vd)
+      if (!(T8_ABL & 4)) flush_vd();
+    load_frag(fa0, fb0, abuf, bbuf, 0);
+    load_frag(fa1, fb1, abuf, bbuf, 1);
+    mfma6(fac, fbc);                                        // slice 3 of the previous step
+    mfma6(fa0, fb0);
+#if T8_SCHED
+    // first half of the step: one vector-memory operation behind each MFMA while there are any, the fragment reads of
+    // slices 0 and 1 (the compiler pairs them across the two slices: 12 ds_read2st64_b32) behind the MFMAs of the carried
+    // slice (0x008 MFMA, 0x010 vector memory, 0x100 LDS read)
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (t < (write_vd ? 10 : 4)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      if (t < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // second half: the transform of step s + 1 beside the MFMAs of slice 1 ...
+    y_in yn;
+    if (!(T8_ABL & 8)) fetch_y(s + 1, wn_, yn);
+    load_frag(fa2, fb2, abuf, bbuf, 2);
+    load_frag(fac, fbc, abuf, bbuf, 3);
+    mfma6(fa1, fb1);
+    if (!(T8_ABL & 8)) compute_y(s + 1, yn);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the last LDS wait of the step, long since met
+    __builtin_amdgcn_sched_barrier(0);
+    // ... then the scalar loads for the transform of step s + 2 under the MFMAs of slice 2
+    if (!(T8_ABL & (8 | 64))) fetch_bits(s + 2, s + 2 < nsteps ? 1 : 0, wn_);
+    __builtin_amdgcn_sched_barrier(0);                      // (the scheduler would sink the loads to the end of the step)
+    mfma6(fa2, fb2);
+    __builtin_amdgcn_sched_barrier(0);                      // (... and hoist the closing wait over these MFMAs)
+    // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2); in flight: 2 x (4 pieces [+ 6 stores])
+#if T8_ABL & 32
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#else
+    if constexpr (write_vd) __builtin_amdgcn_s_waitcnt(0x4074);   // vmcnt(20) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0078);                      // vmcnt(8) lgkmcnt(0)
+#endif
+#if !(T8_ABL & 16)
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+  }
+  mfma6(fac, fbc);
+
+  if (p.colsum != nullptr && m0 == 0) {
+    __syncthreads();
+    float* red = lds;
+    red[wave * 64 + lane] = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < T4_Q; ++q) t += red[q * 64 + tid];
+      p.colsum[(long long)z * p.Ndim + n0 + tid] = t;
+    }
+  }
+  float* out = p.slab + (long long)z * p.slab_stride;
+  const int col = n0 + wn * 32 + lr;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      out[((long long)i * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
     }
 }
 
@@ -741,23 +1130,37 @@ extern "C" int tl_conv3_wino43v_tn(const tl_tn_params* pp, void* stream) {
   const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
   TL_REQUIRE((per + 4) * (long long)T4_Q * 6 * p.lda * 4 < (1LL << 31), "wino43v_tn: a reduction split spans more than 2 GB of V: raise splitk");
   TL_REQUIRE(p.vd == nullptr || (p.ld_vd >= p.Ndim && p.ld_vd % 2 == 0), "wino43v_tn: ld_vd must cover Ndim");
-  const int ntm = (p.Mdim + T4_BM - 1) / T4_BM, ntn = (p.Ndim + T4_BN - 1) / T4_BN;
+  TL_REQUIRE(p.vd == nullptr || (per + 4) * (long long)T4_Q * 6 * p.ld_vd * 4 < (1LL << 31), "wino43v_tn: a reduction split spans more than 2 GB of Vd: raise splitk");
+  // C_in tile: 128 (8 waves) when C_in allows it, 64 (4 waves) otherwise or on request (p.bm; 127 = the 128-wide tile on
+  // the kernel that stages Y through registers - the A/B partner of wino43v_tn8_kernel)
+  TL_REQUIRE(p.bm == 0 || p.bm == 64 || ((p.bm == 128 || p.bm == 127) && p.Mdim % 128 == 0),
+             "wino43v_tn: bm must be 0, 64, or 127 / 128 with Mdim %% 128 == 0");
+  const bool dma8_ok = p.Mdim % 128 == 0 && p.Ndim % 64 == 0 && p.ld_bbits % 2 == 0 && p.B_rows < (1LL << 30) &&
+                       (per + 5) * 2LL * T4_Q * p.ldb * 4 < (1LL << 31);
+  TL_REQUIRE(p.bm != 128 || dma8_ok, "wino43v_tn: bm 128 needs Mdim %% 128 == 0, Ndim %% 64 == 0, an even ld_bbits");
+  const bool dma8 = p.bm == 128 || (p.bm == 0 && dma8_ok);
+  const int bm = p.bm == 64 ? 64 : (p.bm ? 128 : (p.Mdim % 128 == 0 ? 128 : 64));
+  const int ntm = (p.Mdim + bm - 1) / bm, ntn = (p.Ndim + T4_BN - 1) / T4_BN;
   TL_REQUIRE((long long)ntm * ntn < (1LL << 31), "wino43v_tn: grid too large");
   hipStream_t st = (hipStream_t)stream;
+  auto launch = [&](auto WVD, int mt0, int mtn) {
+    constexpr bool wvd = decltype(WVD)::value;
+    const dim3 grid((unsigned)(mtn * ntn), (unsigned)p.splitk, 1);
+    if (dma8) hipLaunchKernelGGL((wino43v_tn8_kernel<wvd>), grid, dim3(512), 0, st, p, mt0, mtn);
+    else if (bm == 128) hipLaunchKernelGGL((wino43v_tn_kernel<wvd, 4>), grid, dim3(512), 0, st, p, mt0, mtn);
+    else hipLaunchKernelGGL((wino43v_tn_kernel<wvd, 2>), grid, dim3(256), 0, st, p, mt0, mtn);
+  };
   if (p.vd != nullptr) {
     // first C_in tile: the instantiation that also writes Vd; the other tiles: the plain one.  p.part selects one of the
     // two launches (1: the Vd tile, 2: the rest) so a caller can put them on different streams; 0: both, in order
     if (p.part != 2) {
-      hipLaunchKernelGGL((wino43v_tn_kernel<true>), dim3((unsigned)ntn, (unsigned)p.splitk, 1), dim3(256), 0, st, p, 0, 1);
+      launch(std::true_type{}, 0, 1);
       int rc = check_launch("wino43v_tn (Vd)");
       if (rc) return rc;
     }
-    if (ntm > 1 && p.part != 1)
-      hipLaunchKernelGGL((wino43v_tn_kernel<false>), dim3((unsigned)((ntm - 1) * ntn), (unsigned)p.splitk, 1), dim3(256), 0, st,
-                         p, 1, ntm - 1);
+    if (ntm > 1 && p.part != 1) launch(std::false_type{}, 1, ntm - 1);
   } else {
-    hipLaunchKernelGGL((wino43v_tn_kernel<false>), dim3((unsigned)(ntm * ntn), (unsigned)p.splitk, 1), dim3(256), 0, st, p, 0,
-                       ntm);
+    launch(std::false_type{}, 0, ntm);
   }
   return check_launch("wino43v_tn");
 }

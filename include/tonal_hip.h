@@ -105,6 +105,7 @@ typedef struct {
                          (tl_conv3_wino43v_nt, MASK / conv1-weight-gradient epilogue); Krows / 4 quads, or null    */
   int part;           /* with vd: 0 both launches (the Vd-writing first C_in tile, then the other tiles), 1 / 2 only the
                          first / second of them (to put them on different streams)                                  */
+  int bm;             /* tl_conv3_wino43v_tn: C_in tile, 0 = 128 when Mdim % 128 == 0 else 64; 64 / 128 force one   */
 } tl_tn_params;
 int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
 
