@@ -495,6 +495,18 @@ def main():
                                        if t.rsplit("_", 1)[-1] in ("fwd", "dgrad", "wgrad") or t in tag_share
                                        else {"ms": round(tsum[t][1], 3)})
                                    for t in sorted(tsum)}}
+            # an op split over two kernel names (the weight gradient: the Vd-writing C_in tile + the other tiles): the whole op
+            ops = {}
+            for t in tsum:
+                if t.endswith("_wgrad_vd") and t[:-3] in tsum:
+                    ops[t[:-3]] = (conv_flops(eng, int(t[4]), B), tsum[t][1] + tsum[t[:-3]][1])
+            if ops:
+                fl, ms = sum(v[0] for v in ops.values()), sum(v[1] for v in ops.values())
+                iss = issued_of[next(k for k, tags in fams.items() if next(iter(ops)) in tags)]
+                roof["whole_ops"] = {"conv2/conv3 weight gradient (both launches)": {
+                    "ms_per_step": round(ms, 2), "issued_tflops": round(fl * iss / (ms * 1e-3) / 1e12, 2),
+                    "frac": round(fl * iss / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "per_stage_frac": {k: round(v[0] * iss / (v[1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) for k, v in sorted(ops.items())}}}
         extras = {}
         if world == 1 and args.model == "full" and not args.no_extras:
             for key, fn in (("c2_lite", lambda: lite_subresult(dev)),

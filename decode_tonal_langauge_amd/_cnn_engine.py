@@ -121,8 +121,9 @@ class CnnEngine:
         # the streaming kernels (which stage through LDS too) find no free CU and the two streams serialise.  Off.
         self.overlap = os.environ.get("TONAL_OVERLAP", "0") == "1"
         self.vd_mode = os.environ.get("TONAL_WINO_VD", "tn")
-        # C_in tile of the V-form weight-gradient kernel: 0 = 128 (8 waves) where C_in % 128 == 0, else 64; 64 forces the
-        # 4-wave kernel (the A/B partner: same results bit for bit)
+        # C_in tile of the V-form weight-gradient kernel: 0 = 128 (8 waves, wino43v_tn8_kernel) where the shape allows, else
+        # 64; 64 / 127 force the 4-wave kernel / the 8-wave kernel that stages Y through registers (the A/B partners: same
+        # results bit for bit)
         self.tn_bm = int(os.environ.get("TONAL_TN_BM", "0"))
         self._side = None
         self._B = None
@@ -300,7 +301,11 @@ class CnnEngine:
         return (self._use_wino_v(st) and self._use_wino43_tn(st) and _r4(st.cout) % 16 == 0 and self.vd_mode != "0")
 
     def _tn_bm(self, st) -> int:
-        return self.tn_bm if self.tn_bm else (128 if st.cin % 128 == 0 else 64)
+        """64: 64 x 64 tile, 4 waves; 128: 128 x 64 tile, 8 waves, the Y side by LDS-DMA (wino43v_tn8_kernel: needs C_in % 128 ==
+        0, C_out % 64 == 0); 127: the 128-wide tile on the kernel that stages Y through registers."""
+        if self.tn_bm:
+            return self.tn_bm
+        return 128 if (st.cin % 128 == 0 and _r4(st.cout) % 64 == 0 and (st.cout // 32) % 2 == 0) else 64
 
     def _conv1_writes_v(self) -> bool:
         """The first stage hands its output to stage 2 as V (tl_conv1_fwd_v) - nothing else reads P1 then."""
@@ -360,9 +365,11 @@ class CnnEngine:
                 if self.vd_mode == "tn" and all(self._use_wino_vd(st) for st in self.stages[:2]):
                     # the op is two launches, named apart by rocprofv3: the first C_in tile (1 / ntm of the MFMA work) also
                     # writes Vd, the operand of the input gradient; the plain instantiation does the other tiles
-                    ntm = (self.stages[0].cin + self._tn_bm(self.stages[0]) - 1) // self._tn_bm(self.stages[0])
-                    tn = f"wino43v_tn_kernel<false> (conv2/conv3 weight gradient, C_in tiles 1..{ntm - 1} of {ntm}, Winograd F(4,3) on V, LDS-DMA)"
-                    vdn = f"wino43v_tn_kernel<true> (conv2/conv3 weight gradient, C_in tile 0 of {ntm}, + writes Vd for the input gradient)"
+                    bm = self._tn_bm(self.stages[0])
+                    ntm = (self.stages[0].cin + (64 if bm == 64 else 128) - 1) // (64 if bm == 64 else 128)
+                    kn = {64: "wino43v_tn_kernel<{}, 2>", 127: "wino43v_tn_kernel<{}, 4>", 128: "wino43v_tn8_kernel<{}>"}[bm]
+                    tn = f"{kn.format('false')} (conv2/conv3 weight gradient, C_in tiles 1..{ntm - 1} of {ntm}, Winograd F(4,3) on V, LDS-DMA)"
+                    vdn = f"{kn.format('true')} (conv2/conv3 weight gradient, C_in tile 0 of {ntm}, Winograd F(4,3) on V, + writes Vd for the input gradient)"
                     extra[vdn] = ["conv2_wgrad_vd", "conv3_wgrad_vd"]
                     self._fam_share = {tn: (ntm - 1) / ntm, vdn: 1.0 / ntm}
         fams = {fwd: ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}

@@ -727,35 +727,37 @@ __global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void wino43v_tn_kernel(c
 
 // ------------------------------------------------------------------------------------------
 // Weight gradient on V, 128 x 64 tile, 8 waves, one workgroup per CU: the product kernel where C_in % 128 == 0 and
-// C_out % 64 == 0.  Against wino43v_tn_kernel<., 4> (same tile, same MFMA side, bit-identical results) the Y side has
-// no vector-memory load that returns into registers left - timing-only ablations priced those at 55 cycles of matrix
-// time each (4 per wave and K-step: 3.6 of 32.3 ms at conv2), more than the whole transform:
-//   * the pooled gradient rows of a K-step (16 rows x 64 channels, 4 KB) arrive RAW by LDS-DMA, four steps ahead, in an
-//     8-slot ring (1 piece per wave and step; waves 4-7 repeat the pieces of waves 0-3, which keeps the step free of
-//     branches); a wave then owns one quad, a lane one channel: two ds_read_b32 fetch its pooled pair;
-//   * the arg-max words of a quad's pooled rows are wave-uniform: scalar loads, and the 64-bit word pair IS the lane
-//     mask of the un-pool select (v_cndmask on an SGPR pair; row validity folds into the mask on the scalar ALU);
-//   * the vector-memory operations that are left - 3 V pieces, 1 G piece and, for the workgroups that also write Vd, the
-//     six stores of the PREVIOUS step's transform (kept in registers across the barrier) - are issued one per MFMA in
-//     the first half of the step (sched_group_barrier), the transform runs in the second half.
+// C_out % 64 == 0.  Same tile, same MFMA side and bit-identical results as wino43v_tn_kernel<., 4>; the Y side has no
+// load that returns into registers:
+//   * the pooled gradient rows of a K-step (16 rows x 64 channels, 4 KB) AND their arg-max words (16 rows x 8 bytes)
+//     arrive raw by LDS-DMA, four steps ahead, in a 6-slot ring: waves 0-3 fetch one gradient piece each, waves 4-7 the
+//     piece with the words (all four the same one: every wave issues exactly one piece, the step stays free of branches);
+//   * a wave owns one quad, a lane one channel: one ds_read2st64_b32 fetches its pooled pair, a ds_read2_b64 at a
+//     wave-uniform address the two 64-bit arg-max words, v_readfirstlane moves them to scalar registers - where the word
+//     pair IS the lane mask of the un-pool select (v_cndmask on an SGPR pair; row validity folds in on the scalar ALU);
+//   * the vector-memory operations that are left - 3 V pieces, 1 G / word piece and, for the workgroups that also write
+//     Vd, the six stores of the PREVIOUS step's transform (kept in registers across the barrier) - are issued one per
+//     MFMA in the first half of the step (sched_group_barrier), the transform runs in the second half.
+// (Scalar loads for the words were tried first: they return out of order, so none may be pending at a counted LDS wait,
+// which leaves them one half-step to complete - and they miss to HBM every step: 3.5 of 32.7 ms at conv2.)
 // One K-step body serves every step: prefetches past the end of a split read memory the resource still covers (or
-// zeros), a step past the end is transformed with all-zero masks, so the vmcnt arithmetic of the closing wait never
+// zeros), the quads of a step past the end get all-zero masks, so the vmcnt arithmetic of the closing wait never
 // changes: what may stay in flight are the operations of this step and the one before, 2 x (4 or 10).
 // ------------------------------------------------------------------------------------------
 #ifndef T8_SCHED
 #define T8_SCHED 1
 #endif
 #ifndef T8_ABL
-#define T8_ABL 0           // timing-only: 1 no V pieces, 2 no G piece, 4 no Vd stores, 8 no transform, 16 no barrier,
-                           // 32 no vmcnt wait, 64 no scalar loads / row logic (the masks of the first step throughout)
+#define T8_ABL 0           // timing-only: 1 no V pieces, 2 no G piece, 4 no Vd stores, 8 no transform, 16 no barrier
 #endif
 template <bool WVD>
 __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params p, int mt0, int mtn) {
-  constexpr int NA = T4V_NA, NG = 8, GT = 16 * 64;   // V ring slots; raw-gradient ring slots, floats per raw tile
+  constexpr int NA = T4V_NA, NG = 6;             // V ring slots; raw ring slots (steps s - 1 .. s + 4 are live)
+  constexpr int GW = 16 * 64, GT = GW + 64 * 4;  // floats per raw slot: 16 gradient rows, then 64 x 16 bytes of arg-max words
   __shared__ __attribute__((aligned(1024))) float lds[(NA * 2 + 2) * T4_TILE + NG * GT];
   float* As = lds;                               // [4][2][6][8][64]  V ring (two 64-channel half-tiles)
   float* Bs = lds + NA * 2 * T4_TILE;            // [2][6][8][64]     Y
-  float* Gs = Bs + 2 * T4_TILE;                  // [8][16][64]       raw pooled gradient rows
+  float* Gs = Bs + 2 * T4_TILE;                  // [6]{[16][64] raw pooled gradient rows, [64][4] words (row r: its two at 4 r)}
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
@@ -808,17 +810,26 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
 #pragma unroll
     for (int t = 0; t < 3; ++t) dma16(rsV, base + vdst[t], vvoff[t], soff);
   };
-  // ---- raw pooled gradient rows by LDS-DMA: piece wave & 3 = rows 4 t .. 4 t + 3 of the step's 16; lane -> (row
-  // lane >> 4, 16-byte chunk lane & 15); the LDS image is row-major [16][64]
+  // ---- raw pooled gradient rows and arg-max words by LDS-DMA.  Waves 0-3: gradient piece wave = rows 4 t .. 4 t + 3 of
+  // the step's 16, lane -> (row lane >> 4, 16-byte chunk lane & 15), LDS image row-major [16][64].  Waves 4-7: the word
+  // piece, lane r < 16 -> 16 bytes from the first word of this column tile in row r (two words used), lanes >= 16 carry
+  // an offset past the resource (zeros, no memory access)
   const long long g_r0 = ks_begin * 2 * T4_Q;
+  const bool wpiece = wave >= 4;
+  const int ldw4 = p.ld_bbits * 4;
   const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.B + g_r0 * (long long)p.ldb + n0), 0, clip31((p.B_rows - g_r0) * (long long)p.ldb * 4 - (long long)n0 * 4), 0x00020000);
-  const unsigned gvoff = (unsigned)((((wave & 3) * 4 + (lane >> 4)) * (long long)p.ldb + (lane & 15) * 4) * 4);
-  const unsigned gdst = (unsigned)((wave & 3) * 256 * 4);
-  const unsigned g_step = (unsigned)(2 * T4_Q * p.ldb * 4);
-  auto issue_g = [&](int step) {
-    dma16(rsG, reinterpret_cast<char*>(Gs) + (step & (NG - 1)) * (GT * 4) + gdst, gvoff, (unsigned)step * g_step);
+      wpiece ? (void*)(p.bbits + g_r0 * (long long)p.ld_bbits + (n0 >> 5)) : (void*)(p.B + g_r0 * (long long)p.ldb + n0), 0,
+      wpiece ? clip31((p.B_rows - g_r0) * (long long)ldw4 - (long long)(n0 >> 5) * 4)
+             : clip31((p.B_rows - g_r0) * (long long)p.ldb * 4 - (long long)n0 * 4),
+      0x00020000);
+  const unsigned gvoff = wpiece ? (lane < 16 ? (unsigned)(lane * ldw4) : 0xfffffff0u)
+                                : (unsigned)((((wave & 3) * 4 + (lane >> 4)) * (long long)p.ldb + (lane & 15) * 4) * 4);
+  const unsigned gdst = wpiece ? (unsigned)(GW * 4) : (unsigned)((wave & 3) * 256 * 4);
+  const unsigned g_step = wpiece ? (unsigned)(2 * T4_Q * ldw4) : (unsigned)(2 * T4_Q * p.ldb * 4);
+  auto issue_g = [&](int step, int slot) {
+    dma16(rsG, reinterpret_cast<char*>(Gs) + slot * (GT * 4) + gdst, gvoff, (unsigned)step * g_step);
   };
+  auto next6 = [](int v) { return v == NG - 1 ? 0 : v + 1; };
 
   // ---- Y side: wave = quad of the K-step, lane = channel ----
   constexpr bool write_vd = WVD;
@@ -826,20 +837,12 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
   // (integer division runs on the vector ALU: without the readfirstlane everything derived from tq stays there)
   int tq = __builtin_amdgcn_readfirstlane((int)((4 * (v_q0 + wave)) % p.Tp));   // first conv row of the NEXT quad to transform
   const int dstep = __builtin_amdgcn_readfirstlane((4 * T4_Q) % p.Tp);
-  // the arg-max words are never written by this kernel: read them through the constant address space, where a load
-  // from a wave-uniform address is a scalar load (through the global one it is a vector load into 64 identical lanes)
-  typedef const __attribute__((address_space(4))) unsigned long long* cmask_ptr;
-  const uint32_t* bits0 = p.bbits + (n0 >> 5);
-  auto bits_of = [&](int row) -> unsigned long long {
-    return *reinterpret_cast<cmask_ptr>(reinterpret_cast<uintptr_t>(bits0 + row * (long long)p.ld_bbits));
-  };
   float bsum = 0.f;
   const unsigned vd_qstride = (unsigned)(6 * p.ld_vd * 4);
   const __amdgpu_buffer_rsrc_t rsVd = __builtin_amdgcn_make_buffer_rsrc(
       write_vd ? (void*)(p.vd + v_q0 * 6 * (long long)p.ld_vd + n0) : (void*)p.slab, 0,
       write_vd ? clip31((quads_all - v_q0) * 6 * (long long)p.ld_vd * 4 - (long long)n0 * 4) : 0, 0x00020000);
   float pend[6];                                            // Vd of the last transform, stored in the next step
-  // (declared below: y_bits wn_ = arg-max words and row flags of the NEXT step to transform)
   unsigned pend_off = 0xfffffff0u;
 #pragma unroll
   for (int i = 0; i < 6; ++i) pend[i] = 0.f;
@@ -848,60 +851,54 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
     return r;
   };
-  // Y(sd) -> Bs[sd & 1]; with WVD also Vd of the step's quads -> pend.  live = 0: a step past the end of the split.
-  // Three parts.  fetch_bits: the scalar loads of the arg-max words and the row logic, ONE STEP AHEAD of their use and
-  // behind the last counted LDS wait of a step - scalar loads return out of order, so while one is pending every lgkmcnt
-  // wait has to be a full drain, and the first use of its result drains the LDS queue too (measured: 5 of 33 ms at conv2
-  // with the loads next to their use).  fetch_y: masks from those words (scalar ALU) and the LDS reads of the raw rows.
-  // compute_y: the arithmetic.  All row logic is 32-bit scalar arithmetic without short-circuit evaluation (a branch would
-  // split the K-step into basic blocks).
-  const int krows = (int)p.Krows, blast = (int)(p.B_rows - 1), nquads = (int)quads_all, q_first = (int)v_q0;
-  struct y_bits {
-    unsigned long long wa, wb, wp;
-    int va, vb, vp;
-    unsigned off;
-  };
+  // Y(sd) -> Bs[sd & 1]; with WVD also Vd of the step's quads -> pend.  Row logic against four loop-invariant quad
+  // limits (a quad q of step sd < nsteps of this split is below q_end), 32-bit scalar arithmetic, no short-circuit
+  // evaluation (a branch would split the K-step into basic blocks):
+  //   pooled row 2 q     usable: q < min(quads, (B_rows + 1) / 2, q_end)      [4 q < Krows, 2 q <= B_rows - 1]
+  //   pooled row 2 q + 1 usable: q < min(quads, B_rows / 2, q_end)
+  //   pooled row 2 q - 1 usable: 0 < q < min(quads + 1, (B_rows + 2) / 2, q_end)
+  const int blast = (int)(p.B_rows - 1), nquads = (int)quads_all, q_first = (int)v_q0;
+  const int q_end = q_first + nsteps * T4_Q;
+  auto min3 = [](int a, int b, int c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); };
+  const int qa_lim = min3(nquads, (blast + 2) / 2, q_end), qb_lim = min3(nquads, (blast + 1) / 2, q_end);
+  const int qp_lim = min3(nquads + 1, (blast + 3) / 2, q_end), qs_lim = nquads < q_end ? nquads : q_end;
   struct y_in {
     float ga, gb, gp;
     unsigned long long m_oa, m_ea, m_ob, m_eb, m_op, m_ep;
     unsigned off;
   };
-  auto fetch_bits = [&](int sd, int live, y_bits& w) {
+  auto uni = [](unsigned long long v) -> unsigned long long {   // a wave-uniform value out of vector registers
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+  };
+  // slot / pslot: ring slots of steps sd and sd - 1
+  auto fetch_y = [&](int sd, int slot, int pslot, y_in& y) {
     const int q = q_first + sd * T4_Q + wave;
-    const int pa = 2 * q, pb = 2 * q + 1;
-    w.va = live & (tq < p.Tvalid) & (4 * q < krows) & (pa <= blast);
-    w.vb = live & (tq + 2 < p.Tvalid) & (4 * q + 2 < krows) & (pb <= blast);
-    w.wa = bits_of(pa < blast ? pa : blast);
-    w.wb = bits_of(pb < blast ? pb : blast);
+    const int va = (tq < p.Tvalid) & (q < qa_lim), vb = (tq + 2 < p.Tvalid) & (q < qb_lim);
+    const float* gs = Gs + slot * GT;
+    y.ga = gs[wave * 128 + lane];
+    y.gb = gs[wave * 128 + 64 + lane];
+    const unsigned long long* ws = reinterpret_cast<const unsigned long long*>(gs + GW + wave * 8);   // rows 2 wave, 2 wave + 1
+    const unsigned long long wa = uni(ws[0]), wb = uni(ws[2]);
+    y.m_oa = va ? wa : 0ull;
+    y.m_ea = va ? ~wa : 0ull;
+    y.m_ob = vb ? wb : 0ull;
+    y.m_eb = vb ? ~wb : 0ull;
     if constexpr (write_vd) {
-      int pr = 2 * q - 1;
-      w.vp = live & (q > 0) & (tq >= 2) & (tq - 2 < p.Tvalid) & (4 * q - 2 < krows) & (pr <= blast);
-      pr = pr < 0 ? 0 : (pr < blast ? pr : blast);
-      w.wp = bits_of(pr);
-      w.off = (live & (q < nquads)) ? (unsigned)(q - q_first) * vd_qstride + (unsigned)lane * 4u : 0xfffffff0u;
+      // rows 4 q - 2, 4 q - 1 = pooled row 2 q - 1: the row in front of this wave's pair, for wave 0 the last row of the
+      // previous step's tile (still in the ring; in front of the first step: the pieces the prologue fetched)
+      const int vp = (q > 0) & (tq >= 2) & (tq - 2 < p.Tvalid) & (q < qp_lim);
+      const int prow = wave > 0 ? slot * GT + (2 * wave - 1) * 64 : pslot * GT + 15 * 64;
+      const int pwrd = wave > 0 ? slot * GT + GW + (2 * wave - 1) * 4 : pslot * GT + GW + 15 * 4;
+      y.gp = Gs[prow + lane];
+      const unsigned long long wp = uni(*reinterpret_cast<const unsigned long long*>(Gs + pwrd));
+      y.m_op = vp ? wp : 0ull;
+      y.m_ep = vp ? ~wp : 0ull;
+      y.off = q < qs_lim ? (unsigned)(q - q_first) * vd_qstride + (unsigned)lane * 4u : 0xfffffff0u;
     }
     tq += dstep;
     if (tq >= p.Tp) tq -= p.Tp;
   };
-  auto fetch_y = [&](int sd, const y_bits& w, y_in& y) {
-    const float* gs = Gs + (sd & (NG - 1)) * GT + wave * 128 + lane;
-    y.ga = gs[0];
-    y.gb = gs[64];
-    y.m_oa = w.va ? w.wa : 0ull;
-    y.m_ea = w.va ? ~w.wa : 0ull;
-    y.m_ob = w.vb ? w.wb : 0ull;
-    y.m_eb = w.vb ? ~w.wb : 0ull;
-    if constexpr (write_vd) {
-      // rows 4 q - 2, 4 q - 1 = pooled row 2 q - 1: the row in front of this wave's pair, for wave 0 the last row of the
-      // previous step's tile (still in the ring; in front of the first step: the piece the prologue fetched)
-      const int poff = wave > 0 ? (sd & (NG - 1)) * GT + wave * 128 - 64 : ((sd - 1) & (NG - 1)) * GT + 15 * 64;
-      y.gp = Gs[poff + lane];
-      y.m_op = w.vp ? w.wp : 0ull;
-      y.m_ep = w.vp ? ~w.wp : 0ull;
-      y.off = w.off;
-    }
-  };
-  y_bits wn_ = {};
   auto compute_y = [&](int sd, const y_in& y) {
     const float o_a = sel(y.m_oa, y.ga), e_a = sel(y.m_ea, y.ga);
     const float o_b = sel(y.m_ob, y.gb), e_b = sel(y.m_eb, y.gb);
@@ -953,36 +950,41 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     issue_v(0);
     issue_v(1);
     issue_v(2);
-    issue_g(0);
-    issue_g(1);
-    issue_g(2);
-    issue_g(3);
-    if (write_vd && g_r0 > 0) {   // pooled rows g_r0 - 4 .. g_r0 - 1 -> rows 12 .. 15 of ring slot -1
+    issue_g(0, 0);
+    issue_g(1, 1);
+    issue_g(2, 2);
+    issue_g(3, 3);
+    if (write_vd && g_r0 > 0) {
+      // slot of step -1: pooled rows g_r0 - 4 .. g_r0 - 1 -> its rows 12 .. 15 (one gradient piece); the word piece
+      // covers the slot's 16 rows, lanes 12 .. 15 fetch (g_r0 is a multiple of 16)
+      const int back = wpiece ? 16 : 4;
+      const long long left = p.B_rows - (g_r0 - back) < back ? p.B_rows - (g_r0 - back) : (long long)back;
       const __amdgpu_buffer_rsrc_t rsGm = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.B + (g_r0 - 4) * (long long)p.ldb + n0), 0,
-          clip31((p.B_rows - (g_r0 - 4) < 4 ? p.B_rows - (g_r0 - 4) : 4LL) * p.ldb * 4 - (long long)n0 * 4), 0x00020000);
-      dma16(rsGm, reinterpret_cast<char*>(Gs) + ((NG - 1) * GT + 12 * 64) * 4,
-            (unsigned)(((lane >> 4) * (long long)p.ldb + (lane & 15) * 4) * 4), 0u);
+          wpiece ? (void*)(p.bbits + (g_r0 - 16) * (long long)p.ld_bbits + (n0 >> 5)) : (void*)(p.B + (g_r0 - 4) * (long long)p.ldb + n0), 0,
+          wpiece ? clip31(left * ldw4 - (long long)(n0 >> 5) * 4) : clip31(left * p.ldb * 4 - (long long)n0 * 4), 0x00020000);
+      dma16(rsGm, reinterpret_cast<char*>(Gs) + ((NG - 1) * GT + (wpiece ? GW : 12 * 64)) * 4,
+            wpiece ? (lane >= 12 && lane < 16 ? (unsigned)(lane * ldw4) : 0xfffffff0u)
+                   : (unsigned)(((lane >> 4) * (long long)p.ldb + (lane & 15) * 4) * 4), 0u);
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
       y_in y0;
-      fetch_bits(0, nsteps > 0 ? 1 : 0, wn_);
-      fetch_y(0, wn_, y0);
+      fetch_y(0, 0, NG - 1, y0);
       compute_y(0, y0);
-      fetch_bits(1, 1 < nsteps ? 1 : 0, wn_);
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  int slot1 = 1, slot4 = 4;                                 // ring slots of steps s + 1 and s + 4
   for (int s = 0; s < nsteps; ++s) {
     const int abuf = s & (NA - 1), bbuf = s & 1;
+    const int slot0 = slot1 == 0 ? NG - 1 : slot1 - 1;
     __builtin_amdgcn_sched_barrier(0);
     if (!(T8_ABL & 1)) issue_v(s + 3);
-    if (!(T8_ABL & 2)) issue_g(s + 4);
+    if (!(T8_ABL & 2)) issue_g(s + 4, slot4);
     if constexpr (write_vd)
       if (!(T8_ABL & 4)) flush_vd();
     load_frag(fa0, fb0, abuf, bbuf, 0);
@@ -1001,31 +1003,24 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    // second half: the transform of step s + 1 beside the MFMAs of slice 1 ...
+    // second half: the transform of step s + 1 beside the MFMAs of slices 1 and 2
     y_in yn;
-    if (!(T8_ABL & 8)) fetch_y(s + 1, wn_, yn);
+    if (!(T8_ABL & 8)) fetch_y(s + 1, slot1, slot0, yn);
     load_frag(fa2, fb2, abuf, bbuf, 2);
     load_frag(fac, fbc, abuf, bbuf, 3);
     mfma6(fa1, fb1);
     if (!(T8_ABL & 8)) compute_y(s + 1, yn);
-    __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the last LDS wait of the step, long since met
-    __builtin_amdgcn_sched_barrier(0);
-    // ... then the scalar loads for the transform of step s + 2 under the MFMAs of slice 2
-    if (!(T8_ABL & (8 | 64))) fetch_bits(s + 2, s + 2 < nsteps ? 1 : 0, wn_);
-    __builtin_amdgcn_sched_barrier(0);                      // (the scheduler would sink the loads to the end of the step)
     mfma6(fa2, fb2);
-    __builtin_amdgcn_sched_barrier(0);                      // (... and hoist the closing wait over these MFMAs)
+    __builtin_amdgcn_sched_barrier(0);                      // (the closing wait would be hoisted over these MFMAs)
     // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2); in flight: 2 x (4 pieces [+ 6 stores])
-#if T8_ABL & 32
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-#else
     if constexpr (write_vd) __builtin_amdgcn_s_waitcnt(0x4074);   // vmcnt(20) lgkmcnt(0)
     else __builtin_amdgcn_s_waitcnt(0x0078);                      // vmcnt(8) lgkmcnt(0)
-#endif
 #if !(T8_ABL & 16)
     __builtin_amdgcn_s_barrier();
 #endif
     asm volatile("" ::: "memory");
+    slot1 = next6(slot1);
+    slot4 = next6(slot4);
   }
   mfma6(fac, fbc);
 
