@@ -736,19 +736,21 @@ __global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void wino43v_tn_kernel(c
 //     wave-uniform address the two 64-bit arg-max words, v_readfirstlane moves them to scalar registers - where the word
 //     pair IS the lane mask of the un-pool select (v_cndmask on an SGPR pair; row validity folds in on the scalar ALU);
 //   * the vector-memory operations that are left - 3 V pieces, 1 G / word piece and, for the workgroups that also write
-//     Vd, the six stores of the PREVIOUS step's transform (kept in registers across the barrier) - are issued one per
+//     Vd, the two 16-byte stores of the PREVIOUS step's transform (transposed over groups of four lanes and kept in
+//     registers across the barrier) - are issued one per
 //     MFMA in the first half of the step (sched_group_barrier), the transform runs in the second half.
 // (Scalar loads for the words were tried first: they return out of order, so none may be pending at a counted LDS wait,
 // which leaves them one half-step to complete - and they miss to HBM every step: 3.5 of 32.7 ms at conv2.)
 // One K-step body serves every step: prefetches past the end of a split read memory the resource still covers (or
 // zeros), the quads of a step past the end get all-zero masks, so the vmcnt arithmetic of the closing wait never
-// changes: what may stay in flight are the operations of this step and the one before, 2 x (4 or 10).
+// changes: what may stay in flight are the operations of this step and the one before, 2 x (4 or 6).
 // ------------------------------------------------------------------------------------------
 #ifndef T8_SCHED
 #define T8_SCHED 1
 #endif
 #ifndef T8_ABL
-#define T8_ABL 0           // timing-only: 1 no V pieces, 2 no G piece, 4 no Vd stores, 8 no transform, 16 no barrier
+#define T8_ABL 0           // timing-only: 1 no V pieces, 2 no G piece, 4 no Vd stores, 8 no transform, 16 no barrier,
+                           // 512 Vd stores issued with offsets past the resource (no memory traffic)
 #endif
 template <bool WVD>
 __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params p, int mt0, int mtn) {
@@ -842,10 +844,15 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
   const __amdgpu_buffer_rsrc_t rsVd = __builtin_amdgcn_make_buffer_rsrc(
       write_vd ? (void*)(p.vd + v_q0 * 6 * (long long)p.ld_vd + n0) : (void*)p.slab, 0,
       write_vd ? clip31((quads_all - v_q0) * 6 * (long long)p.ld_vd * 4 - (long long)n0 * 4) : 0, 0x00020000);
-  float pend[6];                                            // Vd of the last transform, stored in the next step
-  unsigned pend_off = 0xfffffff0u;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) pend[i] = 0.f;
+  // Vd of the last transform, stored in the next step - transposed inside each group of four lanes first, so that a lane
+  // holds four consecutive channels of ONE transform row and the quad goes out in two 16-byte stores per lane instead of
+  // six 4-byte ones (the workgroups that write Vd are bound by vector-memory instruction issue: 10 per wave and K-step
+  // ran at 0.60 of the MFMA peak against 0.80 for the plain kernel's 4; ablation: 0.5 ms per instruction at conv2).
+  // pendA: rows 0..3 (lane & 3 = row), pendB: rows 4, 5 (lanes with lane & 3 < 2)
+  f32x4 pendA = {0.f, 0.f, 0.f, 0.f}, pendB = {0.f, 0.f, 0.f, 0.f};
+  unsigned pend_off = 0xfffffff0u;                          // byte offset of the quad in the resource, or past its end
+  const unsigned vdA_lane = (unsigned)((lane & 3) * p.ld_vd * 4 + (lane & ~3) * 4);
+  const unsigned vdB_lane = (lane & 3) < 2 ? (unsigned)((4 + (lane & 3)) * p.ld_vd * 4 + (lane & ~3) * 4) : 0xfffffff0u;
   auto sel = [](unsigned long long m, float v) -> float {   // lane's bit of m set ? v : 0
     float r;
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
@@ -894,7 +901,7 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
       const unsigned long long wp = uni(*reinterpret_cast<const unsigned long long*>(Gs + pwrd));
       y.m_op = vp ? wp : 0ull;
       y.m_ep = vp ? ~wp : 0ull;
-      y.off = q < qs_lim ? (unsigned)(q - q_first) * vd_qstride + (unsigned)lane * 4u : 0xfffffff0u;
+      y.off = q < qs_lim ? (unsigned)(q - q_first) * vd_qstride : 0xfffffff0u;
     }
     tq += dstep;
     if (tq >= p.Tp) tq -= p.Tp;
@@ -915,15 +922,38 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     for (int i = 0; i < 6; ++i) dst[i * T4_PLANE] = o[i];
     if constexpr (write_vd) {
       const float d1 = sel(y.m_op, y.gp), d0 = sel(y.m_ep, y.gp);
-      vd_transform(d0, d1, e_a, o_a, e_b, o_b, pend);
+      float v[6];
+      vd_transform(d0, d1, e_a, o_a, e_b, o_b, v);
+      // 4 x 4 transpose over the lanes of a group (register n of lane r <- register r of lane n): exchange with lane ^ 1
+      // on the register pairs (0,1) (2,3), then with lane ^ 2 on (0,2) (1,3)
+      const bool odd = lane & 1, hi = lane & 2;
+      auto xch = [](float x, auto CTRL) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(CTRL)::value, 0xf, 0xf, true));
+      };
+      using X1 = std::integral_constant<int, 0xB1>;         // quad_perm [1,0,3,2]
+      using X2 = std::integral_constant<int, 0x4E>;         // quad_perm [2,3,0,1]
+      auto stage = [&](float& a, float& b, bool up, auto CTRL) {
+        const float r = xch(up ? a : b, CTRL);
+        a = up ? r : a;
+        b = up ? b : r;
+      };
+      stage(v[0], v[1], odd, X1{});
+      stage(v[2], v[3], odd, X1{});
+      stage(v[4], v[5], odd, X1{});
+      stage(v[0], v[2], hi, X2{});
+      stage(v[1], v[3], hi, X2{});
+      pendA = f32x4{v[0], v[1], v[2], v[3]};
+      pendB = f32x4{v[4], v[5], xch(v[4], X2{}), xch(v[5], X2{})};   // (rows 4, 5: lanes 0, 1 of a group)
       pend_off = y.off;
     }
   };
+  typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
   auto flush_vd = [&]() {
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[i]), rsVd, pend_off, (unsigned)(i * p.ld_vd * 4),
-                                            T4V_NT_STORE ? 2 : 0);
+    const bool ok = pend_off != 0xfffffff0u && !(T8_ABL & 512);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, pendA), rsVd, ok ? pend_off + vdA_lane : 0xfffffff0u, 0u,
+                                           T4V_NT_STORE ? 2 : 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, pendB), rsVd,
+                                           ok && (lane & 3) < 2 ? pend_off + vdB_lane : 0xfffffff0u, 0u, T4V_NT_STORE ? 2 : 0);
   };
 
   // ---- MFMA side (as wino43v_tn_kernel<., 4>) ----
@@ -998,7 +1028,7 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (t < (write_vd ? 10 : 4)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      if (t < (write_vd ? 6 : 4)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       if (t < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
 #endif
@@ -1012,8 +1042,8 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     if (!(T8_ABL & 8)) compute_y(s + 1, yn);
     mfma6(fa2, fb2);
     __builtin_amdgcn_sched_barrier(0);                      // (the closing wait would be hoisted over these MFMAs)
-    // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2); in flight: 2 x (4 pieces [+ 6 stores])
-    if constexpr (write_vd) __builtin_amdgcn_s_waitcnt(0x4074);   // vmcnt(20) lgkmcnt(0)
+    // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2); in flight: 2 x (4 pieces [+ 2 stores])
+    if constexpr (write_vd) __builtin_amdgcn_s_waitcnt(0x007c);   // vmcnt(12) lgkmcnt(0)
     else __builtin_amdgcn_s_waitcnt(0x0078);                      // vmcnt(8) lgkmcnt(0)
 #if !(T8_ABL & 16)
     __builtin_amdgcn_s_barrier();
