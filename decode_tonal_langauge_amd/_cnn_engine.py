@@ -363,15 +363,20 @@ class CnnEngine:
             if self.wino43_tn:
                 tn = "wino43v_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA)"
                 if self.vd_mode == "tn" and all(self._use_wino_vd(st) for st in self.stages[:2]):
-                    # the op is two launches, named apart by rocprofv3: the first C_in tile (1 / ntm of the MFMA work) also
-                    # writes Vd, the operand of the input gradient; the plain instantiation does the other tiles
                     bm = self._tn_bm(self.stages[0])
-                    ntm = (self.stages[0].cin + (64 if bm == 64 else 128) - 1) // (64 if bm == 64 else 128)
-                    kn = {64: "wino43v_tn_kernel<{}, 2>", 127: "wino43v_tn_kernel<{}, 4>", 128: "wino43v_tn8_kernel<{}>"}[bm]
-                    tn = f"{kn.format('false')} (conv2/conv3 weight gradient, C_in tiles 1..{ntm - 1} of {ntm}, Winograd F(4,3) on V, LDS-DMA)"
-                    vdn = f"{kn.format('true')} (conv2/conv3 weight gradient, C_in tile 0 of {ntm}, Winograd F(4,3) on V, + writes Vd for the input gradient)"
-                    extra[vdn] = ["conv2_wgrad_vd", "conv3_wgrad_vd"]
-                    self._fam_share = {tn: (ntm - 1) / ntm, vdn: 1.0 / ntm}
+                    if bm == 128:
+                        # one launch: its workgroups take turns at writing Vd, the operand of the input gradient
+                        tn = ("wino43v_tn8_kernel<true> (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA; also "
+                              "writes Vd for the input gradient)")
+                    else:
+                        # the op is two launches, named apart by rocprofv3: the first C_in tile (1 / ntm of the MFMA work)
+                        # also writes Vd, the operand of the input gradient; the plain instantiation does the other tiles
+                        ntm = (self.stages[0].cin + (64 if bm == 64 else 128) - 1) // (64 if bm == 64 else 128)
+                        kn = {64: "wino43v_tn_kernel<{}, 2>", 127: "wino43v_tn_kernel<{}, 4>"}[bm]
+                        tn = f"{kn.format('false')} (conv2/conv3 weight gradient, C_in tiles 1..{ntm - 1} of {ntm}, Winograd F(4,3) on V, LDS-DMA)"
+                        vdn = f"{kn.format('true')} (conv2/conv3 weight gradient, C_in tile 0 of {ntm}, Winograd F(4,3) on V, + writes Vd for the input gradient)"
+                        extra[vdn] = ["conv2_wgrad_vd", "conv3_wgrad_vd"]
+                        self._fam_share = {tn: (ntm - 1) / ntm, vdn: 1.0 / ntm}
         fams = {fwd: ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}
         fams.update(extra)
         if all(self._use_wino_vd(st) for st in self.stages[:2]):
@@ -488,7 +493,7 @@ class CnnEngine:
                     self._vd_ready[st.idx] = self.generation
             # (measured and not kept: the Vd-writing launch on a side stream beside the launch of the other seven C_in tiles
             # - tl_tn_params.part - 249.4 vs 244.9 ms per step)
-            if kw.get("vd") and self.timers is not None:
+            if kw.get("vd") and self.timers is not None and kw.get("bm") != 128:
                 # two calls so that the two launches of the op get their own HIP-event timers (rocprofv3 names them apart too)
                 self._tn(tag=f"conv{st.idx}_wgrad_vd", fn=fn, part=1, **kw)
                 self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, part=2, **kw)

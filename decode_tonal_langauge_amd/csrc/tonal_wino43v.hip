@@ -774,7 +774,8 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
   // (integer division runs on the vector ALU: what is derived from its result stays there unless it is moved back)
   const int z = __builtin_amdgcn_readfirstlane((int)(bid / tiles));
   const int tt = __builtin_amdgcn_readfirstlane((int)(bid % tiles));
-  const int m0 = __builtin_amdgcn_readfirstlane((mt0 + tt / ntn) * 128), n0 = __builtin_amdgcn_readfirstlane((tt % ntn) * T4_BN);
+  const int mi = __builtin_amdgcn_readfirstlane(tt / ntn);                          // C_in tile of this workgroup
+  const int m0 = (mt0 + mi) * 128, n0 = __builtin_amdgcn_readfirstlane((tt % ntn) * T4_BN);
 
   const long long quads_all = p.Krows >> 2;
   const long long ksteps_all = (quads_all + T4_Q - 1) / T4_Q;
@@ -844,15 +845,15 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
   const __amdgpu_buffer_rsrc_t rsVd = __builtin_amdgcn_make_buffer_rsrc(
       write_vd ? (void*)(p.vd + v_q0 * 6 * (long long)p.ld_vd + n0) : (void*)p.slab, 0,
       write_vd ? clip31((quads_all - v_q0) * 6 * (long long)p.ld_vd * 4 - (long long)n0 * 4) : 0, 0x00020000);
-  // Vd of the last transform, stored in the next step - transposed inside each group of four lanes first, so that a lane
-  // holds four consecutive channels of ONE transform row and the quad goes out in two 16-byte stores per lane instead of
-  // six 4-byte ones (the workgroups that write Vd are bound by vector-memory instruction issue: 10 per wave and K-step
-  // ran at 0.60 of the MFMA peak against 0.80 for the plain kernel's 4; ablation: 0.5 ms per instruction at conv2).
-  // pendA: rows 0..3 (lane & 3 = row), pendB: rows 4, 5 (lanes with lane & 3 < 2)
-  f32x4 pendA = {0.f, 0.f, 0.f, 0.f}, pendB = {0.f, 0.f, 0.f, 0.f};
-  unsigned pend_off = 0xfffffff0u;                          // byte offset of the quad in the resource, or past its end
+  // Vd: the mtn workgroups of one (split, C_out tile) build the same Y; they take turns at Vd - the workgroup of C_in
+  // tile mi transforms and stores the quads of the steps sd with sd % mtn == mi, in a block of its own behind the Y
+  // transform (a wave-uniform branch: ~40 vector instructions and two 16-byte stores every mtn-th step).  The quad is
+  // transposed inside each group of four lanes first, so that a lane holds four consecutive channels of ONE transform
+  // row: rows 0..3 by lane & 3, rows 4, 5 by the lanes with lane & 3 < 2.  (Measured before: one launch for C_in tile 0
+  // that wrote all of Vd ran at 0.60 of the MFMA peak against 0.80 for the others - 19.7 GB of stores in 13.5 ms at
+  // conv2; fewer, wider stores alone did not help, thinning the stream over the whole op does.)
   const unsigned vdA_lane = (unsigned)((lane & 3) * p.ld_vd * 4 + (lane & ~3) * 4);
-  const unsigned vdB_lane = (lane & 3) < 2 ? (unsigned)((4 + (lane & 3)) * p.ld_vd * 4 + (lane & ~3) * 4) : 0xfffffff0u;
+  const unsigned vdB_lane = (unsigned)((4 + (lane & 3)) * p.ld_vd * 4 + (lane & ~3) * 4);
   auto sel = [](unsigned long long m, float v) -> float {   // lane's bit of m set ? v : 0
     float r;
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
@@ -870,9 +871,12 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
   const int qa_lim = min3(nquads, (blast + 2) / 2, q_end), qb_lim = min3(nquads, (blast + 1) / 2, q_end);
   const int qp_lim = min3(nquads + 1, (blast + 3) / 2, q_end), qs_lim = nquads < q_end ? nquads : q_end;
   struct y_in {
-    float ga, gb, gp;
-    unsigned long long m_oa, m_ea, m_ob, m_eb, m_op, m_ep;
-    unsigned off;
+    float ga, gb;
+    unsigned long long m_oa, m_ea, m_ob, m_eb;
+    int tq;               // time index of the quad's first conv row
+  };
+  struct y_out {
+    float e_a, o_a, e_b, o_b;
   };
   auto uni = [](unsigned long long v) -> unsigned long long {   // a wave-uniform value out of vector registers
     return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
@@ -891,22 +895,11 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     y.m_ea = va ? ~wa : 0ull;
     y.m_ob = vb ? wb : 0ull;
     y.m_eb = vb ? ~wb : 0ull;
-    if constexpr (write_vd) {
-      // rows 4 q - 2, 4 q - 1 = pooled row 2 q - 1: the row in front of this wave's pair, for wave 0 the last row of the
-      // previous step's tile (still in the ring; in front of the first step: the pieces the prologue fetched)
-      const int vp = (q > 0) & (tq >= 2) & (tq - 2 < p.Tvalid) & (q < qp_lim);
-      const int prow = wave > 0 ? slot * GT + (2 * wave - 1) * 64 : pslot * GT + 15 * 64;
-      const int pwrd = wave > 0 ? slot * GT + GW + (2 * wave - 1) * 4 : pslot * GT + GW + 15 * 4;
-      y.gp = Gs[prow + lane];
-      const unsigned long long wp = uni(*reinterpret_cast<const unsigned long long*>(Gs + pwrd));
-      y.m_op = vp ? wp : 0ull;
-      y.m_ep = vp ? ~wp : 0ull;
-      y.off = q < qs_lim ? (unsigned)(q - q_first) * vd_qstride : 0xfffffff0u;
-    }
+    y.tq = tq;
     tq += dstep;
     if (tq >= p.Tp) tq -= p.Tp;
   };
-  auto compute_y = [&](int sd, const y_in& y) {
+  auto compute_y = [&](int sd, const y_in& y) -> y_out {
     const float o_a = sel(y.m_oa, y.ga), e_a = sel(y.m_ea, y.ga);
     const float o_b = sel(y.m_ob, y.gb), e_b = sel(y.m_eb, y.gb);
     float o[6];
@@ -920,40 +913,50 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     float* dst = Bs + (sd & 1) * T4_TILE + wave * 64 + sw;
 #pragma unroll
     for (int i = 0; i < 6; ++i) dst[i * T4_PLANE] = o[i];
-    if constexpr (write_vd) {
-      const float d1 = sel(y.m_op, y.gp), d0 = sel(y.m_ep, y.gp);
-      float v[6];
-      vd_transform(d0, d1, e_a, o_a, e_b, o_b, v);
-      // 4 x 4 transpose over the lanes of a group (register n of lane r <- register r of lane n): exchange with lane ^ 1
-      // on the register pairs (0,1) (2,3), then with lane ^ 2 on (0,2) (1,3)
-      const bool odd = lane & 1, hi = lane & 2;
-      auto xch = [](float x, auto CTRL) -> float {
-        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(CTRL)::value, 0xf, 0xf, true));
-      };
-      using X1 = std::integral_constant<int, 0xB1>;         // quad_perm [1,0,3,2]
-      using X2 = std::integral_constant<int, 0x4E>;         // quad_perm [2,3,0,1]
-      auto stage = [&](float& a, float& b, bool up, auto CTRL) {
-        const float r = xch(up ? a : b, CTRL);
-        a = up ? r : a;
-        b = up ? b : r;
-      };
-      stage(v[0], v[1], odd, X1{});
-      stage(v[2], v[3], odd, X1{});
-      stage(v[4], v[5], odd, X1{});
-      stage(v[0], v[2], hi, X2{});
-      stage(v[1], v[3], hi, X2{});
-      pendA = f32x4{v[0], v[1], v[2], v[3]};
-      pendB = f32x4{v[4], v[5], xch(v[4], X2{}), xch(v[5], X2{})};   // (rows 4, 5: lanes 0, 1 of a group)
-      pend_off = y.off;
-    }
+    return y_out{e_a, o_a, e_b, o_b};
   };
   typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
-  auto flush_vd = [&]() {
-    const bool ok = pend_off != 0xfffffff0u && !(T8_ABL & 512);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, pendA), rsVd, ok ? pend_off + vdA_lane : 0xfffffff0u, 0u,
-                                           T4V_NT_STORE ? 2 : 0);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, pendB), rsVd,
-                                           ok && (lane & 3) < 2 ? pend_off + vdB_lane : 0xfffffff0u, 0u, T4V_NT_STORE ? 2 : 0);
+  // Vd of the quads of step sd (slot / pslot: ring slots of steps sd, sd - 1)
+  auto vd_part = [&](int sd, int slot, int pslot, int tqc, const y_out& u) {
+    const int q = q_first + sd * T4_Q + wave;
+    // rows 4 q - 2, 4 q - 1 = pooled row 2 q - 1: the row in front of this wave's pair, for wave 0 the last row of the
+    // previous step's tile (still in the ring; in front of the first step: the pieces the prologue fetched)
+    const int vp = (q > 0) & (tqc >= 2) & (tqc - 2 < p.Tvalid) & (q < qp_lim);
+    const int prow = wave > 0 ? slot * GT + (2 * wave - 1) * 64 : pslot * GT + 15 * 64;
+    const int pwrd = wave > 0 ? slot * GT + GW + (2 * wave - 1) * 4 : pslot * GT + GW + 15 * 4;
+    const float gp = Gs[prow + lane];
+    const unsigned long long wp = uni(*reinterpret_cast<const unsigned long long*>(Gs + pwrd));
+    const float d1 = sel(vp ? wp : 0ull, gp), d0 = sel(vp ? ~wp : 0ull, gp);
+    float v[6];
+    vd_transform(d0, d1, u.e_a, u.o_a, u.e_b, u.o_b, v);
+    // 4 x 4 transpose over the lanes of a group (register n of lane r <- register r of lane n): exchange with lane ^ 1
+    // on the register pairs (0,1) (2,3), then with lane ^ 2 on (0,2) (1,3)
+    const bool odd = lane & 1, hi = lane & 2;
+    auto xch = [](float x, auto CTRL) -> float {
+      return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(CTRL)::value, 0xf, 0xf, true));
+    };
+    using X1 = std::integral_constant<int, 0xB1>;         // quad_perm [1,0,3,2]
+    using X2 = std::integral_constant<int, 0x4E>;         // quad_perm [2,3,0,1]
+    auto stage = [&](float& a, float& b, bool up, auto CTRL) {
+      const float r = xch(up ? a : b, CTRL);
+      a = up ? r : a;
+      b = up ? b : r;
+    };
+    stage(v[0], v[1], odd, X1{});
+    stage(v[2], v[3], odd, X1{});
+    stage(v[4], v[5], odd, X1{});
+    stage(v[0], v[2], hi, X2{});
+    stage(v[1], v[3], hi, X2{});
+    const f32x4 va4 = {v[0], v[1], v[2], v[3]};
+    const f32x4 vb4 = {v[4], v[5], xch(v[4], X2{}), xch(v[5], X2{})};   // (rows 4, 5: lanes 0, 1 of a group)
+    const bool ok = q < qs_lim && !(T8_ABL & 512);
+    const unsigned qoff = (unsigned)(q - q_first) * vd_qstride;
+    if (!(T8_ABL & 4)) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, va4), rsVd, ok ? qoff + vdA_lane : 0xfffffff0u, 0u,
+                                             T4V_NT_STORE ? 2 : 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, vb4), rsVd,
+                                             ok && (lane & 3) < 2 ? qoff + vdB_lane : 0xfffffff0u, 0u, T4V_NT_STORE ? 2 : 0);
+    }
   };
 
   // ---- MFMA side (as wino43v_tn_kernel<., 4>) ----
@@ -1002,21 +1005,21 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     {
       y_in y0;
       fetch_y(0, 0, NG - 1, y0);
-      compute_y(0, y0);
+      const y_out u0 = compute_y(0, y0);
+      if (write_vd && mi == 0) vd_part(0, 0, NG - 1, y0.tq, u0);
     }
     __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
   int slot1 = 1, slot4 = 4;                                 // ring slots of steps s + 1 and s + 4
+  int turn = mtn > 1 ? 1 : 0;                               // (s + 1) % mtn: whose turn it is to write Vd for step s + 1
   for (int s = 0; s < nsteps; ++s) {
     const int abuf = s & (NA - 1), bbuf = s & 1;
     const int slot0 = slot1 == 0 ? NG - 1 : slot1 - 1;
     __builtin_amdgcn_sched_barrier(0);
     if (!(T8_ABL & 1)) issue_v(s + 3);
     if (!(T8_ABL & 2)) issue_g(s + 4, slot4);
-    if constexpr (write_vd)
-      if (!(T8_ABL & 4)) flush_vd();
     load_frag(fa0, fb0, abuf, bbuf, 0);
     load_frag(fa1, fb1, abuf, bbuf, 1);
     mfma6(fac, fbc);                                        // slice 3 of the previous step
@@ -1028,23 +1031,28 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (t < (write_vd ? 6 : 4)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      if (t < 4) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
       if (t < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
     // second half: the transform of step s + 1 beside the MFMAs of slices 1 and 2
     y_in yn;
+    y_out un = {};
     if (!(T8_ABL & 8)) fetch_y(s + 1, slot1, slot0, yn);
     load_frag(fa2, fb2, abuf, bbuf, 2);
     load_frag(fac, fbc, abuf, bbuf, 3);
     mfma6(fa1, fb1);
-    if (!(T8_ABL & 8)) compute_y(s + 1, yn);
+    if (!(T8_ABL & 8)) un = compute_y(s + 1, yn);
+    if constexpr (write_vd) {
+      if (turn == mi && s + 1 < nsteps && !(T8_ABL & 8)) vd_part(s + 1, slot1, slot0, yn.tq, un);
+      turn = turn + 1 == mtn ? 0 : turn + 1;
+    }
     mfma6(fa2, fb2);
     __builtin_amdgcn_sched_barrier(0);                      // (the closing wait would be hoisted over these MFMAs)
-    // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2); in flight: 2 x (4 pieces [+ 2 stores])
-    if constexpr (write_vd) __builtin_amdgcn_s_waitcnt(0x007c);   // vmcnt(12) lgkmcnt(0)
-    else __builtin_amdgcn_s_waitcnt(0x0078);                      // vmcnt(8) lgkmcnt(0)
+    // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2).  In flight: the 4 pieces of this step and of the
+    // one before (a Vd store among them only makes the wait reach further back)
+    __builtin_amdgcn_s_waitcnt(0x0078);                           // vmcnt(8) lgkmcnt(0)
 #if !(T8_ABL & 16)
     __builtin_amdgcn_s_barrier();
 #endif
@@ -1175,7 +1183,12 @@ extern "C" int tl_conv3_wino43v_tn(const tl_tn_params* pp, void* stream) {
     else if (bm == 128) hipLaunchKernelGGL((wino43v_tn_kernel<wvd, 4>), grid, dim3(512), 0, st, p, mt0, mtn);
     else hipLaunchKernelGGL((wino43v_tn_kernel<wvd, 2>), grid, dim3(256), 0, st, p, mt0, mtn);
   };
-  if (p.vd != nullptr) {
+  if (dma8) {
+    // one launch; with Vd its workgroups take turns at it (p.part 1 = "the Vd launch only" has nothing to do here)
+    if (p.part == 1) return TL_OK;
+    if (p.vd != nullptr) launch(std::true_type{}, 0, ntm);
+    else launch(std::false_type{}, 0, ntm);
+  } else if (p.vd != nullptr) {
     // first C_in tile: the instantiation that also writes Vd; the other tiles: the plain one.  p.part selects one of the
     // two launches (1: the Vd tile, 2: the rest) so a caller can put them on different streams; 0: both, in order
     if (p.part != 2) {

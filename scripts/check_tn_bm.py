@@ -1,6 +1,7 @@
-"""A/B of the two tilings of the V-form F(4,3) weight-gradient kernel (tonal_wino43v.hip::wino43v_tn_kernel<WVD, MW>):
-C_in tile 64 (4 waves, two workgroups per CU) against 128 (8 waves, one workgroup per CU) - same engine, same buffers.
-The two must agree bit for bit (same k order per accumulator): weight gradient, bias gradient and the Vd they write.
+"""A/B of the V-form F(4,3) weight-gradient kernels of tonal_wino43v.hip - same engine, same buffers: C_in tile 64
+(wino43v_tn_kernel<., 2>: 4 waves, two workgroups per CU), 127 (wino43v_tn_kernel<., 4>: 128-wide tile, 8 waves, Y staged
+through registers) and 128 (wino43v_tn8_kernel: 128-wide tile, the Y side by LDS-DMA, one launch whose workgroups take
+turns at Vd).  They must agree bit for bit (same k order per accumulator): weight gradient, bias gradient and the Vd.
 
     python scripts/check_tn_bm.py [--batch 4] [--channels 16] [--iters 5]
 """
@@ -71,7 +72,7 @@ if args.iters:
                 eng.stage_wgrad(st, gw, gb)
             ts = eng.timer_summary()
             eng.enable_timers(False)
-            a, b = ts[f"conv{si}_wgrad_vd"][1], ts[f"conv{si}_wgrad"][1]
+            a, b = ts.get(f"conv{si}_wgrad_vd", (0, 0.0))[1], ts[f"conv{si}_wgrad"][1]     # (bm 128: one launch)
             print(f"bm {bm:3d} conv{si}: Vd tile {a:7.3f} ms + other tiles {b:7.3f} ms = {a + b:7.3f} ms  "
                   f"{50 * fl / (a + b) / 1e9 / 157.3:.1f}% of the fp32 MFMA peak issued", flush=True)
 print("FAIL" if bad else "OK")

@@ -17,8 +17,7 @@ FAMILIES = {
     "wino43v_nt_kernel<2>": "wino43v_nt_kernel<POOL> (conv2/conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)",
     "wino43v_nt_kernel<4>": "wino43v_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd F(4,3) on the pre-transformed dZ, LDS-DMA)",
     "wino43v_nt_kernel<3>": "wino43v_nt_kernel<UNPOOL,MASK> (conv3 input gradient, Winograd F(4,3) on the pre-transformed dZ, LDS-DMA)",
-    "wino43v_tn8_kernel<false>": "wino43v_tn8_kernel<false> (conv2/conv3 weight gradient, C_in tiles 1..3 of 4, Winograd F(4,3) on V, LDS-DMA)",
-    "wino43v_tn8_kernel<true>": "wino43v_tn8_kernel<true> (conv2/conv3 weight gradient, C_in tile 0 of 4, Winograd F(4,3) on V, + writes Vd for the input gradient)",
+    "wino43v_tn8_kernel<true>": "wino43v_tn8_kernel<true> (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA; also writes Vd for the input gradient)",
     "wino43v_tn_kernel<false": "wino43v_tn_kernel<false, .> (conv2/conv3 weight gradient, the other C_in tiles, Winograd F(4,3) on V, LDS-DMA)",
     "wino43v_tn_kernel<true": "wino43v_tn_kernel<true, .> (conv2/conv3 weight gradient, C_in tile 0, + writes Vd for the input gradient)",
     "wino43_nt_kernel<1, 4": "wino43_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd F(4,3))",

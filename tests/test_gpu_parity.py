@@ -583,6 +583,47 @@ def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
             assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(3, 5, 236, (128, 128, 64)), (2, 3, 400, (128, 256, 128)), (1, 1, 44, (128, 128, 128))])
+def test_weight_gradient_tilings_agree_bit_for_bit(dev, shape):
+    """The three V-form F(4,3) weight-gradient kernels (64-wide C_in tile; 128-wide with Y staged through registers; 128-wide
+    with the Y side by LDS-DMA and the workgroups taking turns at Vd - the product path where C_in % 128 == 0 and C_out % 64
+    == 0) keep the same k order per accumulator: weight gradient, bias gradient and the Vd they write must be identical,
+    on shapes with ragged last K-steps, sequences shorter than a K-step and empty reduction splits."""
+    from decode_tonal_langauge_amd._cnn_engine import CnnEngine
+    B, C, T, (c1, c2, c3) = shape
+    defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
+    eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
+    eng.fuse_c1 = False
+    eng._alloc(B, dev)
+    eng._alloc_bwd()
+    g = torch.Generator(device=dev).manual_seed(7)
+    for k in sorted(eng.P):
+        eng.P[k].normal_(generator=g)
+    for k in sorted(eng.G):
+        eng.G[k].normal_(generator=g)
+    for k in sorted(eng.bits):
+        eng.bits[k].random_(-2**31, 2**31 - 1, generator=g)
+    for si in (2, 3):
+        st = eng.stages[si - 2]
+        assert eng._use_wino_vd(st)
+        eng.P[si - 1].view(eng.S, st.tp_in, -1)[:, st.tin:, :] = 0
+        res = {}
+        for bm in (64, 127, 128):
+            eng.tn_bm = bm
+            eng._v_ready = {}
+            if si in eng.Vd:
+                eng.Vd[si].fill_(float("nan"))
+            gw = torch.zeros(st.cout, st.cin, 3, 1, device=dev)
+            gb = torch.zeros(st.cout, device=dev)
+            eng.stage_wgrad(st, gw, gb)
+            nq = eng.S * st.tp_in // 4
+            res[bm] = (gw.clone(), gb.clone(), eng.Vd[si][:nq].clone())
+        assert bool(torch.isfinite(res[128][2]).all()) and float(res[128][0].abs().max()) > 0
+        for bm in (127, 128):
+            for a, b in zip(res[64], res[bm]):
+                assert torch.equal(a, b), (si, bm)
+
+
 def test_multi_tensor_nadam_equals_per_tensor_launches_and_torch(dev):
     """tl_nadam_multi (one launch for a parameter list) is bit-identical to one tl_nadam launch per tensor and
     follows torch.optim.NAdam (reference models/synthesis_trainer.py:131-137): sizes below / above a chunk,
