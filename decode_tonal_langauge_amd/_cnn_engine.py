@@ -455,7 +455,9 @@ class CnnEngine:
             # in step - measured HBM-side reads per conv2 launch 64.6 GB at 4 rounds, 31.4 GB at 16, 27.4 GB
             # (+ 3.2 GB of slab reduction) at 64; the time is the same (50.3 - 51.1 ms)
             tiles = ((st.cin + 63) // 64) * ((nd + 63) // 64)
-            sk = self._splitk(tiles, (rows_in + 31) // 32, int(os.environ.get("TONAL_TN_TARGET", "8192")))
+            # (the 8-wave kernel, one workgroup per CU: 8 rounds of 256 measure 0.3 ms better at conv2 than 16 - 42.2 / 42.55 ms)
+            tn8 = self._use_wino_v(st) and self._tn_bm(st) == 128
+            sk = self._splitk(tiles, (rows_in + 31) // 32, int(os.environ.get("TONAL_TN_TARGET", "4096" if tn8 else "8192")))
             slab = torch.empty(sk, 6 * st.cin, ldg, **f32)
             bias_part = torch.empty(sk, nd, **f32)     # the kernel's Y1 = sum of the quad's dZ rows doubles as the bias gradient
             kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=rows_in, B_rows=Gs.shape[0],
