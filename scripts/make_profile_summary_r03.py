@@ -16,7 +16,7 @@ out = ["# Round 3 - C3 train step, 1x MI355X, rocprofv3 --kernel-trace --stats (
        f"4 train steps (1 warm-up incl. the one-time zero-fills of the activation / V buffers + 3 timed) of SynthesisModelCNN 128ch x 400t, batch 256, "
        f"fp32.  Total kernel time {tot/1e6:.1f} ms = {tot/1e6/4:.1f} ms/step (the one-time fills are ~14 ms of it); un-profiled default run "
        f"(`python bench.py --steps 20 --warmup 5`) {line['ms_per_step']:.1f} ms/step = {line['value']:.0f} mel-frames/s (`r03_c3_bench_line.log`; "
-       f"other boxes of the pool: 241.8 - 246.5 ms): the stream is never idle.\n",
+       f"the boxes of the pool differ by up to 3 %): the stream is never idle.\n",
        "| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|"]
 for r in rows[:26]:
     out.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.1f} |")
@@ -24,9 +24,9 @@ out.append("")
 out.append("Kernel names: `wino43v_nt_kernel<2>` = <POOL>: conv2 / conv3 forward, Winograd F(4,3) on the pre-transformed input V (both operands by "
            "LDS-DMA) + bias + LeakyReLU + max-pool + arg-max and sign bits; `wino43v_nt_kernel<3>` = <MASK>: conv3 input gradient on Vd (the "
            "transformed un-pooled dZ); `wino43v_nt_kernel<4>` = <C1WGRAD>: conv2 input gradient on Vd whose epilogue contracts the result with the "
-           "raw signal into the conv1 weight gradient (G1 is never stored); `wino43v_tn_kernel<false>`: conv2 / conv3 weight gradient, C_in tiles "
-           "1..7 of 8 (V by LDS-DMA, Y transformed at staging); `wino43v_tn_kernel<true>`: C_in tile 0 of the same op, which also writes Vd for the "
-           "input gradient; `conv1_fwd_vq_kernel`: conv1 + LeakyReLU + pool writing V1 (P1 is not stored); `wino43_xform_kernel`: P2 -> V2; "
+           "raw signal into the conv1 weight gradient (G1 is never stored); `wino43v_tn8_kernel<true>`: conv2 / conv3 weight gradient, 128 x 64 tile, "
+           "V, the pooled gradient rows and their arg-max words by LDS-DMA, one launch whose workgroups take turns at writing Vd for the input "
+           "gradient; `conv1_fwd_vq_kernel`: conv1 + LeakyReLU + pool writing V1 (P1 is not stored); `wino43_xform_kernel`: P2 -> V2; "
            "`nt_window_kernel<128,...>` / `tn_window_kernel<.>`: direct-form MFMA kernels for conv4, conv5, the 1x1 stack and the Linear layer; "
            "`nt_window_kernel<32, 0, 0>` / `tn_skinny_kernel`: the h.W_hh^T / dgates.W_hh passes over the 5.4 GB LSTM weight; "
            "`nadam_lowrank_kernel`: NAdam on that weight from its gradient factors.\n")
@@ -41,12 +41,14 @@ out.append("| kernel | read GB | write GB | algorithmic GB read / written |\n|--
 alg = {"<POOL>": "V (20.1 + 9.9) / 2 = 15.0 / pooled output (6.6 + 3.3) / 2 + bits = 5.3",
        "C1WGRAD": "Vd2 19.7 + bit words 1.0 + x 0.05 = 20.8 / partial sums 0.1",
        "UNPOOL,MASK": "Vd3 9.9 + bits 0.2 = 10.1 / G2 6.6",
-       "tn_kernel<false>": "7/8 of V (15.0) + G (6.6 + 3.3) / 2 + bits = 18.3 / split-K slabs 0.7",
-       "tn_kernel<true>": "1/8 of V 1.9 + G 5.0 + bits = 7.0 / Vd (19.7 + 9.9) / 2 = 14.8 + slabs 0.1"}
+       "tn8_kernel<true>": "V 15.0 + G (6.6 + 3.3) / 2 + bits = 20.4 / Vd (19.7 + 9.9) / 2 = 14.8 + split-K slabs 0.4",
+       "tn_kernel<false": "(64-wide tile, not the default) 7/8 of V (15.0) + G (6.6 + 3.3) / 2 + bits = 18.3 / split-K slabs 0.7",
+       "tn_kernel<true": "(64-wide tile, not the default) 1/8 of V 1.9 + G 5.0 + bits = 7.0 / Vd (19.7 + 9.9) / 2 = 14.8 + slabs 0.1"}
 for k, v in tr.items():
     key = [a for a in alg if a in k]
     out.append(f"| {k} | {v['read_bytes']/1e9:.1f} | {v['write_bytes']/1e9:.1f} | {alg[key[0]] if key else ''} |")
-out.append("\nThe NT kernels fetch about 2 x their algorithmic bytes (the six taps of a stage, 6.3 MB, thrash the 4 MB L2 of an XCD beside the streaming "
+out.append("\nThe weight-gradient kernel reads its algorithmic minimum (the four C_in tiles of a (split, C_out tile) share the gradient rows through the "
+           "L2).  The NT kernels fetch about 2 x their algorithmic bytes (the six taps of a stage, 6.3 MB, thrash the 4 MB L2 of an XCD beside the streaming "
            "operand - attribution in `r02_kernel_notes.md` section 4); writes are at the algorithmic minimum.  Ablations, SQ counters and the variants "
            "tried this round: `r03_kernel_notes.md`.")
 open(P("r03_c3_step_summary.md"), "w").write("\n".join(out) + "\n")
