@@ -67,6 +67,69 @@ __global__ __launch_bounds__(256) void gauss_envelope_kernel(const void* __restr
   }
 }
 
+// The same bank with the kernel's Hermitian symmetry used (the reference's per-band DFT multiplier is real, so
+// h_b[-n] = conj(h_b[n])): y = h[0] x[t] + sum_{n>0} Re h[n] (x[t-n] + x[t+n]) + i Im h[n] (x[t-n] - x[t+n]).  The sum and
+// the difference of a sample pair are formed once for all bands: 2 adds + 2 NB FMAs per pair and sample instead of 4 NB
+// FMAs (0.56 x the fp64 operations at NB = 8).  taps: (NB, half + 1, 2) = Re / Im of h_b[n], n = 0..half.
+template <typename TIN, int NB>
+__global__ __launch_bounds__(256) void gauss_envelope_sym_kernel(const void* __restrict__ x, const double* __restrict__ taps,
+                                                                 double* __restrict__ y, long long T, int half, int envelope) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];
+  const int c = blockIdx.y;
+  const long long t0 = (long long)blockIdx.x * SIG_TB;
+  const int win = SIG_TB + 2 * half;
+  // xs[i] = x[(t0 - half + i) mod T]
+  long long base = (t0 - half) % T;
+  if (base < 0) base += T;
+  for (int i = threadIdx.x; i < win; i += blockDim.x) xs[i] = ld_as_f64<TIN>(x, (long long)c * T + (base + i) % T);
+  __syncthreads();
+  const int nt1 = half + 1;
+  double re[SIG_SPT][NB], im[SIG_SPT][NB];
+  {
+    double xv[SIG_SPT];
+#pragma unroll
+    for (int s = 0; s < SIG_SPT; ++s) xv[s] = xs[threadIdx.x + s * 256 + half];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double hr = taps[(long long)b * nt1 * 2], hi = taps[(long long)b * nt1 * 2 + 1];
+#pragma unroll
+      for (int s = 0; s < SIG_SPT; ++s) {
+        re[s][b] = hr * xv[s];
+        im[s][b] = hi * xv[s];
+      }
+    }
+  }
+  for (int n = 1; n <= half; ++n) {
+    double sm[SIG_SPT], df[SIG_SPT];
+#pragma unroll
+    for (int s = 0; s < SIG_SPT; ++s) {
+      const double xm = xs[threadIdx.x + s * 256 + half - n], xp = xs[threadIdx.x + s * 256 + half + n];
+      sm[s] = xm + xp;
+      df[s] = xm - xp;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const double hr = taps[((long long)b * nt1 + n) * 2];
+      const double hi = taps[((long long)b * nt1 + n) * 2 + 1];
+#pragma unroll
+      for (int s = 0; s < SIG_SPT; ++s) {
+        re[s][b] = fma(hr, sm[s], re[s][b]);
+        im[s][b] = fma(hi, df[s], im[s][b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SIG_SPT; ++s) {
+    const long long t = t0 + threadIdx.x + s * 256;
+    if (t < T) {
+      double acc = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc += envelope ? sqrt(re[s][b] * re[s][b] + im[s][b] * im[s][b]) : re[s][b];
+      y[(long long)c * T + t] = acc / NB;
+    }
+  }
+}
+
 // generic band count (slow path): loops bands outermost, one band at a time
 template <typename TIN>
 __global__ __launch_bounds__(256) void gauss_envelope_generic_kernel(const void* __restrict__ x,
@@ -298,6 +361,24 @@ extern "C" int tl_gauss_envelope(const void* x, int x_is_f64, const double* taps
   if (x_is_f64) GE_LAUNCH(double); else GE_LAUNCH(float);
 #undef GE_LAUNCH
   return check_launch("gauss_envelope");
+}
+
+// Hermitian form of tl_gauss_envelope for 8 bands: taps (8, half + 1, 2) = h_b[n], n = 0..half; h_b[-n] = conj(h_b[n]) is implied
+extern "C" int tl_gauss_envelope_sym(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T, int nb,
+                                     int half, int envelope, void* stream) {
+  TL_REQUIRE(x && taps && y, "gauss_envelope_sym: null pointer");
+  TL_REQUIRE(C > 0 && C <= 65535 && T > 0, "gauss_envelope_sym: bad sizes");
+  TL_REQUIRE(nb == 8, "gauss_envelope_sym: 8 bands only (use tl_gauss_envelope)");
+  TL_REQUIRE(half >= 0 && 2LL * half + 1 <= T, "gauss_envelope_sym: 2 half + 1 taps must fit the recording");
+  const size_t lds = (size_t)(SIG_TB + 2 * half) * sizeof(double);
+  TL_REQUIRE(lds <= 64 * 1024, "gauss_envelope_sym: %d taps exceed the LDS window", 2 * half + 1);
+  dim3 grid((unsigned)((T + SIG_TB - 1) / SIG_TB), (unsigned)C);
+  hipStream_t st = (hipStream_t)stream;
+  if (x_is_f64)
+    hipLaunchKernelGGL((gauss_envelope_sym_kernel<double, 8>), grid, dim3(256), lds, st, x, taps, y, (long long)T, half, envelope);
+  else
+    hipLaunchKernelGGL((gauss_envelope_sym_kernel<float, 8>), grid, dim3(256), lds, st, x, taps, y, (long long)T, half, envelope);
+  return check_launch("gauss_envelope_sym");
 }
 
 extern "C" int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, const double* a, const double* zi,

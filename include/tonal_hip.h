@@ -329,6 +329,11 @@ int tl_lite_uncat_dev(const float* dfeat, float* dy2, float* dh, int B, int F, i
  * mean_b |sum_n h_b[n] x[(t-n) mod T]| (envelope != 0) or the mean of the real parts.        */
 int tl_gauss_envelope(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T,
                       int nb, int ntap, int half, int envelope, void* stream);
+/* The same bank through the kernel's Hermitian symmetry (the reference's per-band DFT multiplier is real:
+ * h_b[-n] = conj(h_b[n]), frequency_filter.py:155-175): taps (8, half + 1, 2) = Re / Im of h_b[n], n = 0..half; 0.56 x
+ * the fp64 operations of tl_gauss_envelope.  8 bands, 2 half + 1 <= T taps within the LDS window.                   */
+int tl_gauss_envelope_sym(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T, int nb, int half,
+                          int envelope, void* stream);
 /* The same bank evaluated in the DFT domain exactly as the reference writes it (frequency_filter.py:155-184):
  * X = DFT(x), z_b = IDFT(X . K_b), y = mean_b |z_b| (envelope) or mean_b Re z_b.  Arbitrary T (Bluestein chirp-z
  * over radix-2 Stockham passes, fp64).  kernels (nb, T) real = H_b x analytic multiplier; w (T,2) chirp, bf (m2,2) FFT

@@ -171,6 +171,14 @@ def test_signal_filters_match_reference_golden(dev):
     hil = ff.hilbert_filter(x, 400, freq_ranges=[70., 150.])
     assert hil.dtype == np.float64 and rel(hil, g["hilbert"]) < 1e-9
     assert rel(ff.hilbert_filter(x, 400, freq_ranges=[70., 150.], envelope=False), g["hilbert_real"]) < 1e-9
+    # 8 bands with truncated kernels take the Hermitian-symmetry kernel (tl_gauss_envelope_sym); the plain bank
+    # (tl_gauss_envelope) must give the same numbers far below the golden tolerance
+    os.environ["TONAL_HILBERT_SYM"] = "0"
+    try:
+        plain = ff.hilbert_filter(x, 400, freq_ranges=[70., 150.])
+    finally:
+        os.environ.pop("TONAL_HILBERT_SYM", None)
+    assert rel(plain, g["hilbert"]) < 1e-9 and rel(hil, plain) < 1e-13
     assert rel(ff.butter_filter(x, [0.3, 100], 400), g["butter"]) < 1e-9
     assert rel(ff.butter_filter(x, [0.3, 100], 400, causal=True), g["butter_causal"]) < 1e-9
     assert rel(ff.fir_bandpass_filter(x, 400, 390, [100.]), g["fir"]) < 1e-9
