@@ -1190,6 +1190,80 @@ extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
   return p.bm == 128 ? dispatch_nt<128>(p, st) : dispatch_nt<32>(p, st);
 }
 
+namespace tl {
+// Short reductions (a few hundred rows: the weight gradients of SynthesisLite's Linear / LSTM layers at batch 64): the MFMA
+// kernels' 128 x 128 tiles leave a handful of workgroups with a short K loop of dependent latency (17 - 30 us).  Here a
+// workgroup takes a 32 x 128 tile and walks the rows in chunks of 64: one round of loads per chunk (issued before the
+// arithmetic of the chunk in front of it, 40 KB of LDS), plain FMAs on a 4 x 4 patch per thread, rows in order
+// (deterministic); masked rows ((R % Tp) >= Tvalid) are zero-filled, not read.
+constexpr int TS_K = 64, TS_M = 32, TS_N = 128;
+__global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
+  __shared__ __attribute__((aligned(16))) float As[TS_K * TS_M];
+  __shared__ __attribute__((aligned(16))) float Bs[TS_K * TS_N];
+  const int tid = threadIdx.x, tn = tid & 31, tm = tid >> 5;
+  const int ntn = (p.Ndim + TS_N - 1) / TS_N;
+  const int mt = (int)(blockIdx.x / ntn) * TS_M, nt = (int)(blockIdx.x % ntn) * TS_N;
+  const int kr = (int)(p.Krows < p.A_rows ? (p.Krows < p.B_rows ? p.Krows : p.B_rows) : (p.A_rows < p.B_rows ? p.A_rows : p.B_rows));
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // a chunk: A 64 rows x 8 float4, B 64 rows x 32 float4 (Mdim, Ndim % 4 == 0: a float4 is whole or absent)
+  f32x4 ra[2], rb[8];
+  // (every load is issued, from a clamped address, and zeroed afterwards: predicated loads come out as one exec-masked
+  // region each, with the latencies in series)
+  int ta[2], tb[8];                                          // (row offset in the chunk) % Tp: the division is done once
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ta[i] = ((tid + i * 256) >> 3) % p.Tp;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tb[i] = ((tid + i * 256) >> 5) % p.Tp;
+  const int kstep_mod = TS_K % p.Tp;
+  int r0m = 0;                                               // r0 % Tp of the chunk being fetched
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256, R = r0 + (idx >> 3), c = mt + (idx & 7) * 4;
+      int t = ta[i] + r0m;
+      t = t >= p.Tp ? t - p.Tp : t;
+      const bool ok = R < kr && t < p.Tvalid && c < p.Mdim;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.A + (long long)(R < kr ? R : kr - 1) * p.lda + (c < p.Mdim ? c : p.Mdim - 4));
+      ra[i] = ok ? v : zero;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + i * 256, R = r0 + (idx >> 5), c = nt + (idx & 31) * 4;
+      int t = tb[i] + r0m;
+      t = t >= p.Tp ? t - p.Tp : t;
+      const bool ok = R < kr && t < p.Tvalid && c < p.Ndim;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.B + (long long)(R < kr ? R : kr - 1) * p.ldb + (c < p.Ndim ? c : p.Ndim - 4));
+      rb[i] = ok ? v : zero;
+    }
+    r0m += kstep_mod;
+    r0m = r0m >= p.Tp ? r0m - p.Tp : r0m;
+  };
+  f32x4 acc[4] = {zero, zero, zero, zero};
+  fetch(0);
+  for (int r0 = 0; r0 < kr; r0 += TS_K) {
+    __syncthreads();                                       // the chunk in front has been consumed
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(As + ((tid + i * 256) >> 3) * TS_M + ((tid + i * 256) & 7) * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Bs + ((tid + i * 256) >> 5) * TS_N + ((tid + i * 256) & 31) * 4) = rb[i];
+    __syncthreads();
+    if (r0 + TS_K < kr) fetch(r0 + TS_K);
+#pragma unroll 8
+    for (int R = 0; R < TS_K; ++R) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(As + R * TS_M + tm * 4);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(Bs + R * TS_N + tn * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += av[i] * bv;
+    }
+  }
+  const int m0 = mt + tm * 4, n0 = nt + tn * 4;
+  if (m0 < p.Mdim && n0 < p.Ndim) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(p.slab + (long long)(m0 + i) * p.ldc + n0) = acc[i];
+  }
+}
+}  // namespace tl
+
 extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
   using namespace tl;
   TL_REQUIRE(pp != nullptr, "tn_window: null params");
@@ -1208,6 +1282,12 @@ extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
     TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim, "tn_window: bbits row too short");
   }
   hipStream_t st = (hipStream_t)stream;
+  if (p.J == 1 && p.loader == LOAD_DIRECT && p.splitk == 1 && p.Krows <= 8 * TS_K && (long long)p.Mdim * p.Ndim <= (1 << 20) &&
+      p.ldc % 4 == 0) {                                             // short reduction, small output: latency-bound
+    const long long nwg = (long long)((p.Mdim + TS_M - 1) / TS_M) * ((p.Ndim + TS_N - 1) / TS_N);
+    hipLaunchKernelGGL(tn_short_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+    return check_launch("tn_short");
+  }
   if (p.Mdim <= 32 && p.J == 1 && p.loader == LOAD_DIRECT) {       // skinny-M streaming variant
     dim3 grid((unsigned)((p.Ndim + SK_BN - 1) / SK_BN), (unsigned)p.splitk, 1);
     hipLaunchKernelGGL(tn_skinny_kernel, grid, dim3(256), 0, st, p);

@@ -726,10 +726,10 @@ __global__ __launch_bounds__(256) void concat_dh_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------
 // L1 loss gradient + L1 / MCD statistics: one workgroup, thread per row, fixed-order reduction
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void l1_mcd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+__global__ __launch_bounds__(1024) void l1_mcd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                      float* __restrict__ dout, float* __restrict__ stats, int B, int D,
                                                      int ldd, int trunc_targets, float grad_scale) {
-  __shared__ float s1[256], s2[256];
+  __shared__ float s1[1024], s2[1024];    // (16 waves: a batch of 64 rows is four dependent rounds of loads, not sixteen)
   float l1 = 0.f, mcd = 0.f;
   const float gs = grad_scale / ((float)B * (float)D);
   // a wave per row, lanes across the D outputs (coalesced), a shuffle tree per row: the row sums are formed in a
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void l1_mcd_kernel(const float* __restrict__ o
   s1[threadIdx.x] = l1;
   s2[threadIdx.x] = mcd;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = 512; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) {
       s1[threadIdx.x] += s1[threadIdx.x + off];
       s2[threadIdx.x] += s2[threadIdx.x + off];
@@ -1186,7 +1186,7 @@ extern "C" int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int
 extern "C" int tl_l1_mcd(const float* out, const float* targets, float* dout, float* stats, int B, int D, int ldd,
                          int trunc_targets, float grad_scale, void* stream) {
   TL_REQUIRE(out && targets && stats && B > 0 && D > 0 && ldd >= D, "l1_mcd: bad arguments");
-  hipLaunchKernelGGL(l1_mcd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, targets, dout, stats, B, D, ldd,
+  hipLaunchKernelGGL(l1_mcd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, out, targets, dout, stats, B, D, ldd,
                      trunc_targets, grad_scale);
   return check_launch("l1_mcd");
 }
