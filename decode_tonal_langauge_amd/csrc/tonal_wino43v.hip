@@ -147,6 +147,9 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 #ifndef V4_STAGGER
 #define V4_STAGGER 0      // 1: waves 4-7 issue their LDS-DMA pieces in the second half of a K-step (see kstep)
 #endif
+#ifndef V4_PERSIST
+#define V4_PERSIST 1      // workgroups per CU of the persistent launch (the next tile's first fetch overlaps the epilogue); 0:
+#endif                    // one workgroup per tile, as before
 #ifndef V4_SCHED
 #define V4_SCHED 1        // 1: hand-specified issue order of a K-step (see kstep)
 #endif
@@ -170,66 +173,74 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
   const int ntn = (p.N + V4_BN - 1) / V4_BN;
   const long long ntm = (p.M + 4 * V4_BQ - 1) / (4 * V4_BQ);
   const long long nwg = ntm * ntn;
-  long long bid = blockIdx.x;
-  {
-    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-  }
-  const long long tm = bid / ntn;
-  const int tn = (int)(bid % ntn);
-  const long long R0 = tm * (4 * V4_BQ);
-  const long long Qt = tm * V4_BQ;                         // first quad of the tile
-  const int n0 = tn * V4_BN;
   const int nsteps = p.K / V4_BK;                          // host-checked: K % 16 == 0, K >= 16
-
   f32x16 acc[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
   // ---- LDS-DMA plan.  Piece = 16 rows x 64 B; lane -> (row = lane >> 2, physical chunk = lane & 3); the
   // source chunk is the swizzled one, chunk ^ ((row >> 2) & 3) with row % 16 == lane >> 2.
   const int prow = lane >> 2;
   const int src_chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  // A pieces of this wave: pa = 6 wave + t -> (transform i = pa >> 3, 16-quad block j = pa & 7).  Quads past the
-  // end of V are clamped (they only feed rows the epilogue masks).
-  const long long q_left = p.A_rows - Qt;                  // quads addressable from the tile start (> 0)
-  const long long a_span = q_left * 6 * (long long)p.lda * 4;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.A + Qt * 6 * (long long)p.lda), 0, (int)(a_span < 0x7fffffffLL ? a_span : 0x7fffffffLL), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.Bw, 0, (int)(6LL * p.N * p.ldb * 4), 0x00020000);
-  unsigned avoff[6], bvoff[3];
   unsigned adst[6], bdst[3];
 #pragma unroll
-  for (int t = 0; t < 6; ++t) {
-    const int pa = wave * 6 + t;
-    const int i = pa >> 3, j = pa & 7;
-    long long ql = j * 16 + prow;
-    if (ql > q_left - 1) ql = q_left - 1;
-    avoff[t] = (unsigned)(((ql * 6 + i) * p.lda + src_chunk * 4) * 4);
-    adst[t] = (unsigned)((i * V4_BQ + j * 16) * V4_ROWB);
-  }
+  for (int t = 0; t < 6; ++t) adst[t] = (unsigned)((((wave * 6 + t) >> 3) * V4_BQ + ((wave * 6 + t) & 7) * 16) * V4_ROWB);
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int pb = wave * 3 + t;
-    const int i = pb >> 2, j = pb & 3;
-    int n = n0 + j * 16 + prow;
-    if (n > p.N - 1) n = p.N - 1;                          // clamped columns are masked by the epilogue
-    bvoff[t] = (unsigned)((((long long)i * p.N + n) * p.ldb + src_chunk * 4) * 4);
-    bdst[t] = (unsigned)(V4_A_BYTES + (i * V4_BN + j * 16) * V4_ROWB);
-  }
-  auto issue = [&](int step) {
+  for (int t = 0; t < 3; ++t) bdst[t] = (unsigned)(V4_A_BYTES + (((wave * 3 + t) >> 2) * V4_BN + ((wave * 3 + t) & 3) * 16) * V4_ROWB);
+  // A workgroup walks the tiles blockIdx.x, + gridDim.x, ... (the host launches one workgroup per CU, a multiple of 8: a
+  // tile sequence stays on one XCD) and fetches the first K-step of its next tile BEFORE the epilogue of the current one:
+  // the epilogue (5 % of a tile) then runs beside that fetch instead of in front of it.
+  struct tile_t {
+    long long tm, R0;
+    int n0;
+    __amdgpu_buffer_rsrc_t rsA;
+    unsigned avoff[6], bvoff[3];
+  };
+  auto setup = [&](long long bid) -> tile_t {
+    {
+      const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+      bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    tile_t t;
+    t.tm = bid / ntn;
+    t.R0 = t.tm * (4 * V4_BQ);
+    t.n0 = (int)(bid % ntn) * V4_BN;
+    const long long Qt = t.tm * V4_BQ;                     // first quad of the tile
+    // A pieces of this wave: pa = 6 wave + t -> (transform i = pa >> 3, 16-quad block j = pa & 7).  Quads past the
+    // end of V are clamped (they only feed rows the epilogue masks).
+    const long long q_left = p.A_rows - Qt;                // quads addressable from the tile start (> 0)
+    const long long a_span = q_left * 6 * (long long)p.lda * 4;
+    t.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + Qt * 6 * (long long)p.lda), 0,
+                                              (int)(a_span < 0x7fffffffLL ? a_span : 0x7fffffffLL), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int pa = wave * 6 + k;
+      const int i = pa >> 3, j = pa & 7;
+      long long ql = j * 16 + prow;
+      if (ql > q_left - 1) ql = q_left - 1;
+      t.avoff[k] = (unsigned)(((ql * 6 + i) * p.lda + src_chunk * 4) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int pb = wave * 3 + k;
+      const int i = pb >> 2, j = pb & 3;
+      int n = t.n0 + j * 16 + prow;
+      if (n > p.N - 1) n = p.N - 1;                        // clamped columns are masked by the epilogue
+      t.bvoff[k] = (unsigned)((((long long)i * p.N + n) * p.ldb + src_chunk * 4) * 4);
+    }
+    return t;
+  };
+  tile_t cur = setup(blockIdx.x);
+  auto issue = [&](const tile_t& tl_, int step) {
     char* base = lds + (step & 1) * V4_STAGE;
     const unsigned soff = (unsigned)step * (V4_BK * 4);
     if (!(V4_ABL & 64) || step < 2) {
 #pragma unroll
-      for (int t = 0; t < 6; ++t) dma16(rsA, base + adst[t], avoff[t], soff);
+      for (int t = 0; t < 6; ++t) dma16(tl_.rsA, base + adst[t], tl_.avoff[t], soff);
     }
     if (!(V4_ABL & 128) || step < 2) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t) dma16(rsB, base + bdst[t], bvoff[t], soff);
+      for (int t = 0; t < 3; ++t) dma16(rsB, base + bdst[t], tl_.bvoff[t], soff);
     }
   };
 
@@ -253,18 +264,12 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
 #pragma unroll
       for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[i][q], acc[i], 0, 0, 0);
   };
-#pragma unroll
-  for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // carried k-group of step -1: adds nothing
-
-  issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  issue(cur, 0);
   auto kstep = [&](auto LAST, auto LATE, int s) {
     const int stage = s & 1;
     if (!(V4_ABL & 16) || s == 0) load_frag(fa0, fb0, stage, c_g0);
     if constexpr (!decltype(LAST)::value)
-      if (!(V4_ABL & 1) || s == 0) issue(s + 1);            // the other stage was released at the last barrier
+      if (!(V4_ABL & 1) || s == 0) issue(cur, s + 1);       // the other stage was released at the last barrier
     mfma_group(fa1, fb1);                                   // k-group 1 of the previous step (registers)
     if (!(V4_ABL & 16) || s == 0) load_frag(fa1, fb1, stage, c_g1);
     mfma_group(fa0, fb0);
@@ -309,32 +314,59 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
       asm volatile("" ::: "memory");
     }
   };
-#if V4_STAGGER
-  if (wave >= 4) {
-    for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::true_type{}, s);
-  } else
-#endif
-  {
-    for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::false_type{}, s);
-  }
-  kstep(std::true_type{}, std::false_type{}, nsteps - 1);
-  mfma_group(fa1, fb1);
-
-#if V4_ABL & 2
-  {
-    float t = 0.f;
+  for (long long vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) t += acc[i][e];
-    if (t == 12345.678f) p.out[tid] = t;
-    return;
-  }
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // carried k-group of step -1: adds nothing
+    // stage 0 of this tile has landed (so have the stores of the epilogue in front of it), every wave is past that epilogue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#if V4_STAGGER
+    if (wave >= 4) {
+      for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::true_type{}, s);
+    } else
 #endif
-  // ---- epilogue (shared with the in-loop-transform kernels, tonal_wino43_epi.h): the four conv rows of a quad from its
-  // six products, then pool / mask / fused first-stage weight gradient ----
-  if constexpr (EPI == W_EPI_C1W) __syncthreads();        // its reduction reuses the LDS other waves may still be reading
-  wino43_epilogue<EPI>(p, acc, reinterpret_cast<float*>(lds), R0, n0, wm, wn, lr, lh, tm);
+    {
+      for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::false_type{}, s);
+    }
+    kstep(std::true_type{}, std::false_type{}, nsteps - 1);
+    mfma_group(fa1, fb1);
+
+#if V4_ABL & 2
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[i][e];
+      if (t == 12345.678f) p.out[tid] = t;
+      return;
+    }
+#endif
+    // the first K-step of the next tile goes into stage 0 - last read in step nsteps - 2 when nsteps is even, and every
+    // wave is past that step's closing barrier; the last step's stage is still being read by slower waves
+    const tile_t done = cur;
+    const long long nb = vb + gridDim.x;
+    if (V4_PERSIST && nb < nwg) {
+      if (nsteps & 1) __syncthreads();
+      cur = setup(nb);
+      issue(cur, 0);
+    }
+    // ---- epilogue (shared with the in-loop-transform kernels, tonal_wino43_epi.h): the four conv rows of a quad from
+    // its six products, then pool / mask / fused first-stage weight gradient.  The reduction of the fused weight gradient
+    // takes the LAST step's stage as its scratch (behind a barrier: other waves may still be reading it) ----
+    if constexpr (EPI == W_EPI_C1W) __syncthreads();
+    wino43_epilogue<EPI>(p, acc, reinterpret_cast<float*>(lds + ((nsteps - 1) & 1) * V4_STAGE), done.R0, done.n0, wm, wn, lr, lh, done.tm);
+    if (!V4_PERSIST && nb < nwg) {                         // (no prefetch: plain sequence of tiles)
+      __syncthreads();
+      cur = setup(nb);
+      issue(cur, 0);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1120,20 +1152,25 @@ extern "C" int tl_conv3_wino43v_nt(const tl_nt_params* pp, void* stream) {
   const long long nwg = ((p.M + 4 * V4_BQ - 1) / (4 * V4_BQ)) * ((p.N + V4_BN - 1) / V4_BN);
   TL_REQUIRE(nwg < (1LL << 31), "wino43v_nt: grid too large");
   hipStream_t st = (hipStream_t)stream;
+#if V4_PERSIST
+  const long long ngrid = nwg < 256 * V4_PERSIST ? nwg : 256 * V4_PERSIST;      // one workgroup per CU (144 KB of LDS each)
+#else
+  const long long ngrid = nwg;
+#endif
   if (p.epilogue == W_EPI_POOL) {
     TL_REQUIRE(p.row_shift == 0 && p.out && p.ldo >= p.N, "wino43v_nt: forward needs row_shift 0 and an output");
     TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino43v_nt: POOL needs obits and an even Tvalid");
     TL_REQUIRE(p.N % 32 == 0 && p.ld_obits * 32 >= p.N, "wino43v_nt: POOL needs N %% 32 == 0");
-    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_POOL>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_POOL>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
   } else if (p.epilogue == W_EPI_MASK) {
     TL_REQUIRE(p.row_shift == -2 && p.ldo >= p.N, "wino43v_nt: input gradient needs row_shift -2");
     TL_REQUIRE(p.aux != nullptr || p.auxbits != nullptr, "wino43v_nt: MASK needs aux or auxbits");
-    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_MASK>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_MASK>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
   } else if (p.epilogue == W_EPI_C1W) {
     TL_REQUIRE(p.row_shift == -2, "wino43v_nt: input gradient needs row_shift -2");
     TL_REQUIRE(p.auxbits && p.c1x && p.c1bits && p.c1partial, "wino43v_nt: epilogue 4 needs auxbits, c1x, c1bits, c1partial");
     TL_REQUIRE(p.c1kt >= 1 && p.c1kt <= 3 && p.c1T >= 2 * p.Tvalid + 2, "wino43v_nt: epilogue 4: 1..3 taps, c1T >= 2*Tvalid + 2");
-    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_C1W>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_C1W>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
   } else {
     set_error("wino43v_nt: unsupported epilogue %d", p.epilogue);
     return TL_EINVAL;

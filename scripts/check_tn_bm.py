@@ -7,6 +7,7 @@ turns at Vd).  They must agree bit for bit (same k order per accumulator): weigh
 """
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("TONAL_TN_TARGET", "4096")     # the same reduction splits for every tiling (bit-identity needs that)
 import torch
 from decode_tonal_langauge_amd._cnn_engine import CnnEngine
 
