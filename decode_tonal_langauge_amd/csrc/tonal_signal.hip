@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256) void gauss_envelope_generic_kernel(const void*
 // |p| = 0.998 and an fp32 recurrence diverges.
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_TAPS = 17;
+#ifndef FF_LANES8
+#define FF_LANES8 1       // filtfilt with ntaps <= 9: the state over 8 lanes per channel (0: one lane per channel)
+#endif
 
 template <typename TIN>
 __device__ __forceinline__ double ext_sample(const void* x, long long cbase, long long T, int edge, long long i) {
@@ -256,6 +259,82 @@ __global__ __launch_bounds__(64) void filtfilt_iir_kernel(const double* __restri
 #pragma unroll
       for (int k = 0; k < NT - 1; ++k) z[k] = (z[k + 1] + xs * bb[k + 1]) - yv * aa[k + 1];
       out[(first + dir * n) * C] = yv;
+    }
+  }
+}
+
+// The same recurrence with the STATE spread over lanes (ntaps <= 9): lane = 8 x channel + k holds z_k of its channel, a
+// wave 8 channels.  One lane per channel leaves 4 wavefronts on the chip for 256 channels, each issuing the ~34 dependent
+// fp64 operations of a sample back to back (214 cycles per sample); here a sample is the output y = z_0 + b_0 x in the
+// k = 0 lanes, its broadcast over the 8 lanes of the channel (two DPP moves per 32-bit half), the shift z_{k+1} -> lane k
+// (one DPP move per half), and ONE state update per lane - the same operations in the same order on every element as
+// scipy's loop (the file is compiled without FMA contraction), so the result stays bit-identical to it.  Parallel in time
+// it cannot be: the reference's (b, a) form is a rounding trajectory, not a well-conditioned function.
+__device__ __forceinline__ double dpp_bcast8(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false);          // quad_perm [0,0,0,0]
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xf, 0xa, false);         // row_shr:4 into lanes 4-7, 12-15 of a row
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xf, 0xa, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_shl1(double v) {                       // lane i <- lane i + 1 (0 past the row)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(64) void filtfilt_iir8_kernel(const double* __restrict__ b, const double* __restrict__ a,
+                                                           const double* __restrict__ zi, double* __restrict__ work, int C,
+                                                           long long next, int ntaps) {
+  const int lane = threadIdx.x, k = lane & 7;
+  const int ch = blockIdx.x * 8 + (lane >> 3);
+  const bool live = ch < C;
+  const int chc = live ? ch : C - 1;
+  const double b0 = b[0];
+  const double bk = k + 1 < ntaps ? b[k + 1] : 0.0, ak = k + 1 < ntaps ? a[k + 1] : 0.0;
+  const double zik = k < ntaps - 1 ? zi[k] : 0.0;
+  constexpr int U = 8;                                      // = lanes per channel: lane k stores sample k of a chunk
+  for (int pass = 0; pass < 2; ++pass) {
+    const double* __restrict__ in = work + (long long)pass * next * C + chc;
+    double* __restrict__ out = work + (long long)(1 - pass) * next * C + chc;
+    const long long first = pass == 0 ? 0 : next - 1;
+    const long long dir = pass == 0 ? 1 : -1;
+    double z = zik * in[first * C];
+    double cur[U], nxt[U];
+    long long n = 0;
+    if (next >= U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = in[(first + dir * u) * C];
+    }
+    for (; n + U <= next; n += U) {
+      const bool more = n + 2 * U <= next;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = in[(first + dir * (n + U + u)) * C];
+      }
+      double mine = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // scipy lfilter order: y = z0 + b0*x;  z_k = (z_{k+1} + x*b_{k+1}) - y*a_{k+1}
+        const double yv = dpp_bcast8(z + b0 * cur[u]);
+        const double sh = dpp_shl1(z);                      // (every lane must run the DPP move: a lane reads its neighbour)
+        const double zs = k == 7 ? 0.0 : sh;
+        z = (zs + cur[u] * bk) - yv * ak;
+        mine = k == u ? yv : mine;
+      }
+      if (live) out[(first + dir * (n + k)) * C] = mine;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+      }
+    }
+    for (; n < next; ++n) {
+      const double xs = in[(first + dir * n) * C];
+      const double yv = dpp_bcast8(z + b0 * xs);
+      const double sh = dpp_shl1(z);
+      const double zs = k == 7 ? 0.0 : sh;
+      z = (zs + xs * bk) - yv * ak;
+      if (live && k == 0) out[(first + dir * n) * C] = yv;
     }
   }
 }
@@ -396,7 +475,9 @@ extern "C" int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, con
   else
     hipLaunchKernelGGL((filtfilt_build_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, x, work, C, (long long)T, edge);
   dim3 grid((unsigned)((C + 63) / 64));
-  if (ntaps <= 5)
+  if (ntaps <= 9 && FF_LANES8)                              // state over 8 lanes per channel: 8 channels per wave
+    hipLaunchKernelGGL(filtfilt_iir8_kernel, dim3((unsigned)((C + 7) / 8)), dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
+  else if (ntaps <= 5)
     hipLaunchKernelGGL((filtfilt_iir_kernel<5>), grid, dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
   else if (ntaps <= 9)
     hipLaunchKernelGGL((filtfilt_iir_kernel<9>), grid, dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
