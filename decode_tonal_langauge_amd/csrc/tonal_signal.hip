@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void gauss_envelope_kernel(const void* __restr
 // The same bank with the kernel's Hermitian symmetry used (the reference's per-band DFT multiplier is real, so
 // h_b[-n] = conj(h_b[n])): y = h[0] x[t] + sum_{n>0} Re h[n] (x[t-n] + x[t+n]) + i Im h[n] (x[t-n] - x[t+n]).  The sum and
 // the difference of a sample pair are formed once for all bands: 2 adds + 2 NB FMAs per pair and sample instead of 4 NB
-// FMAs (0.56 x the fp64 operations at NB = 8).  taps: (NB, half + 1, 2) = Re / Im of h_b[n], n = 0..half.
+// FMAs (0.56 x the fp64 operations at NB = 8).  taps: (half + 1, NB, 2) = Re / Im of h_b[n], n = 0..half, tap-major: the 16
+// coefficients of a tap are one 128-byte run for the scalar loads.
 template <typename TIN, int NB>
 __global__ __launch_bounds__(256) void gauss_envelope_sym_kernel(const void* __restrict__ x, const double* __restrict__ taps,
                                                                  double* __restrict__ y, long long T, int half, int envelope) {
@@ -83,7 +84,6 @@ __global__ __launch_bounds__(256) void gauss_envelope_sym_kernel(const void* __r
   if (base < 0) base += T;
   for (int i = threadIdx.x; i < win; i += blockDim.x) xs[i] = ld_as_f64<TIN>(x, (long long)c * T + (base + i) % T);
   __syncthreads();
-  const int nt1 = half + 1;
   double re[SIG_SPT][NB], im[SIG_SPT][NB];
   {
     double xv[SIG_SPT];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gauss_envelope_sym_kernel(const void* __r
     for (int s = 0; s < SIG_SPT; ++s) xv[s] = xs[threadIdx.x + s * 256 + half];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const double hr = taps[(long long)b * nt1 * 2], hi = taps[(long long)b * nt1 * 2 + 1];
+      const double hr = taps[b * 2], hi = taps[b * 2 + 1];
 #pragma unroll
       for (int s = 0; s < SIG_SPT; ++s) {
         re[s][b] = hr * xv[s];
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void gauss_envelope_sym_kernel(const void* __r
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const double hr = taps[((long long)b * nt1 + n) * 2];
-      const double hi = taps[((long long)b * nt1 + n) * 2 + 1];
+      const double hr = taps[((long long)n * NB + b) * 2];
+      const double hi = taps[((long long)n * NB + b) * 2 + 1];
 #pragma unroll
       for (int s = 0; s < SIG_SPT; ++s) {
         re[s][b] = fma(hr, sm[s], re[s][b]);
@@ -442,7 +442,7 @@ extern "C" int tl_gauss_envelope(const void* x, int x_is_f64, const double* taps
   return check_launch("gauss_envelope");
 }
 
-// Hermitian form of tl_gauss_envelope for 8 bands: taps (8, half + 1, 2) = h_b[n], n = 0..half; h_b[-n] = conj(h_b[n]) is implied
+// Hermitian form of tl_gauss_envelope for 8 bands: taps (half + 1, 8, 2) = h_b[n], n = 0..half (tap-major); h_b[-n] = conj(h_b[n]) is implied
 extern "C" int tl_gauss_envelope_sym(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T, int nb,
                                      int half, int envelope, void* stream) {
   TL_REQUIRE(x && taps && y, "gauss_envelope_sym: null pointer");

@@ -162,7 +162,7 @@ def _device_taps(T, sampling_rate, cfs, sds, dev):
             # the DFT multiplier is real, so h[-n] = conj(h[n]) up to the rounding of the inverse DFT (1e-17): the
             # Hermitian part, n = 0..half, for tl_gauss_envelope_sym (0.56 x the fp64 operations)
             fw, bw = taps[:, half:], taps[:, half::-1]
-            h = 0.5 * (fw + np.conj(bw))
+            h = (0.5 * (fw + np.conj(bw))).T                # (half + 1, 8): tap-major
             sym = torch.from_numpy(np.ascontiguousarray(np.stack([h.real, h.imag], axis=-1))).to(dev)
         if len(_TAPS_CACHE) > 32:
             _TAPS_CACHE.clear()

@@ -330,7 +330,7 @@ int tl_lite_uncat_dev(const float* dfeat, float* dy2, float* dh, int B, int F, i
 int tl_gauss_envelope(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T,
                       int nb, int ntap, int half, int envelope, void* stream);
 /* The same bank through the kernel's Hermitian symmetry (the reference's per-band DFT multiplier is real:
- * h_b[-n] = conj(h_b[n]), frequency_filter.py:155-175): taps (8, half + 1, 2) = Re / Im of h_b[n], n = 0..half; 0.56 x
+ * h_b[-n] = conj(h_b[n]), frequency_filter.py:155-175): taps (half + 1, 8, 2) = Re / Im of h_b[n], n = 0..half (tap-major); 0.56 x
  * the fp64 operations of tl_gauss_envelope.  8 bands, 2 half + 1 <= T taps within the LDS window.                   */
 int tl_gauss_envelope_sym(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T, int nb, int half,
                           int envelope, void* stream);
