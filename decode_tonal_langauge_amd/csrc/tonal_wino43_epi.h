@@ -98,14 +98,16 @@ __device__ __forceinline__ void c1w_reduce_store(const tl_nt_params& p, float* r
 // Accumulator layout: wave (wm, wn) of a workgroup tile that starts at conv row R0 / column n0 holds, for transform i,
 // acc[i][e] = M_i[quad (R0 >> 2) + wm * 32 + 4 * lh + (e & 3) + 8 * (e >> 2)][column n0 + wn * 32 + lr].
 // `lds`: the workgroup's LDS, free for scratch when this is called (every wave past its last fragment read).
-template <int EPI>
+// FULL: the tile lies wholly inside the output (rows R0 .. R0 + 511 < M, columns n0 .. n0 + 63 < N) - the per-store
+// bounds tests are compile-time true and the 32 - 64 stores of a lane are straight-line code instead of exec-masked regions.
+template <int EPI, bool FULL = false>
 __device__ __forceinline__ void wino43_epilogue(const tl_nt_params& p, const f32x16 (&acc)[6], float* lds, long long R0,
                                                 int n0, int wm, int wn, int lr, int lh, long long tm) {
   // ---- epilogue: the four conv rows of a quad from its six products ----
   const long long Q0 = (R0 >> 2) + wm * 32 + 4 * lh;       // quad of accumulator element e = 0
   const int col = n0 + wn * 32 + lr;
   const int colbase = n0 + wn * 32;
-  const bool colok = col < p.N;
+  const bool colok = FULL || col < p.N;
   float bv = 0.f;
   if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_LRELU) bv = (colok && p.bias) ? p.bias[col] : 0.f;
   uint32_t wbits = 0, wsign = 0;
@@ -117,8 +119,8 @@ __device__ __forceinline__ void wino43_epilogue(const tl_nt_params& p, const f32
       // lane lr holds the word of row index lr (e = lr >> 2, h = lr & 3) in A and of row index 32 + lr in B
       const int eA = lr >> 2, eB = 8 + (lr >> 2), hh = lr & 3;
       const long long RA = 4 * (Q0 + (eA & 3) + 8 * (eA >> 2)) + hh, RB = 4 * (Q0 + (eB & 3) + 8 * (eB >> 2)) + hh;
-      if (RA < p.M && colbase < p.N) swordA = p.auxbits[RA * (long long)p.ld_auxbits + (colbase >> 5)];
-      if (RB < p.M && colbase < p.N) swordB = p.auxbits[RB * (long long)p.ld_auxbits + (colbase >> 5)];
+      if (FULL || (RA < p.M && colbase < p.N)) swordA = p.auxbits[RA * (long long)p.ld_auxbits + (colbase >> 5)];
+      if (FULL || (RB < p.M && colbase < p.N)) swordB = p.auxbits[RB * (long long)p.ld_auxbits + (colbase >> 5)];
     }
   }
   // C1WGRAD: per row two bit words and four signal samples.  Lane lr of each half-wave fetches them for
@@ -130,13 +132,13 @@ __device__ __forceinline__ void wino43_epilogue(const tl_nt_params& p, const f32
     const int eA = lr >> 2, eB = 8 + (lr >> 2), hh = lr & 3;
     const long long RA = 4 * (Q0 + (eA & 3) + 8 * (eA >> 2)) + hh, RB = 4 * (Q0 + (eB & 3) + 8 * (eB >> 2)) + hh;
     c1w_cursor c;
-    if (RA < p.M && colbase < p.N) {
+    if (FULL || (RA < p.M && colbase < p.N)) {
       c.init(p, RA, colbase);
       swordA = p.auxbits[c.wofs];
       cwA = p.c1bits[c.wofs];
       if (c.t < p.Tvalid) xsA = f32x4{p.c1x[c.xo], p.c1x[c.xo + 1], p.c1x[c.xo + 2], p.c1x[c.xo + 3]};
     }
-    if (RB < p.M && colbase < p.N) {
+    if (FULL || (RB < p.M && colbase < p.N)) {
       c.init(p, RB, colbase);
       swordB = p.auxbits[c.wofs];
       cwB = p.c1bits[c.wofs];
@@ -165,7 +167,7 @@ __device__ __forceinline__ void wino43_epilogue(const tl_nt_params& p, const f32
       for (int h = 0; h < 2; ++h) {
         const long long P = 2 * Q + h;                      // pooled row
         const float y0 = lrelu(y[2 * h] + bv, p.slope), y1 = lrelu(y[2 * h + 1] + bv, p.slope);
-        const bool rowok = 2 * P < p.M;
+        const bool rowok = FULL || 2 * P < p.M;
         const bool valid = rowok && (cur.t + 2 * h) < p.Tvalid;     // Tp % 4 == 0: a quad never wraps
         const bool sel = valid && colok && (y1 > y0);
         const float o = valid ? (sel ? y1 : y0) : 0.f;
@@ -180,7 +182,7 @@ __device__ __forceinline__ void wino43_epilogue(const tl_nt_params& p, const f32
       }
     } else if constexpr (EPI == W_EPI_LRELU) {
       const long long R = 4 * Q;
-      if (R < p.M && colok) {                               // M % 4 == 0: the quad shares validity
+      if (FULL || (R < p.M && colok)) {                     // M % 4 == 0: the quad shares validity
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           // aux: taps the segments do not cover, accumulated by the caller (pre-activation, no bias)
@@ -190,7 +192,7 @@ __device__ __forceinline__ void wino43_epilogue(const tl_nt_params& p, const f32
       }
     } else if constexpr (EPI == W_EPI_C1W) {
       {
-        const bool live = 4 * Q < p.M && colok;               // Tp % 4 == 0: the quad stays inside one sequence
+        const bool live = FULL || (4 * Q < p.M && colok);     // Tp % 4 == 0: the quad stays inside one sequence
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           const int src = ((4 * e + h) & 31) + 32 * lh;
@@ -202,7 +204,7 @@ __device__ __forceinline__ void wino43_epilogue(const tl_nt_params& p, const f32
       }
     } else {
       const long long R = 4 * Q;
-      if (R < p.M && colok) {                               // M % 4 == 0: the quad shares validity
+      if (FULL || (R < p.M && colok)) {                     // M % 4 == 0: the quad shares validity
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           bool pos;
@@ -222,7 +224,7 @@ __device__ __forceinline__ void wino43_epilogue(const tl_nt_params& p, const f32
   if constexpr (EPI == W_EPI_POOL) {
     const int e = lr >> 1, h = lr & 1;
     const long long P = 2 * (Q0 + (e & 3) + 8 * (e >> 2)) + h;
-    if (2 * P < p.M && colbase < p.N) {
+    if (FULL || (2 * P < p.M && colbase < p.N)) {
       p.obits[P * (long long)p.ld_obits + (colbase >> 5)] = wbits;
       if (p.osign != nullptr) p.osign[P * (long long)p.ld_obits + (colbase >> 5)] = wsign;
     }
