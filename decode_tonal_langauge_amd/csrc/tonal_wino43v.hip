@@ -344,7 +344,6 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
 #pragma unroll
         for (int e = 0; e < 16; ++e) t += acc[i][e];
       if (t == 12345.678f) p.out[tid] = t;
-      return;
     }
 #endif
     // the first K-step of the next tile goes into stage 0 - last read in step nsteps - 2 when nsteps is even, and every
@@ -360,11 +359,13 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
     // its six products, then pool / mask / fused first-stage weight gradient.  The reduction of the fused weight gradient
     // takes the LAST step's stage as its scratch (behind a barrier: other waves may still be reading it) ----
     if constexpr (EPI == W_EPI_C1W) __syncthreads();
+#if !(V4_ABL & 2)
     float* scratch = reinterpret_cast<float*>(lds + ((nsteps - 1) & 1) * V4_STAGE);
     if (done.R0 + 4 * V4_BQ <= p.M && done.n0 + V4_BN <= p.N)     // (workgroup-uniform) interior tile: no per-store bounds tests
       wino43_epilogue<EPI, true>(p, acc, scratch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
     else
       wino43_epilogue<EPI, false>(p, acc, scratch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+#endif
     if (!V4_PERSIST && nb < nwg) {                         // (no prefetch: plain sequence of tiles)
       __syncthreads();
       cur = setup(nb);
