@@ -235,8 +235,14 @@ class LiteEngine:
             kr = B * L - 1          # pairs (dg[b,t], h[b,t-1]): A row R+1, B row R, rows with R%L == L-1 masked
             h4 = _r4(H)
             if h4 == H:
-                self._tn(A=dg.data_ptr() + 4 * 4 * H, B=ptr(self.hs), slab=ptr(gwhh), Krows=kr, A_rows=kr, B_rows=kr,
-                         Mdim=4 * H, Ndim=H, lda=4 * H, ldb=H, ldc=H, loader=LOAD_DIRECT, Tp=L, Tvalid=L - 1)
+                # a few hundred rows: the reduction is split over 64-row chunks (tn_short_kernel), the slabs summed in order
+                sk = max(1, min(8, (kr + 63) // 64))
+                slab = gwhh if sk == 1 else torch.empty(sk, 4 * H, H, **f32)
+                self._tn(A=dg.data_ptr() + 4 * 4 * H, B=ptr(self.hs), slab=ptr(slab), Krows=kr, A_rows=kr, B_rows=kr,
+                         Mdim=4 * H, Ndim=H, lda=4 * H, ldb=H, ldc=H, loader=LOAD_DIRECT, Tp=L, Tvalid=L - 1, splitk=sk,
+                         slab_stride=4 * H * H)
+                if sk > 1:
+                    self._permute(slab, gwhh, (1, 1, 1, 4 * H * H), (0, 0, 0, 1), nz=sk, zs=4 * H * H)
             else:
                 raise ValueError("lstm_hidden must be a multiple of 4 on the MI355X path")
         else:

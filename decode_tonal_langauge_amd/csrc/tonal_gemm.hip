@@ -1203,7 +1203,11 @@ __global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
   const int tid = threadIdx.x, tn = tid & 31, tm = tid >> 5;
   const int ntn = (p.Ndim + TS_N - 1) / TS_N;
   const int mt = (int)(blockIdx.x / ntn) * TS_M, nt = (int)(blockIdx.x % ntn) * TS_N;
-  const int kr = (int)(p.Krows < p.A_rows ? (p.Krows < p.B_rows ? p.Krows : p.B_rows) : (p.A_rows < p.B_rows ? p.A_rows : p.B_rows));
+  const int kall = (int)(p.Krows < p.A_rows ? (p.Krows < p.B_rows ? p.Krows : p.B_rows) : (p.A_rows < p.B_rows ? p.A_rows : p.B_rows));
+  // reduction split blockIdx.y: rows [kb, kr) = whole 64-row chunks (slab blockIdx.y; the caller sums the splitk slabs)
+  const int per = ((kall + (int)gridDim.y - 1) / (int)gridDim.y + TS_K - 1) / TS_K * TS_K;
+  const int kb = (int)blockIdx.y * per;
+  const int kr = kb + per < kall ? kb + per : kall;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   // a chunk: A 64 rows x 8 float4, B 64 rows x 32 float4 (Mdim, Ndim % 4 == 0: a float4 is whole or absent)
   f32x4 ra[2], rb[8];
@@ -1215,7 +1219,7 @@ __global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) tb[i] = ((tid + i * 256) >> 5) % p.Tp;
   const int kstep_mod = TS_K % p.Tp;
-  int r0m = 0;                                               // r0 % Tp of the chunk being fetched
+  int r0m = kb % p.Tp;                                       // r0 % Tp of the chunk being fetched
   auto fetch = [&](int r0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1223,7 +1227,7 @@ __global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
       int t = ta[i] + r0m;
       t = t >= p.Tp ? t - p.Tp : t;
       const bool ok = R < kr && t < p.Tvalid && c < p.Mdim;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.A + (long long)(R < kr ? R : kr - 1) * p.lda + (c < p.Mdim ? c : p.Mdim - 4));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.A + (long long)(R < kall ? R : kall - 1) * p.lda + (c < p.Mdim ? c : p.Mdim - 4));
       ra[i] = ok ? v : zero;
     }
 #pragma unroll
@@ -1232,15 +1236,15 @@ __global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
       int t = tb[i] + r0m;
       t = t >= p.Tp ? t - p.Tp : t;
       const bool ok = R < kr && t < p.Tvalid && c < p.Ndim;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.B + (long long)(R < kr ? R : kr - 1) * p.ldb + (c < p.Ndim ? c : p.Ndim - 4));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.B + (long long)(R < kall ? R : kall - 1) * p.ldb + (c < p.Ndim ? c : p.Ndim - 4));
       rb[i] = ok ? v : zero;
     }
     r0m += kstep_mod;
     r0m = r0m >= p.Tp ? r0m - p.Tp : r0m;
   };
   f32x4 acc[4] = {zero, zero, zero, zero};
-  fetch(0);
-  for (int r0 = 0; r0 < kr; r0 += TS_K) {
+  fetch(kb);
+  for (int r0 = kb; r0 < kr; r0 += TS_K) {
     __syncthreads();                                       // the chunk in front has been consumed
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(As + ((tid + i * 256) >> 3) * TS_M + ((tid + i * 256) & 7) * 4) = ra[i];
@@ -1259,7 +1263,8 @@ __global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
   const int m0 = mt + tm * 4, n0 = nt + tn * 4;
   if (m0 < p.Mdim && n0 < p.Ndim) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(p.slab + (long long)(m0 + i) * p.ldc + n0) = acc[i];
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(p.slab + (long long)blockIdx.y * p.slab_stride + (long long)(m0 + i) * p.ldc + n0) = acc[i];
   }
 }
 }  // namespace tl
@@ -1282,10 +1287,11 @@ extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
     TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim, "tn_window: bbits row too short");
   }
   hipStream_t st = (hipStream_t)stream;
-  if (p.J == 1 && p.loader == LOAD_DIRECT && p.splitk == 1 && p.Krows <= 8 * TS_K && (long long)p.Mdim * p.Ndim <= (1 << 20) &&
+  if (p.J == 1 && p.loader == LOAD_DIRECT && p.Krows <= 8 * TS_K && p.splitk <= 8 && (long long)p.Mdim * p.Ndim <= (1 << 20) &&
+      (p.splitk == 1 || p.slab_stride >= (long long)p.Mdim * p.ldc) &&
       p.ldc % 4 == 0) {                                             // short reduction, small output: latency-bound
     const long long nwg = (long long)((p.Mdim + TS_M - 1) / TS_M) * ((p.Ndim + TS_N - 1) / TS_N);
-    hipLaunchKernelGGL(tn_short_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(tn_short_kernel, dim3((unsigned)nwg, (unsigned)p.splitk), dim3(256), 0, st, p);
     return check_launch("tn_short");
   }
   if (p.Mdim <= 32 && p.J == 1 && p.loader == LOAD_DIRECT) {       // skinny-M streaming variant
