@@ -303,9 +303,13 @@ class CnnEngine:
     def _tn_bm(self, st) -> int:
         """64: 64 x 64 tile, 4 waves; 128: 128 x 64 tile, 8 waves, the Y side by LDS-DMA (wino43v_tn8_kernel: needs C_in % 128 ==
         0, C_out % 64 == 0); 127: the 128-wide tile on the kernel that stages Y through registers."""
-        if self.tn_bm:
-            return self.tn_bm
-        return 128 if (st.cin % 128 == 0 and _r4(st.cout) % 64 == 0 and (st.cout // 32) % 2 == 0) else 64
+        wide = st.cin % 128 == 0
+        dma8 = wide and _r4(st.cout) % 64 == 0 and (st.cout // 32) % 2 == 0
+        if self.tn_bm == 127:
+            return 127 if wide else 64
+        if self.tn_bm == 128 or not self.tn_bm:
+            return 128 if dma8 else 64
+        return 64
 
     def _conv1_writes_v(self) -> bool:
         """The first stage hands its output to stage 2 as V (tl_conv1_fwd_v) - nothing else reads P1 then."""
