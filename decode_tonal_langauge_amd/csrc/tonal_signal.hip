@@ -263,20 +263,19 @@ __global__ __launch_bounds__(64) void filtfilt_iir_kernel(const double* __restri
   }
 }
 
-// The same recurrence with the STATE spread over lanes (ntaps <= 9): lane = 8 x channel + k holds z_k of its channel, a
-// wave 8 channels.  One lane per channel leaves 4 wavefronts on the chip for 256 channels, each issuing the ~34 dependent
-// fp64 operations of a sample back to back (214 cycles per sample); here a sample is the output y = z_0 + b_0 x in the
-// k = 0 lanes, its broadcast over the 8 lanes of the channel (two DPP moves per 32-bit half), the shift z_{k+1} -> lane k
-// (one DPP move per half), and ONE state update per lane - the same operations in the same order on every element as
-// scipy's loop (the file is compiled without FMA contraction), so the result stays bit-identical to it.  Parallel in time
-// it cannot be: the reference's (b, a) form is a rounding trajectory, not a well-conditioned function.
-__device__ __forceinline__ double dpp_bcast8(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false);          // quad_perm [0,0,0,0]
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xf, 0xa, false);         // row_shr:4 into lanes 4-7, 12-15 of a row
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xf, 0xa, false);
-  return __hiloint2double(hi, lo);
+// The same recurrence with the STATE spread over lanes (ntaps <= 9): a channel owns a 16-lane DPP row, lane k < 8 of it
+// holds z_k (lanes 8..15 carry zero coefficients and stay zero), a wave 4 channels.  One lane per channel leaves 4
+// wavefronts on the chip for 256 channels, each issuing the ~34 fp64 operations of a sample back to back (214 cycles per
+// sample; the stream is bound by instruction issue, ~7 cycles per dependent fp64 / DPP instruction: interleaving a second
+// channel set per wave doubled the time).  Here a sample is 9 instructions: the output y = z_0 + b_0 x in lane 0, its
+// broadcast over the row (one v_mov_b64_dpp row_newbcast), the shift z_{k+1} -> lane k (one DPP move per 32-bit half), and
+// ONE state update per lane - the same operations in the same order on every element as scipy's loop (the file is
+// compiled without FMA contraction), so the result stays bit-identical to it.  Parallel in time it cannot be: the
+// reference's (b, a) form is a rounding trajectory, not a well-conditioned function.
+__device__ __forceinline__ double dpp_bcast_row(double v) {                  // lane 0 of each 16-lane row to the row
+  const long long x = __builtin_bit_cast(long long, v);
+  const long long y = __builtin_amdgcn_update_dpp(x, x, 0x150, 0xf, 0xf, false);   // v_mov_b64_dpp row_newbcast:0
+  return __builtin_bit_cast(double, y);
 }
 __device__ __forceinline__ double dpp_shl1(double v) {                       // lane i <- lane i + 1 (0 past the row)
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xf, 0xf, true);
@@ -286,8 +285,8 @@ __device__ __forceinline__ double dpp_shl1(double v) {                       // 
 __global__ __launch_bounds__(64) void filtfilt_iir8_kernel(const double* __restrict__ b, const double* __restrict__ a,
                                                            const double* __restrict__ zi, double* __restrict__ work, int C,
                                                            long long next, int ntaps) {
-  const int lane = threadIdx.x, k = lane & 7;
-  const int ch = blockIdx.x * 8 + (lane >> 3);
+  const int lane = threadIdx.x, k = lane & 15;
+  const int ch = blockIdx.x * 4 + (lane >> 4);
   const bool live = ch < C;
   const int chc = live ? ch : C - 1;
   const double b0 = b[0];
@@ -316,13 +315,12 @@ __global__ __launch_bounds__(64) void filtfilt_iir8_kernel(const double* __restr
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // scipy lfilter order: y = z0 + b0*x;  z_k = (z_{k+1} + x*b_{k+1}) - y*a_{k+1}
-        const double yv = dpp_bcast8(z + b0 * cur[u]);
-        const double sh = dpp_shl1(z);                      // (every lane must run the DPP move: a lane reads its neighbour)
-        const double zs = k == 7 ? 0.0 : sh;
+        const double yv = dpp_bcast_row(z + b0 * cur[u]);
+        const double zs = dpp_shl1(z);                      // (lanes 8..15 of the row hold zeros: z_8 = 0 comes for free)
         z = (zs + cur[u] * bk) - yv * ak;
         mine = k == u ? yv : mine;
       }
-      if (live) out[(first + dir * (n + k)) * C] = mine;
+      if (live && k < U) out[(first + dir * (n + k)) * C] = mine;
       if (more) {
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
@@ -330,9 +328,8 @@ __global__ __launch_bounds__(64) void filtfilt_iir8_kernel(const double* __restr
     }
     for (; n < next; ++n) {
       const double xs = in[(first + dir * n) * C];
-      const double yv = dpp_bcast8(z + b0 * xs);
-      const double sh = dpp_shl1(z);
-      const double zs = k == 7 ? 0.0 : sh;
+      const double yv = dpp_bcast_row(z + b0 * xs);
+      const double zs = dpp_shl1(z);
       z = (zs + xs * bk) - yv * ak;
       if (live && k == 0) out[(first + dir * n) * C] = yv;
     }
@@ -476,7 +473,7 @@ extern "C" int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, con
     hipLaunchKernelGGL((filtfilt_build_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, x, work, C, (long long)T, edge);
   dim3 grid((unsigned)((C + 63) / 64));
   if (ntaps <= 9 && FF_LANES8)                              // state over 8 lanes per channel: 8 channels per wave
-    hipLaunchKernelGGL(filtfilt_iir8_kernel, dim3((unsigned)((C + 7) / 8)), dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
+    hipLaunchKernelGGL(filtfilt_iir8_kernel, dim3((unsigned)((C + 3) / 4)), dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
   else if (ntaps <= 5)
     hipLaunchKernelGGL((filtfilt_iir_kernel<5>), grid, dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
   else if (ntaps <= 9)
