@@ -14,7 +14,10 @@ The arithmetic runs in HIP kernels (``csrc/tonal_signal.hip``):
    kernels are longer than that kernel's LDS window (low bands at a raw recording rate: sigma_t of hundreds to
    thousands of samples) go through the DFT domain exactly as the reference writes it - forward DFT, per-band
    multiplier, inverse DFT - with the arbitrary-length DFT as a Bluestein chirp-z over power-of-two Stockham
-   passes (``tl_hilbert_fft``; ``TONAL_HILBERT=fft`` forces that path, ``=taps`` forbids it);
+   passes (``tl_hilbert_fft``; ``TONAL_HILBERT=fft`` forces that path, ``=taps`` forbids it).  Eight-band banks with
+   truncated kernels of up to 513 taps - the high-gamma bank of the pipeline - take the fastest form of the same
+   convolution: overlap-save on an LDS-resident 1024-point fp64 FFT (``tl_hilbert_ols``; the spectra of the SAME truncated
+   kernels; ``TONAL_HILBERT=sym`` keeps the time-domain kernel, which uses the kernels' Hermitian symmetry);
  * ``filtfilt`` / ``sosfilt`` are fp64 direct-form-II-transposed recurrences, one lane per channel;
  * the FIR bank is a causal convolution with zero initial state.
 Filter *design* (``butter``, ``lfilter_zi``, ``firwin``) stays on scipy: coefficient generation,
@@ -38,6 +41,7 @@ from ... import _lib
 from ..._lib import check, ptr
 
 _MAX_TAPS_LDS = 7169      # (1024 + ntap - 1) * 8 B <= 64 KiB
+_OLS_N = 4096             # FFT length of the overlap-save path (tl_hilbert_ols)
 
 
 def _device() -> torch.device:
@@ -152,7 +156,7 @@ _TAPS_CACHE = {}
 def _device_taps(T, sampling_rate, cfs, sds, dev):
     """Device copy of the band kernels, cached per (length, rate, bank): the host-side inverse DFT
     is coefficient generation and must not sit in front of every call."""
-    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev))
+    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev), os.environ.get("TONAL_OLS_N", "1024"))
     hit = _TAPS_CACHE.get(key)
     if hit is None:
         taps, half = analytic_taps(T, sampling_rate, cfs, sds)
@@ -164,9 +168,20 @@ def _device_taps(T, sampling_rate, cfs, sds, dev):
             fw, bw = taps[:, half:], taps[:, half::-1]
             h = (0.5 * (fw + np.conj(bw))).T                # (half + 1, 8): tap-major
             sym = torch.from_numpy(np.ascontiguousarray(np.stack([h.real, h.imag], axis=-1))).to(dev)
+        ols = None
+        nfft = int(os.environ.get("TONAL_OLS_N", "1024"))
+        if nfft in (1024, 4096) and 0 < half <= nfft // 4 and taps.shape[0] == 8 and taps.shape[1] == 2 * half + 1 and T >= nfft:
+            # overlap-save on an LDS-resident FFT (tl_hilbert_ols): the spectra of the same truncated kernels, / N, and the
+            # twiddle table (cos, -sin)
+            g = np.zeros((8, nfft), dtype=np.complex128)
+            g[:, :2 * half + 1] = taps
+            G = np.fft.fft(g, axis=1) / nfft
+            ang = 2.0 * np.pi * np.arange(nfft) / nfft
+            ols = (torch.from_numpy(np.ascontiguousarray(np.stack([G.real, G.imag], axis=-1))).to(dev),
+                   torch.from_numpy(np.ascontiguousarray(np.stack([np.cos(ang), -np.sin(ang)], axis=-1))).to(dev), nfft)
         if len(_TAPS_CACHE) > 32:
             _TAPS_CACHE.clear()
-        hit = _TAPS_CACHE[key] = (tp, taps.shape[1], half, sym)
+        hit = _TAPS_CACHE[key] = (tp, taps.shape[1], half, sym, ols)
     return hit
 
 
@@ -179,7 +194,7 @@ def _hilbert_dft(x: torch.Tensor, sampling_rate, cfs, sds, envelope: bool) -> to
     C, T = x.shape
     dev = x.device
     w, bf, tw, m2 = _bluestein_coeffs(T, dev)
-    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev))
+    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev), os.environ.get("TONAL_OLS_N", "1024"))
     kd = _MULT_CACHE.get(key)
     if kd is None:
         if len(_MULT_CACHE) > 8:
@@ -209,13 +224,17 @@ def hilbert_filter(data, sampling_rate: int, freq_ranges: Union[List[Tuple[float
         # the reference's mean over an empty band axis yields NaN
         return _ret(torch.full((C, T), float("nan"), dtype=torch.float64, device=x.device), was_np)
     mode = os.environ.get("TONAL_HILBERT", "auto")
-    tp, ntap, half, sym = (None, 0, 0, None) if mode == "fft" else _device_taps(T, sampling_rate, cfs, sds, x.device)
+    tp, ntap, half, sym, ols = (None, 0, 0, None, None) if mode == "fft" else _device_taps(T, sampling_rate, cfs, sds, x.device)
     if mode == "fft" or ntap > _MAX_TAPS_LDS:
         if mode == "taps":
             raise ValueError(f"hilbert_filter: the band kernels need {ntap} taps at this sampling rate; the time-domain "
                              f"kernel supports up to {_MAX_TAPS_LDS} (TONAL_HILBERT=taps forbids the DFT-domain path)")
         return _ret(_hilbert_dft(x, sampling_rate, cfs, sds, bool(envelope)), was_np)
     y = torch.empty(C, T, dtype=torch.float64, device=x.device)
+    if ols is not None and mode in ("auto", "ols"):
+        check(_lib.load().tl_hilbert_ols(ptr(x), int(x.dtype == torch.float64), ptr(ols[0]), ptr(ols[1]), ptr(y), C, T, len(cfs),
+                                         half, ols[2], int(bool(envelope)), _stream()), "tl_hilbert_ols")
+        return _ret(y, was_np)
     if sym is not None and os.environ.get("TONAL_HILBERT_SYM", "1") != "0":
         check(_lib.load().tl_gauss_envelope_sym(ptr(x), int(x.dtype == torch.float64), ptr(sym), ptr(y), C, T, len(cfs), half,
                                                 int(bool(envelope)), _stream()), "tl_gauss_envelope_sym")

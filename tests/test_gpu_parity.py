@@ -171,14 +171,27 @@ def test_signal_filters_match_reference_golden(dev):
     hil = ff.hilbert_filter(x, 400, freq_ranges=[70., 150.])
     assert hil.dtype == np.float64 and rel(hil, g["hilbert"]) < 1e-9
     assert rel(ff.hilbert_filter(x, 400, freq_ranges=[70., 150.], envelope=False), g["hilbert_real"]) < 1e-9
-    # 8 bands with truncated kernels take the Hermitian-symmetry kernel (tl_gauss_envelope_sym); the plain bank
-    # (tl_gauss_envelope) must give the same numbers far below the golden tolerance
+    # 8 bands with truncated kernels: short recordings take the Hermitian-symmetry kernel (tl_gauss_envelope_sym), recordings
+    # of >= 1024 samples overlap-save on the LDS FFT (tl_hilbert_ols); the plain bank (tl_gauss_envelope) must give the same
+    # numbers far below the golden tolerance, and so must the three on a longer recording
     os.environ["TONAL_HILBERT_SYM"] = "0"
     try:
         plain = ff.hilbert_filter(x, 400, freq_ranges=[70., 150.])
     finally:
         os.environ.pop("TONAL_HILBERT_SYM", None)
     assert rel(plain, g["hilbert"]) < 1e-9 and rel(hil, plain) < 1e-13
+    xl = np.random.default_rng(5).standard_normal((3, 5003))
+    res = {}
+    for mode, symflag in (("ols", "1"), ("sym", "1"), ("sym", "0")):
+        os.environ["TONAL_HILBERT"], os.environ["TONAL_HILBERT_SYM"] = mode, symflag
+        try:
+            res[mode + symflag] = (ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.]),
+                                   ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.], envelope=False))
+        finally:
+            os.environ.pop("TONAL_HILBERT", None)
+            os.environ.pop("TONAL_HILBERT_SYM", None)
+    for k in ("ols1", "sym1"):
+        assert rel(res[k][0], res["sym0"][0]) < 1e-13 and rel(res[k][1], res["sym0"][1]) < 1e-12
     assert rel(ff.butter_filter(x, [0.3, 100], 400), g["butter"]) < 1e-9
     assert rel(ff.butter_filter(x, [0.3, 100], 400, causal=True), g["butter_causal"]) < 1e-9
     assert rel(ff.fir_bandpass_filter(x, 400, 390, [100.]), g["fir"]) < 1e-9
