@@ -131,124 +131,126 @@ __global__ __launch_bounds__(256) void gauss_envelope_sym_kernel(const void* __r
 }
 
 // ------------------------------------------------------------------------------------------
-// The same bank by overlap-save on an LDS-resident FFT: a workgroup takes one channel and one segment of
-// N - 2 half output samples (N = 1024 or 4096), transforms the N-sample window once (Stockham radix-4, ping-pong between
-// two padded LDS buffers), keeps the spectrum in registers (4 - 8 bins per thread), and for each band multiplies by the
-// band's N-point kernel spectrum (host: FFT of the same truncated taps the time-domain kernel convolves with, / N),
-// transforms back and accumulates |.|.  2.4 x fewer fp64 operations per output than the symmetric time-domain kernel.
-// Index padding d + (d >> 5) keeps the stride-4 stores of the first stages off the same banks.
+// The same bank by overlap-save on an LDS-resident FFT: a workgroup (256 threads) takes one channel and one segment of
+// 1024 - 2 half output samples.  The transform is a 1024-point Stockham radix-4 (five stages); a thread owns the four
+// positions tid + 256 r of the natural order, which are exactly the inputs of its first-stage butterfly and the outputs of
+// its last-stage one - so a transform takes its input from registers and leaves its output in registers, with four LDS
+// round trips (and barriers) between; the thread's twelve twiddles are loaded once.  Per segment: the window straight from
+// memory -> forward transform -> the spectrum stays in registers; per band: x the band's kernel spectrum (host: FFT_1024
+// of the same truncated taps the time-domain kernels convolve with, / 1024) -> inverse transform -> |.| accumulated.
+// 2.4 x fewer fp64 operations per output than the symmetric time-domain kernel; four workgroups per CU (34 KB of LDS).
+// Index padding d + (d >> 5) keeps the strided stores of the first stages off the same banks.
 // ------------------------------------------------------------------------------------------
+constexpr int OLS_N = 1024, OLS_Q = OLS_N / 4, OLS_PAD = OLS_N + (OLS_N >> 5);
 __device__ __forceinline__ int ols_idx(int d) { return d + (d >> 5); }
 typedef double ols_d2 __attribute__((ext_vector_type(2)));
 
-// LOG4 Stockham radix-4 stages a -> b -> a ...; the result is in a for an even stage count, in b for an odd one (the caller
-// picks the pointers).  tw[m] = (cos, -sin)(2 pi m / N).  N = 4^LOG4, THREADS x BPT = N / 4 butterflies per stage.
-template <bool INV, int LOG4, int THREADS>
-__device__ __forceinline__ void ols_fft(double* __restrict__ are, double* __restrict__ aim, double* __restrict__ bre,
-                                        double* __restrict__ bim, const ols_d2* __restrict__ tw, int tid) {
-  constexpr int N = 1 << (2 * LOG4), BPT = (N / 4) / THREADS;
+template <bool INV>
+__device__ __forceinline__ void ols_bfly(const double (&xr)[4], const double (&xi)[4], double (&yr)[4], double (&yi)[4]) {
+  const double t0r = xr[0] + xr[2], t0i = xi[0] + xi[2], t1r = xr[0] - xr[2], t1i = xi[0] - xi[2];
+  const double t2r = xr[1] + xr[3], t2i = xi[1] + xi[3];
+  const double dr = xr[1] - xr[3], di = xi[1] - xi[3];
+  const double t3r = INV ? -di : di, t3i = INV ? dr : -dr;    // (a1 - a3) * (-i) forward, (+i) inverse
+  yr[0] = t0r + t2r; yi[0] = t0i + t2i;
+  yr[1] = t1r + t3r; yi[1] = t1i + t3i;
+  yr[2] = t0r - t2r; yi[2] = t0i - t2i;
+  yr[3] = t1r - t3r; yi[3] = t1i - t3i;
+}
+// v: the thread's values at positions tid + 256 r, in and out.  wc / ws: its twiddles (cos, -sin) of stages 1..4.
+template <bool INV>
+__device__ __forceinline__ void ols_fft(double (&vr)[4], double (&vi)[4], double* __restrict__ lds, const double (&wc)[4][3],
+                                        const double (&ws)[4][3], int tid) {
+  double* bre[2] = {lds, lds + 2 * OLS_PAD};
+  double* bim[2] = {lds + OLS_PAD, lds + 3 * OLS_PAD};
+  double yr[4], yi[4];
+  ols_bfly<INV>(vr, vi, yr, yi);                            // stage 0 (Ns = 1, no twiddles): outputs 4 tid + r
 #pragma unroll
-  for (int st = 0; st < LOG4; ++st) {
-    const double* sre = (st & 1) ? bre : are;
-    const double* sim = (st & 1) ? bim : aim;
-    double* dre = (st & 1) ? are : bre;
-    double* dim_ = (st & 1) ? aim : bim;
-    const int Ns = 1 << (2 * st);
+  for (int r = 0; r < 4; ++r) {
+    bre[0][ols_idx(4 * tid + r)] = yr[r];
+    bim[0][ols_idx(4 * tid + r)] = yi[r];
+  }
+  __syncthreads();
 #pragma unroll
-    for (int m = 0; m < BPT; ++m) {
-      const int j = tid + THREADS * m;                      // butterfly 0 .. N / 4 - 1
-      const int k = j & (Ns - 1);
-      double xr[4], xi[4];
+  for (int st = 1; st < 5; ++st) {
+    const int src = (st - 1) & 1, dst = st & 1, Ns = 1 << (2 * st);
+    double xr[4], xi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xr[r] = bre[src][ols_idx(tid + r * OLS_Q)];
+      xi[r] = bim[src][ols_idx(tid + r * OLS_Q)];
+    }
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      const double c = wc[st - 1][r - 1], sn = INV ? -ws[st - 1][r - 1] : ws[st - 1][r - 1];
+      const double tr = fma(-xi[r], sn, xr[r] * c), ti = fma(xr[r], sn, xi[r] * c);
+      xr[r] = tr;
+      xi[r] = ti;
+    }
+    if (st < 4) {
+      ols_bfly<INV>(xr, xi, yr, yi);
+      const int base = ((tid >> (2 * st)) << (2 * st + 2)) + (tid & (Ns - 1));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int idx = ols_idx(j + r * (N / 4));
-        xr[r] = sre[idx];
-        xi[r] = sim[idx];
+        bre[dst][ols_idx(base + r * Ns)] = yr[r];
+        bim[dst][ols_idx(base + r * Ns)] = yi[r];
       }
-      if (st > 0) {                                         // W_{4 Ns}^{r k} = W_N^{r k N / (4 Ns)}
-        const int step = k * ((N / 4) >> (2 * st));
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-          const ols_d2 w = tw[r * step];
-          const double c = w[0], sn = INV ? -w[1] : w[1];
-          const double tr = fma(-xi[r], sn, xr[r] * c), ti = fma(xr[r], sn, xi[r] * c);
-          xr[r] = tr;
-          xi[r] = ti;
-        }
-      }
-      const double t0r = xr[0] + xr[2], t0i = xi[0] + xi[2], t1r = xr[0] - xr[2], t1i = xi[0] - xi[2];
-      const double t2r = xr[1] + xr[3], t2i = xi[1] + xi[3];
-      const double dr = xr[1] - xr[3], di = xi[1] - xi[3];
-      const double t3r = INV ? -di : di, t3i = INV ? dr : -dr;                    // (a1 - a3) * (-i) forward, (+i) inverse
-      const int base = ((j >> (2 * st)) << (2 * st + 2)) + k;
-      dre[ols_idx(base)] = t0r + t2r;
-      dim_[ols_idx(base)] = t0i + t2i;
-      dre[ols_idx(base + Ns)] = t1r + t3r;
-      dim_[ols_idx(base + Ns)] = t1i + t3i;
-      dre[ols_idx(base + 2 * Ns)] = t0r - t2r;
-      dim_[ols_idx(base + 2 * Ns)] = t0i - t2i;
-      dre[ols_idx(base + 3 * Ns)] = t1r - t3r;
-      dim_[ols_idx(base + 3 * Ns)] = t1i - t3i;
+      __syncthreads();
+    } else {
+      ols_bfly<INV>(xr, xi, vr, vi);                        // last stage (Ns = 256): outputs tid + 256 r = the thread's own
     }
-    __syncthreads();
   }
 }
 
-template <typename TIN, int NB, int LOG4, int THREADS>
-__global__ __launch_bounds__(THREADS) void hilbert_ols_kernel(const void* __restrict__ x, const ols_d2* __restrict__ G,
-                                                              const ols_d2* __restrict__ tw, double* __restrict__ y,
-                                                              long long T, int half, int envelope) {
-  constexpr int N = 1 << (2 * LOG4), PAD = N + (N >> 5), PER = N / THREADS;
-  __shared__ __attribute__((aligned(16))) double lds[4 * PAD];
-  double* are = lds;
-  double* aim = lds + PAD;
-  double* bre = lds + 2 * PAD;
-  double* bim = lds + 3 * PAD;
-  // the buffer a transform ends in: a for an even number of stages, b for an odd one
-  double* ore = (LOG4 & 1) ? bre : are;
-  double* oim = (LOG4 & 1) ? bim : aim;
+template <typename TIN, int NB>
+__global__ __launch_bounds__(OLS_Q) void hilbert_ols_kernel(const void* __restrict__ x, const ols_d2* __restrict__ G,
+                                                            const ols_d2* __restrict__ tw, double* __restrict__ y, long long T,
+                                                            int half, int envelope) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * OLS_PAD];
   const int tid = threadIdx.x, c = blockIdx.y;
-  const int Lv = N - 2 * half;
+  const int Lv = OLS_N - 2 * half;
   const long long t0 = (long long)blockIdx.x * Lv;
   long long base = (t0 - half) % T;
   if (base < 0) base += T;
-  for (int i = tid; i < N; i += THREADS) {
-    are[ols_idx(i)] = ld_as_f64<TIN>(x, (long long)c * T + (base + i) % T);
-    aim[ols_idx(i)] = 0.0;
-  }
-  __syncthreads();
-  ols_fft<false, LOG4, THREADS>(are, aim, bre, bim, tw, tid);
-  double Xr[PER], Xi[PER], acc[PER];
+  double wc[4][3], ws[4][3];                                // W_{4 Ns}^{r k} = W_N^{r k N / (4 Ns)}, k = tid % Ns
 #pragma unroll
-  for (int m = 0; m < PER; ++m) {
-    const int idx = ols_idx(tid + THREADS * m);
-    Xr[m] = ore[idx];
-    Xi[m] = oim[idx];
-    acc[m] = 0.0;
+  for (int st = 1; st < 5; ++st) {
+    const int step = (tid & ((1 << (2 * st)) - 1)) * (OLS_Q >> (2 * st));
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      const ols_d2 w = tw[r * step];
+      wc[st - 1][r - 1] = w[0];
+      ws[st - 1][r - 1] = w[1];
+    }
+  }
+  double vr[4], vi[4], Xr[4], Xi[4], acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    vr[r] = ld_as_f64<TIN>(x, (long long)c * T + (base + tid + r * OLS_Q) % T);
+    vi[r] = 0.0;
+    acc[r] = 0.0;
+  }
+  ols_fft<false>(vr, vi, lds, wc, ws, tid);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Xr[r] = vr[r];
+    Xi[r] = vi[r];
   }
   for (int b = 0; b < NB; ++b) {
-    __syncthreads();                                        // every thread has read what it needs from the buffers
 #pragma unroll
-    for (int m = 0; m < PER; ++m) {
-      const int i = tid + THREADS * m;
-      const ols_d2 g = G[(long long)b * N + i];
-      are[ols_idx(i)] = fma(-Xi[m], g[1], Xr[m] * g[0]);
-      aim[ols_idx(i)] = fma(Xr[m], g[1], Xi[m] * g[0]);
+    for (int r = 0; r < 4; ++r) {
+      const ols_d2 g = G[(long long)b * OLS_N + tid + r * OLS_Q];
+      vr[r] = fma(-Xi[r], g[1], Xr[r] * g[0]);
+      vi[r] = fma(Xr[r], g[1], Xi[r] * g[0]);
     }
-    __syncthreads();
-    ols_fft<true, LOG4, THREADS>(are, aim, bre, bim, tw, tid);
+    ols_fft<true>(vr, vi, lds, wc, ws, tid);
 #pragma unroll
-    for (int m = 0; m < PER; ++m) {
-      const int idx = ols_idx(tid + THREADS * m);
-      const double re = ore[idx], im = oim[idx];
-      acc[m] += envelope ? sqrt(re * re + im * im) : re;
-    }
+    for (int r = 0; r < 4; ++r) acc[r] += envelope ? sqrt(vr[r] * vr[r] + vi[r] * vi[r]) : vr[r];
   }
 #pragma unroll
-  for (int m = 0; m < PER; ++m) {
-    const int i = tid + THREADS * m;
+  for (int r = 0; r < 4; ++r) {
+    const int i = tid + r * OLS_Q;
     const long long t = t0 + i - 2 * half;
-    if (i >= 2 * half && t < T) y[(long long)c * T + t] = acc[m] / NB;
+    if (i >= 2 * half && t < T) y[(long long)c * T + t] = acc[r] / NB;
   }
 }
 
@@ -579,29 +581,24 @@ extern "C" int tl_gauss_envelope_sym(const void* x, int x_is_f64, const double* 
   return check_launch("gauss_envelope_sym");
 }
 
-// overlap-save form of tl_gauss_envelope for 8 bands, FFT length nfft = 1024 or 4096: G (8, nfft, 2) = FFT_nfft of each band's
-// truncated kernel h_b[n], n = -half..half placed at 0..2 half, divided by nfft; tw (nfft, 2) = (cos, -sin)(2 pi m / nfft)
+// overlap-save form of tl_gauss_envelope for 8 bands on a 1024-point FFT: G (8, 1024, 2) = FFT_1024 of each band's truncated
+// kernel h_b[n], n = -half..half placed at 0..2 half, divided by 1024; tw (1024, 2) = (cos, -sin)(2 pi m / 1024)
 extern "C" int tl_hilbert_ols(const void* x, int x_is_f64, const double* G, const double* tw, double* y, int C, int64_t T,
                               int nb, int half, int nfft, int envelope, void* stream) {
   TL_REQUIRE(x && G && tw && y, "hilbert_ols: null pointer");
   TL_REQUIRE(C > 0 && C <= 65535 && T > 0, "hilbert_ols: bad sizes");
   TL_REQUIRE(nb == 8, "hilbert_ols: 8 bands only (use tl_gauss_envelope)");
-  TL_REQUIRE(nfft == 1024 || nfft == 4096, "hilbert_ols: nfft must be 1024 or 4096");
-  TL_REQUIRE(half >= 0 && 2 * half <= nfft / 2 && 2LL * half + 1 <= T, "hilbert_ols: the kernels must span at most %d taps", nfft / 2 + 1);
-  const int Lv = nfft - 2 * half;
+  TL_REQUIRE(nfft == OLS_N, "hilbert_ols: nfft must be %d", OLS_N);
+  TL_REQUIRE(half >= 0 && 2 * half <= OLS_N / 2 && 2LL * half + 1 <= T, "hilbert_ols: the kernels must span at most %d taps", OLS_N / 2 + 1);
+  const int Lv = OLS_N - 2 * half;
   dim3 grid((unsigned)((T + Lv - 1) / Lv), (unsigned)C);
   hipStream_t st = (hipStream_t)stream;
   const ols_d2* g2 = reinterpret_cast<const ols_d2*>(G);
   const ols_d2* t2 = reinterpret_cast<const ols_d2*>(tw);
-#define OLS_RUN(TIN)                                                                                                          \
-  do {                                                                                                                        \
-    if (nfft == 4096)                                                                                                         \
-      hipLaunchKernelGGL((hilbert_ols_kernel<TIN, 8, 6, 512>), grid, dim3(512), 0, st, x, g2, t2, y, (long long)T, half, envelope); \
-    else                                                                                                                      \
-      hipLaunchKernelGGL((hilbert_ols_kernel<TIN, 8, 5, 256>), grid, dim3(256), 0, st, x, g2, t2, y, (long long)T, half, envelope); \
-  } while (0)
-  if (x_is_f64) OLS_RUN(double); else OLS_RUN(float);
-#undef OLS_RUN
+  if (x_is_f64)
+    hipLaunchKernelGGL((hilbert_ols_kernel<double, 8>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, half, envelope);
+  else
+    hipLaunchKernelGGL((hilbert_ols_kernel<float, 8>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, half, envelope);
   return check_launch("hilbert_ols");
 }
 

@@ -41,7 +41,7 @@ from ... import _lib
 from ..._lib import check, ptr
 
 _MAX_TAPS_LDS = 7169      # (1024 + ntap - 1) * 8 B <= 64 KiB
-_OLS_N = 4096             # FFT length of the overlap-save path (tl_hilbert_ols)
+_OLS_N = 1024             # FFT length of the overlap-save path (tl_hilbert_ols)
 
 
 def _device() -> torch.device:
@@ -156,7 +156,7 @@ _TAPS_CACHE = {}
 def _device_taps(T, sampling_rate, cfs, sds, dev):
     """Device copy of the band kernels, cached per (length, rate, bank): the host-side inverse DFT
     is coefficient generation and must not sit in front of every call."""
-    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev), os.environ.get("TONAL_OLS_N", "1024"))
+    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev))
     hit = _TAPS_CACHE.get(key)
     if hit is None:
         taps, half = analytic_taps(T, sampling_rate, cfs, sds)
@@ -169,8 +169,8 @@ def _device_taps(T, sampling_rate, cfs, sds, dev):
             h = (0.5 * (fw + np.conj(bw))).T                # (half + 1, 8): tap-major
             sym = torch.from_numpy(np.ascontiguousarray(np.stack([h.real, h.imag], axis=-1))).to(dev)
         ols = None
-        nfft = int(os.environ.get("TONAL_OLS_N", "1024"))
-        if nfft in (1024, 4096) and 0 < half <= nfft // 4 and taps.shape[0] == 8 and taps.shape[1] == 2 * half + 1 and T >= nfft:
+        nfft = _OLS_N
+        if 0 < half <= nfft // 4 and taps.shape[0] == 8 and taps.shape[1] == 2 * half + 1 and T >= nfft:
             # overlap-save on an LDS-resident FFT (tl_hilbert_ols): the spectra of the same truncated kernels, / N, and the
             # twiddle table (cos, -sin)
             g = np.zeros((8, nfft), dtype=np.complex128)
@@ -194,7 +194,7 @@ def _hilbert_dft(x: torch.Tensor, sampling_rate, cfs, sds, envelope: bool) -> to
     C, T = x.shape
     dev = x.device
     w, bf, tw, m2 = _bluestein_coeffs(T, dev)
-    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev), os.environ.get("TONAL_OLS_N", "1024"))
+    key = (int(T), float(sampling_rate), cfs.tobytes(), sds.tobytes(), str(dev))
     kd = _MULT_CACHE.get(key)
     if kd is None:
         if len(_MULT_CACHE) > 8:

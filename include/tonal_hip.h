@@ -334,7 +334,7 @@ int tl_gauss_envelope(const void* x, int x_is_f64, const double* taps, double* y
  * the fp64 operations of tl_gauss_envelope.  8 bands, 2 half + 1 <= T taps within the LDS window.                   */
 int tl_gauss_envelope_sym(const void* x, int x_is_f64, const double* taps, double* y, int C, int64_t T, int nb, int half,
                           int envelope, void* stream);
-/* The same bank by overlap-save on an LDS-resident FFT (fp64) of nfft = 1024 or 4096 points: G (8, nfft, 2) = FFT_nfft of each
+/* The same bank by overlap-save on an LDS-resident FFT (fp64) of nfft = 1024 points: G (8, nfft, 2) = FFT_nfft of each
  * band's truncated kernel (h_b[n], n = -half..half, placed at 0..2 half) / nfft, tw (nfft, 2) = (cos, -sin)(2 pi m / nfft);
  * 2 half <= nfft / 2.
  * 2.4 x fewer fp64 operations per sample than tl_gauss_envelope_sym at 209 taps.                                       */
