@@ -145,6 +145,17 @@ constexpr int OLS_N = 1024, OLS_Q = OLS_N / 4, OLS_PAD = OLS_N + (OLS_N >> 5);
 __device__ __forceinline__ int ols_idx(int d) { return d + (d >> 5); }
 typedef double ols_d2 __attribute__((ext_vector_type(2)));
 
+// sqrt for the magnitudes: v_rsq_f64 (2^-23) and one Newton step on the residual x - y^2 (fused): ~2^-45 relative, far inside
+// the 1e-9 the golden holds; the library sqrt spends three times the instructions on the last bits and on denormal scaling,
+// and 32 magnitudes per thread were a third of the kernel's vector instructions
+__device__ __forceinline__ double ols_sqrt(double v) {
+  const double r = __builtin_amdgcn_rsq(v);
+  double yv = v * r;
+  const double e = fma(-yv, yv, v);
+  yv = fma(e, 0.5 * r, yv);
+  return v > 0.0 ? yv : 0.0;
+}
+
 template <bool INV>
 __device__ __forceinline__ void ols_bfly(const double (&xr)[4], const double (&xi)[4], double (&yr)[4], double (&yi)[4]) {
   const double t0r = xr[0] + xr[2], t0i = xi[0] + xi[2], t1r = xr[0] - xr[2], t1i = xi[0] - xi[2];
@@ -235,16 +246,23 @@ __global__ __launch_bounds__(OLS_Q) void hilbert_ols_kernel(const void* __restri
     Xr[r] = vr[r];
     Xi[r] = vi[r];
   }
+  ols_d2 g[4], gn[4];                                       // this band's kernel spectrum, the next band's (in flight)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) g[r] = G[tid + r * OLS_Q];
   for (int b = 0; b < NB; ++b) {
+    const int bn = b + 1 < NB ? b + 1 : b;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const ols_d2 g = G[(long long)b * OLS_N + tid + r * OLS_Q];
-      vr[r] = fma(-Xi[r], g[1], Xr[r] * g[0]);
-      vi[r] = fma(Xr[r], g[1], Xi[r] * g[0]);
+      gn[r] = G[(long long)bn * OLS_N + tid + r * OLS_Q];
+      vr[r] = fma(-Xi[r], g[r][1], Xr[r] * g[r][0]);
+      vi[r] = fma(Xr[r], g[r][1], Xi[r] * g[r][0]);
     }
     ols_fft<true>(vr, vi, lds, wc, ws, tid);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += envelope ? sqrt(vr[r] * vr[r] + vi[r] * vi[r]) : vr[r];
+    for (int r = 0; r < 4; ++r) {
+      acc[r] += envelope ? ols_sqrt(fma(vr[r], vr[r], vi[r] * vi[r])) : vr[r];
+      g[r] = gn[r];
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
