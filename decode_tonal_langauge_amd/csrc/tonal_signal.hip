@@ -478,13 +478,25 @@ __global__ __launch_bounds__(64) void filtfilt_iir8_kernel(const double* __restr
   }
 }
 
+// centre part of the time-major work buffer back to channel-major: 64 x 64 tiles through LDS (both sides coalesced)
 __global__ __launch_bounds__(256) void filtfilt_out_kernel(const double* __restrict__ work, double* __restrict__ y, int C,
                                                            long long T, int edge) {
-  const long long total = T * C;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long t = i % T;
-    const int c = (int)(i / T);
-    y[i] = work[(t + edge) * C + c];
+  __shared__ double tile[64][65];
+  const long long t0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;       // 64 x 4
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long long t = t0 + ly + 4 * r;
+    const int c = c0 + lx;
+    if (t < T && c < C) tile[ly + 4 * r][lx] = work[(t + edge) * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = c0 + ly + 4 * r;
+    const long long t = t0 + lx;
+    if (t < T && c < C) y[(long long)c * T + t] = tile[lx][ly + 4 * r];
   }
 }
 
@@ -643,9 +655,8 @@ extern "C" int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, con
     hipLaunchKernelGGL((filtfilt_iir_kernel<9>), grid, dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
   else
     hipLaunchKernelGGL((filtfilt_iir_kernel<MAX_TAPS>), grid, dim3(64), 0, st, b, a, zi, work, C, next, ntaps);
-  long long g2 = ((long long)T * C + 255) / 256;
-  if (g2 > 8192) g2 = 8192;
-  hipLaunchKernelGGL(filtfilt_out_kernel, dim3((unsigned)g2), dim3(256), 0, st, work, y, C, (long long)T, edge);
+  hipLaunchKernelGGL(filtfilt_out_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, st, work, y, C,
+                     (long long)T, edge);
   return check_launch("filtfilt");
 }
 
