@@ -323,7 +323,8 @@ def signal_subresult(dev, with_cpu: bool):
         elif name == "butter_filtfilt":
             rec["bound"] = "latency (fp64 IIR recurrence, sequential in time)"
         else:
-            rec["bound"] = "fp64 VALU (391-tap causal FIR)"
+            rec["bound"] = ("LDS round trips and barriers of the in-LDS FFT (391-tap causal FIR by overlap-save on the 1024-point "
+                            "fp64 transform of tl_hilbert_ols; the time-domain kernel: 0.32 ms, fp64-VALU bound)")
         out[name] = rec
     if with_cpu:
         from oracle import signal_oracle as sg

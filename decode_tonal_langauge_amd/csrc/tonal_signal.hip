@@ -212,16 +212,23 @@ __device__ __forceinline__ void ols_fft(double (&vr)[4], double (&vi)[4], double
   }
 }
 
-template <typename TIN, int NB>
-__global__ __launch_bounds__(OLS_Q) void hilbert_ols_kernel(const void* __restrict__ x, const ols_d2* __restrict__ G,
-                                                            const ols_d2* __restrict__ tw, double* __restrict__ y, long long T,
-                                                            int half, int envelope) {
+// lead: the window starts at t0 - lead; skip: its first skip outputs are the wrapped ones (dropped); circular: indices wrap
+// over the recording (the Gaussian bank) or samples before the start are zero (the causal FIR bank).
+// NBT: compile-time band count (0: the run-time argument nb)
+template <typename TIN, typename TOUT, int NBT>
+__global__ __launch_bounds__(OLS_Q) void ols_bank_kernel(const void* __restrict__ x, const ols_d2* __restrict__ G,
+                                                         const ols_d2* __restrict__ tw, TOUT* __restrict__ y, long long T, int nb,
+                                                         int lead, int skip, int circular, int envelope) {
+  const int NB = NBT ? NBT : nb;
   __shared__ __attribute__((aligned(16))) double lds[4 * OLS_PAD];
   const int tid = threadIdx.x, c = blockIdx.y;
-  const int Lv = OLS_N - 2 * half;
+  const int Lv = OLS_N - skip;
   const long long t0 = (long long)blockIdx.x * Lv;
-  long long base = (t0 - half) % T;
-  if (base < 0) base += T;
+  long long base = t0 - lead;
+  if (circular) {
+    base %= T;
+    if (base < 0) base += T;
+  }
   double wc[4][3], ws[4][3];                                // W_{4 Ns}^{r k} = W_N^{r k N / (4 Ns)}, k = tid % Ns
 #pragma unroll
   for (int st = 1; st < 5; ++st) {
@@ -236,7 +243,9 @@ __global__ __launch_bounds__(OLS_Q) void hilbert_ols_kernel(const void* __restri
   double vr[4], vi[4], Xr[4], Xi[4], acc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    vr[r] = ld_as_f64<TIN>(x, (long long)c * T + (base + tid + r * OLS_Q) % T);
+    const long long ti = base + tid + r * OLS_Q;
+    vr[r] = circular ? ld_as_f64<TIN>(x, (long long)c * T + ti % T)
+                     : ((ti >= 0 && ti < T) ? ld_as_f64<TIN>(x, (long long)c * T + ti) : 0.0);
     vi[r] = 0.0;
     acc[r] = 0.0;
   }
@@ -267,8 +276,8 @@ __global__ __launch_bounds__(OLS_Q) void hilbert_ols_kernel(const void* __restri
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = tid + r * OLS_Q;
-    const long long t = t0 + i - 2 * half;
-    if (i >= 2 * half && t < T) y[(long long)c * T + t] = acc[r] / NB;
+    const long long t = t0 + i - skip;
+    if (i >= skip && t < T) y[(long long)c * T + t] = (TOUT)(acc[r] / NB);
   }
 }
 
@@ -617,7 +626,7 @@ extern "C" int tl_hilbert_ols(const void* x, int x_is_f64, const double* G, cons
                               int nb, int half, int nfft, int envelope, void* stream) {
   TL_REQUIRE(x && G && tw && y, "hilbert_ols: null pointer");
   TL_REQUIRE(C > 0 && C <= 65535 && T > 0, "hilbert_ols: bad sizes");
-  TL_REQUIRE(nb == 8, "hilbert_ols: 8 bands only (use tl_gauss_envelope)");
+  TL_REQUIRE(nb >= 1 && nb <= 64, "hilbert_ols: 1..64 bands");
   TL_REQUIRE(nfft == OLS_N, "hilbert_ols: nfft must be %d", OLS_N);
   TL_REQUIRE(half >= 0 && 2 * half <= OLS_N / 2 && 2LL * half + 1 <= T, "hilbert_ols: the kernels must span at most %d taps", OLS_N / 2 + 1);
   const int Lv = OLS_N - 2 * half;
@@ -626,9 +635,11 @@ extern "C" int tl_hilbert_ols(const void* x, int x_is_f64, const double* G, cons
   const ols_d2* g2 = reinterpret_cast<const ols_d2*>(G);
   const ols_d2* t2 = reinterpret_cast<const ols_d2*>(tw);
   if (x_is_f64)
-    hipLaunchKernelGGL((hilbert_ols_kernel<double, 8>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, half, envelope);
+    if (nb == 8) hipLaunchKernelGGL((ols_bank_kernel<double, double, 8>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, nb, half, 2 * half, 1, envelope);
+    else hipLaunchKernelGGL((ols_bank_kernel<double, double, 0>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, nb, half, 2 * half, 1, envelope);
   else
-    hipLaunchKernelGGL((hilbert_ols_kernel<float, 8>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, half, envelope);
+    if (nb == 8) hipLaunchKernelGGL((ols_bank_kernel<float, double, 8>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, nb, half, 2 * half, 1, envelope);
+    else hipLaunchKernelGGL((ols_bank_kernel<float, double, 0>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, nb, half, 2 * half, 1, envelope);
   return check_launch("hilbert_ols");
 }
 
@@ -671,6 +682,29 @@ extern "C" int tl_sosfilt_f64(const void* x, int x_is_f64, const double* sos, do
   else
     hipLaunchKernelGGL((sosfilt_kernel<float>), grid, dim3(64), 0, st, x, sos, y, C, (long long)T, nsec);
   return check_launch("sosfilt");
+}
+
+// overlap-save form of tl_fir_bank (same causal convolution, zero initial state): G (nb, 1024, 2) = FFT_1024 of each band's taps
+// / 1024, tw as for tl_hilbert_ols; ntap <= 513
+extern "C" int tl_fir_bank_ols(const void* x, int x_is_f64, const double* G, const double* tw, void* y, int y_is_f64, int C,
+                               int64_t T, int nb, int ntap, void* stream) {
+  TL_REQUIRE(x && G && tw && y, "fir_bank_ols: null pointer");
+  TL_REQUIRE(C > 0 && C <= 65535 && T > 0 && nb >= 1 && nb <= 64, "fir_bank_ols: bad sizes");
+  TL_REQUIRE(ntap >= 1 && ntap - 1 <= OLS_N / 2, "fir_bank_ols: at most %d taps", OLS_N / 2 + 1);
+  const int skip = ntap - 1, Lv = OLS_N - skip;
+  dim3 grid((unsigned)((T + Lv - 1) / Lv), (unsigned)C);
+  hipStream_t st = (hipStream_t)stream;
+  const ols_d2* g2 = reinterpret_cast<const ols_d2*>(G);
+  const ols_d2* t2 = reinterpret_cast<const ols_d2*>(tw);
+  if (x_is_f64 && y_is_f64)
+    hipLaunchKernelGGL((ols_bank_kernel<double, double, 0>), grid, dim3(OLS_Q), 0, st, x, g2, t2, (double*)y, (long long)T, nb, skip, skip, 0, 0);
+  else if (!x_is_f64 && y_is_f64)
+    hipLaunchKernelGGL((ols_bank_kernel<float, double, 0>), grid, dim3(OLS_Q), 0, st, x, g2, t2, (double*)y, (long long)T, nb, skip, skip, 0, 0);
+  else if (!x_is_f64 && !y_is_f64)
+    hipLaunchKernelGGL((ols_bank_kernel<float, float, 0>), grid, dim3(OLS_Q), 0, st, x, g2, t2, (float*)y, (long long)T, nb, skip, skip, 0, 0);
+  else
+    hipLaunchKernelGGL((ols_bank_kernel<double, float, 0>), grid, dim3(OLS_Q), 0, st, x, g2, t2, (float*)y, (long long)T, nb, skip, skip, 0, 0);
+  return check_launch("fir_bank_ols");
 }
 
 extern "C" int tl_fir_bank(const void* x, int x_is_f64, const double* taps, void* y, int y_is_f64, int C, int64_t T,

@@ -151,6 +151,16 @@ def analytic_taps(T: int, sampling_rate: float, cfs: np.ndarray, sds: np.ndarray
 
 
 _TAPS_CACHE = {}
+_TW_CACHE = {}
+
+
+def _ols_twiddles(dev):
+    """(cos, -sin)(2 pi m / N), m < N, of the overlap-save transforms."""
+    hit = _TW_CACHE.get(str(dev))
+    if hit is None:
+        ang = 2.0 * np.pi * np.arange(_OLS_N) / _OLS_N
+        hit = _TW_CACHE[str(dev)] = torch.from_numpy(np.ascontiguousarray(np.stack([np.cos(ang), -np.sin(ang)], axis=-1))).to(dev)
+    return hit
 
 
 def _device_taps(T, sampling_rate, cfs, sds, dev):
@@ -176,9 +186,7 @@ def _device_taps(T, sampling_rate, cfs, sds, dev):
             g = np.zeros((8, nfft), dtype=np.complex128)
             g[:, :2 * half + 1] = taps
             G = np.fft.fft(g, axis=1) / nfft
-            ang = 2.0 * np.pi * np.arange(nfft) / nfft
-            ols = (torch.from_numpy(np.ascontiguousarray(np.stack([G.real, G.imag], axis=-1))).to(dev),
-                   torch.from_numpy(np.ascontiguousarray(np.stack([np.cos(ang), -np.sin(ang)], axis=-1))).to(dev), nfft)
+            ols = (torch.from_numpy(np.ascontiguousarray(np.stack([G.real, G.imag], axis=-1))).to(dev), _ols_twiddles(dev), nfft)
         if len(_TAPS_CACHE) > 32:
             _TAPS_CACHE.clear()
         hit = _TAPS_CACHE[key] = (tp, taps.shape[1], half, sym, ols)
@@ -298,8 +306,20 @@ def fir_bandpass_filter(data, fs: float, order: int, center_frequencies: List[fl
         squeeze = True
     x, was_np = _to_device(data)
     C, T = x.shape
-    td = torch.from_numpy(taps).to(x.device)
     y = torch.empty(C, T, dtype=x.dtype, device=x.device)
+    if taps.shape[1] - 1 <= _OLS_N // 2 and T >= _OLS_N and os.environ.get("TONAL_FIR", "ols") == "ols":
+        # the same causal convolution by overlap-save on the LDS-resident FFT (tl_fir_bank_ols): ~5 x fewer fp64 operations
+        # at 391 taps
+        g = np.zeros((taps.shape[0], _OLS_N), dtype=np.float64)
+        g[:, :taps.shape[1]] = taps
+        G = np.fft.fft(g, axis=1) / _OLS_N
+        Gd = torch.from_numpy(np.ascontiguousarray(np.stack([G.real, G.imag], axis=-1))).to(x.device)
+        check(_lib.load().tl_fir_bank_ols(ptr(x), int(x.dtype == torch.float64), ptr(Gd), ptr(_ols_twiddles(x.device)), ptr(y),
+                                          int(y.dtype == torch.float64), C, T, taps.shape[0], taps.shape[1], _stream()),
+              "tl_fir_bank_ols")
+        out = _ret(y, was_np)
+        return out[0] if squeeze else out
+    td = torch.from_numpy(taps).to(x.device)
     check(_lib.load().tl_fir_bank(ptr(x), int(x.dtype == torch.float64), ptr(td), ptr(y),
                                   int(y.dtype == torch.float64), C, T, taps.shape[0], taps.shape[1], _stream()),
           "tl_fir_bank")

@@ -358,6 +358,10 @@ int tl_sosfilt_f64(const void* x, int x_is_f64, const double* sos, double* y, in
 /* causal FIR bank, mean over bands (frequency_filter.py:260-274); taps (nb, ntap) float64      */
 int tl_fir_bank(const void* x, int x_is_f64, const double* taps, void* y, int y_is_f64, int C, int64_t T,
                 int nb, int ntap, void* stream);
+/* the same causal bank by overlap-save on the LDS-resident 1024-point FFT of tl_hilbert_ols: G (nb, 1024, 2) = FFT_1024 of each
+ * band's taps / 1024, tw (1024, 2) the twiddle table; ntap <= 513                                                      */
+int tl_fir_bank_ols(const void* x, int x_is_f64, const double* G, const double* tw, void* y, int y_is_f64, int C, int64_t T,
+                    int nb, int ntap, void* stream);
 
 /* ---- other preprocess/signal steps (same run(data, params) plugin ABI) --------------------------
  * per-channel z-score with statistics over [t0, t1): channel_zscore.py:22-27 (t0=0, t1=T) and

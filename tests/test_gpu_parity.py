@@ -196,6 +196,18 @@ def test_signal_filters_match_reference_golden(dev):
     assert rel(ff.butter_filter(x, [0.3, 100], 400, causal=True), g["butter_causal"]) < 1e-9
     assert rel(ff.fir_bandpass_filter(x, 400, 390, [100.]), g["fir"]) < 1e-9
     assert rel(ff.fir_bandpass_filter(x, 400, 64, [60., 120.]), g["fir2"]) < 1e-9
+    # recordings of >= 1024 samples take the overlap-save form (tl_fir_bank_ols): same numbers as the time-domain kernel
+    for order, cfs_ in ((390, [100.]), (64, [60., 120.]), (512, [90.])):
+        a_ = ff.fir_bandpass_filter(xl, 400, order, cfs_)
+        os.environ["TONAL_FIR"] = "taps"
+        try:
+            b_ = ff.fir_bandpass_filter(xl, 400, order, cfs_)
+        finally:
+            os.environ.pop("TONAL_FIR", None)
+        assert rel(a_, b_) < 1e-12
+    x32 = xl.astype(np.float32)
+    a_ = ff.fir_bandpass_filter(x32, 400, 390, [100.])
+    assert a_.dtype == np.float32 and rel(a_, ff.fir_bandpass_filter(xl, 400, 390, [100.])) < 1e-5
     # float32 input, odd length, two ranges: the reference itself computes this in complex64
     h2 = ff.hilbert_filter(x2, 400, freq_ranges=[(70., 110.), (110., 150.)])
     assert h2.dtype == np.float64 and rel(h2, g["hilbert2"]) < 1e-5
