@@ -169,8 +169,8 @@ __device__ __forceinline__ void ols_bfly(const double (&xr)[4], const double (&x
 }
 // v: the thread's values at positions tid + 256 r, in and out.  wc / ws: its twiddles (cos, -sin) of stages 1..4.
 template <bool INV>
-__device__ __forceinline__ void ols_fft(double (&vr)[4], double (&vi)[4], double* __restrict__ lds, const double (&wc)[4][3],
-                                        const double (&ws)[4][3], int tid) {
+__device__ __forceinline__ void ols_fft(double (&vr)[4], double (&vi)[4], double* __restrict__ lds, const ols_d2* __restrict__ twl,
+                                        const double (&wc)[2][3], const double (&ws)[2][3], int tid) {
   double* bre[2] = {lds, lds + 2 * OLS_PAD};
   double* bim[2] = {lds + OLS_PAD, lds + 3 * OLS_PAD};
   double yr[4], yi[4];
@@ -192,7 +192,16 @@ __device__ __forceinline__ void ols_fft(double (&vr)[4], double (&vi)[4], double
     }
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
-      const double c = wc[st - 1][r - 1], sn = INV ? -ws[st - 1][r - 1] : ws[st - 1][r - 1];
+      // stages 1, 2 have 4 / 16 distinct twiddle sets: a 60-entry LDS table; stages 3, 4: the thread's own, in registers
+      double c, sn;
+      if (st < 3) {
+        const ols_d2 w = twl[(st == 1 ? 0 : 12) + (tid & (Ns - 1)) * 3 + r - 1];
+        c = w[0];
+        sn = INV ? -w[1] : w[1];
+      } else {
+        c = wc[st - 3][r - 1];
+        sn = INV ? -ws[st - 3][r - 1] : ws[st - 3][r - 1];
+      }
       const double tr = fma(-xi[r], sn, xr[r] * c), ti = fma(xr[r], sn, xi[r] * c);
       xr[r] = tr;
       xi[r] = ti;
@@ -229,15 +238,21 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_kernel(const void* __restrict_
     base %= T;
     if (base < 0) base += T;
   }
-  double wc[4][3], ws[4][3];                                // W_{4 Ns}^{r k} = W_N^{r k N / (4 Ns)}, k = tid % Ns
+  // W_{4 Ns}^{r k} = W_N^{r k N / (4 Ns)}, k = tid % Ns
+  __shared__ __attribute__((aligned(16))) ols_d2 twl[60];   // stages 1 (k < 4) and 2 (k < 16), [k][r - 1]
+  if (tid < 60) {
+    const int st = tid < 12 ? 1 : 2, e = tid < 12 ? tid : tid - 12;
+    twl[tid] = tw[(e % 3 + 1) * (e / 3) * (OLS_Q >> (2 * st))];
+  }
+  double wc[2][3], ws[2][3];
 #pragma unroll
-  for (int st = 1; st < 5; ++st) {
+  for (int st = 3; st < 5; ++st) {
     const int step = (tid & ((1 << (2 * st)) - 1)) * (OLS_Q >> (2 * st));
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
       const ols_d2 w = tw[r * step];
-      wc[st - 1][r - 1] = w[0];
-      ws[st - 1][r - 1] = w[1];
+      wc[st - 3][r - 1] = w[0];
+      ws[st - 3][r - 1] = w[1];
     }
   }
   double vr[4], vi[4], Xr[4], Xi[4], acc[4];
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_kernel(const void* __restrict_
     vi[r] = 0.0;
     acc[r] = 0.0;
   }
-  ols_fft<false>(vr, vi, lds, wc, ws, tid);
+  ols_fft<false>(vr, vi, lds, twl, wc, ws, tid);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     Xr[r] = vr[r];
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_kernel(const void* __restrict_
       vr[r] = fma(-Xi[r], g[r][1], Xr[r] * g[r][0]);
       vi[r] = fma(Xr[r], g[r][1], Xi[r] * g[r][0]);
     }
-    ols_fft<true>(vr, vi, lds, wc, ws, tid);
+    ols_fft<true>(vr, vi, lds, twl, wc, ws, tid);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       acc[r] += envelope ? ols_sqrt(fma(vr[r], vr[r], vi[r] * vi[r])) : vr[r];
