@@ -18,8 +18,10 @@ The arithmetic runs in HIP kernels (``csrc/tonal_signal.hip``):
    truncated kernels of up to 513 taps - the high-gamma bank of the pipeline - take the fastest form of the same
    convolution: overlap-save on an LDS-resident 1024-point fp64 FFT (``tl_hilbert_ols``; the spectra of the SAME truncated
    kernels; ``TONAL_HILBERT=sym`` keeps the time-domain kernel, which uses the kernels' Hermitian symmetry);
- * ``filtfilt`` / ``sosfilt`` are fp64 direct-form-II-transposed recurrences, one lane per channel;
- * the FIR bank is a causal convolution with zero initial state.
+ * ``filtfilt`` / ``sosfilt`` are fp64 direct-form-II-transposed recurrences, sequential in time exactly like scipy's loop
+   (``filtfilt``: the state spread over the lanes of a DPP row per channel, bit-identical; ``sosfilt``: one lane per channel);
+ * the FIR bank is a causal convolution with zero initial state (recordings of >= 1024 samples: overlap-save on the same
+   LDS FFT as the Hilbert bank, ``tl_fir_bank_ols``).
 Filter *design* (``butter``, ``lfilter_zi``, ``firwin``) stays on scipy: coefficient generation,
 not the hot path.
 
