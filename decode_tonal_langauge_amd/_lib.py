@@ -101,8 +101,10 @@ SIGNATURES = {
     "tl_nadam_multi_dev": (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_lowrank": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_tone_dynamics": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "tl_splitk_bias_lrelu": (_I, [_P, _P, _P, _I, _L, _I, _F, _P]),
+    "tl_labels_from_scores": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tl_lite_conv_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "tl_lite_bn_finalize": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _P]),
+    "tl_lite_bn_finalize": (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _I, _P, _P]),
     "tl_lite_bn_act_pool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "tl_lite_bn_act_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "tl_lite_conv_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

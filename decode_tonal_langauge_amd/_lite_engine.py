@@ -96,7 +96,7 @@ class LiteEngine:
         self.m1, self.r1 = torch.empty(CC, **f32), torch.empty(CC, **f32)
         check(lib.tl_lite_bn_finalize(ptr(part), ptr(self.m1), ptr(self.r1), ptr(t["ecog_conv.1.running_mean"]),
                                       ptr(t["ecog_conv.1.running_var"]), B * nt1, CC, B * T, 0.1, 1e-5, int(training),
-                                      st), "tl_lite_bn_finalize")
+                                      ptr(t["ecog_conv.1.num_batches_tracked"]), st), "tl_lite_bn_finalize")
         self.y1 = torch.empty(B, CC, T1, **f32)
         check(lib.tl_lite_bn_act_pool_fwd(ptr(self.z1), ptr(self.m1), ptr(self.r1), ptr(t["ecog_conv.1.weight"]),
                                           ptr(t["ecog_conv.1.bias"]), ptr(self.y1), B, CC, T, self.slope, st),
@@ -109,14 +109,11 @@ class LiteEngine:
         self.m2, self.r2 = torch.empty(CC, **f32), torch.empty(CC, **f32)
         check(lib.tl_lite_bn_finalize(ptr(part2), ptr(self.m2), ptr(self.r2), ptr(t["ecog_conv.5.running_mean"]),
                                       ptr(t["ecog_conv.5.running_var"]), B * nt2, CC, B * T1, 0.1, 1e-5,
-                                      int(training), st), "tl_lite_bn_finalize")
+                                      int(training), ptr(t["ecog_conv.5.num_batches_tracked"]), st), "tl_lite_bn_finalize")
         y2 = torch.empty(B, CC, T2, **f32)
         check(lib.tl_lite_bn_act_pool_fwd(ptr(self.z2), ptr(self.m2), ptr(self.r2), ptr(t["ecog_conv.5.weight"]),
                                           ptr(t["ecog_conv.5.bias"]), ptr(y2), B, CC, T1, self.slope, st),
               "tl_lite_bn_act_pool_fwd")
-        if training:
-            t["ecog_conv.1.num_batches_tracked"] += 1
-            t["ecog_conv.5.num_batches_tracked"] += 1
         # label LSTM
         L = labels.shape[2]
         self._L = L
@@ -149,9 +146,9 @@ class LiteEngine:
         self._nt(A=ptr(self.feat), Bw=ptr(w1), out=ptr(slab), M=B, A_rows=B, N=self.hid, K=self.ldf, lda=self.ldf,
                  ldb=self.ldf, ldo=self.hid, loader=LOAD_DIRECT, epilogue=EPI_STORE, bm=bm, splitk=sk,
                  slab_stride=B * self.hid)
-        pre = torch.empty(B, self.hid, **f32)
-        self._permute(slab, pre, (1, 1, B, self.hid), (0, 0, self.hid, 1), nz=sk, zs=B * self.hid, bias=t["fc.1.bias"])
-        self.a1 = torch.nn.functional.leaky_relu(pre, self.slope)
+        self.a1 = torch.empty(B, self.hid, **f32)
+        check(lib.tl_splitk_bias_lrelu(ptr(slab), ptr(t["fc.1.bias"]), ptr(self.a1), sk, B * self.hid, self.hid, self.slope, st),
+              "tl_splitk_bias_lrelu")
         out = torch.empty(B, self.out_dim, **f32)
         tiles3 = ((B + bm - 1) // bm) * ((self.out_dim + 127) // 128)
         sk3 = int(max(1, min((self.hid + 31) // 32, 64 // tiles3)))

@@ -84,9 +84,11 @@ __global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(64) void lite_bn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
                                                               float* __restrict__ rstd, float* __restrict__ run_mean,
                                                               float* __restrict__ run_var, int nparts, int C, long long count,
-                                                              float momentum, float eps, int training) {
+                                                              float momentum, float eps, int training,
+                                                              long long* __restrict__ tracked) {
   const int c = blockIdx.x;                      // one wave per channel, lanes stride over the partials
   const int lane = threadIdx.x;
+  if (training && tracked != nullptr && c == 0 && lane == 0) tracked[0] += 1;     // BatchNorm's num_batches_tracked
   if (training) {
     double s1 = 0.0, s2 = 0.0;
     for (int i = lane; i < nparts; i += 64) {
@@ -509,10 +511,10 @@ extern "C" int tl_lite_conv_fwd(const float* x, const float* w, const float* bia
   return check_launch("lite_conv_fwd");
 }
 extern "C" int tl_lite_bn_finalize(const float* part, float* mean, float* rstd, float* run_mean, float* run_var,
-                                   int nparts, int C, int64_t count, float momentum, float eps, int training, void* stream) {
+                                   int nparts, int C, int64_t count, float momentum, float eps, int training, int64_t* tracked, void* stream) {
   TL_REQUIRE(mean && rstd && run_mean && run_var && C > 0 && (part || !training), "lite_bn_finalize: bad arguments");
   hipLaunchKernelGGL(lite_bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, part, mean, rstd,
-                     run_mean, run_var, nparts, C, (long long)count, momentum, eps, training);
+                     run_mean, run_var, nparts, C, (long long)count, momentum, eps, training, (long long*)tracked);
   return check_launch("lite_bn_finalize");
 }
 extern "C" int tl_lite_bn_act_pool_fwd(const float* z, const float* mean, const float* rstd, const float* gamma,

@@ -939,6 +939,48 @@ __global__ void tone_dynamics_kernel(const long long* __restrict__ tone, const l
   }
 }
 
+// out[i] = LeakyReLU(sum_z slab[z][i] + bias[i % ncols]): the split-K reduction of a Linear layer with its bias and activation
+__global__ __launch_bounds__(256) void splitk_bias_lrelu_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                                float* __restrict__ out, int nz, long long n, int ncols,
+                                                                float slope) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int z = 0; z < nz; ++z) acc += slab[(long long)z * n + i];
+    if (bias) acc += bias[i % ncols];
+    out[i] = acc > 0.f ? acc : acc * slope;
+  }
+}
+
+// arg-max of both classifiers' scores + the gather above + the (tone, syllable) pair id, one thread per window: the label pass
+// of a train step in one launch (five ATen kernels + tone_dynamics_kernel otherwise).  First maximum wins, as torch.argmax.
+__global__ void labels_from_scores_kernel(const float* __restrict__ st, const float* __restrict__ ss, const float* __restrict__ table,
+                                          float* __restrict__ labels, long long* __restrict__ tone, long long* __restrict__ syl,
+                                          int32_t* __restrict__ pair, int32_t* err, int B, int nt, int ns, int n_rows, int n_syl,
+                                          int L) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int t = 0, y = 0;
+  float best = st[(long long)b * nt];
+  for (int i = 1; i < nt; ++i) {
+    const float v = st[(long long)b * nt + i];
+    if (v > best) { best = v; t = i; }
+  }
+  best = ss[(long long)b * ns];
+  for (int i = 1; i < ns; ++i) {
+    const float v = ss[(long long)b * ns + i];
+    if (v > best) { best = v; y = i; }
+  }
+  tone[b] = t;
+  syl[b] = y;
+  if (pair != nullptr) pair[b] = t * n_syl + y;
+  const bool ok = t < n_rows;
+  if (!ok) *err = 1;
+  for (int l = 0; l < L; ++l) {
+    labels[((long long)b * 2) * L + l] = (float)y;
+    labels[((long long)b * 2 + 1) * L + l] = ok ? table[(long long)t * L + l] : 0.f;
+  }
+}
+
 static inline unsigned grid_for(long long total, int block = 256, long long cap = 256LL * 32) {
   long long g = (total + block - 1) / block;
   if (g < 1) g = 1;
@@ -1250,6 +1292,24 @@ extern "C" int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, c
                      m, v, fa, fb, kr, rows, cols, ldfa, ldfb, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps,
                      weight_decay, grad_scale);
   return check_launch("nadam_lowrank");
+}
+
+extern "C" int tl_splitk_bias_lrelu(const float* slab, const float* bias, float* out, int nz, int64_t n, int ncols, float slope,
+                                    void* stream) {
+  TL_REQUIRE(slab && out && nz > 0 && n > 0 && ncols > 0, "splitk_bias_lrelu: bad arguments");
+  hipLaunchKernelGGL(splitk_bias_lrelu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, slab, bias, out, nz,
+                     (long long)n, ncols, slope);
+  return check_launch("splitk_bias_lrelu");
+}
+
+extern "C" int tl_labels_from_scores(const float* tone_scores, const float* syl_scores, const float* table, float* labels,
+                                     int64_t* tone, int64_t* syl, int32_t* pair, int32_t* err, int B, int n_tone_cls,
+                                     int n_syl_cls, int n_rows, int n_syl, int L, void* stream) {
+  TL_REQUIRE(tone_scores && syl_scores && table && labels && tone && syl && err, "labels_from_scores: null pointer");
+  TL_REQUIRE(B > 0 && n_tone_cls > 0 && n_syl_cls > 0 && n_rows > 0 && L > 0, "labels_from_scores: bad sizes");
+  hipLaunchKernelGGL(labels_from_scores_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tone_scores, syl_scores,
+                     table, labels, (long long*)tone, (long long*)syl, pair, err, B, n_tone_cls, n_syl_cls, n_rows, n_syl, L);
+  return check_launch("labels_from_scores");
 }
 
 extern "C" int tl_tone_dynamics(const int64_t* tone, const int64_t* syl, const float* table, float* labels,

@@ -126,16 +126,30 @@ class SynthesisTrainer:
     # ------------------------------------------------------------------ helpers
     def _labels(self, inputs_tone, inputs_syllable) -> torch.Tensor:
         """argmax of both classifiers + device gather of the dynamics (reference :207-218)."""
-        tone = torch.argmax(self.tone_model(inputs_tone), dim=1).contiguous()
-        syl = torch.argmax(self.syllable_model(inputs_syllable), dim=1).contiguous()
-        B = tone.shape[0]
+        st, ss = self.tone_model(inputs_tone), self.syllable_model(inputs_syllable)
+        B = st.shape[0]
         labels = torch.empty(B, 2, self._L, dtype=torch.float32, device=self.device)
         self._pair_ids = None
-        if self._pair_table is not None:          # ids are valid for exactly this label tensor
-            self._pair_ids = ((tone * self._n_syl + syl).to(torch.int32), labels)
-        check(self.lib.tl_tone_dynamics(ptr(tone), ptr(syl), ptr(self._table), ptr(labels), ptr(self._err), B,
-                                        self._n_rows, self._L, torch.cuda.current_stream().cuda_stream),
-              "tl_tone_dynamics")
+        if st.dim() == 2 and ss.dim() == 2 and st.dtype == torch.float32 and ss.dtype == torch.float32 and st.is_cuda and ss.is_cuda:
+            # arg-max of both score matrices, the dynamics gather and the pair id in one launch
+            st, ss = st.detach().contiguous(), ss.detach().contiguous()
+            tone = torch.empty(B, dtype=torch.int64, device=self.device)
+            syl = torch.empty(B, dtype=torch.int64, device=self.device)
+            pair = torch.empty(B, dtype=torch.int32, device=self.device) if self._pair_table is not None else None
+            check(self.lib.tl_labels_from_scores(ptr(st), ptr(ss), ptr(self._table), ptr(labels), ptr(tone), ptr(syl),
+                                                 ptr(pair) if pair is not None else None, ptr(self._err), B, st.shape[1],
+                                                 ss.shape[1], self._n_rows, self._n_syl if pair is not None else 1, self._L,
+                                                 torch.cuda.current_stream().cuda_stream), "tl_labels_from_scores")
+            if pair is not None:                  # ids are valid for exactly this label tensor
+                self._pair_ids = (pair, labels)
+        else:
+            tone = torch.argmax(st, dim=1).contiguous()
+            syl = torch.argmax(ss, dim=1).contiguous()
+            if self._pair_table is not None:          # ids are valid for exactly this label tensor
+                self._pair_ids = ((tone * self._n_syl + syl).to(torch.int32), labels)
+            check(self.lib.tl_tone_dynamics(ptr(tone), ptr(syl), ptr(self._table), ptr(labels), ptr(self._err), B,
+                                            self._n_rows, self._L, torch.cuda.current_stream().cuda_stream),
+                  "tl_tone_dynamics")
         if self._need_check:
             # a predicted tone may be absent from the mapping: keep the reference's immediate error.  Under
             # data parallelism the decision is taken by all ranks together (a rank that raised alone would

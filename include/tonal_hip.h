@@ -285,6 +285,15 @@ int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float*
 /* labels[b][0][l] = syl[b]; labels[b][1][l] = table[tone[b]][l]; err flag set if tone out of range */
 int tl_tone_dynamics(const int64_t* tone, const int64_t* syl, const float* table, float* labels,
                      int32_t* err, int B, int n_tones, int L, void* stream);
+/* out[i] = LeakyReLU(sum_z slab[z][i] + bias[i % ncols]), i < n: split-K reduction + bias + activation of a Linear layer
+ * (models/synthesis_models.py:252-256, fc.1 of SynthesisLite)                                                       */
+int tl_splitk_bias_lrelu(const float* slab, const float* bias, float* out, int nz, int64_t n, int ncols, float slope, void* stream);
+/* the whole label pass of a train step (models/synthesis_trainer.py:207-218) in one launch: tone = argmax of tone_scores
+ * (B, n_tone_cls), syl = argmax of syl_scores (B, n_syl_cls) (first maximum), the gather of tl_tone_dynamics (n_rows table
+ * rows) and, if pair is given, pair[b] = tone * n_syl + syl                                                        */
+int tl_labels_from_scores(const float* tone_scores, const float* syl_scores, const float* table, float* labels, int64_t* tone,
+                          int64_t* syl, int32_t* pair, int32_t* err, int B, int n_tone_cls, int n_syl_cls, int n_rows, int n_syl,
+                          int L, void* stream);
 
 /* ---- SynthesisLite blocks (models/synthesis_models.py:236-263,265-296) ----------------------
  * x (B,Cin,T) channels-first like the reference's Conv1d; 'same' padding (2*pad == k-1).       */
@@ -294,7 +303,8 @@ int tl_lite_conv_fwd(const float* x, const float* w, const float* bias, float* z
 /* BatchNorm1d statistics: training -> batch mean / rstd from `part` (+ running-stat update,
  * unbiased variance); eval -> from the running buffers                                        */
 int tl_lite_bn_finalize(const float* part, float* mean, float* rstd, float* run_mean, float* run_var,
-                        int nparts, int C, int64_t count, float momentum, float eps, int training, void* stream);
+                        int nparts, int C, int64_t count, float momentum, float eps, int training,
+                        int64_t* tracked /* optional: BatchNorm's num_batches_tracked, += 1 in training */, void* stream);
 /* y (B,C,T/2) = MaxPool1d(2)(LeakyReLU(BN(z)))                                                 */
 int tl_lite_bn_act_pool_fwd(const float* z, const float* mean, const float* rstd, const float* gamma,
                             const float* beta, float* y, int B, int C, int T, float slope, void* stream);
