@@ -183,11 +183,14 @@ class LiteEngine:
         # ones (out_dim and F + H multiples of 4 - the reference's sizes are): no slab, no copy
         direct3 = ldd == self.out_dim and grads["fc.3.weight"].is_contiguous()
         slab = grads["fc.3.weight"] if direct3 else torch.empty(ldd, hid, **f32)
+        # (short reductions: the bias gradient = the column sums of the same operand comes out of the weight-gradient kernel)
+        cs3 = ldd == self.out_dim and B <= 512 and ldd * hid <= (1 << 20)
         self._tn(A=ptr(dout), B=ptr(self.a1), slab=ptr(slab), Krows=B, A_rows=B, B_rows=B, Mdim=ldd, Ndim=hid, lda=ldd,
-                 ldb=hid, ldc=hid, loader=LOAD_DIRECT)
+                 ldb=hid, ldc=hid, loader=LOAD_DIRECT, colsum=ptr(grads["fc.3.bias"]) if cs3 else None)
         if not direct3:
             grads["fc.3.weight"].copy_(slab[:self.out_dim])
-        self._colsum(dout, B, self.out_dim, ldd, grads["fc.3.bias"])
+        if not cs3:
+            self._colsum(dout, B, self.out_dim, ldd, grads["fc.3.bias"])
         w2t = torch.empty(hid, ldd, **f32)
         self._permute(t["fc.3.weight"], w2t, (1, 1, hid, ldd), (0, 0, 1, hid), (1, 1, hid, self.out_dim))
         g1 = torch.empty(B, hid, **f32)
@@ -197,11 +200,13 @@ class LiteEngine:
         # fc.1
         direct1 = ldf == fh and grads["fc.1.weight"].is_contiguous()
         slab1 = grads["fc.1.weight"] if direct1 else torch.empty(hid, ldf, **f32)
+        cs1 = B <= 512 and hid * ldf <= (1 << 20)
         self._tn(A=ptr(g1), B=ptr(self.feat), slab=ptr(slab1), Krows=B, A_rows=B, B_rows=B, Mdim=hid, Ndim=ldf, lda=hid,
-                 ldb=ldf, ldc=ldf, loader=LOAD_DIRECT)
+                 ldb=ldf, ldc=ldf, loader=LOAD_DIRECT, colsum=ptr(grads["fc.1.bias"]) if cs1 else None)
         if not direct1:
             grads["fc.1.weight"].copy_(slab1[:, :fh])
-        self._colsum(g1, B, hid, hid, grads["fc.1.bias"])
+        if not cs1:
+            self._colsum(g1, B, hid, hid, grads["fc.1.bias"])
         w1t = torch.empty(ldf, hid, **f32)
         self._permute(t["fc.1.weight"], w1t, (1, 1, ldf, hid), (0, 0, 1, fh), (1, 1, fh, hid))
         dfeat = torch.empty(B, ldf, **f32)

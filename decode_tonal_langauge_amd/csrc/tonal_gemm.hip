@@ -1243,6 +1243,10 @@ __global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
     r0m = r0m >= p.Tp ? r0m - p.Tp : r0m;
   };
   f32x4 acc[4] = {zero, zero, zero, zero};
+  // optional column sums of A (the bias gradient of a Linear layer rides along): the workgroups of the first column tile,
+  // threads 0..31, one column each, rows in order
+  const bool do_cs = p.colsum != nullptr && nt == 0 && gridDim.y == 1 && tid < TS_M;
+  float csum = 0.f;
   fetch(kb);
   for (int r0 = kb; r0 < kr; r0 += TS_K) {
     __syncthreads();                                       // the chunk in front has been consumed
@@ -1252,6 +1256,10 @@ __global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
     for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Bs + ((tid + i * 256) >> 5) * TS_N + ((tid + i * 256) & 31) * 4) = rb[i];
     __syncthreads();
     if (r0 + TS_K < kr) fetch(r0 + TS_K);
+    if (do_cs) {
+#pragma unroll 8
+      for (int R = 0; R < TS_K; ++R) csum += As[R * TS_M + tid];
+    }
 #pragma unroll 8
     for (int R = 0; R < TS_K; ++R) {
       const f32x4 av = *reinterpret_cast<const f32x4*>(As + R * TS_M + tm * 4);
@@ -1266,6 +1274,7 @@ __global__ __launch_bounds__(256) void tn_short_kernel(const tl_tn_params p) {
     for (int i = 0; i < 4; ++i)
       *reinterpret_cast<f32x4*>(p.slab + (long long)blockIdx.y * p.slab_stride + (long long)(m0 + i) * p.ldc + n0) = acc[i];
   }
+  if (do_cs && mt + tid < p.Mdim) p.colsum[mt + tid] = csum;
 }
 }  // namespace tl
 
@@ -1294,6 +1303,7 @@ extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
     hipLaunchKernelGGL(tn_short_kernel, dim3((unsigned)nwg, (unsigned)p.splitk), dim3(256), 0, st, p);
     return check_launch("tn_short");
   }
+  TL_REQUIRE(p.colsum == nullptr, "tn_window: colsum is produced by the short-reduction kernel only (Krows <= 512, splitk <= 8, Mdim * Ndim <= 2^20)");
   if (p.Mdim <= 32 && p.J == 1 && p.loader == LOAD_DIRECT) {       // skinny-M streaming variant
     dim3 grid((unsigned)((p.Ndim + SK_BN - 1) / SK_BN), (unsigned)p.splitk, 1);
     hipLaunchKernelGGL(tn_skinny_kernel, grid, dim3(256), 0, st, p);

@@ -98,7 +98,9 @@ typedef struct {
   int Tp, Tvalid;
   int loader;
   int splitk; int64_t slab_stride;
-  float* colsum;      /* optional (tl_conv3_wino43_tn): colsum[z][n] = sum over split z of the un-pooled
+  float* colsum;      /* optional.  tl_gemm_tn_window on its short-reduction kernel (Krows <= 512, splitk 1): colsum[m] = sum
+                         over the rows of A[.][m], Mdim floats (the bias gradient of a Linear layer); tl_conv3_wino43_tn:
+                         colsum[z][n] = sum over split z of the un-pooled
                          dZ column n (the bias gradient partial sums; Ndim floats per split), or null */
   float* vd; int ld_vd; /* optional (tl_conv3_wino43v_tn): also write Vd[quad][6][ld_vd] = the F(4,3) input transform of
                          the un-pooled dZ rows 4q-2 .. 4q+3 - the operand of the stage's input-gradient pass
