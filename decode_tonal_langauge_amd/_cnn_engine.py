@@ -841,9 +841,8 @@ class CnnEngine:
         else:
             dense_whh().zero_()
         gb = grads["label_lstm.bias_ih_l0"]
-        check(lib.tl_lstm_ih_grad(ptr(dg), ptr(self._xu), ptr(grads["label_lstm.weight_ih_l0"]), ptr(gb), L, U, H, 2,
-                                  st_), "tl_lstm_ih_grad")
-        grads["label_lstm.bias_hh_l0"].copy_(gb)
+        check(lib.tl_lstm_ih_grad(ptr(dg), ptr(self._xu), ptr(grads["label_lstm.weight_ih_l0"]), ptr(gb),
+                                  ptr(grads["label_lstm.bias_hh_l0"]), L, U, H, 2, st_), "tl_lstm_ih_grad")
         del dg, dgt
         if on_factors is not None:
             on_factors()

@@ -89,7 +89,7 @@ SIGNATURES = {
     "tl_lstm_infer_seq_fused": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, C.POINTER(C.c_int), _P]),
     "tl_lstm_infer_seq": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "tl_lstm_ih_grad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tl_lstm_ih_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_concat_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint64, _L, _P]),
     "tl_concat_unpack_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F,
                                   C.c_uint64, _L, _P]),

@@ -250,9 +250,8 @@ class LiteEngine:
         else:
             gwhh.zero_()
         gb = grads["label_lstm.bias_ih_l0"]
-        check(lib.tl_lstm_ih_grad(ptr(dg), ptr(self.xl), ptr(grads["label_lstm.weight_ih_l0"]), ptr(gb), 1, B * L, H,
-                                  self.in_dim, st), "tl_lstm_ih_grad")
-        grads["label_lstm.bias_hh_l0"].copy_(gb)
+        check(lib.tl_lstm_ih_grad(ptr(dg), ptr(self.xl), ptr(grads["label_lstm.weight_ih_l0"]), ptr(gb),
+                                  ptr(grads["label_lstm.bias_hh_l0"]), 1, B * L, H, self.in_dim, st), "tl_lstm_ih_grad")
         # block 2
         work = torch.empty(B * CC * 2 + CC * 2, **f32)
         dz2 = torch.empty(B, CC, T1, **f32)

@@ -502,8 +502,8 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(256) void lstm_ih_grad_kernel(const float* __restrict__ dgates, const float* __restrict__ x,
-                                                           float* __restrict__ dw_ih, float* __restrict__ db, int L, int U,
-                                                           int H, int in_dim) {
+                                                           float* __restrict__ dw_ih, float* __restrict__ db,
+                                                           float* __restrict__ db2, int L, int U, int H, int in_dim) {
   const long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (r >= 4LL * H) return;
   float accw[MAXKT];
@@ -521,12 +521,13 @@ __global__ __launch_bounds__(256) void lstm_ih_grad_kernel(const float* __restri
   for (int d = 0; d < MAXKT; ++d)
     if (d < in_dim) dw_ih[r * in_dim + d] = accw[d];
   db[r] = accb;
+  if (db2) db2[r] = accb;
 }
 
 // few gate rows (SynthesisLite: 4H = 256): one wave per row, lanes stride over the (t,u) pairs
 __global__ __launch_bounds__(64) void lstm_ih_grad_wave_kernel(const float* __restrict__ dgates, const float* __restrict__ x,
-                                                               float* __restrict__ dw_ih, float* __restrict__ db, int LU,
-                                                               int H, int in_dim) {
+                                                               float* __restrict__ dw_ih, float* __restrict__ db,
+                                                               float* __restrict__ db2, int LU, int H, int in_dim) {
   const long long r = blockIdx.x;
   const int lane = threadIdx.x;
   float accw[MAXKT];
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(64) void lstm_ih_grad_wave_kernel(const float* __re
     for (int d = 0; d < MAXKT; ++d)
       if (d < in_dim) dw_ih[r * in_dim + d] = accw[d];
     db[r] = accb;
+    if (db2) db2[r] = accb;
   }
 }
 
@@ -1183,17 +1185,17 @@ extern "C" int tl_lstm_cell_bwd(const float* dh, const float* dh_rec, const floa
   return check_launch("lstm_cell_bwd");
 }
 
-extern "C" int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih, float* db, int L, int U, int H,
+extern "C" int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih, float* db, float* db2, int L, int U, int H,
                                int in_dim, void* stream) {
   TL_REQUIRE(dgates && x && dw_ih && db, "lstm_ih_grad: null pointer");
   TL_REQUIRE(in_dim >= 1 && in_dim <= MAXKT, "lstm_ih_grad: in_dim must be 1..%d", MAXKT);
   const long long total = 4LL * H;
   if (total <= 8192 && (long long)L * U >= 64)
     hipLaunchKernelGGL(lstm_ih_grad_wave_kernel, dim3((unsigned)total), dim3(64), 0, (hipStream_t)stream, dgates, x, dw_ih,
-                       db, L * U, H, in_dim);
+                       db, db2, L * U, H, in_dim);
   else
     hipLaunchKernelGGL(lstm_ih_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       dgates, x, dw_ih, db, L, U, H, in_dim);
+                       dgates, x, dw_ih, db, db2, L, U, H, in_dim);
   return check_launch("lstm_ih_grad");
 }
 

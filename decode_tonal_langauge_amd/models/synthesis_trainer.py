@@ -241,7 +241,8 @@ class SynthesisTrainer:
                           seed=0 if graph else model._next_seed(), row0=getattr(self, "_row0", 0), **kw)
         B, D = out.shape
         self._last_out = out             # the step's outputs (pre-update), for callers that track them (tests)
-        dout = torch.zeros(B, eng.ldd, dtype=torch.float32, device=out.device)
+        # (tl_l1_mcd writes all D columns of a row: the zero fill is only for padding columns)
+        dout = (torch.empty if eng.ldd == D else torch.zeros)(B, eng.ldd, dtype=torch.float32, device=out.device)
         self._loss_stats(out, targets, dout, eng.ldd, 1)
         gather = self._timed(parallel.gather_lowrank) if self.dp else None
         reduce_rows = self._timed(parallel.all_reduce_) if self.dp else None

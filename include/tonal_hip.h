@@ -229,7 +229,7 @@ int tl_lstm_cell_bwd(const float* dh, const float* dh_rec, const float* dc_next,
                      const float* c, const float* c_prev, float* dgates, float* dgates_t, float* dc_prev,
                      int U, int H, int ldt, void* stream);
 /* dW_ih (4H,in_dim), db (4H) from dgates (L,U,4H) and x (L,U,in_dim)                        */
-int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih, float* db,
+int tl_lstm_ih_grad(const float* dgates, const float* x, float* dw_ih, float* db, float* db2 /* optional second copy of db: bias_hh */,
                     int L, int U, int H, int in_dim, void* stream);
 
 /* ---- concat / dropout glue (models/synthesis_models.py:107,160-170) ----------------------- */
