@@ -121,6 +121,7 @@ SIGNATURES = {
     "tl_gauss_envelope": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_gauss_envelope_sym": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _I, _P]),
     "tl_hilbert_ols": (_I, [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
+    "tl_hilbert_ols_bl": (_I, [_P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_hilbert_fft": (_I, [_P, _I, _P, _I, _L, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "tl_filtfilt_f64": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
     "tl_sosfilt_f64": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),

@@ -168,6 +168,12 @@ __device__ __forceinline__ void ols_bfly(const double (&xr)[4], const double (&x
   yr[3] = t1r - t3r; yi[3] = t1i - t3i;
 }
 // v: the thread's values at positions tid + 256 r, in and out.  wc / ws: its twiddles (cos, -sin) of stages 1..4.
+// LDS layouts, one per exchange (a layout only has to agree between a stage's stores and the next stage's loads): the
+// outputs of stages 0 and 1 are stored digit-major - element d at (digit of d the store's r runs over) x 264 + (the rest of
+// d) = r x 264 + tid - so a ds_write_b64's 16-lane groups and the next stage's 32-lane read groups (which then start at
+// (tid & 3) x 264 + ..: +8 banks per digit) each touch every bank once; stages 2 and 3 are conflict-free in natural order.
+// (The padded natural order used before, d + (d >> 5), stored stage 0 two-way and stage 1 four-way conflicted.)
+constexpr int OLS_DS = OLS_Q + 8;                            // digit stride; 4 OLS_DS = OLS_PAD
 template <bool INV>
 __device__ __forceinline__ void ols_fft(double (&vr)[4], double (&vi)[4], double* __restrict__ lds, const ols_d2* __restrict__ twl,
                                         const double (&wc)[2][3], const double (&ws)[2][3], int tid) {
@@ -177,18 +183,21 @@ __device__ __forceinline__ void ols_fft(double (&vr)[4], double (&vi)[4], double
   ols_bfly<INV>(vr, vi, yr, yi);                            // stage 0 (Ns = 1, no twiddles): outputs 4 tid + r
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    bre[0][ols_idx(4 * tid + r)] = yr[r];
-    bim[0][ols_idx(4 * tid + r)] = yi[r];
+    bre[0][tid + r * OLS_DS] = yr[r];
+    bim[0][tid + r * OLS_DS] = yi[r];
   }
   __syncthreads();
 #pragma unroll
   for (int st = 1; st < 5; ++st) {
     const int src = (st - 1) & 1, dst = st & 1, Ns = 1 << (2 * st);
+    // element tid + 256 r of the previous stage's output
+    const int rd = st == 1 ? (tid & 3) * OLS_DS + (tid >> 2) : st == 2 ? ((tid >> 2) & 3) * OLS_DS + 4 * (tid >> 4) + (tid & 3) : tid;
+    const int rds = st < 3 ? OLS_Q / 4 : OLS_Q;
     double xr[4], xi[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      xr[r] = bre[src][ols_idx(tid + r * OLS_Q)];
-      xi[r] = bim[src][ols_idx(tid + r * OLS_Q)];
+      xr[r] = bre[src][rd + r * rds];
+      xi[r] = bim[src][rd + r * rds];
     }
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
@@ -208,11 +217,13 @@ __device__ __forceinline__ void ols_fft(double (&vr)[4], double (&vi)[4], double
     }
     if (st < 4) {
       ols_bfly<INV>(xr, xi, yr, yi);
-      const int base = ((tid >> (2 * st)) << (2 * st + 2)) + (tid & (Ns - 1));
+      // outputs ((tid >> 2 st) << (2 st + 2)) + (tid & (Ns - 1)) + r Ns
+      const int wr = st == 1 ? tid : ((tid >> (2 * st)) << (2 * st + 2)) + (tid & (Ns - 1));
+      const int wrs = st == 1 ? OLS_DS : Ns;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        bre[dst][ols_idx(base + r * Ns)] = yr[r];
-        bim[dst][ols_idx(base + r * Ns)] = yi[r];
+        bre[dst][wr + r * wrs] = yr[r];
+        bim[dst][wr + r * wrs] = yi[r];
       }
       __syncthreads();
     } else {
@@ -293,6 +304,174 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_kernel(const void* __restrict_
     const int i = tid + r * OLS_Q;
     const long long t = t0 + i - skip;
     if (i >= skip && t < T) y[(long long)c * T + t] = (TOUT)(acc[r] / NB);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Band-limited form of the same overlap-save bank.  A Gaussian band's kernel spectrum is non-zero (above 1e-12 of its peak:
+// the caller checks) on fewer than 256 of the 1024 bins, k0 <= k < k0 + 256, so its inverse transform is
+//   z[4 m + r] = W^{-k0 n} . IDFT_256( Z[k0 + k'] W_1024^{-k' r} )[m]
+// : four independent 256-point transforms, one per residue r - ONE WAVE EACH (lane l owns k' = l + 64 j going in and
+// m = l + 64 j coming out), with the residue's twiddle folded into the kernel spectrum on the host (Gp[b][r][k']).  A
+// 256-point radix-4 Stockham has four stages = three exchanges, and they are private to the wave: no workgroup barrier in
+// the band loop, 4/5 of the butterflies, 3/4 of the LDS round trips of the 1024-point inverse.  The forward transform is the
+// 1024-point one above; its result goes to LDS once (16 KB) and every wave reads its window of it per band.  |z| does not
+// see the modulation W^{-k0 n}; the real part (envelope = 0) multiplies it back from the twiddle table.
+// ------------------------------------------------------------------------------------------
+constexpr int OLS_WQ = 256;
+__device__ __forceinline__ void ols_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// v: the lane's values at l + 64 j, in and out; re / im: the wave's own planes (OLS_WPL doubles); tc / ts: (cos, -sin) of
+// stages 1..3.  Layouts per exchange as in ols_fft: digit-major (stride 72) after stages 0 and 1, natural after stage 2.
+constexpr int OLS_WDS = 64 + 8, OLS_WPL = 4 * OLS_WDS;
+template <bool INV>
+__device__ __forceinline__ void ols_fft256_wave(double (&vr)[4], double (&vi)[4], double* __restrict__ re, double* __restrict__ im,
+                                                const double (&tc)[3][3], const double (&ts)[3][3], int l) {
+  double yr[4], yi[4];
+  ols_bfly<INV>(vr, vi, yr, yi);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    re[l + r * OLS_WDS] = yr[r];
+    im[l + r * OLS_WDS] = yi[r];
+  }
+  ols_wave_sync();
+#pragma unroll
+  for (int st = 1; st < 4; ++st) {
+    const int rd = st == 1 ? (l & 3) * OLS_WDS + (l >> 2) : st == 2 ? ((l >> 2) & 3) * OLS_WDS + 4 * (l >> 4) + (l & 3) : l;
+    const int rds = st < 3 ? 16 : 64;
+    double xr[4], xi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xr[r] = re[rd + r * rds];
+      xi[r] = im[rd + r * rds];
+    }
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      const double c = tc[st - 1][r - 1], sn = INV ? -ts[st - 1][r - 1] : ts[st - 1][r - 1];
+      const double tr = fma(-xi[r], sn, xr[r] * c), ti = fma(xr[r], sn, xi[r] * c);
+      xr[r] = tr;
+      xi[r] = ti;
+    }
+    if (st < 3) {
+      ols_bfly<INV>(xr, xi, yr, yi);
+      const int wr = st == 1 ? l : ((l >> 4) << 6) + (l & 15);
+      const int wrs = st == 1 ? OLS_WDS : 16;
+      ols_wave_sync();                                        // (the LDS queue of a wave is in order: reads above, then writes)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        re[wr + r * wrs] = yr[r];
+        im[wr + r * wrs] = yi[r];
+      }
+      ols_wave_sync();
+    } else {
+      ols_bfly<INV>(xr, xi, vr, vi);                          // last stage (Ns = 64): outputs l + 64 r = the lane's own
+    }
+  }
+}
+
+template <typename TIN, int NBT>
+__global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restrict__ x, const ols_d2* __restrict__ Gp,
+                                                            const int* __restrict__ k0s, const ols_d2* __restrict__ tw,
+                                                            double* __restrict__ y, long long T, int nb, int lead, int skip,
+                                                            int envelope) {
+  const int NB = NBT ? NBT : nb;
+  __shared__ __attribute__((aligned(16))) double lds[2 * OLS_N + 8 * OLS_WPL];      // >= 4 OLS_PAD
+  __shared__ __attribute__((aligned(16))) ols_d2 twl[60];
+  const int tid = threadIdx.x, c = blockIdx.y;
+  const int Lv = OLS_N - skip;
+  const long long t0 = (long long)blockIdx.x * Lv;
+  long long base = (t0 - lead) % T;
+  if (base < 0) base += T;
+  double vr[4], vi[4], acc[4];
+  {
+    if (tid < 60) {
+      const int st = tid < 12 ? 1 : 2, e = tid < 12 ? tid : tid - 12;
+      twl[tid] = tw[(e % 3 + 1) * (e / 3) * (OLS_Q >> (2 * st))];
+    }
+    double wc[2][3], ws[2][3];
+#pragma unroll
+    for (int st = 3; st < 5; ++st) {
+      const int step = (tid & ((1 << (2 * st)) - 1)) * (OLS_Q >> (2 * st));
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {
+        const ols_d2 w = tw[r * step];
+        wc[st - 3][r - 1] = w[0];
+        ws[st - 3][r - 1] = w[1];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long ti = base + tid + r * OLS_Q;
+      vr[r] = ld_as_f64<TIN>(x, (long long)c * T + ti % T);
+      vi[r] = 0.0;
+      acc[r] = 0.0;
+    }
+    ols_fft<false>(vr, vi, lds, twl, wc, ws, tid);
+  }
+  // the spectrum, once, where every wave can read its band's window of it (the plane the last forward stage did not read)
+  ols_d2* Xs = reinterpret_cast<ols_d2*>(lds);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ols_d2 v2;
+    v2[0] = vr[r];
+    v2[1] = vi[r];
+    Xs[tid + r * OLS_Q] = v2;
+  }
+  const int w = tid >> 6, l = tid & 63;
+  double* wre = lds + 2 * OLS_N + w * 2 * OLS_WPL;
+  double* wim = wre + OLS_WPL;
+  double tc[3][3], ts[3][3];                                  // W_{4 Ns}^{r k}, k = l % Ns, as W_1024^{r k 256 / Ns}
+#pragma unroll
+  for (int st = 1; st < 4; ++st) {
+    const int step = (l & ((1 << (2 * st)) - 1)) * (OLS_WQ >> (2 * st));
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      const ols_d2 t = tw[r * step];
+      tc[st - 1][r - 1] = t[0];
+      ts[st - 1][r - 1] = t[1];
+    }
+  }
+  ols_d2 g[4], gn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) g[r] = Gp[w * OLS_WQ + l + 64 * r];
+  __syncthreads();
+  for (int b = 0; b < NB; ++b) {
+    const int bn = b + 1 < NB ? b + 1 : b;
+    const int k0 = k0s[b];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gn[r] = Gp[(long long)(bn * 4 + w) * OLS_WQ + l + 64 * r];
+      const ols_d2 X = Xs[(k0 + l + 64 * r) & (OLS_N - 1)];
+      vr[r] = fma(-X[1], g[r][1], X[0] * g[r][0]);
+      vi[r] = fma(X[0], g[r][1], X[1] * g[r][0]);
+    }
+    ols_fft256_wave<true>(vr, vi, wre, wim, tc, ts, l);
+    if (envelope) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += ols_sqrt(fma(vr[r], vr[r], vi[r] * vi[r]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                           // Re(z W^{-k0 n}), n = 4 (l + 64 r) + w
+        const ols_d2 e = tw[(k0 * (4 * (l + 64 * r) + w)) & (OLS_N - 1)];
+        acc[r] += fma(vi[r], e[1], vr[r] * e[0]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[r] = gn[r];
+    ols_wave_sync();
+  }
+  __syncthreads();                                            // every wave is done with the spectrum: its plane takes the outputs
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lds[l + OLS_WDS * w + OLS_WPL * r] = acc[r];   // sample 4 l + w + 256 r, residue-major
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = tid + r * OLS_Q;
+    const long long t = t0 + i - skip;
+    if (i >= skip && t < T) y[(long long)c * T + t] = lds[(tid >> 2) + OLS_WDS * (tid & 3) + OLS_WPL * r] / NB;
   }
 }
 
@@ -656,6 +835,30 @@ extern "C" int tl_hilbert_ols(const void* x, int x_is_f64, const double* G, cons
     if (nb == 8) hipLaunchKernelGGL((ols_bank_kernel<float, double, 8>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, nb, half, 2 * half, 1, envelope);
     else hipLaunchKernelGGL((ols_bank_kernel<float, double, 0>), grid, dim3(OLS_Q), 0, st, x, g2, t2, y, (long long)T, nb, half, 2 * half, 1, envelope);
   return check_launch("hilbert_ols");
+}
+
+// band-limited overlap-save form (ols_bank_bl_kernel): Gp (nb, 4, 256, 2) = G_b[(k0_b + k) % 1024] . exp(+2 pi i k r / 1024)
+// for residue r < 4 and k < 256, where G_b is tl_hilbert_ols's spectrum and every |G_b| outside its window
+// [k0_b, k0_b + 256) is negligible (the caller's check); k0 (nb) int32 on the device
+extern "C" int tl_hilbert_ols_bl(const void* x, int x_is_f64, const double* Gp, const int* k0, const double* tw, double* y, int C,
+                                 int64_t T, int nb, int half, int nfft, int envelope, void* stream) {
+  TL_REQUIRE(x && Gp && k0 && tw && y, "hilbert_ols_bl: null pointer");
+  TL_REQUIRE(C > 0 && C <= 65535 && T > 0, "hilbert_ols_bl: bad sizes");
+  TL_REQUIRE(nb >= 1 && nb <= 64, "hilbert_ols_bl: 1..64 bands");
+  TL_REQUIRE(nfft == OLS_N, "hilbert_ols_bl: nfft must be %d", OLS_N);
+  TL_REQUIRE(half >= 0 && 2 * half <= OLS_N / 2 && 2LL * half + 1 <= T, "hilbert_ols_bl: the kernels must span at most %d taps", OLS_N / 2 + 1);
+  const int Lv = OLS_N - 2 * half;
+  dim3 grid((unsigned)((T + Lv - 1) / Lv), (unsigned)C);
+  hipStream_t st = (hipStream_t)stream;
+  const ols_d2* g2 = reinterpret_cast<const ols_d2*>(Gp);
+  const ols_d2* t2 = reinterpret_cast<const ols_d2*>(tw);
+  if (x_is_f64)
+    if (nb == 8) hipLaunchKernelGGL((ols_bank_bl_kernel<double, 8>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+    else hipLaunchKernelGGL((ols_bank_bl_kernel<double, 0>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+  else
+    if (nb == 8) hipLaunchKernelGGL((ols_bank_bl_kernel<float, 8>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+    else hipLaunchKernelGGL((ols_bank_bl_kernel<float, 0>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+  return check_launch("hilbert_ols_bl");
 }
 
 extern "C" int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, const double* a, const double* zi,

@@ -352,6 +352,12 @@ int tl_gauss_envelope_sym(const void* x, int x_is_f64, const double* taps, doubl
  * 2.4 x fewer fp64 operations per sample than tl_gauss_envelope_sym at 209 taps.                                       */
 int tl_hilbert_ols(const void* x, int x_is_f64, const double* G, const double* tw, double* y, int C, int64_t T, int nb,
                    int half, int nfft, int envelope, void* stream);
+/* tl_hilbert_ols for band-limited kernels (the Gaussian bank: frequency_filter.py:155-175): when every |G_b| outside a window
+ * of nfft / 4 bins [k0_b, k0_b + nfft / 4) is negligible (the caller checks: < 1e-10 of the peak in sum), band b's inverse
+ * transform is four independent (nfft / 4)-point transforms, one wave each, with no workgroup barrier in the band loop.
+ * Gp (nb, 4, nfft / 4, 2) = G_b[(k0_b + k) % nfft] . exp(+2 pi i k r / nfft), r < 4; k0 (nb) int32, device memory.     */
+int tl_hilbert_ols_bl(const void* x, int x_is_f64, const double* Gp, const int* k0, const double* tw, double* y, int C,
+                      int64_t T, int nb, int half, int nfft, int envelope, void* stream);
 /* The same bank evaluated in the DFT domain exactly as the reference writes it (frequency_filter.py:155-184):
  * X = DFT(x), z_b = IDFT(X . K_b), y = mean_b |z_b| (envelope) or mean_b Re z_b.  Arbitrary T (Bluestein chirp-z
  * over radix-2 Stockham passes, fp64).  kernels (nb, T) real = H_b x analytic multiplier; w (T,2) chirp, bf (m2,2) FFT
