@@ -270,7 +270,10 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_kernel(const void* __restrict_
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const long long ti = base + tid + r * OLS_Q;
-    vr[r] = circular ? ld_as_f64<TIN>(x, (long long)c * T + ti % T)
+    // circular: base < T; one conditional subtraction wraps it when T >= 1024 (the 64-bit % was a third of the kernel's
+    // instructions); shorter recordings keep the division
+    const long long tw_ = T >= OLS_N ? (ti >= T ? ti - T : ti) : ti % T;
+    vr[r] = circular ? ld_as_f64<TIN>(x, (long long)c * T + tw_)
                      : ((ti >= 0 && ti < T) ? ld_as_f64<TIN>(x, (long long)c * T + ti) : 0.0);
     vi[r] = 0.0;
     acc[r] = 0.0;
@@ -324,52 +327,86 @@ __device__ __forceinline__ void ols_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// v: the lane's values at l + 64 j, in and out; re / im: the wave's own planes (OLS_WPL doubles); tc / ts: (cos, -sin) of
-// stages 1..3.  Layouts per exchange as in ols_fft: digit-major (stride 72) after stages 0 and 1, natural after stage 2.
-constexpr int OLS_WDS = 64 + 8, OLS_WPL = 4 * OLS_WDS;
+// v: the lane's values at l + 64 j, in and out; buf: the wave's own OLS_WPL (re, im) pairs; tc / ts: (cos, -sin) of stages
+// 1..3.  16-byte accesses (two 8-byte planes get merged by the compiler into ds_read2_b64, which moves half the bytes per
+// clock of ds_read_b64 / ds_read_b128).  Layouts per exchange as in ols_fft: digit-major after stages 0 and 1 - digit stride
+// 68 resp. 72 elements, which is what keeps the ds_read_b128 lane groups {0-3, 12-15, 20-27}, .. of the NEXT stage on
+// sixteen different 16-byte slots - natural order after stage 2.
+// The last exchange does not go through LDS at all: stage 3 wants, in register r of lane (h, lo) [h = l >> 4], what stage 2
+// left in register h of lane (r, lo) - a 4 x 4 transpose between the register index and the lane's top two bits, which is
+// v_permlane32_swap (register bit 1 <-> lane bit 5) followed by v_permlane16_swap (register bit 0 <-> lane bit 4): sixteen
+// one-pass instructions for the four complex doubles instead of four 16-byte stores, a wait and four 16-byte loads.
+constexpr int OLS_WS0 = 64 + 4, OLS_WS1 = 64 + 8, OLS_WPL = 4 * OLS_WS1;
+template <bool S32>
+__device__ __forceinline__ void ols_lane_swap(double& a, double& b) {
+  unsigned a0 = (unsigned)__double2loint(a), a1 = (unsigned)__double2hiint(a);
+  unsigned b0 = (unsigned)__double2loint(b), b1 = (unsigned)__double2hiint(b);
+  const auto r0 = S32 ? __builtin_amdgcn_permlane32_swap(a0, b0, false, false) : __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+  const auto r1 = S32 ? __builtin_amdgcn_permlane32_swap(a1, b1, false, false) : __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+  a = __hiloint2double((int)r1[0], (int)r0[0]);
+  b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void ols_lane_transpose(double (&v)[4]) {
+  ols_lane_swap<true>(v[0], v[2]);
+  ols_lane_swap<true>(v[1], v[3]);
+  ols_lane_swap<false>(v[0], v[1]);
+  ols_lane_swap<false>(v[2], v[3]);
+}
 template <bool INV>
-__device__ __forceinline__ void ols_fft256_wave(double (&vr)[4], double (&vi)[4], double* __restrict__ re, double* __restrict__ im,
-                                                const double (&tc)[3][3], const double (&ts)[3][3], int l) {
-  double yr[4], yi[4];
-  ols_bfly<INV>(vr, vi, yr, yi);
+__device__ __forceinline__ void ols_twiddle(double (&xr)[4], double (&xi)[4], const double (&tc)[3], const double (&ts)[3]) {
+#pragma unroll
+  for (int r = 1; r < 4; ++r) {
+    const double c = tc[r - 1], sn = INV ? -ts[r - 1] : ts[r - 1];
+    const double tr = fma(-xi[r], sn, xr[r] * c), ti = fma(xr[r], sn, xi[r] * c);
+    xr[r] = tr;
+    xi[r] = ti;
+  }
+}
+template <bool INV>
+__device__ __forceinline__ void ols_fft256_wave(double (&vr)[4], double (&vi)[4], ols_d2* __restrict__ buf, const double (&tc)[3][3],
+                                                const double (&ts)[3][3], int l) {
+  double xr[4], xi[4], yr[4], yi[4];
+  ols_bfly<INV>(vr, vi, yr, yi);                              // stage 0: outputs 4 l + r, stored digit-major (stride 68)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    re[l + r * OLS_WDS] = yr[r];
-    im[l + r * OLS_WDS] = yi[r];
+    ols_d2 t;
+    t[0] = yr[r];
+    t[1] = yi[r];
+    buf[l + r * OLS_WS0] = t;
   }
   ols_wave_sync();
+  const int rd0 = (l & 3) * OLS_WS0 + (l >> 2);
 #pragma unroll
-  for (int st = 1; st < 4; ++st) {
-    const int rd = st == 1 ? (l & 3) * OLS_WDS + (l >> 2) : st == 2 ? ((l >> 2) & 3) * OLS_WDS + 4 * (l >> 4) + (l & 3) : l;
-    const int rds = st < 3 ? 16 : 64;
-    double xr[4], xi[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      xr[r] = re[rd + r * rds];
-      xi[r] = im[rd + r * rds];
-    }
-#pragma unroll
-    for (int r = 1; r < 4; ++r) {
-      const double c = tc[st - 1][r - 1], sn = INV ? -ts[st - 1][r - 1] : ts[st - 1][r - 1];
-      const double tr = fma(-xi[r], sn, xr[r] * c), ti = fma(xr[r], sn, xi[r] * c);
-      xr[r] = tr;
-      xi[r] = ti;
-    }
-    if (st < 3) {
-      ols_bfly<INV>(xr, xi, yr, yi);
-      const int wr = st == 1 ? l : ((l >> 4) << 6) + (l & 15);
-      const int wrs = st == 1 ? OLS_WDS : 16;
-      ols_wave_sync();                                        // (the LDS queue of a wave is in order: reads above, then writes)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        re[wr + r * wrs] = yr[r];
-        im[wr + r * wrs] = yi[r];
-      }
-      ols_wave_sync();
-    } else {
-      ols_bfly<INV>(xr, xi, vr, vi);                          // last stage (Ns = 64): outputs l + 64 r = the lane's own
-    }
+  for (int r = 0; r < 4; ++r) {
+    const ols_d2 t = buf[rd0 + r * 16];
+    xr[r] = t[0];
+    xi[r] = t[1];
   }
+  ols_twiddle<INV>(xr, xi, tc[0], ts[0]);
+  ols_bfly<INV>(xr, xi, yr, yi);                              // stage 1: outputs 16 (l >> 2) + (l & 3) + 4 r, digit-major (72)
+  ols_wave_sync();                                            // (the LDS queue of a wave is in order: reads above, then writes)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ols_d2 t;
+    t[0] = yr[r];
+    t[1] = yi[r];
+    buf[l + r * OLS_WS1] = t;
+  }
+  ols_wave_sync();
+  const int rd1 = ((l >> 2) & 3) * OLS_WS1 + 4 * (l >> 4) + (l & 3);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const ols_d2 t = buf[rd1 + r * 16];
+    xr[r] = t[0];
+    xi[r] = t[1];
+  }
+  ols_twiddle<INV>(xr, xi, tc[1], ts[1]);
+  ols_bfly<INV>(xr, xi, yr, yi);                              // stage 2: outputs 64 (l >> 4) + (l & 15) + 16 r
+  ols_lane_transpose(yr);                                     // -> element l + 64 r in register r
+  ols_lane_transpose(yi);
+  ols_twiddle<INV>(yr, yi, tc[2], ts[2]);
+  ols_bfly<INV>(yr, yi, vr, vi);                              // stage 3 (Ns = 64): outputs l + 64 r = the lane's own
+  ols_wave_sync();                                            // the next transform's stores stay behind this one's loads
 }
 
 template <typename TIN, int NBT>
@@ -383,8 +420,9 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
   const int tid = threadIdx.x, c = blockIdx.y;
   const int Lv = OLS_N - skip;
   const long long t0 = (long long)blockIdx.x * Lv;
-  long long base = (t0 - lead) % T;
+  long long base = t0 - lead;                                 // in (-T, 2 T): T >= 1024 >= lead, t0 < T + 1024
   if (base < 0) base += T;
+  if (base >= T) base -= T;
   double vr[4], vi[4], acc[4];
   {
     if (tid < 60) {
@@ -404,8 +442,9 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const long long ti = base + tid + r * OLS_Q;
-      vr[r] = ld_as_f64<TIN>(x, (long long)c * T + ti % T);
+      long long ti = base + tid + r * OLS_Q;                  // < 2 T (the host requires T >= 1024): no 64-bit division
+      if (ti >= T) ti -= T;
+      vr[r] = ld_as_f64<TIN>(x, (long long)c * T + ti);
       vi[r] = 0.0;
       acc[r] = 0.0;
     }
@@ -421,8 +460,7 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
     Xs[tid + r * OLS_Q] = v2;
   }
   const int w = tid >> 6, l = tid & 63;
-  double* wre = lds + 2 * OLS_N + w * 2 * OLS_WPL;
-  double* wim = wre + OLS_WPL;
+  ols_d2* wbuf = reinterpret_cast<ols_d2*>(lds + 2 * OLS_N) + w * OLS_WPL;
   double tc[3][3], ts[3][3];                                  // W_{4 Ns}^{r k}, k = l % Ns, as W_1024^{r k 256 / Ns}
 #pragma unroll
   for (int st = 1; st < 4; ++st) {
@@ -448,7 +486,7 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
       vr[r] = fma(-X[1], g[r][1], X[0] * g[r][0]);
       vi[r] = fma(X[0], g[r][1], X[1] * g[r][0]);
     }
-    ols_fft256_wave<true>(vr, vi, wre, wim, tc, ts, l);
+    ols_fft256_wave<true>(vr, vi, wbuf, tc, ts, l);
     if (envelope) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] += ols_sqrt(fma(vr[r], vr[r], vi[r] * vi[r]));
@@ -465,13 +503,13 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
   }
   __syncthreads();                                            // every wave is done with the spectrum: its plane takes the outputs
 #pragma unroll
-  for (int r = 0; r < 4; ++r) lds[l + OLS_WDS * w + OLS_WPL * r] = acc[r];   // sample 4 l + w + 256 r, residue-major
+  for (int r = 0; r < 4; ++r) lds[l + 72 * w + 288 * r] = acc[r];   // sample 4 l + w + 256 r, residue-major
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = tid + r * OLS_Q;
     const long long t = t0 + i - skip;
-    if (i >= skip && t < T) y[(long long)c * T + t] = lds[(tid >> 2) + OLS_WDS * (tid & 3) + OLS_WPL * r] / NB;
+    if (i >= skip && t < T) y[(long long)c * T + t] = lds[(tid >> 2) + 72 * (tid & 3) + 288 * r] / NB;
   }
 }
 
@@ -847,6 +885,7 @@ extern "C" int tl_hilbert_ols_bl(const void* x, int x_is_f64, const double* Gp, 
   TL_REQUIRE(nb >= 1 && nb <= 64, "hilbert_ols_bl: 1..64 bands");
   TL_REQUIRE(nfft == OLS_N, "hilbert_ols_bl: nfft must be %d", OLS_N);
   TL_REQUIRE(half >= 0 && 2 * half <= OLS_N / 2 && 2LL * half + 1 <= T, "hilbert_ols_bl: the kernels must span at most %d taps", OLS_N / 2 + 1);
+  TL_REQUIRE(T >= OLS_N, "hilbert_ols_bl: the recording must hold at least %d samples", OLS_N);
   const int Lv = OLS_N - 2 * half;
   dim3 grid((unsigned)((T + Lv - 1) / Lv), (unsigned)C);
   hipStream_t st = (hipStream_t)stream;
