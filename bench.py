@@ -304,15 +304,17 @@ def signal_subresult(dev, with_cpu: bool):
                 taps = int(ff.analytic_taps(T, FS, cfs, sds)[0].shape[1])
             except Exception:                          # noqa: BLE001 - helper names are internal
                 pass
-            # Default path for this bank: overlap-save on an LDS-resident 1024-point fp64 FFT (tl_hilbert_ols): per segment of
-            # 1024 - (taps - 1) outputs one forward and 8 inverse transforms (5 radix-4 stages of 256 butterflies, ~40 FLOP
-            # each), 8 spectrum products and 8 magnitudes.  The time-domain bank it replaces: 8 bands x taps complex FMAs.
+            # Default path for this bank: band-limited overlap-save (tl_hilbert_ols_bl): per segment of 1024 - (taps - 1) outputs
+            # one forward 1024-point transform (5 radix-4 stages of 256 butterflies, ~40 FLOP each) and, per band, four
+            # wave-private 256-point inverses (4 stages of 64 butterflies each), the spectrum product and the magnitudes.
+            # The time-domain bank it replaces: 8 bands x taps complex FMAs.
             nfft = 1024
             segs = C * -(-T // (nfft - (taps - 1)))
-            fl = segs * (9 * 5 * (nfft // 4) * 40.0 + 8 * nfft * (8 + 5))
+            fl = segs * ((5 + 8 * 4) * (nfft // 4) * 40.0 + 8 * nfft * (8 + 5))
             fl_plain = 2.0 * 2 * 8 * taps * C * T      # 8 bands x taps complex FMAs (2 real FMA = 4 FLOP) per sample
-            rec.update({"bound": "LDS round trips and barriers of the in-LDS FFT (overlap-save, 1024-point fp64 Stockham radix-4; "
-                                 "4 workgroups per CU); the time-domain form of the same convolution is fp64-VALU bound at 0.47 ms",
+            rec.update({"bound": "fp64 VALU issue + LDS round trips of the in-LDS FFTs (band-limited overlap-save: 1024-point forward, "
+                                 "four wave-private 256-point inverses per band, last exchange by lane swaps; 4 workgroups per CU); "
+                                 "the time-domain form of the same convolution is fp64-VALU bound at 0.47 ms",
                         "taps": taps, "fp64_tflops_issued": round(fl / (ms * 1e-3) / 1e12, 2),
                         "fp64_tflops_plain_bank_equivalent": round(fl_plain / (ms * 1e-3) / 1e12, 2),
                         "fp64_peak_tflops": PEAK_FP64_VALU_TFLOPS,

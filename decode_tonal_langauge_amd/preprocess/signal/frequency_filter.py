@@ -290,66 +290,99 @@ def butter_filter(data, freqs: Union[Tuple[float, float], float], fs: float, ord
     C, T = x.shape
     lib = _lib.load()
     y = torch.empty(C, T, dtype=torch.float64, device=x.device)
+    key = (int(order), tuple(np.atleast_1d(wn).tolist()), str(filter_type), bool(causal), str(x.device))
+    coef = _BUTTER_CACHE.get(key)
+    if coef is None:
+        # coefficient design (scipy, as the reference calls it) and its host-to-device copies, once per filter
+        if causal:
+            sos = np.ascontiguousarray(butter(order, wn, btype=filter_type, output='sos'), dtype=np.float64)
+            coef = (torch.from_numpy(sos).to(x.device), sos.shape[0])
+        else:
+            b, a = butter(order, wn, btype=filter_type)
+            ntaps = max(len(a), len(b))
+            bb = np.zeros(ntaps)
+            aa = np.zeros(ntaps)
+            bb[:len(b)] = b / a[0]
+            aa[:len(a)] = a / a[0]
+            zi = lfilter_zi(bb, aa)
+            coef = tuple(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(x.device) for v in (bb, aa, zi)) + (ntaps,)
+        if len(_BUTTER_CACHE) > 32:
+            _BUTTER_CACHE.clear()
+        _BUTTER_CACHE[key] = coef
     if causal:
-        sos = np.ascontiguousarray(butter(order, wn, btype=filter_type, output='sos'), dtype=np.float64)
-        sd = torch.from_numpy(sos).to(x.device)
-        check(lib.tl_sosfilt_f64(ptr(x), int(x.dtype == torch.float64), ptr(sd), ptr(y), C, T, sos.shape[0], _stream()),
+        sd, nsec = coef
+        check(lib.tl_sosfilt_f64(ptr(x), int(x.dtype == torch.float64), ptr(sd), ptr(y), C, T, nsec, _stream()),
               "tl_sosfilt_f64")
     else:
-        b, a = butter(order, wn, btype=filter_type)
-        ntaps = max(len(a), len(b))
+        bd, ad, zd, ntaps = coef
         edge = 3 * ntaps
         if T <= edge:
             raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
-        bb = np.zeros(ntaps)
-        aa = np.zeros(ntaps)
-        bb[:len(b)] = b / a[0]
-        aa[:len(a)] = a / a[0]
-        zi = lfilter_zi(bb, aa)
-        dev = x.device
-        bd, ad, zd = (torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev) for v in (bb, aa, zi))
-        work = torch.empty(2, T + 2 * edge, C, dtype=torch.float64, device=dev)
+        work = torch.empty(2, T + 2 * edge, C, dtype=torch.float64, device=x.device)
         check(lib.tl_filtfilt_f64(ptr(x), int(x.dtype == torch.float64), ptr(bd), ptr(ad), ptr(zd), ptr(y), ptr(work),
                                   C, T, ntaps, _stream()), "tl_filtfilt_f64")
     out = _ret(y, was_np)
     return out[0] if squeeze else out
 
 
+_BUTTER_CACHE = {}
+
+
 def fir_bandpass_filter(data, fs: float, order: int, center_frequencies: List[float]):
     """Causal FIR band-pass bank, mean over centre frequencies (reference :232-274), including its
     double normalisation of the cut-offs (:265-268).  Output dtype follows the input (:261)."""
-    nyquist = 0.5 * fs
-    taps = []
-    for fc in center_frequencies:
-        taps.append(firwin(order + 1, [fc * 0.9 / nyquist, fc * 1.1 / nyquist], pass_zero=False, fs=fs))
-    taps = np.ascontiguousarray(np.array(taps), dtype=np.float64)
-    if taps.shape[1] > _MAX_TAPS_LDS:
-        raise ValueError(f"fir_bandpass_filter: order {order} exceeds the kernel limit {_MAX_TAPS_LDS - 1}")
     squeeze = False
     if not isinstance(data, torch.Tensor) and np.asarray(data).ndim == 1:
         data = np.asarray(data)[None, :]
         squeeze = True
     x, was_np = _to_device(data)
     C, T = x.shape
+    use_ols = T >= _OLS_N and os.environ.get("TONAL_FIR", "ols") == "ols"
+    coef, nb, ntap, ols = _fir_coefficients(float(fs), int(order), tuple(float(f) for f in center_frequencies), bool(use_ols),
+                                            x.device)
     y = torch.empty(C, T, dtype=x.dtype, device=x.device)
-    if taps.shape[1] - 1 <= _OLS_N // 2 and T >= _OLS_N and os.environ.get("TONAL_FIR", "ols") == "ols":
+    if ols:
         # the same causal convolution by overlap-save on the LDS-resident FFT (tl_fir_bank_ols): ~5 x fewer fp64 operations
         # at 391 taps
-        g = np.zeros((taps.shape[0], _OLS_N), dtype=np.float64)
-        g[:, :taps.shape[1]] = taps
-        G = np.fft.fft(g, axis=1) / _OLS_N
-        Gd = torch.from_numpy(np.ascontiguousarray(np.stack([G.real, G.imag], axis=-1))).to(x.device)
-        check(_lib.load().tl_fir_bank_ols(ptr(x), int(x.dtype == torch.float64), ptr(Gd), ptr(_ols_twiddles(x.device)), ptr(y),
-                                          int(y.dtype == torch.float64), C, T, taps.shape[0], taps.shape[1], _stream()),
+        check(_lib.load().tl_fir_bank_ols(ptr(x), int(x.dtype == torch.float64), ptr(coef), ptr(_ols_twiddles(x.device)), ptr(y),
+                                          int(y.dtype == torch.float64), C, T, nb, ntap, _stream()),
               "tl_fir_bank_ols")
-        out = _ret(y, was_np)
-        return out[0] if squeeze else out
-    td = torch.from_numpy(taps).to(x.device)
-    check(_lib.load().tl_fir_bank(ptr(x), int(x.dtype == torch.float64), ptr(td), ptr(y),
-                                  int(y.dtype == torch.float64), C, T, taps.shape[0], taps.shape[1], _stream()),
-          "tl_fir_bank")
+    else:
+        check(_lib.load().tl_fir_bank(ptr(x), int(x.dtype == torch.float64), ptr(coef), ptr(y),
+                                      int(y.dtype == torch.float64), C, T, nb, ntap, _stream()),
+              "tl_fir_bank")
     out = _ret(y, was_np)
     return out[0] if squeeze else out
+
+
+_FIR_CACHE = {}
+
+
+def _fir_coefficients(fs, order, cfs, use_ols, dev):
+    """Device copy of the bank's coefficients, cached per (rate, order, centre frequencies, form): ``firwin`` (reference
+    :265-268, with its double normalisation of the cut-offs) and, for the overlap-save form, the kernels' 1024-point spectra
+    / 1024 - coefficient generation and its host-to-device copy do not sit in front of every call.
+    Returns (tensor, n_bands, n_taps, is_overlap_save)."""
+    key = (fs, order, cfs, use_ols, str(dev))
+    hit = _FIR_CACHE.get(key)
+    if hit is None:
+        nyquist = 0.5 * fs
+        taps = np.ascontiguousarray(np.array([firwin(order + 1, [fc * 0.9 / nyquist, fc * 1.1 / nyquist], pass_zero=False, fs=fs)
+                                              for fc in cfs]), dtype=np.float64)
+        if taps.shape[1] > _MAX_TAPS_LDS:
+            raise ValueError(f"fir_bandpass_filter: order {order} exceeds the kernel limit {_MAX_TAPS_LDS - 1}")
+        ols = use_ols and taps.shape[1] - 1 <= _OLS_N // 2
+        if ols:
+            g = np.zeros((taps.shape[0], _OLS_N), dtype=np.float64)
+            g[:, :taps.shape[1]] = taps
+            G = np.fft.fft(g, axis=1) / _OLS_N
+            coef = torch.from_numpy(np.ascontiguousarray(np.stack([G.real, G.imag], axis=-1))).to(dev)
+        else:
+            coef = torch.from_numpy(taps).to(dev)
+        if len(_FIR_CACHE) > 32:
+            _FIR_CACHE.clear()
+        hit = _FIR_CACHE[key] = (coef, taps.shape[0], taps.shape[1], ols)
+    return hit
 
 
 def run(data, params: Namespace):

@@ -182,16 +182,21 @@ def test_signal_filters_match_reference_golden(dev):
     assert rel(plain, g["hilbert"]) < 1e-9 and rel(hil, plain) < 1e-13
     xl = np.random.default_rng(5).standard_normal((3, 5003))
     res = {}
-    for mode, symflag in (("ols", "1"), ("sym", "1"), ("sym", "0")):
-        os.environ["TONAL_HILBERT"], os.environ["TONAL_HILBERT_SYM"] = mode, symflag
+    # (overlap-save comes in two forms: tl_hilbert_ols_bl, the default - it drops the bins of a band's kernel spectrum that lie
+    # below 1e-12 of its peak, outside a 256-bin window - and tl_hilbert_ols with all 1024 bins, TONAL_HILBERT_BL=0)
+    for mode, symflag, bl in (("ols", "1", "1"), ("ols", "1", "0"), ("sym", "1", "1"), ("sym", "0", "1")):
+        os.environ["TONAL_HILBERT"], os.environ["TONAL_HILBERT_SYM"], os.environ["TONAL_HILBERT_BL"] = mode, symflag, bl
         try:
-            res[mode + symflag] = (ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.]),
-                                   ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.], envelope=False))
+            res[mode + symflag + bl] = (ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.]),
+                                        ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.], envelope=False))
         finally:
             os.environ.pop("TONAL_HILBERT", None)
             os.environ.pop("TONAL_HILBERT_SYM", None)
-    for k in ("ols1", "sym1"):
-        assert rel(res[k][0], res["sym0"][0]) < 1e-13 and rel(res[k][1], res["sym0"][1]) < 1e-12
+            os.environ.pop("TONAL_HILBERT_BL", None)
+    for k in ("ols10", "sym11"):
+        assert rel(res[k][0], res["sym01"][0]) < 1e-13 and rel(res[k][1], res["sym01"][1]) < 1e-12
+    assert rel(res["ols11"][0], res["sym01"][0]) < 1e-12 and rel(res["ols11"][1], res["sym01"][1]) < 1e-12
+    assert not np.array_equal(res["ols11"][0], res["ols10"][0])          # (the two forms really are different kernels)
     assert rel(ff.butter_filter(x, [0.3, 100], 400), g["butter"]) < 1e-9
     assert rel(ff.butter_filter(x, [0.3, 100], 400, causal=True), g["butter_causal"]) < 1e-9
     assert rel(ff.fir_bandpass_filter(x, 400, 390, [100.]), g["fir"]) < 1e-9
