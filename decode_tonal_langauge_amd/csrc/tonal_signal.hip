@@ -148,12 +148,14 @@ typedef double ols_d2 __attribute__((ext_vector_type(2)));
 // sqrt for the magnitudes: v_rsq_f64 (2^-23) and one Newton step on the residual x - y^2 (fused): ~2^-45 relative, far inside
 // the 1e-9 the golden holds; the library sqrt spends three times the instructions on the last bits and on denormal scaling,
 // and 32 magnitudes per thread were a third of the kernel's vector instructions
+// (rsq(0) = inf is clamped to 2^500, so v = 0 gives exactly 0 without a compare and two selects; v below 1e-300 comes out
+// wrong in relative terms and right to 1e-150 in absolute ones)
 __device__ __forceinline__ double ols_sqrt(double v) {
-  const double r = __builtin_amdgcn_rsq(v);
+  const double r = __builtin_fmin(__builtin_amdgcn_rsq(v), 0x1p500);
   double yv = v * r;
   const double e = fma(-yv, yv, v);
   yv = fma(e, 0.5 * r, yv);
-  return v > 0.0 ? yv : 0.0;
+  return yv;
 }
 
 template <bool INV>
@@ -317,9 +319,10 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_kernel(const void* __restrict_
 // : four independent 256-point transforms, one per residue r - ONE WAVE EACH (lane l owns k' = l + 64 j going in and
 // m = l + 64 j coming out), with the residue's twiddle folded into the kernel spectrum on the host (Gp[b][r][k']).  A
 // 256-point radix-4 Stockham has four stages = three exchanges, and they are private to the wave: no workgroup barrier in
-// the band loop, 4/5 of the butterflies, 3/4 of the LDS round trips of the 1024-point inverse.  The forward transform is the
-// 1024-point one above; its result goes to LDS once (16 KB) and every wave reads its window of it per band.  |z| does not
-// see the modulation W^{-k0 n}; the real part (envelope = 0) multiplies it back from the twiddle table.
+// the band loop, 4/5 of the butterflies, 3/4 of the LDS round trips of the 1024-point inverse.  The forward transform runs
+// the same way round (radix-4 over the thread's four samples, one workgroup-wide exchange, then a wave-private 256-point
+// transform per residue of the BIN index); its result goes to LDS once (16 KB) and every wave reads its window of it per
+// band.  |z| does not see the modulation W^{-k0 n}; the real part (envelope = 0) multiplies it back from the twiddle table.
 // ------------------------------------------------------------------------------------------
 constexpr int OLS_WQ = 256;
 __device__ __forceinline__ void ols_wave_sync() {
@@ -336,7 +339,7 @@ __device__ __forceinline__ void ols_wave_sync() {
 // left in register h of lane (r, lo) - a 4 x 4 transpose between the register index and the lane's top two bits, which is
 // v_permlane32_swap (register bit 1 <-> lane bit 5) followed by v_permlane16_swap (register bit 0 <-> lane bit 4): sixteen
 // one-pass instructions for the four complex doubles instead of four 16-byte stores, a wait and four 16-byte loads.
-constexpr int OLS_WS0 = 64 + 4, OLS_WS1 = 64 + 8, OLS_WPL = 4 * OLS_WS1;
+constexpr int OLS_WS0 = 64 + 4, OLS_WS1 = 64 + 8, OLS_WPL = 4 * OLS_WS1, OLS_XS = OLS_Q + 4;
 template <bool S32>
 __device__ __forceinline__ void ols_lane_swap(double& a, double& b) {
   unsigned a0 = (unsigned)__double2loint(a), a1 = (unsigned)__double2hiint(a);
@@ -415,52 +418,26 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
                                                             double* __restrict__ y, long long T, int nb, int lead, int skip,
                                                             int envelope) {
   const int NB = NBT ? NBT : nb;
-  __shared__ __attribute__((aligned(16))) double lds[2 * OLS_N + 8 * OLS_WPL];      // >= 4 OLS_PAD
-  __shared__ __attribute__((aligned(16))) ols_d2 twl[60];
+  // region A: the forward transform's exchange [q][t], then the spectrum, bin 4 k + q at q x OLS_XS + k; region B: the waves' planes
+  __shared__ __attribute__((aligned(16))) ols_d2 ldsA[4 * OLS_XS];
+  __shared__ __attribute__((aligned(16))) ols_d2 ldsB[4 * OLS_WPL];
   const int tid = threadIdx.x, c = blockIdx.y;
+  const int w = tid >> 6, l = tid & 63;
   const int Lv = OLS_N - skip;
   const long long t0 = (long long)blockIdx.x * Lv;
   long long base = t0 - lead;                                 // in (-T, 2 T): T >= 1024 >= lead, t0 < T + 1024
   if (base < 0) base += T;
   if (base >= T) base -= T;
   double vr[4], vi[4], acc[4];
-  {
-    if (tid < 60) {
-      const int st = tid < 12 ? 1 : 2, e = tid < 12 ? tid : tid - 12;
-      twl[tid] = tw[(e % 3 + 1) * (e / 3) * (OLS_Q >> (2 * st))];
-    }
-    double wc[2][3], ws[2][3];
-#pragma unroll
-    for (int st = 3; st < 5; ++st) {
-      const int step = (tid & ((1 << (2 * st)) - 1)) * (OLS_Q >> (2 * st));
-#pragma unroll
-      for (int r = 1; r < 4; ++r) {
-        const ols_d2 w = tw[r * step];
-        wc[st - 3][r - 1] = w[0];
-        ws[st - 3][r - 1] = w[1];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      long long ti = base + tid + r * OLS_Q;                  // < 2 T (the host requires T >= 1024): no 64-bit division
-      if (ti >= T) ti -= T;
-      vr[r] = ld_as_f64<TIN>(x, (long long)c * T + ti);
-      vi[r] = 0.0;
-      acc[r] = 0.0;
-    }
-    ols_fft<false>(vr, vi, lds, twl, wc, ws, tid);
-  }
-  // the spectrum, once, where every wave can read its band's window of it (the plane the last forward stage did not read)
-  ols_d2* Xs = reinterpret_cast<ols_d2*>(lds);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    ols_d2 v2;
-    v2[0] = vr[r];
-    v2[1] = vi[r];
-    Xs[tid + r * OLS_Q] = v2;
+    long long ti = base + tid + r * OLS_Q;                    // < 2 T (the host requires T >= 1024): no 64-bit division
+    if (ti >= T) ti -= T;
+    vr[r] = ld_as_f64<TIN>(x, (long long)c * T + ti);
+    vi[r] = 0.0;
+    acc[r] = 0.0;
   }
-  const int w = tid >> 6, l = tid & 63;
-  ols_d2* wbuf = reinterpret_cast<ols_d2*>(lds + 2 * OLS_N) + w * OLS_WPL;
+  ols_d2* wbuf = ldsB + w * OLS_WPL;
   double tc[3][3], ts[3][3];                                  // W_{4 Ns}^{r k}, k = l % Ns, as W_1024^{r k 256 / Ns}
 #pragma unroll
   for (int st = 1; st < 4; ++st) {
@@ -472,6 +449,45 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
       ts[st - 1][r - 1] = t[1];
     }
   }
+  // Forward transform, the same way round: X[4 k + q] = DFT_256_t( W_1024^{t q} . sum_r x[t + 256 r] W_4^{r q} )[k] - the
+  // radix-4 over r and the twiddle in the thread's registers (t = tid), ONE workgroup-wide exchange that hands residue q to
+  // wave q (lane l takes t = l + 64 j), then the wave-private 256-point transform.  Three barriers up to the band loop
+  // instead of the five of the 1024-point Stockham (ols_fft).
+  {
+    double yr[4], yi[4], c3[3], s3[3];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      const ols_d2 t = tw[tid * q];
+      c3[q - 1] = t[0];
+      s3[q - 1] = t[1];
+    }
+    ols_bfly<false>(vr, vi, yr, yi);
+    ols_twiddle<false>(yr, yi, c3, s3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ols_d2 t;
+      t[0] = yr[q];
+      t[1] = yi[q];
+      ldsA[q * OLS_Q + tid] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const ols_d2 t = ldsA[w * OLS_Q + l + 64 * j];
+      vr[j] = t[0];
+      vi[j] = t[1];
+    }
+    __syncthreads();                                          // region A is read: the spectrum may overwrite it
+    ols_fft256_wave<false>(vr, vi, wbuf, tc, ts, l);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                             // bin 4 (l + 64 j) + w
+      ols_d2 t;
+      t[0] = vr[j];
+      t[1] = vi[j];
+      ldsA[w * OLS_XS + l + 64 * j] = t;
+    }
+  }
+  const ols_d2* Xs = ldsA;
   ols_d2 g[4], gn[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) g[r] = Gp[w * OLS_WQ + l + 64 * r];
@@ -482,7 +498,8 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       gn[r] = Gp[(long long)(bn * 4 + w) * OLS_WQ + l + 64 * r];
-      const ols_d2 X = Xs[(k0 + l + 64 * r) & (OLS_N - 1)];
+      const int bin = (k0 + l + 64 * r) & (OLS_N - 1);
+      const ols_d2 X = Xs[(bin & 3) * OLS_XS + (bin >> 2)];
       vr[r] = fma(-X[1], g[r][1], X[0] * g[r][0]);
       vi[r] = fma(X[0], g[r][1], X[1] * g[r][0]);
     }
@@ -501,7 +518,8 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
     for (int r = 0; r < 4; ++r) g[r] = gn[r];
     ols_wave_sync();
   }
-  __syncthreads();                                            // every wave is done with the spectrum: its plane takes the outputs
+  __syncthreads();                                            // every wave is done with the spectrum: its region takes the outputs
+  double* lds = reinterpret_cast<double*>(ldsA);
 #pragma unroll
   for (int r = 0; r < 4; ++r) lds[l + 72 * w + 288 * r] = acc[r];   // sample 4 l + w + 256 r, residue-major
   __syncthreads();

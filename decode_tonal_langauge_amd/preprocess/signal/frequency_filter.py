@@ -172,7 +172,7 @@ def _band_limited(G: np.ndarray, dev, tol: float = 1e-10):
     nb, nfft = G.shape
     q = nfft // 4
     mag = np.abs(G)
-    k0 = (mag.argmax(axis=1) - q // 2) % nfft
+    k0 = ((mag.argmax(axis=1) - q // 2) & ~3) % nfft                         # multiples of 4: the kernel's LDS reads stay aligned
     idx = (k0[:, None] + np.arange(q)[None, :]) % nfft                      # (nb, q)
     win = np.take_along_axis(G, idx, axis=1)
     if np.any(mag.sum(axis=1) - np.abs(win).sum(axis=1) > tol * mag.max(axis=1)):

@@ -44,5 +44,25 @@ for name, x in (("f64", x64), ("f32", x32)):
 for rep in range(2):
     for name, x in (("f64", x64), ("f32", x32)):
         print(f"{name}: ols {timed(x, False):.4f} ms   band-limited {timed(x, True):.4f} ms", flush=True)
+
+# cost split: t(nb) = (window load + forward transform + output) + nb x (band); straight through the C ABI
+if os.environ.get("TONAL_HILBERT_SPLIT", "1") != "0":
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._lib import check, ptr
+    cfs, sds = ff.gaussian_bank([70., 150.], FS, 0.018, 1 / 7, np.log10(0.39), 0.5)
+    tp, ntap, half, sym, ols = ff._device_taps(T, FS, cfs, sds, dev)
+    y = torch.empty(C, T, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for nb in (1, 2, 4, 7):
+        def call():
+            check(_lib.load().tl_hilbert_ols_bl(ptr(x32), 0, ptr(ols[3][0]), ptr(ols[3][1]), ptr(ols[1]), ptr(y), C, T, nb, half,
+                                                ols[2], 1, st), "tl_hilbert_ols_bl")
+        call(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            call()
+        e1.record(); torch.cuda.synchronize()
+        print(f"nb = {nb}: {e0.elapsed_time(e1) / args.iters:.4f} ms", flush=True)
 print("FAIL" if bad else "OK")
 sys.exit(1 if bad else 0)

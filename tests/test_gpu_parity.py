@@ -197,6 +197,12 @@ def test_signal_filters_match_reference_golden(dev):
         assert rel(res[k][0], res["sym01"][0]) < 1e-13 and rel(res[k][1], res["sym01"][1]) < 1e-12
     assert rel(res["ols11"][0], res["sym01"][0]) < 1e-12 and rel(res["ols11"][1], res["sym01"][1]) < 1e-12
     assert not np.array_equal(res["ols11"][0], res["ols10"][0])          # (the two forms really are different kernels)
+    for bl in ("1", "0"):                                                # a silent channel stays exactly zero (magnitude guard)
+        os.environ["TONAL_HILBERT_BL"] = bl
+        try:
+            assert not ff.hilbert_filter(np.zeros((2, 2048)), 400, freq_ranges=[70., 150.]).any()
+        finally:
+            os.environ.pop("TONAL_HILBERT_BL", None)
     assert rel(ff.butter_filter(x, [0.3, 100], 400), g["butter"]) < 1e-9
     assert rel(ff.butter_filter(x, [0.3, 100], 400, causal=True), g["butter_causal"]) < 1e-9
     assert rel(ff.fir_bandpass_filter(x, 400, 390, [100.]), g["fir"]) < 1e-9
