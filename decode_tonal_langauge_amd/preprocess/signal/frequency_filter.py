@@ -16,14 +16,16 @@ The arithmetic runs in HIP kernels (``csrc/tonal_signal.hip``):
    multiplier, inverse DFT - with the arbitrary-length DFT as a Bluestein chirp-z over power-of-two Stockham
    passes (``tl_hilbert_fft``; ``TONAL_HILBERT=fft`` forces that path, ``=taps`` forbids it).  Eight-band banks with
    truncated kernels of up to 513 taps - the high-gamma bank of the pipeline - take the fastest form of the same
-   convolution: overlap-save on an LDS-resident 1024-point fp64 FFT (``tl_hilbert_ols``; the spectra of the SAME truncated
-   kernels; ``TONAL_HILBERT=sym`` keeps the time-domain kernel, which uses the kernels' Hermitian symmetry);
+   convolution: overlap-save on LDS-resident fp64 FFTs (the spectra of the SAME truncated kernels) - ``tl_hilbert_ols_bl``
+   when every band's kernel spectrum fits a window of 256 of the 1024 bins (the Gaussian bank does: four wave-private
+   256-point inverses per band), ``tl_hilbert_ols`` with all bins otherwise or under ``TONAL_HILBERT_BL=0``;
+   ``TONAL_HILBERT=sym`` keeps the time-domain kernel, which uses the kernels' Hermitian symmetry;
  * ``filtfilt`` / ``sosfilt`` are fp64 direct-form-II-transposed recurrences, sequential in time exactly like scipy's loop
    (``filtfilt``: the state spread over the lanes of a DPP row per channel, bit-identical; ``sosfilt``: one lane per channel);
  * the FIR bank is a causal convolution with zero initial state (recordings of >= 1024 samples: overlap-save on the same
    LDS FFT as the Hilbert bank, ``tl_fir_bank_ols``).
 Filter *design* (``butter``, ``lfilter_zi``, ``firwin``) stays on scipy: coefficient generation,
-not the hot path.
+not the hot path - done once per filter, the device copies are cached.
 
 Inputs may be NumPy arrays (copied to the GPU and back, like a drop-in step must) or CUDA torch
 tensors (stay resident; a CUDA tensor is returned).
