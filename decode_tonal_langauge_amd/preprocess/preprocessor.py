@@ -11,6 +11,13 @@ every step as a device tensor (each step of ``preprocess/signal`` accepts one) a
 instead of one PCIe round trip per step.  Module names of the reference layout
 (``preprocess.signal.<step>`` / the stale ``preprocess.<step>`` of the sample YAML) resolve to this
 package's kernels.
+
+Multi-GPU (signal path): with ``shard_channels=True`` under an initialised process group every rank
+carries rows [r C / N, (r + 1) C / N) of the recording through the channel-local steps (resampling, band extraction,
+z-scores - the expensive ones) with no communication at all; only in front of a step that mixes channels
+(``car_rereference``: the mean over channels at every sample) are the shards all-gathered, the step run on the whole
+array by every rank, and the rank's rows cut out again.  The result (all-gathered once more at the end) is the same
+array on every rank, produced by the same kernels on the same numbers as a single process produces it.
 """
 from __future__ import annotations
 
@@ -36,11 +43,61 @@ def resolve_step_module(name: str):
     return importlib.import_module(name)
 
 
+_MIXES_CHANNELS = ("car_rereference",)                  # steps whose output rows depend on other rows
+
+
+class _ChannelShards:
+    """Bookkeeping of a recording split by rows over the ranks.  A band-extraction step with E entries turns (C, T) into
+    (E C, T), entry-major (reference frequency_filter.py:74-77): a shard then holds E groups of its own rows, and the
+    whole array is groups x (all ranks' rows)."""
+
+    def __init__(self, n_channels: int):
+        from .. import parallel
+        self.parallel = parallel
+        self.rank, self.world = parallel.world()
+        self.C = n_channels
+        self.per = -(-n_channels // self.world)                      # equal blocks for the all-gather; the last is padded
+        self.lo = min(self.rank * self.per, n_channels)
+        self.hi = min(self.lo + self.per, n_channels)
+        self.groups = 1
+
+    def cut(self, full):
+        """This rank's rows of every group, zero-padded to ``per`` rows per group."""
+        import torch
+        g = full.reshape(self.groups, self.C, full.shape[-1])
+        out = torch.zeros(self.groups, self.per, full.shape[-1], dtype=full.dtype, device=full.device)
+        out[:, : self.hi - self.lo] = g[:, self.lo:self.hi]
+        if self.hi - self.lo < self.per:
+            out[:, self.hi - self.lo:] = 1.0                         # padding rows: a harmless constant, dropped on gather
+        return out.reshape(self.groups * self.per, full.shape[-1])
+
+    def gather(self, local):
+        """(groups x per, T) on every rank -> (groups x C, T), the single-process row order."""
+        import torch
+        T = local.shape[-1]
+        out = torch.empty(self.world, self.groups * self.per, T, dtype=local.dtype, device=local.device)
+        self.parallel.all_gather_blocks(out, local)
+        full = out.reshape(self.world, self.groups, self.per, T).permute(1, 0, 2, 3).reshape(self.groups, self.world * self.per, T)
+        return full[:, : self.C].reshape(self.groups * self.C, T).contiguous()
+
+
 def preprocess_signal(data, steps: List[Dict], block_params: Namespace, figure_dir: Optional[str] = None,
-                      num_channels: int = 5, duration: float = 1.0, resident: bool = False):
+                      num_channels: int = 5, duration: float = 1.0, resident: bool = False, shard_channels: bool = False):
     """Apply the steps in order (reference :39-70).  Returns ``(data, block_params.signal_freq)``."""
     was_np = isinstance(data, np.ndarray)
-    if resident and was_np:
+    shards = None
+    if shard_channels:
+        from .. import parallel
+        if parallel.world()[1] > 1 and getattr(data, "ndim", 0) == 2:
+            import torch
+            if was_np:
+                data = torch.from_numpy(np.ascontiguousarray(data))
+                data = data.to("cuda") if torch.cuda.is_available() else data
+            shards = _ChannelShards(data.shape[0])
+            data = shards.cut(data)
+            if figure_dir is not None:
+                raise ValueError("preprocess_signal: per-step figures need the whole recording; not available with shard_channels")
+    if resident and was_np and shards is None:
         import torch
         data = torch.from_numpy(np.ascontiguousarray(data)).to("cuda")
     for i, step in enumerate(steps):
@@ -52,17 +109,28 @@ def preprocess_signal(data, steps: List[Dict], block_params: Namespace, figure_d
             setattr(block_params, key, value)
         before_freq = block_params.signal_freq
         before = data if figure_dir is None else (data.copy() if isinstance(data, np.ndarray) else data.clone())
-        data = resolve_step_module(module_name).run(data, block_params)
+        tail = module_name.rsplit(".", 1)[-1]
+        if shards is not None and tail in _MIXES_CHANNELS:
+            data = shards.cut(resolve_step_module(module_name).run(shards.gather(data), block_params))
+        else:
+            rows = data.shape[0]
+            data = resolve_step_module(module_name).run(data, block_params)
+            if shards is not None and data.shape[0] != rows:           # band entries stacked along the rows
+                shards.groups *= data.shape[0] // rows
         if figure_dir and getattr(data, "ndim", 0) == 2:
             _plot_step(before, before_freq, data, block_params.signal_freq, figure_dir, i, module_name,
                        num_channels, duration)
-    if resident and was_np:
+    if shards is not None:
+        data = shards.gather(data)
+        if was_np:
+            data = data.cpu().numpy()
+    elif resident and was_np:
         data = data.cpu().numpy()
     return data, block_params.signal_freq
 
 
 def preprocess_modalities(data_dict: Dict, modalities_cfg: Dict, base_params: Namespace,
-                          figure_dir: Optional[str] = None, resident: bool = False) -> Dict:
+                          figure_dir: Optional[str] = None, resident: bool = False, shard_channels: bool = False) -> Dict:
     """Per modality: copy the base parameters, take ``signal_freq`` from ``<modality>_sf``, run the
     configured steps, write the data and the new sampling rate back (reference :8-36)."""
     for modality, cfg in modalities_cfg.items():
@@ -80,7 +148,7 @@ def preprocess_modalities(data_dict: Dict, modalities_cfg: Dict, base_params: Na
             raise ValueError(f"Modality '{modality}': unsupported type '{mod_type}' (only 'signal' is preprocessed)")
         params.signal_freq = data_dict.get(f"{modality}_sf")
         processed, freq = preprocess_signal(data_dict[modality], steps, params, figure_dir=mod_fig_dir,
-                                            resident=resident)
+                                            resident=resident, shard_channels=shard_channels)
         if freq is not None:
             data_dict[f"{modality}_sf"] = freq
         data_dict[modality] = processed

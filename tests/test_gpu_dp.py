@@ -234,3 +234,49 @@ def test_bench_ends_non_zero_when_a_rank_dies():
                      "--no-extras", timeout=600)
     assert r.returncode != 0 and line is None
     assert "exits on request" in r.stderr
+
+
+def _signal_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from argparse import Namespace
+    from copy import deepcopy
+    from decode_tonal_langauge_amd import parallel
+    from decode_tonal_langauge_amd.preprocess import preprocessor
+    from tests import golden_inputs as gi
+    parallel.init_from_env(backend="gloo")
+    x = gi.chain_input()
+    outs = []
+    for rows in (6, 5):                               # 3 + 3 rows, then 3 + 2 (the last shard padded)
+        out, fs = preprocessor.preprocess_signal(x[:rows].copy(), deepcopy(gi.CHAIN_STEPS), Namespace(signal_freq=1000),
+                                                 shard_channels=True)
+        outs.append((out, fs))
+    q.put((rank, outs))
+    torch.distributed.destroy_process_group()
+
+
+def test_channel_sharded_signal_chain_equals_single_process():
+    """SURVEY 8e, signal path: downsample -> CAR -> band extraction (two entries) -> z-score with the recording's
+    channels split over two ranks (both on the test GPU, gloo): channel-local steps without communication, shards
+    gathered in front of the common-average step and at the end.  Same kernels on the same numbers: identical output."""
+    import numpy as np
+    from argparse import Namespace
+    from copy import deepcopy
+    from decode_tonal_langauge_amd.preprocess import preprocessor
+    from tests import golden_inputs as gi
+    x = gi.chain_input()
+    refs = [preprocessor.preprocess_signal(x[:rows].copy(), deepcopy(gi.CHAIN_STEPS), Namespace(signal_freq=1000))
+            for rows in (6, 5)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_signal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outs in res:
+        for (out, fs), (ref, ref_fs) in zip(outs, refs):
+            assert fs == ref_fs == 400 and isinstance(out, np.ndarray) and out.shape == ref.shape
+            assert np.array_equal(out, ref, equal_nan=True), (rank, float(np.nanmax(np.abs(out - ref))))

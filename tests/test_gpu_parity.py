@@ -337,6 +337,28 @@ def test_signal_full_size_properties(dev):
     assert np.max(np.abs(h - taps)) < 1e-15
 
 
+def test_hilbert_overlap_save_forms_match_oracle_at_ragged_sizes(dev, monkeypatch):
+    """Both overlap-save kernels (tl_hilbert_ols_bl, tl_hilbert_ols) against the CPU oracle (pinned by G6) at the sizes where
+    segments wrap, end ragged or are exactly one transform long; fp64 input 1e-9, fp32 input 1e-5 (the reference itself
+    computes that case in complex64: frequency_filter.py:167)."""
+    from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
+    from oracle import signal_oracle as sg
+    rng = np.random.default_rng(11)
+    for C, T, dt in ((1, 1024, np.float64), (3, 1025, np.float64), (2, 1840, np.float64), (5, 5003, np.float64),
+                     (4, 2449, np.float32), (2, 24000, np.float32)):
+        x = rng.standard_normal((C, T)).astype(dt)
+        x[-1, : T // 3] = 0.0                                          # a stretch of silence in one channel
+        tol = 1e-9 if dt == np.float64 else 1e-5
+        for env in (True, False):
+            ref = sg.hilbert_filter(x.astype(np.float64) if dt == np.float64 else x, 400, [70., 150.], envelope=env)
+            for bl in ("1", "0"):
+                monkeypatch.setenv("TONAL_HILBERT_BL", bl)
+                out = ff.hilbert_filter(x, 400, freq_ranges=[70., 150.], envelope=env)
+                assert out.dtype == np.float64 and out.shape == (C, T)
+                assert rel(out, ref) < tol, (C, T, dt, env, bl, rel(out, ref))
+    monkeypatch.delenv("TONAL_HILBERT_BL", raising=False)
+
+
 def test_cnn_full_size_batch_properties(dev):
     """North-star shape (128 ch x 400, batch 256), small LSTM width to keep the test light:
     eval-mode outputs are per-sample (permutation equivariance, sub-batch equality)."""
