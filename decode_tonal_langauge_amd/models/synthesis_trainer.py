@@ -306,8 +306,20 @@ class SynthesisTrainer:
         parallel.all_gather_param_rows_(p.data, self.rank * rows, rows)
         self._whh_dirty = False
 
+    def model_state_dict(self):
+        """``model.state_dict()`` with the shard-wise updated parameters re-assembled first.  Collective under data
+        parallelism (every rank must call it).  The NAdam moments of a row-sharded parameter stay per rank and
+        shard-shaped: an optimizer checkpoint is only resumable with the same world size."""
+        self.sync_parameters()
+        return self.model.state_dict()
+
     def train_step(self, inputs_non, inputs_syllable, inputs_tone, targets) -> None:
-        """One body of the batch loop (reference :201-229).  Loss / MCD go to ``self._stats``."""
+        """One body of the batch loop (reference :201-229).  Loss / MCD go to ``self._stats``.
+
+        Under data parallelism with the row-sharded label LSTM a rank holds current values only for its own gate rows of
+        ``label_lstm.weight_hh_l0`` between steps: ``train`` and ``evaluate`` re-assemble them (``sync_parameters``); a caller
+        that drives ``train_step`` itself must call ``sync_parameters()`` (or ``model_state_dict()``) on every rank before it
+        reads, evaluates or saves the model."""
         dev = self.device
         inputs_non = inputs_non.to(dev, non_blocking=True)
         inputs_syllable = inputs_syllable.to(dev, non_blocking=True)
