@@ -69,6 +69,15 @@ def test_abi_argument_validation_without_gpu():
     assert b"multiple of 8" in lib.tl_last_error()
     assert lib.tl_lstm_infer_seq_fused(16, 10, 16, 16, 16, 16, 4, 8, 3, C2.byref(flag), None) == -1
     assert b"row stride" in lib.tl_last_error()
+    # round-3 signal entry points: overlap-save banks
+    assert lib.tl_hilbert_ols(None, 1, 16, 16, 16, 2, 4096, 8, 104, 1024, 1, None) == -1 and b"null" in lib.tl_last_error()
+    assert lib.tl_hilbert_ols(16, 1, 16, 16, 16, 2, 4096, 8, 104, 512, 1, None) == -1 and b"nfft" in lib.tl_last_error()
+    assert lib.tl_hilbert_ols(16, 1, 16, 16, 16, 2, 4096, 8, 300, 1024, 1, None) == -1 and b"taps" in lib.tl_last_error()
+    assert lib.tl_hilbert_ols_bl(16, 1, 16, None, 16, 16, 2, 4096, 8, 104, 1024, 1, None) == -1 and b"null" in lib.tl_last_error()
+    assert lib.tl_hilbert_ols_bl(16, 1, 16, 16, 16, 16, 2, 1000, 8, 104, 1024, 1, None) == -1
+    assert b"at least 1024 samples" in lib.tl_last_error()
+    assert lib.tl_hilbert_ols_bl(16, 1, 16, 16, 16, 16, 2, 4096, 65, 104, 1024, 1, None) == -1 and b"bands" in lib.tl_last_error()
+    assert lib.tl_fir_bank_ols(16, 1, 16, 16, 16, 1, 2, 4096, 1, 600, None) == -1 and b"taps" in lib.tl_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(-1, "x")
 
