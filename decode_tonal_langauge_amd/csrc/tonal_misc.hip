@@ -953,6 +953,32 @@ __global__ __launch_bounds__(256) void splitk_bias_lrelu_kernel(const float* __r
   }
 }
 
+// out[r][n] = sum_k x[r][k] w[n][k] + bias[n] for a handful of output columns (a logistic-regression head on the flattened
+// window: models/simple_classifiers.py:34-60): one workgroup per row, wave w takes columns w, w + 4, ..; the row and the
+// weight rows stream through 16-byte loads (the weights stay in L2 across rows), partial sums meet in a wave reduction.
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int K, int N,
+                                                          long long ldx) {
+  const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xr = x + (long long)r * ldx;
+  const int K4 = K >> 2;
+  for (int n = wave; n < N; n += 4) {
+    const float* wr = w + (long long)n * K;
+    float acc = 0.f;
+    for (int i = lane; i < K4; i += 64) {
+      const float4 a = reinterpret_cast<const float4*>(xr)[i];
+      const float4 b = reinterpret_cast<const float4*>(wr)[i];
+      acc = fmaf(a.x, b.x, acc);
+      acc = fmaf(a.y, b.y, acc);
+      acc = fmaf(a.z, b.z, acc);
+      acc = fmaf(a.w, b.w, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[(long long)r * N + n] = acc + (bias ? bias[n] : 0.f);
+  }
+}
+
 // arg-max of both classifiers' scores + the gather above + the (tone, syllable) pair id, one thread per window: the label pass
 // of a train step in one launch (five ATen kernels + tone_dynamics_kernel otherwise).  First maximum wins, as torch.argmax.
 __global__ void labels_from_scores_kernel(const float* __restrict__ st, const float* __restrict__ ss, const float* __restrict__ table,
@@ -1302,6 +1328,17 @@ extern "C" int tl_splitk_bias_lrelu(const float* slab, const float* bias, float*
   hipLaunchKernelGGL(splitk_bias_lrelu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, slab, bias, out, nz,
                      (long long)n, ncols, slope);
   return check_launch("splitk_bias_lrelu");
+}
+
+extern "C" int tl_linear_rows(const float* x, const float* w, const float* bias, float* out, int B, int K, int N, int64_t ldx,
+                              void* stream) {
+  using namespace tl;
+  TL_REQUIRE(x && w && out, "linear_rows: null pointer");
+  TL_REQUIRE(B > 0 && K > 0 && N > 0 && N <= 64, "linear_rows: bad sizes (1 <= N <= 64 output columns)");
+  TL_REQUIRE(K % 4 == 0 && ldx >= K && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
+             "linear_rows: K and ldx must be multiples of 4 and x, w 16-byte aligned (rows are read as float4)");
+  hipLaunchKernelGGL(linear_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, K, N, (long long)ldx);
+  return check_launch("linear_rows");
 }
 
 extern "C" int tl_labels_from_scores(const float* tone_scores, const float* syl_scores, const float* table, float* labels,

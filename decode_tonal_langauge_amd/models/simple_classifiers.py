@@ -19,6 +19,28 @@ def _flatten_checked(x: torch.Tensor, input_dim: int) -> torch.Tensor:
     return x
 
 
+def _linear_rows(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """``layer(x)`` for a head with a handful of outputs.  Inference on the GPU (no autograd graph wanted: the label pass of
+    the synthesis trainer, reference models/synthesis_trainer.py:207-210) goes through ``tl_linear_rows``; training of the
+    classifier itself and CPU tensors (BASELINE config C1) keep ``nn.Linear``."""
+    w = layer.weight
+    if (x.is_cuda and w.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2
+            and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))
+            and w.shape[0] <= 64 and x.shape[1] % 4 == 0 and x.shape[0] > 0):
+        from .. import _lib
+        from .._lib import check, ptr
+        x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
+        out = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+        wd = w.detach()
+        wd = wd if wd.is_contiguous() else wd.contiguous()
+        b = layer.bias
+        check(_lib.load().tl_linear_rows(ptr(x), ptr(wd), ptr(b.detach()) if b is not None else None, ptr(out), x.shape[0],
+                                         x.shape[1], w.shape[0], x.stride(0), torch.cuda.current_stream().cuda_stream),
+              "tl_linear_rows")
+        return out
+    return layer(x)
+
+
 class LogisticRegressionClassifier(ClassifierModel):
     def __init__(self, input_dim: int, n_classes: int):
         super().__init__(n_classes)
@@ -26,7 +48,7 @@ class LogisticRegressionClassifier(ClassifierModel):
         self.linear = nn.Linear(input_dim, n_classes)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.linear(_flatten_checked(x, self.input_dim))
+        return _linear_rows(self.linear, _flatten_checked(x, self.input_dim))
 
 
 class ShallowNNClassifier(ClassifierModel):
@@ -40,4 +62,4 @@ class ShallowNNClassifier(ClassifierModel):
         self.activation = get_activation(activation)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.output(self.activation(self.hidden(_flatten_checked(x, self.input_dim))))
+        return _linear_rows(self.output, self.activation(self.hidden(_flatten_checked(x, self.input_dim))))

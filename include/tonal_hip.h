@@ -290,6 +290,10 @@ int tl_tone_dynamics(const int64_t* tone, const int64_t* syl, const float* table
 /* out[i] = LeakyReLU(sum_z slab[z][i] + bias[i % ncols]), i < n: split-K reduction + bias + activation of a Linear layer
  * (models/synthesis_models.py:252-256, fc.1 of SynthesisLite)                                                       */
 int tl_splitk_bias_lrelu(const float* slab, const float* bias, float* out, int nz, int64_t n, int ncols, float slope, void* stream);
+/* out (B, N) = x (B, K; row stride ldx) . w (N, K)^T + bias (N, may be NULL): the Linear layer of LogisticRegressionClassifier
+ * on the flattened window (models/simple_classifiers.py:34-60) and the output layer of ShallowNNClassifier (:112-121) - a
+ * handful of columns over a long K, where a GEMM tile would be empty.  N <= 64, K % 4 == 0, 16-byte aligned rows.      */
+int tl_linear_rows(const float* x, const float* w, const float* bias, float* out, int B, int K, int N, int64_t ldx, void* stream);
 /* the whole label pass of a train step (models/synthesis_trainer.py:207-218) in one launch: tone = argmax of tone_scores
  * (B, n_tone_cls), syl = argmax of syl_scores (B, n_syl_cls) (first maximum), the gather of tl_tone_dynamics (n_rows table
  * rows) and, if pair is given, pair[b] = tone * n_syl + syl                                                        */

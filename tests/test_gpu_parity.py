@@ -926,3 +926,32 @@ def test_lite_hip_graph_replay_equals_eager_steps(dev, monkeypatch):
     for k, v in res["1"][0].items():
         assert torch.equal(v, res["0"][0][k]), k
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
+
+
+def test_small_classifier_heads_run_on_hip_for_inference(dev):
+    """LogisticRegressionClassifier / the output layer of ShallowNNClassifier (reference models/simple_classifiers.py:34-60,
+    107-134): under no_grad on the GPU the head is tl_linear_rows, with autograd it stays nn.Linear - same numbers."""
+    from decode_tonal_langauge_amd.models.simple_classifiers import LogisticRegressionClassifier, ShallowNNClassifier
+    torch.manual_seed(3)
+    for C_, T_, ncls, B in ((8, 400, 4, 256), (8, 200, 2, 64), (4, 100, 5, 7), (3, 33, 4, 5)):
+        m = LogisticRegressionClassifier(C_ * T_, ncls).to(dev)
+        x = torch.randn(B, C_, T_, device=dev)
+        ref = torch.nn.functional.linear(x.reshape(B, -1).double(), m.linear.weight.double(), m.linear.bias.double())
+        with torch.no_grad():
+            out = m(x)
+            sub = m(x[1:])                                      # an offset view: rows stay 16-byte aligned or are copied
+        assert out.shape == (B, ncls) and out.dtype == torch.float32
+        assert float((out.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+        assert torch.equal(sub, out[1:])
+        g = m(x)                                                # autograd path: trainable as before
+        assert g.requires_grad and float((g.double() - ref).abs().max()) < 1e-4
+        g.square().mean().backward()
+        assert m.linear.weight.grad is not None
+    s = ShallowNNClassifier(8 * 100, 4).to(dev)
+    x = torch.randn(16, 8, 100, device=dev)
+    with torch.no_grad():
+        out = s(x)
+        ref = s.output(s.activation(s.hidden(x.reshape(16, -1))))
+    assert float((out - ref).abs().max()) < 1e-5
+    with pytest.raises(ValueError, match="Expected input dimension"):
+        LogisticRegressionClassifier(10, 2).to(dev)(torch.randn(2, 11, device=dev))
