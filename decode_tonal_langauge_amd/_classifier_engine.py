@@ -111,10 +111,9 @@ class CnnClassifierEngine(CnnEngine):
             self._nt(A=ptr(feat), Bw=ptr(wp1), out=ptr(slab), M=B, A_rows=B, N=self.hidden, K=self.kflat_cls,
                      lda=self.kflat_cls, ldb=self.kflat_cls, ldo=self.hidden, loader=LOAD_DIRECT, epilogue=EPI_STORE,
                      splitk=sk, slab_stride=B * self.hidden)
-            pre = torch.empty(B, self.hidden, **f32)
-            self._permute(slab, pre, (1, 1, B, self.hidden), (0, 0, self.hidden, 1), nz=sk, zs=B * self.hidden,
-                          bias=b_fc1)
-            a1 = torch.nn.functional.leaky_relu(pre, self.slope)
+            a1 = torch.empty(B, self.hidden, **f32)             # split-K sum + bias + LeakyReLU in one launch
+            check(lib.tl_splitk_bias_lrelu(ptr(slab), ptr(b_fc1), ptr(a1), sk, B * self.hidden, self.hidden, float(self.slope), st_),
+                  "tl_splitk_bias_lrelu")
         else:
             a1 = torch.empty(B, self.hidden, **f32)
             self._nt(A=ptr(feat), Bw=ptr(wp1), bias=ptr(b_fc1), out=ptr(a1), M=B, A_rows=B, N=self.hidden,
@@ -122,6 +121,10 @@ class CnnClassifierEngine(CnnEngine):
                      epilogue=EPI_LRELU, slope=self.slope)
         w_fc2, b_fc2 = fc2
         out = torch.empty(B, self.n_classes, **f32)
+        if self.n_classes <= 64 and self.hidden % 4 == 0:          # output layer + sigmoid in one launch
+            check(lib.tl_linear_rows(ptr(a1), ptr(w_fc2.contiguous()), ptr(b_fc2), ptr(out), B, self.hidden, self.n_classes,
+                                     self.hidden, 1, st_), "tl_linear_rows")
+            return out
         self._nt(A=ptr(a1), Bw=ptr(w_fc2.contiguous()), bias=ptr(b_fc2), out=ptr(out), M=B, A_rows=B,
                  N=self.n_classes, K=self.hidden, lda=self.hidden, ldb=self.hidden, ldo=self.n_classes,
                  loader=LOAD_DIRECT, epilogue=EPI_STORE)
@@ -320,17 +323,21 @@ class CnnRnnConvEngine:
             check(self.lib.tl_gemm_nt_window(C.byref(p), st_), "tl_gemm_nt_window")
 
     @torch.no_grad()
-    def linear(self, a: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-        """a (B, K) @ w (N, K)^T + b on the NT GEMM kernel (the classifier's output layer)."""
+    def linear(self, a: torch.Tensor, w: torch.Tensor, b: torch.Tensor, sigmoid: bool = False) -> torch.Tensor:
+        """a (B, K) @ w (N, K)^T + b (the classifier's output layer; ``sigmoid``: the activation it ends with)."""
         a = a.contiguous().float()
         B, K = a.shape
         if K % 4 != 0:
             raise ValueError("linear: the feature width must be a multiple of 4")
         N = w.shape[0]
         out = torch.empty(B, N, dtype=torch.float32, device=a.device)
+        if N <= 64:
+            check(self.lib.tl_linear_rows(ptr(a), ptr(w.contiguous()), ptr(b), ptr(out), B, K, N, K, int(sigmoid),
+                                          torch.cuda.current_stream().cuda_stream), "tl_linear_rows")
+            return out
         _launch_nt(self.lib, A=ptr(a), Bw=ptr(w.contiguous()), bias=ptr(b), out=ptr(out), M=B, A_rows=B, N=N, K=K, lda=K,
                    ldb=K, ldo=N, loader=LOAD_DIRECT, epilogue=EPI_STORE)
-        return out
+        return torch.sigmoid(out) if sigmoid else out
 
     @torch.no_grad()
     def features(self, x: torch.Tensor, h1: torch.Tensor, block1, block2, conv3a, conv3b, p_drop: float = 0.0,

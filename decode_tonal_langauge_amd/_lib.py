@@ -120,7 +120,7 @@ SIGNATURES = {
     "tl_fft_resample": (_I, [_P, _I, _P, _I, _L, _L, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P]),
     "tl_gauss_envelope": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_gauss_envelope_sym": (_I, [_P, _I, _P, _P, _I, _L, _I, _I, _I, _P]),
-    "tl_linear_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _P]),
+    "tl_linear_rows": (_I, [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P]),
     "tl_hilbert_ols": (_I, [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_hilbert_ols_bl": (_I, [_P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_hilbert_fft": (_I, [_P, _I, _P, _I, _L, _P, _I, _P, _P, _P, _I, _I, _P, _P]),

@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void splitk_bias_lrelu_kernel(const float* __r
 // weight rows stream through 16-byte loads (the weights stay in L2 across rows), partial sums meet in a wave reduction.
 __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out, int K, int N,
-                                                          long long ldx) {
+                                                          long long ldx, int act) {
   const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* xr = x + (long long)r * ldx;
   const int K4 = K >> 2;
@@ -975,7 +975,10 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) out[(long long)r * N + n] = acc + (bias ? bias[n] : 0.f);
+    if (lane == 0) {
+      const float v = acc + (bias ? bias[n] : 0.f);
+      out[(long long)r * N + n] = act == 1 ? 1.f / (1.f + expf(-v)) : v;
+    }
   }
 }
 
@@ -1331,13 +1334,14 @@ extern "C" int tl_splitk_bias_lrelu(const float* slab, const float* bias, float*
 }
 
 extern "C" int tl_linear_rows(const float* x, const float* w, const float* bias, float* out, int B, int K, int N, int64_t ldx,
-                              void* stream) {
+                              int act, void* stream) {
   using namespace tl;
   TL_REQUIRE(x && w && out, "linear_rows: null pointer");
   TL_REQUIRE(B > 0 && K > 0 && N > 0 && N <= 64, "linear_rows: bad sizes (1 <= N <= 64 output columns)");
+  TL_REQUIRE(act == 0 || act == 1, "linear_rows: act must be 0 (none) or 1 (sigmoid)");
   TL_REQUIRE(K % 4 == 0 && ldx >= K && ldx % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0,
              "linear_rows: K and ldx must be multiples of 4 and x, w 16-byte aligned (rows are read as float4)");
-  hipLaunchKernelGGL(linear_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, K, N, (long long)ldx);
+  hipLaunchKernelGGL(linear_rows_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, K, N, (long long)ldx, act);
   return check_launch("linear_rows");
 }
 

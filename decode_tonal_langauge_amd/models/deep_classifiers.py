@@ -153,7 +153,7 @@ class CNNRNNClassifier(ClassifierModel):
             f = self._hip.features(x, h1, wb(self.conv_pool_block1[0]), wb(self.conv_pool_block2[0]),
                                    wb(self.conv_block3[0]), wb(self.conv_block3[2]), p_drop, self._last_seed)
             h2 = self._hip_lstm2.last_hidden(f, *lw(self.lstm2))
-            return torch.sigmoid(self._hip.linear(h2, self.output.weight.detach(), self.output.bias.detach()))
+            return self._hip.linear(h2, self.output.weight.detach(), self.output.bias.detach(), sigmoid=True)
         h1 = self.lstm1(xt)[0][:, -1, :]                   # (B, lstm_dim)
         a = self.conv_pool_block1(xt.unsqueeze(1))         # (B, 1024, t, C)
         b = self.conv_pool_block2(h1.reshape(B, 1, T, -1))  # (B, 1024, t, lstm_dim // T)

@@ -35,7 +35,7 @@ def _linear_rows(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
         wd = wd if wd.is_contiguous() else wd.contiguous()
         b = layer.bias
         check(_lib.load().tl_linear_rows(ptr(x), ptr(wd), ptr(b.detach()) if b is not None else None, ptr(out), x.shape[0],
-                                         x.shape[1], w.shape[0], x.stride(0), torch.cuda.current_stream().cuda_stream),
+                                         x.shape[1], w.shape[0], x.stride(0), 0, torch.cuda.current_stream().cuda_stream),
               "tl_linear_rows")
         return out
     return layer(x)

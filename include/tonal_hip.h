@@ -292,8 +292,10 @@ int tl_tone_dynamics(const int64_t* tone, const int64_t* syl, const float* table
 int tl_splitk_bias_lrelu(const float* slab, const float* bias, float* out, int nz, int64_t n, int ncols, float slope, void* stream);
 /* out (B, N) = x (B, K; row stride ldx) . w (N, K)^T + bias (N, may be NULL): the Linear layer of LogisticRegressionClassifier
  * on the flattened window (models/simple_classifiers.py:34-60) and the output layer of ShallowNNClassifier (:112-121) - a
- * handful of columns over a long K, where a GEMM tile would be empty.  N <= 64, K % 4 == 0, 16-byte aligned rows.      */
-int tl_linear_rows(const float* x, const float* w, const float* bias, float* out, int B, int K, int N, int64_t ldx, void* stream);
+ * handful of columns over a long K, where a GEMM tile would be empty.  act = 1 applies the sigmoid the deep classifiers end
+ * with (models/deep_classifiers.py:97-99,265-267).  N <= 64, K % 4 == 0, 16-byte aligned rows.                        */
+int tl_linear_rows(const float* x, const float* w, const float* bias, float* out, int B, int K, int N, int64_t ldx, int act,
+                   void* stream);
 /* the whole label pass of a train step (models/synthesis_trainer.py:207-218) in one launch: tone = argmax of tone_scores
  * (B, n_tone_cls), syl = argmax of syl_scores (B, n_syl_cls) (first maximum), the gather of tl_tone_dynamics (n_rows table
  * rows) and, if pair is given, pair[b] = tone * n_syl + syl                                                        */
