@@ -41,6 +41,29 @@ def _linear_rows(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     return layer(x)
 
 
+def _hidden_layer(layer: nn.Linear, act: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """``act(layer(x))`` of ShallowNNClassifier's hidden layer (reference :112-134).  Inference on the GPU: one launch of the
+    NT MFMA GEMM with bias and ReLU / LeakyReLU in its epilogue (other activations: the GEMM, then the module); with
+    autograd or on the CPU: the modules."""
+    w = layer.weight
+    if (x.is_cuda and w.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2
+            and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))
+            and layer.bias is not None and x.shape[1] % 4 == 0 and x.shape[0] > 0):
+        from .. import _lib
+        from .._classifier_engine import _launch_nt
+        from .._lib import EPI_LRELU, EPI_STORE, LOAD_DIRECT, ptr
+        x = x.contiguous()
+        B, K = x.shape
+        N = w.shape[0]
+        out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+        slope = 0.0 if isinstance(act, nn.ReLU) else (float(act.negative_slope) if isinstance(act, nn.LeakyReLU) else None)
+        _launch_nt(_lib.load(), A=ptr(x), Bw=ptr(w.detach().contiguous()), bias=ptr(layer.bias.detach()), out=ptr(out), M=B,
+                   A_rows=B, N=N, K=K, lda=K, ldb=K, ldo=N, loader=LOAD_DIRECT,
+                   epilogue=EPI_STORE if slope is None else EPI_LRELU, slope=slope or 0.0)
+        return out if slope is not None else act(out)
+    return act(layer(x))
+
+
 class LogisticRegressionClassifier(ClassifierModel):
     def __init__(self, input_dim: int, n_classes: int):
         super().__init__(n_classes)
@@ -62,4 +85,5 @@ class ShallowNNClassifier(ClassifierModel):
         self.activation = get_activation(activation)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return _linear_rows(self.output, self.activation(self.hidden(_flatten_checked(x, self.input_dim))))
+        x = _flatten_checked(x, self.input_dim)
+        return _linear_rows(self.output, _hidden_layer(self.hidden, self.activation, x))

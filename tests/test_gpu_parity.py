@@ -936,7 +936,7 @@ def test_small_classifier_heads_run_on_hip_for_inference(dev):
     for C_, T_, ncls, B in ((8, 400, 4, 256), (8, 200, 2, 64), (4, 100, 5, 7), (3, 33, 4, 5)):
         m = LogisticRegressionClassifier(C_ * T_, ncls).to(dev)
         x = torch.randn(B, C_, T_, device=dev)
-        ref = torch.nn.functional.linear(x.reshape(B, -1).double(), m.linear.weight.double(), m.linear.bias.double())
+        ref = torch.nn.functional.linear(x.reshape(B, -1).double(), m.linear.weight.double(), m.linear.bias.double()).detach()
         with torch.no_grad():
             out = m(x)
             sub = m(x[1:])                                      # an offset view: rows stay 16-byte aligned or are copied
@@ -944,14 +944,16 @@ def test_small_classifier_heads_run_on_hip_for_inference(dev):
         assert float((out.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
         assert torch.equal(sub, out[1:])
         g = m(x)                                                # autograd path: trainable as before
-        assert g.requires_grad and float((g.double() - ref).abs().max()) < 1e-4
+        assert g.requires_grad and float((g.detach().double() - ref).abs().max()) < 1e-4
         g.square().mean().backward()
         assert m.linear.weight.grad is not None
-    s = ShallowNNClassifier(8 * 100, 4).to(dev)
-    x = torch.randn(16, 8, 100, device=dev)
-    with torch.no_grad():
-        out = s(x)
-        ref = s.output(s.activation(s.hidden(x.reshape(16, -1))))
-    assert float((out - ref).abs().max()) < 1e-5
+    for act in ("ReLU", "LeakyReLU", "ELU"):                    # hidden layer: NT GEMM + fused (Leaky)ReLU, or + the module
+        s = ShallowNNClassifier(8 * 100, 4, activation=act).to(dev)
+        x = torch.randn(16, 8, 100, device=dev)
+        with torch.no_grad():
+            out = s(x)
+            ref = s.output(s.activation(s.hidden(x.reshape(16, -1))))
+        assert float((out - ref).abs().max()) < 1e-5, act
+        assert s(x).requires_grad                               # autograd path untouched
     with pytest.raises(ValueError, match="Expected input dimension"):
         LogisticRegressionClassifier(10, 2).to(dev)(torch.randn(2, 11, device=dev))
