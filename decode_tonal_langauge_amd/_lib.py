@@ -98,6 +98,7 @@ SIGNATURES = {
     "tl_nadam_multi": (_I, [_P, _I, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_multi_chunk": (_I, []),
     "tl_set_step_scalars": (_I, [_P, _P, _F, _F, _F, C.c_uint64, _P]),
+    "tl_stage_step": (_I, [_P, _P, _F, _F, _F, C.c_uint64, _P, _P, _P, _I, _P]),
     "tl_nadam_multi_dev": (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_lowrank": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_tone_dynamics": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),

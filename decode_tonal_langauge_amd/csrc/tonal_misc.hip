@@ -262,6 +262,39 @@ __global__ void set_step_scalars_kernel(float* __restrict__ sc, uint64_t* __rest
   }
 }
 
+// The same plus the step's input tensors copied into the graph's static buffers: everything a replay needs, one launch
+// instead of one small copy per tensor and the scalar launch.  16-byte units where source, destination and size allow.
+struct stage_args {
+  const char* src[4];
+  char* dst[4];
+  long long nbytes[4];
+  int n;
+};
+__global__ __launch_bounds__(256) void stage_step_kernel(stage_args a, float* __restrict__ sc, uint64_t* __restrict__ seed, float cg,
+                                                         float cm, float bc2, uint64_t seedval) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (sc != nullptr) {
+      sc[0] = cg;
+      sc[1] = cm;
+      sc[2] = bc2;
+    }
+    if (seed != nullptr) *seed = seedval;
+  }
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+  for (int i = 0; i < a.n; ++i) {
+    const char* s = a.src[i];
+    char* d = a.dst[i];
+    const long long nb = a.nbytes[i];
+    if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)nb) & 15) == 0) {
+      for (long long k = t; k < (nb >> 4); k += nt) reinterpret_cast<float4*>(d)[k] = reinterpret_cast<const float4*>(s)[k];
+    } else if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)nb) & 3) == 0) {
+      for (long long k = t; k < (nb >> 2); k += nt) reinterpret_cast<float*>(d)[k] = reinterpret_cast<const float*>(s)[k];
+    } else {
+      for (long long k = t; k < nb; k += nt) d[k] = s[k];
+    }
+  }
+}
+
 // conv1 weight/bias gradient partials: block handles a contiguous range of sequences;
 // thread owns channels tid and tid + 256 (C1 <= 512), barriers are outside every guard.
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ G,
@@ -1084,6 +1117,28 @@ extern "C" int tl_set_step_scalars(float* scalars_dev, uint64_t* seed_dev, float
   hipLaunchKernelGGL(set_step_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scalars_dev, seed_dev, coef_grad, coef_mom,
                      bias_corr2, seed);
   return check_launch("set_step_scalars");
+}
+
+extern "C" int tl_stage_step(float* scalars_dev, uint64_t* seed_dev, float coef_grad, float coef_mom, float bias_corr2, uint64_t seed,
+                             const void* const* src, void* const* dst, const int64_t* nbytes, int n, void* stream) {
+  TL_REQUIRE(n >= 0 && n <= 4, "stage_step: at most 4 tensors");
+  TL_REQUIRE(n == 0 || (src && dst && nbytes), "stage_step: null table");
+  stage_args a;
+  long long most = 0;
+  a.n = n;
+  for (int i = 0; i < 4; ++i) {
+    a.src[i] = i < n ? (const char*)src[i] : nullptr;
+    a.dst[i] = i < n ? (char*)dst[i] : nullptr;
+    a.nbytes[i] = i < n ? (long long)nbytes[i] : 0;
+    TL_REQUIRE(i >= n || (a.src[i] && a.dst[i] && a.nbytes[i] >= 0), "stage_step: null tensor %d", i);
+    if (a.nbytes[i] > most) most = a.nbytes[i];
+  }
+  long long blocks = (most / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(stage_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, scalars_dev, seed_dev, coef_grad,
+                     coef_mom, bias_corr2, seed);
+  return check_launch("stage_step");
 }
 
 extern "C" int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bits, float* partial, int nblk,

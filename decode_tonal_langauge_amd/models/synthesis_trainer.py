@@ -382,14 +382,26 @@ class SynthesisTrainer:
                 return False            # nothing was executed during the failed capture: run this step eagerly
             eng.seed_dev = None                      # eager steps (other shapes) keep passing the seed by value
             st["graph"], st["params"] = g, set(params)
+            staged = ()
         else:
-            for d, t in zip(st["in"], (inputs_non, inputs_syllable, inputs_tone, targets)):
-                d.copy_(t, non_blocking=True)
+            staged = tuple(zip(st["in"], (inputs_non, inputs_syllable, inputs_tone, targets)))
         cg, cm, bc2 = self.optimizer.advance_scalars(st["params"])
         # the values travel as launch arguments (a pinned host buffer would be overwritten by the next step before an
-        # asynchronous copy of this one has read it: the host runs ahead of the stream)
-        check(self.lib.tl_set_step_scalars(ptr(self._g_scal), ptr(self._g_seed), cg, cm, bc2, self.model._next_seed(),
-                                           torch.cuda.current_stream().cuda_stream), "tl_set_step_scalars")
+        # asynchronous copy of this one has read it: the host runs ahead of the stream); the batch goes into the graph's
+        # static input buffers by the same launch
+        if all(t.is_cuda and t.is_contiguous() and t.dtype == d.dtype and t.shape == d.shape for d, t in staged):
+            import ctypes as C
+            n = len(staged)
+            src = (C.c_void_p * 4)(*[t.data_ptr() for _, t in staged])
+            dst = (C.c_void_p * 4)(*[d.data_ptr() for d, _ in staged])
+            nby = (C.c_int64 * 4)(*[t.numel() * t.element_size() for _, t in staged])
+            check(self.lib.tl_stage_step(ptr(self._g_scal), ptr(self._g_seed), cg, cm, bc2, self.model._next_seed(), src, dst, nby, n,
+                                         torch.cuda.current_stream().cuda_stream), "tl_stage_step")
+        else:
+            for d, t in staged:
+                d.copy_(t, non_blocking=True)
+            check(self.lib.tl_set_step_scalars(ptr(self._g_scal), ptr(self._g_seed), cg, cm, bc2, self.model._next_seed(),
+                                               torch.cuda.current_stream().cuda_stream), "tl_set_step_scalars")
         st["graph"].replay()
         return True
 

@@ -274,6 +274,11 @@ int tl_nadam_multi_chunk(void);
  * launch arguments, stream-ordered in front of a graph replay that reads them                                       */
 int tl_set_step_scalars(float* scalars_dev, uint64_t* seed_dev, float coef_grad, float coef_mom, float bias_corr2,
                         uint64_t seed, void* stream);
+/* tl_set_step_scalars plus the step's input tensors (n <= 4: host tables of device pointers and byte counts) copied into the
+ * static buffers a captured step reads - all a replay needs in ONE launch (models/synthesis_trainer.py:201-205, the batch
+ * tuple of the loop)                                                                                                    */
+int tl_stage_step(float* scalars_dev, uint64_t* seed_dev, float coef_grad, float coef_mom, float bias_corr2, uint64_t seed,
+                  const void* const* src, void* const* dst, const int64_t* nbytes, int n, void* stream);
 int tl_nadam_multi_dev(const tl_nadam_entry* entries_dev, int count, int64_t total_blocks, const float* scalars_dev,
                        float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 /* the same update for a parameter (rows x cols) whose gradient is low rank, g = fa^T . fb with
