@@ -78,6 +78,8 @@ def test_abi_argument_validation_without_gpu():
     assert b"at least 1024 samples" in lib.tl_last_error()
     assert lib.tl_hilbert_ols_bl(16, 1, 16, 16, 16, 16, 2, 4096, 65, 104, 1024, 1, None) == -1 and b"bands" in lib.tl_last_error()
     assert lib.tl_fir_bank_ols(16, 1, 16, 16, 16, 1, 2, 4096, 1, 600, None) == -1 and b"taps" in lib.tl_last_error()
+    assert lib.tl_stage_step(16, 16, 0., 0., 0., 1, None, None, None, 5, None) == -1 and b"at most 4" in lib.tl_last_error()
+    assert lib.tl_stage_step(16, 16, 0., 0., 0., 1, None, None, None, 2, None) == -1 and b"null table" in lib.tl_last_error()
     assert lib.tl_linear_rows(None, 16, 16, 16, 4, 8, 2, 8, 0, None) == -1 and b"null" in lib.tl_last_error()
     assert lib.tl_linear_rows(16, 16, 16, 16, 4, 8, 65, 8, 0, None) == -1 and b"output columns" in lib.tl_last_error()
     assert lib.tl_linear_rows(16, 16, 16, 16, 4, 6, 2, 8, 0, None) == -1 and b"multiples of 4" in lib.tl_last_error()
