@@ -97,6 +97,7 @@ SIGNATURES = {
     "tl_nadam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_multi": (_I, [_P, _I, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_multi_chunk": (_I, []),
+    "tl_sum_slabs2": (_I, [_P, _P, _L, _P, _P, _L, _I, _P]),
     "tl_set_step_scalars": (_I, [_P, _P, _F, _F, _F, C.c_uint64, _P]),
     "tl_stage_step": (_I, [_P, _P, _F, _F, _F, C.c_uint64, _P, _P, _P, _I, _P]),
     "tl_nadam_multi_dev": (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _P]),

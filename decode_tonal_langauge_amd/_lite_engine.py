@@ -265,8 +265,8 @@ class LiteEngine:
         dbp = torch.empty(B, CC, **f32)
         check(lib.tl_lite_conv_bwd(ptr(dz2), ptr(self.y1), ptr(t["ecog_conv.4.weight"]), ptr(dy1), ptr(dwp), ptr(dbp), B,
                                    CC, CC, T1, 3, 1, st), "tl_lite_conv_bwd")
-        self._permute(dwp, grads["ecog_conv.4.weight"], (1, 1, 1, n2), (0, 0, 0, 1), nz=B, zs=n2)
-        self._permute(dbp, grads["ecog_conv.4.bias"], (1, 1, 1, CC), (0, 0, 0, 1), nz=B, zs=CC)
+        check(lib.tl_sum_slabs2(ptr(dwp), ptr(grads["ecog_conv.4.weight"]), n2, ptr(dbp), ptr(grads["ecog_conv.4.bias"]), CC, B, st),
+              "tl_sum_slabs2")
         # block 1
         dz1 = torch.empty(B, CC, T, **f32)
         check(lib.tl_lite_bn_act_pool_bwd(ptr(dy1), ptr(self.z1), ptr(self.m1), ptr(self.r1), ptr(t["ecog_conv.1.weight"]),
@@ -277,5 +277,5 @@ class LiteEngine:
         dwp1 = torch.empty(B, n1, **f32)
         check(lib.tl_lite_conv_bwd(ptr(dz1), ptr(self._x), ptr(t["ecog_conv.0.weight"]), None, ptr(dwp1), ptr(dbp), B,
                                    self.C, CC, T, 5, 2, st), "tl_lite_conv_bwd")
-        self._permute(dwp1, grads["ecog_conv.0.weight"], (1, 1, 1, n1), (0, 0, 0, 1), nz=B, zs=n1)
-        self._permute(dbp, grads["ecog_conv.0.bias"], (1, 1, 1, CC), (0, 0, 0, 1), nz=B, zs=CC)
+        check(lib.tl_sum_slabs2(ptr(dwp1), ptr(grads["ecog_conv.0.weight"]), n1, ptr(dbp), ptr(grads["ecog_conv.0.bias"]), CC, B, st),
+              "tl_sum_slabs2")

@@ -390,6 +390,22 @@ __global__ __launch_bounds__(256) void permute_reduce_kernel(const float* __rest
   }
 }
 
+// two slab sums in one launch: dstA[i] = sum_z srcA[z nA + i], dstB[j] = sum_z srcB[z nB + j] (z ascending) - the per-window
+// partials of a convolution's weight and bias gradient (tl_lite_conv_bwd) reduced together
+__global__ __launch_bounds__(256) void sum_slabs2_kernel(const float* __restrict__ srcA, float* __restrict__ dstA, long long nA,
+                                                         const float* __restrict__ srcB, float* __restrict__ dstB, long long nB,
+                                                         int nz) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nA + nB; i += (long long)gridDim.x * blockDim.x) {
+    const bool second = i >= nA;
+    const float* s = second ? srcB + (i - nA) : srcA + i;
+    const long long zs = second ? nB : nA;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < nz; ++z) acc += s[z * zs];
+    if (second) dstB[i - nA] = acc; else dstA[i] = acc;
+  }
+}
+
 // same, for few outputs and many slabs: one wave per output element, lanes stride over the slabs,
 // fixed-shape shuffle tree (deterministic)
 __global__ __launch_bounds__(256) void permute_reduce_zpar_kernel(const float* __restrict__ src, float* __restrict__ dst,
@@ -1176,6 +1192,14 @@ extern "C" int tl_permute_reduce(const float* src, float* dst, const int64_t dim
     hipLaunchKernelGGL(permute_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst,
                        bias_last, a, total);
   return check_launch("permute_reduce");
+}
+
+extern "C" int tl_sum_slabs2(const float* srcA, float* dstA, int64_t nA, const float* srcB, float* dstB, int64_t nB, int nz,
+                             void* stream) {
+  TL_REQUIRE(srcA && dstA && nA > 0 && nz > 0 && nB >= 0 && (nB == 0 || (srcB && dstB)), "sum_slabs2: bad arguments");
+  hipLaunchKernelGGL(sum_slabs2_kernel, dim3(grid_for(nA + nB)), dim3(256), 0, (hipStream_t)stream, srcA, dstA, (long long)nA, srcB,
+                     dstB, (long long)nB, nz);
+  return check_launch("sum_slabs2");
 }
 
 extern "C" int tl_colsum(const float* G, float* partial, int nblk, int64_t rows, int ncols, int ld, int Tp,

@@ -274,6 +274,9 @@ int tl_nadam_multi_chunk(void);
  * launch arguments, stream-ordered in front of a graph replay that reads them                                       */
 int tl_set_step_scalars(float* scalars_dev, uint64_t* seed_dev, float coef_grad, float coef_mom, float bias_corr2,
                         uint64_t seed, void* stream);
+/* dstA[i] = sum_{z < nz} srcA[z nA + i], dstB[j] = sum_z srcB[z nB + j] (nB may be 0): two slab reductions in one launch - the
+ * per-window partials of a Conv1d's weight and bias gradient (SynthesisLite, models/synthesis_models.py:236-244)          */
+int tl_sum_slabs2(const float* srcA, float* dstA, int64_t nA, const float* srcB, float* dstB, int64_t nB, int nz, void* stream);
 /* tl_set_step_scalars plus the step's input tensors (n <= 4: host tables of device pointers and byte counts) copied into the
  * static buffers a captured step reads - all a replay needs in ONE launch (models/synthesis_trainer.py:201-205, the batch
  * tuple of the loop)                                                                                                    */
