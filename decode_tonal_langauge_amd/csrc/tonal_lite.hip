@@ -180,39 +180,48 @@ __global__ __launch_bounds__(256) void lite_bn_act_pool_bwd_kernel(const float* 
 
 // dgamma, dbeta and, in place, dz = gamma*rstd*(dbn - mean(dbn) - xhat*mean(dbn*xhat))  (train)
 //                                dz = gamma*rstd*dbn                                      (eval)
-__global__ __launch_bounds__(64) void lite_bn_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ sums, int B, int C) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = lane; b < B; b += 64) {
-    s1 += part[((long long)b * C + c) * 2];
-    s2 += part[((long long)b * C + c) * 2 + 1];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s1 += __shfl_down(s1, o);
-    s2 += __shfl_down(s2, o);
-  }
-  if (lane == 0) {
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
-    sums[c * 2] = (float)s1;
-    sums[c * 2 + 1] = (float)s2;
-  }
-}
+// one workgroup per (channel, window): the channel's two sums over the batch partials are re-formed by the first wave of
+// every workgroup (B loads per lane-strided pass, the same fp64 tree in every workgroup: identical values everywhere), so
+// no separate reduction launch stands between the partials and their use; window 0 also writes dgamma / dbeta
 __global__ __launch_bounds__(256) void lite_bn_dz_kernel(float* __restrict__ dbn, const float* __restrict__ z,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                         long long total, int C, int T, long long count, int training) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)((i / T) % C);
-    const float gr = gamma[c] * rstd[c];
-    float d = dbn[i];
-    if (training) {
-      const float xh = (z[i] - mean[c]) * rstd[c];
-      d = d - sums[c * 2] / (float)count - xh * sums[c * 2 + 1] / (float)count;
+                                                         const float* __restrict__ gamma, const float* __restrict__ part,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int T,
+                                                         long long count, int training) {
+  __shared__ float sm[2];
+  const int c = blockIdx.x, b = blockIdx.y;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < B; i += 64) {
+      s1 += part[((long long)i * C + c) * 2];
+      s2 += part[((long long)i * C + c) * 2 + 1];
     }
-    dbn[i] = gr * d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s1 += __shfl_down(s1, o);
+      s2 += __shfl_down(s2, o);
+    }
+    if (lane == 0) {
+      sm[0] = (float)s1;
+      sm[1] = (float)s2;
+      if (b == 0) {
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+      }
+    }
+  }
+  __syncthreads();
+  const float su1 = sm[0], su2 = sm[1];
+  const float gr = gamma[c] * rstd[c], mu = mean[c], rs = rstd[c];
+  const long long row = ((long long)b * C + c) * T;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float d = dbn[row + t];
+    if (training) {
+      const float xh = (z[row + t] - mu) * rs;
+      d = d - su1 / (float)count - xh * su2 / (float)count;
+    }
+    dbn[row + t] = gr * d;
   }
 }
 
@@ -532,11 +541,8 @@ extern "C" int tl_lite_bn_act_pool_bwd(const float* dy, const float* z, const fl
   TL_REQUIRE(B > 0 && B <= 65535 && C > 0 && T >= 2, "lite_bn_act_pool_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   float* part = work;                         // [B][C][2]
-  float* sums = work + (size_t)B * C * 2;     // [C][2]
   hipLaunchKernelGGL(lite_bn_act_pool_bwd_kernel, dim3(C, B), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, dz, part, C, T, slope);
-  hipLaunchKernelGGL(lite_bn_reduce_kernel, dim3(C), dim3(64), 0, st, part, dgamma, dbeta, sums, B, C);
-  const long long total = (long long)B * C * T;
-  hipLaunchKernelGGL(lite_bn_dz_kernel, dim3(lgrid(total)), dim3(256), 0, st, dz, z, mean, rstd, gamma, sums, total, C, T,
+  hipLaunchKernelGGL(lite_bn_dz_kernel, dim3(C, B), dim3(256), 0, st, dz, z, mean, rstd, gamma, part, dgamma, dbeta, B, C, T,
                      (long long)B * T, training);
   return check_launch("lite_bn_act_pool_bwd");
 }
