@@ -957,3 +957,36 @@ def test_small_classifier_heads_run_on_hip_for_inference(dev):
         assert s(x).requires_grad                               # autograd path untouched
     with pytest.raises(ValueError, match="Expected input dimension"):
         LogisticRegressionClassifier(10, 2).to(dev)(torch.randn(2, 11, device=dev))
+
+
+def test_stage_step_and_slab_sums_small_entry_points(dev):
+    """tl_stage_step (scalars + up to four tensor copies in one launch: 16-byte, 4-byte and byte paths) and tl_sum_slabs2
+    (two slab reductions in one launch) straight through the C ABI."""
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._lib import check, ptr
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(7)
+    srcs = [torch.randn(64, 32, 200, device=dev, generator=g),                       # 16-byte units
+            torch.randn(1001, device=dev, generator=g)[1:],                          # 4-byte aligned only (offset view)
+            torch.randint(0, 255, (1003,), device=dev, dtype=torch.uint8, generator=g)[1:],   # bytes
+            torch.randint(0, 9, (64, 80), device=dev, generator=g)]                  # int64
+    dsts = [torch.zeros_like(s.contiguous()) if s.is_contiguous() else None for s in srcs]
+    assert all(d is not None for d in dsts)
+    scal = torch.zeros(4, device=dev)
+    seed = torch.zeros(1, dtype=torch.int64, device=dev)
+    S = (C_.c_void_p * 4)(*[s.data_ptr() for s in srcs])
+    D = (C_.c_void_p * 4)(*[d.data_ptr() for d in dsts])
+    N = (C_.c_int64 * 4)(*[s.numel() * s.element_size() for s in srcs])
+    check(lib.tl_stage_step(ptr(scal), ptr(seed), 0.25, -1.5, 3.0, 123456789012345, S, D, N, 4, st), "tl_stage_step")
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)
+    assert scal.tolist() == [0.25, -1.5, 3.0, 0.0] and int(seed.item()) == 123456789012345
+    a = torch.randn(17, 300, device=dev, generator=g)
+    b = torch.randn(17, 5, device=dev, generator=g)
+    ra, rb = torch.empty(300, device=dev), torch.empty(5, device=dev)
+    check(lib.tl_sum_slabs2(ptr(a), ptr(ra), 300, ptr(b), ptr(rb), 5, 17, st), "tl_sum_slabs2")
+    assert float((ra - a.double().sum(0).float()).abs().max()) < 1e-5 and float((rb - b.double().sum(0).float()).abs().max()) < 1e-5
+    check(lib.tl_sum_slabs2(ptr(a), ptr(ra), 300, None, None, 0, 17, st), "tl_sum_slabs2")      # second tensor optional
+    assert float((ra - a.double().sum(0).float()).abs().max()) < 1e-5
