@@ -13,7 +13,7 @@ constexpr int LT = 64;   // time tile of the direct conv kernels
 
 // z[b][o][t] = bias[o] + sum_{i,j} w[o][i][j] * x[b][i][t + j - pad]   (zero padding)
 // part[(b*ntile + tile)][o][0..1] = (sum_t z, sum_t z^2) over the tile
-__global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void lite_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ z,
                                                             float* __restrict__ part, int Cin, int Cout, int T, int k,
                                                             int pad) {
@@ -43,10 +43,13 @@ __global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restr
       pp[1] = s2;
     }
   };
-  constexpr int OB = 8;        // output channels a lane accumulates at once: one LDS read feeds OB FMAs
+  // output channels a lane accumulates at once (one LDS read feeds OB FMAs).  4 with eight waves, not 8 with four: the
+  // weights of an input channel are then ONE batch of scalar loads behind one drained wait instead of two
+  constexpr int OB = 4;
+  const int nwaves = blockDim.x >> 6;
   auto blocked = [&](auto KC) {
     constexpr int K = decltype(KC)::value;            // compile-time tap count: the j loops unroll without branches
-    for (int o0 = wave * OB; o0 < Cout; o0 += 4 * OB) {
+    for (int o0 = wave * OB; o0 < Cout; o0 += nwaves * OB) {
       float acc[OB];
 #pragma unroll
       for (int u = 0; u < OB; ++u) acc[u] = bias[o0 + u];
@@ -65,12 +68,12 @@ __global__ __launch_bounds__(256) void lite_conv_fwd_kernel(const float* __restr
       for (int u = 0; u < OB; ++u) finish(o0 + u, acc[u]);
     }
   };
-  if (Cout % (4 * OB) == 0 && k == 5) {
+  if (Cout % (nwaves * OB) == 0 && k == 5) {
     blocked(std::integral_constant<int, 5>{});
-  } else if (Cout % (4 * OB) == 0 && k == 3) {
+  } else if (Cout % (nwaves * OB) == 0 && k == 3) {
     blocked(std::integral_constant<int, 3>{});
   } else {
-    for (int o = wave; o < Cout; o += 4) {
+    for (int o = wave; o < Cout; o += nwaves) {
       float acc = bias[o];
       const float* wo = w + (long long)o * Cin * k;
       for (int ci = 0; ci < Cin; ++ci)
@@ -516,7 +519,7 @@ extern "C" int tl_lite_conv_fwd(const float* x, const float* w, const float* bia
   const size_t lds = (size_t)Cin * (LT + k - 1) * 4;
   TL_REQUIRE(lds <= 64 * 1024, "lite_conv_fwd: Cin too large for the LDS tile");
   dim3 grid((T + LT - 1) / LT, B);
-  hipLaunchKernelGGL(lite_conv_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, z, part, Cin, Cout, T, k, pad);
+  hipLaunchKernelGGL(lite_conv_fwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, x, w, bias, z, part, Cin, Cout, T, k, pad);
   return check_launch("lite_conv_fwd");
 }
 extern "C" int tl_lite_bn_finalize(const float* part, float* mean, float* rstd, float* run_mean, float* run_var,
