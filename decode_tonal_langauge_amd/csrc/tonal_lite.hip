@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void lite_bn_dz_kernel(float* __restrict__ dbn
 }
 
 // conv backward: dx[b][i][t] = sum_{o,j} dz[b][o][t - j + pad] w[o][i][j];  per-b weight-gradient partials
-__global__ __launch_bounds__(256) void lite_conv_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void lite_conv_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w,
                                                            float* __restrict__ dx, int Cin, int Cout, int T, int k, int pad) {
   extern __shared__ __attribute__((aligned(16))) float ds[];      // [Cout][LT + k - 1]
   const int b = blockIdx.y, t0 = blockIdx.x * LT;
@@ -242,10 +242,11 @@ __global__ __launch_bounds__(256) void lite_conv_dx_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = t0 + lane;
-  constexpr int CB = 8;        // input channels a lane accumulates at once
+  constexpr int CB = 4;        // input channels a lane accumulates at once (eight waves: see lite_conv_fwd_kernel)
+  const int nwaves = blockDim.x >> 6;
   auto blocked = [&](auto KC) {
     constexpr int K = decltype(KC)::value;
-    for (int c0 = wave * CB; c0 < Cin; c0 += 4 * CB) {
+    for (int c0 = wave * CB; c0 < Cin; c0 += nwaves * CB) {
       float acc[CB];
 #pragma unroll
       for (int u = 0; u < CB; ++u) acc[u] = 0.f;
@@ -266,12 +267,12 @@ __global__ __launch_bounds__(256) void lite_conv_dx_kernel(const float* __restri
       }
     }
   };
-  if (Cin % (4 * CB) == 0 && k == 5) {
+  if (Cin % (nwaves * CB) == 0 && k == 5) {
     blocked(std::integral_constant<int, 5>{});
-  } else if (Cin % (4 * CB) == 0 && k == 3) {
+  } else if (Cin % (nwaves * CB) == 0 && k == 3) {
     blocked(std::integral_constant<int, 3>{});
   } else {
-    for (int ci = wave; ci < Cin; ci += 4) {
+    for (int ci = wave; ci < Cin; ci += nwaves) {
       float acc = 0.f;
       for (int o = 0; o < Cout; ++o)
         for (int j = 0; j < k; ++j)      // dz index t - j + pad = t0 + lane + (k-1-j) - (k-1-pad)
@@ -557,7 +558,7 @@ extern "C" int tl_lite_conv_bwd(const float* dz, const float* x, const float* w,
   if (dx) {
     const size_t lds = (size_t)Cout * (LT + k - 1) * 4;
     TL_REQUIRE(lds <= 64 * 1024, "lite_conv_bwd: Cout too large for the LDS tile");
-    hipLaunchKernelGGL(lite_conv_dx_kernel, dim3((T + LT - 1) / LT, B), dim3(256), lds, st, dz, w, dx, Cin, Cout, T, k, pad);
+    hipLaunchKernelGGL(lite_conv_dx_kernel, dim3((T + LT - 1) / LT, B), dim3(512), lds, st, dz, w, dx, Cin, Cout, T, k, pad);
   }
   const int max_o = (255 + Cin * k - 1) / (Cin * k) + 1;              // output channels a block of 256 elements can touch
   const size_t lds_dw = ((size_t)Cin * T + (size_t)max_o * T) * 4;
