@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_POOL, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, LOAD_V, NtParams, TnParams,
+from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_POOL, EPI_POOLV, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, LOAD_V, NtParams, TnParams,
                    check, ptr)
 
 
@@ -113,6 +113,10 @@ class CnnEngine:
         # with V written by the first stage the raw pooled rows P1 (13.4 GB at the north-star shape) have no reader
         # left (the LeakyReLU' mask of the backward pass comes from the 1-bit sign array); store_p1 keeps them anyway
         self.store_p1 = os.environ.get("TONAL_STORE_P1", "0") == "1"
+        # round 4: the forward epilogue of a pooled 3-tap stage whose successor reads V writes that V itself (epilogue 5 of
+        # tl_conv3_wino43v_nt + tl_wino43_v_fixup): the stand-alone transform kernel and the raw pooled rows of stage 2
+        # (6.6 GB written, 6.6 GB re-read at the north-star shape) go; store_p1 keeps the raw rows as well (tests).  0: off
+        self.wino_vout = os.environ.get("TONAL_WINO_VOUT", "1") != "0"
         # fold the first stage's weight gradient into the stage-2 input-gradient epilogue (Winograd kernels)
         self.fuse_c1 = os.environ.get("TONAL_FUSE_C1", "1") != "0"
         # TONAL_OVERLAP=1: run the label LSTM (forward and BPTT: HBM-bound streams of the 5.4 GB W_hh) and the W_hh update
@@ -149,7 +153,8 @@ class CnnEngine:
         for st in self.stages:
             rows = S * st.tp_out
             ld = st.cout if st.pool else self.ld5
-            self.P[st.idx] = z(rows, ld)
+            if not self._writes_v(st) or self.store_p1:
+                self.P[st.idx] = z(rows, ld)
             if st.pool:
                 self.bits[st.idx] = zi(rows, st.cout // 32)
                 self.sbits[st.idx] = zi(rows, st.cout // 32)
@@ -316,6 +321,15 @@ class CnnEngine:
         return (self._use_wino_v(self.stages[0]) and self._use_wino43_tn(self.stages[0]) and self.tp1 % 4 == 0
                 and self.c1 in (128, 256, 512, 1024) and (self.fuse_c1 and self._c1_fusable()))
 
+    def _writes_v(self, st) -> bool:
+        """The forward pass of this stage writes V of its own output for the next stage (nothing else reads the raw rows:
+        the next stage's forward and weight gradient read V, its input gradient's LeakyReLU' mask the 1-bit sign array)."""
+        if not (self.wino_vout and st.pool and st.idx - 1 < len(self.stages)):
+            return False
+        nxt = self.stages[st.idx - 1]                      # stages[k] has idx k + 2
+        return (self._use_wino_v(st) and self._use_wino_v(nxt) and self._use_wino43_tn(nxt) and st.tp_in % 8 == 0
+                and nxt.cin == st.cout)
+
     def _pin(self, st):
         """Input activation of a stage, or None when only its V form exists (stage 2 behind tl_conv1_fwd_v)."""
         return self.P.get(st.idx - 1)
@@ -416,9 +430,13 @@ class CnnEngine:
         f43 = self._use_wino43(st)
         wp = self._pack_wino(w, True, f43) if wino else self._pack_conv(w, st.cin, False)
         src = self._pin(st)
-        kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(self.P[st.idx]), M=S * st.tp_in,
+        vout = self._writes_v(st)
+        if vout and self.store_p1 and st.idx not in self.P:
+            self.P[st.idx] = torch.zeros(S * st.tp_out, st.cout, dtype=torch.float32, device=self._dev)
+        Pout = self.P.get(st.idx) if (not vout or self.store_p1) else None
+        kw = dict(A=ptr(src), Bw=ptr(wp), bias=ptr(bia), out=ptr(Pout), M=S * st.tp_in,
                   A_rows=S * st.tp_in, N=st.cout, K=st.cin, lda=st.cin, ldb=st.cin,
-                  ldo=self.P[st.idx].shape[1], J=st.k, row_shift=0, Tp=st.tp_in, slope=self.slope,
+                  ldo=Pout.shape[1] if Pout is not None else st.cout, J=st.k, row_shift=0, Tp=st.tp_in, slope=self.slope,
                   loader=LOAD_DIRECT)
         if st.pool:
             kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), osign=ptr(self.sbits[st.idx]),
@@ -430,6 +448,21 @@ class CnnEngine:
             if V is None:
                 V = self._v_ready[st.idx - 1] = self._input_transform(st)
             kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], loader=LOAD_V)
+            if vout:
+                rows_out = S * st.tp_out
+                Vn = self._v_buffer(st.idx, rows_out, st.cout)
+                ntm = (S * st.tp_in + 511) // 512
+                halo = getattr(self, "_vhalo", {}).get(st.idx)
+                if halo is None or halo.shape[0] != ntm or halo.shape[2] != st.cout:
+                    if not hasattr(self, "_vhalo"):
+                        self._vhalo = {}
+                    halo = self._vhalo[st.idx] = torch.zeros(ntm, 2, st.cout, dtype=torch.float32, device=self._dev)
+                kw.update(epilogue=EPI_POOLV, vout=ptr(Vn), vhalo=ptr(halo), vout_quads=Vn.shape[0], ld_vout=Vn.shape[2])
+                self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino43v_nt", **kw)
+                check(self.lib.tl_wino43_v_fixup(ptr(Vn), ptr(halo), rows_out // 4, ntm, st.tp_out, st.cout, Vn.shape[2],
+                                                 self._stream()), "tl_wino43_v_fixup")
+                self._v_ready[st.idx] = Vn
+                return
             self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino43v_nt", **kw)
             return
         self._nt(tag=f"conv{st.idx}_fwd", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino

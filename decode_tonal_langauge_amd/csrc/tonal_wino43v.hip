@@ -27,6 +27,7 @@
 // index that is applied to the per-lane SOURCE address and to the fragment read.
 #include "tonal_common.h"
 #include "tonal_wino43_epi.h"
+#include "tonal_wino43v_epi.h"
 #include <type_traits>
 
 namespace tl {
@@ -127,6 +128,41 @@ __global__ __launch_bounds__(256, 4) void wino43_unpool_xform_kernel(const float
 }
 
 // ------------------------------------------------------------------------------------------
+// Second half of the V-writing forward epilogue (tonal_wino43v_epi.h, POOLV): the last output quad of every 512-row tile
+// needs pooled rows 4, 5 from the next tile.  The tile left rows 0..3 raw in the quad's transform slots 0..3 and every
+// tile stored its first two pooled rows to vhalo; thread = (tile, 4 channels) transforms the quad in place with the
+// expressions of wino43_xform_kernel.  Rows 4, 5 are zero where the quad ends its sequence or the matrix.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void wino43_v_fixup_kernel(float* __restrict__ V, const float* __restrict__ halo, long long quads,
+                                                              long long tiles, int Tq, int C, int ldv) {
+  const int c4n = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tiles * c4n) return;
+  const long long t = idx / c4n;
+  const int c = (int)(idx - t * c4n) * 4;
+  const long long q = t * 64 + 63;
+  if (q >= quads) return;
+  float* v = V + q * 6 * (long long)ldv + c;
+  f32x4 d[6];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) d[j] = *reinterpret_cast<const f32x4*>(v + (long long)j * ldv);
+  const int tq = (int)((4 * q) % Tq);
+  if (tq + 4 < Tq && t + 1 < tiles) {
+    d[4] = *reinterpret_cast<const f32x4*>(halo + ((t + 1) * 2) * (long long)C + c);
+    d[5] = *reinterpret_cast<const f32x4*>(halo + ((t + 1) * 2 + 1) * (long long)C + c);
+  } else {
+    d[4] = d[5] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4 s1 = d[4] - 4.f * d[2], s2 = d[3] - 4.f * d[1], s3 = d[4] - d[2], tt = d[3] - d[1];
+  *reinterpret_cast<f32x4*>(v) = 4.f * d[0] + (d[4] - 5.f * d[2]);
+  *reinterpret_cast<f32x4*>(v + ldv) = s1 + s2;
+  *reinterpret_cast<f32x4*>(v + 2LL * ldv) = s1 - s2;
+  *reinterpret_cast<f32x4*>(v + 3LL * ldv) = s3 + 2.f * tt;
+  *reinterpret_cast<f32x4*>(v + 4LL * ldv) = s3 - 2.f * tt;
+  *reinterpret_cast<f32x4*>(v + 5LL * ldv) = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+
+// ------------------------------------------------------------------------------------------
 // Forward NT kernel on V.  Workgroup: 8 waves as 4 (quads) x 2 (columns); block tile 128 quads (512 conv
 // rows) x 64 columns; wave tile 32 quads x 32 columns x 6 transforms = 96 accumulator registers.  A K-step
 // is 16 channels: A stage [6][128 quads][64 B] = 48 KB, B stage [6][64 columns][64 B] = 24 KB, two stages
@@ -153,6 +189,9 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 #ifndef V4_SCHED
 #define V4_SCHED 1        // 1: hand-specified issue order of a K-step (see kstep)
 #endif
+#ifndef V4_LEAN
+#define V4_LEAN 1         // round 4: quads of a wave in the order of tonal_wino43v_epi.h (a lane owns 16 consecutive quads), scalar-side
+#endif                    // epilogues, first K-step of a tile without the empty carried group; 0: the round-3 kernel (A/B partner)
 #ifndef V4_ABL
 #define V4_ABL 0          // timing-only build variants (scripts/build_v_variants.sh): 1 no steady-state DMA, 2 no epilogue,
 #endif                    // 4 no barrier, 8 order pinned at the top of a K-step, 16 no fragment reads
@@ -163,7 +202,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, 
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p) {
-  __shared__ __attribute__((aligned(1024))) char lds[2 * V4_STAGE];
+  __shared__ __attribute__((aligned(1024))) char lds[2 * V4_STAGE + (EPI == W_EPI_POOLV ? 4096 : (EPI == W_EPI_C1W && V4_LEAN) ? 16384 : 0)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,7 +255,14 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
     for (int k = 0; k < 6; ++k) {
       const int pa = wave * 6 + k;
       const int i = pa >> 3, j = pa & 7;
+#if V4_LEAN
+      // LDS row rho = 8 g + 4 lh + j' of a wave's 32 (the MFMA row whose results lane half lh holds in accumulator
+      // elements 4 g + j') takes quad 16 lh + 4 g + j': a lane owns 16 consecutive quads (tonal_wino43v_epi.h)
+      const int rho = (j & 1) * 16 + prow;
+      long long ql = (j >> 1) * 32 + ((rho & 3) | ((rho >> 3) << 2) | (((rho >> 2) & 1) << 4));
+#else
       long long ql = j * 16 + prow;
+#endif
       if (ql > q_left - 1) ql = q_left - 1;
       t.avoff[k] = (unsigned)(((ql * 6 + i) * p.lda + src_chunk * 4) * 4);
     }
@@ -314,17 +360,84 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
       asm volatile("" ::: "memory");
     }
   };
+#if V4_LEAN
+  // First K-step of a tile: the accumulators start from the zero constant of the first MFMA of each (no 96 moves) and there
+  // is no carried k-group (round 3 ran 24 MFMAs on zero operands per tile here: 1.5 % of a tile's matrix time).
+  auto mfma_group0 = [&](const f32x4 (&fa)[6], const f32x4 (&fb)[6]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][0], fb[i][0], zero, 0, 0, 0);
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[i][q], acc[i], 0, 0, 0);
+  };
+  auto kstep_first = [&](auto LAST) {
+    load_frag(fa0, fb0, 0, c_g0);
+    if constexpr (!decltype(LAST)::value) issue(cur, 1);
+    load_frag(fa1, fb1, 0, c_g1);
+    mfma_group0(fa0, fb0);
+#if V4_SCHED
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if constexpr (!decltype(LAST)::value)
+        if (t < 9) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+#endif
+    if constexpr (!decltype(LAST)::value) {
+      __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0) lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
+#endif
+#if V4_LEAN
+  __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0): the first tile's first stage
+#endif
   for (long long vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+#if !V4_LEAN
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) fa1[i] = fb1[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // carried k-group of step -1: adds nothing
+#endif
+#if V4_LEAN
+    // stage 0 of this tile has landed (waited for at the end of the tile in front), every wave is past that epilogue
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
     // stage 0 of this tile has landed (so have the stores of the epilogue in front of it), every wave is past that epilogue
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#endif
+#if V4_LEAN
+    // What the epilogue reads from global memory is requested in front of the LAST K-step: the loads return under its 72
+    // MFMAs and - vmcnt counts in issue order - in front of the next tile's LDS-DMA pieces, so their consumer does not
+    // wait for those (tonal_wino43v_epi.h)
+    auto prefetch = [&] {
+      if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_POOLV) return v5_prefetch_pool(p, cur.n0, wn, lr);
+      else if constexpr (EPI == W_EPI_MASK) return v5_prefetch_mask(p, cur.R0, cur.n0, wm, wn, lr, lh);
+      else return v5_prefetch_c1w(p, cur.R0, cur.n0, wm, wn, lr, lh);
+    };
+    decltype(prefetch()) pre;
+    if (nsteps > 1) {
+      kstep_first(std::false_type{});
+      for (int s = 1; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::false_type{}, s);
+      pre = prefetch();
+      __builtin_amdgcn_sched_barrier(0);
+      kstep(std::true_type{}, std::false_type{}, nsteps - 1);
+    } else {
+      pre = prefetch();
+      __builtin_amdgcn_sched_barrier(0);
+      kstep_first(std::true_type{});
+    }
+#else
 #if V4_STAGGER
     if (wave >= 4) {
       for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::true_type{}, s);
@@ -334,6 +447,7 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
       for (int s = 0; s + 1 < nsteps; ++s) kstep(std::false_type{}, std::false_type{}, s);
     }
     kstep(std::true_type{}, std::false_type{}, nsteps - 1);
+#endif
     mfma_group(fa1, fb1);
 
 #if V4_ABL & 2
@@ -350,11 +464,43 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
     // wave is past that step's closing barrier; the last step's stage is still being read by slower waves
     const tile_t done = cur;
     const long long nb = vb + gridDim.x;
+#if V4_LEAN
+    // the prefetched words have landed (they were requested a K-step ago; nothing else is in flight).  Stated here so that the
+    // compiler does not place a vmcnt(0) of its own behind the conditional LDS-DMA issue below - in front of the epilogue
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+#endif
     if (V4_PERSIST && nb < nwg) {
       if (nsteps & 1) __syncthreads();
       cur = setup(nb);
       issue(cur, 0);
     }
+#if V4_LEAN
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue (tonal_wino43v_epi.h): the four conv rows of a quad from its six products, then pool (-> P and / or V
+    // of the next stage) / mask / fused first-stage weight gradient; row logic on the scalar ALU ----
+#if !(V4_ABL & 2)
+    float* scratch = reinterpret_cast<float*>(lds + ((nsteps - 1) & 1) * V4_STAGE);
+    (void)scratch;
+    if constexpr (EPI == W_EPI_POOL) {
+      v5_epilogue_pool<false>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+    } else if constexpr (EPI == W_EPI_POOLV) {
+      v5_epilogue_pool<true>(p, acc, pre, reinterpret_cast<float*>(lds + 2 * V4_STAGE), done.R0, done.n0, wm, wn, lr, lh, done.tm);
+    } else if constexpr (EPI == W_EPI_MASK) {
+      v5_epilogue_mask(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
+    } else {
+      // (the reduction takes the LAST step's stage as its scratch, behind a barrier: slower waves may still be reading it)
+      v5_epilogue_c1w(p, acc, pre, reinterpret_cast<float*>(lds + 2 * V4_STAGE) + wave * 512, scratch, done.R0, done.n0, wm, wn,
+                      lr, lh, done.tm);
+    }
+#endif
+    {
+      // The next tile's first stage (issued in front of the epilogue) has landed; the epilogue's own stores need not: a
+      // wave issues v5_stores<EPI>() of them per tile and vmcnt counts in issue order.  (Round 3 waited for vmcnt(0) here:
+      // every tile paid the write latency of its last store with no MFMA in flight.)
+      constexpr int N = V4_PERSIST ? v5_stores<EPI>() : 0;
+      __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    }
+#else
     // ---- epilogue (shared with the in-loop-transform kernels, tonal_wino43_epi.h): the four conv rows of a quad from
     // its six products, then pool / mask / fused first-stage weight gradient.  The reduction of the fused weight gradient
     // takes the LAST step's stage as its scratch (behind a barrier: other waves may still be reading it) ----
@@ -365,6 +511,7 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
       wino43_epilogue<EPI, true>(p, acc, scratch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
     else
       wino43_epilogue<EPI, false>(p, acc, scratch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+#endif
 #endif
     if (!V4_PERSIST && nb < nwg) {                         // (no prefetch: plain sequence of tiles)
       __syncthreads();
@@ -1145,7 +1292,7 @@ extern "C" int tl_conv3_wino43v_nt(const tl_nt_params* pp, void* stream) {
   using namespace tl;
   TL_REQUIRE(pp != nullptr, "wino43v_nt: null params");
   const tl_nt_params& p = *pp;
-  TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W), "wino43v_nt: null V/Bw/out");
+  TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W || p.epilogue == W_EPI_POOLV), "wino43v_nt: null V/Bw/out");
   TL_REQUIRE(p.loader == W_LOAD_V, "wino43v_nt: loader 2 (pre-transformed operand) only");
   TL_REQUIRE(p.J == 3 && p.splitk <= 1, "wino43v_nt: 3 taps, no split-K");
   TL_REQUIRE(p.M > 0 && p.M % 4 == 0 && p.N > 0 && p.K >= 16 && p.K % 16 == 0, "wino43v_nt: M %% 4, K %% 16 needed");
@@ -1156,6 +1303,11 @@ extern "C" int tl_conv3_wino43v_nt(const tl_nt_params* pp, void* stream) {
   TL_REQUIRE(128LL * 6 * p.lda * 4 + 4LL * p.K < (1LL << 31), "wino43v_nt: tile span too large");
   const long long nwg = ((p.M + 4 * V4_BQ - 1) / (4 * V4_BQ)) * ((p.N + V4_BN - 1) / V4_BN);
   TL_REQUIRE(nwg < (1LL << 31), "wino43v_nt: grid too large");
+#if V4_LEAN
+  // (the epilogues of tonal_wino43v_epi.h: a wave's 32 columns are in or out of the matrix together; 32-bit row arithmetic)
+  TL_REQUIRE(p.N % 32 == 0 && p.M + 4 * V4_BQ < (1LL << 31), "wino43v_nt: N %% 32 == 0 and M < 2^31 - 512 needed");
+  TL_REQUIRE(p.slope >= 0.f && p.slope <= 1.f, "wino43v_nt: LeakyReLU slope must lie in [0, 1]");
+#endif
   hipStream_t st = (hipStream_t)stream;
 #if V4_PERSIST
   const long long ngrid = nwg < 256 * V4_PERSIST ? nwg : 256 * V4_PERSIST;      // one workgroup per CU (144 KB of LDS each)
@@ -1167,9 +1319,22 @@ extern "C" int tl_conv3_wino43v_nt(const tl_nt_params* pp, void* stream) {
     TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino43v_nt: POOL needs obits and an even Tvalid");
     TL_REQUIRE(p.N % 32 == 0 && p.ld_obits * 32 >= p.N, "wino43v_nt: POOL needs N %% 32 == 0");
     hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_POOL>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
+#if V4_LEAN
+  } else if (p.epilogue == W_EPI_POOLV) {
+    TL_REQUIRE(p.row_shift == 0 && (p.out == nullptr || p.ldo >= p.N), "wino43v_nt: forward needs row_shift 0");
+    TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino43v_nt: POOLV needs obits and an even Tvalid");
+    TL_REQUIRE(p.ld_obits * 32 >= p.N && p.Tp % 8 == 0, "wino43v_nt: POOLV needs Tp %% 8 == 0 (output quads inside one sequence)");
+    TL_REQUIRE(p.vout && p.vhalo && p.ld_vout >= p.N && p.vout_quads >= p.M / 8, "wino43v_nt: POOLV needs vout (>= M / 8 quads) and vhalo");
+    TL_REQUIRE(64LL * 6 * p.ld_vout * 4 < (1LL << 31), "wino43v_nt: ld_vout too large");
+    hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_POOLV>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
+#endif
   } else if (p.epilogue == W_EPI_MASK) {
     TL_REQUIRE(p.row_shift == -2 && p.ldo >= p.N, "wino43v_nt: input gradient needs row_shift -2");
+#if V4_LEAN
+    TL_REQUIRE(p.auxbits != nullptr, "wino43v_nt: MASK needs auxbits (the sign bits of the stage input)");
+#else
     TL_REQUIRE(p.aux != nullptr || p.auxbits != nullptr, "wino43v_nt: MASK needs aux or auxbits");
+#endif
     hipLaunchKernelGGL((wino43v_nt_kernel<W_EPI_MASK>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
   } else if (p.epilogue == W_EPI_C1W) {
     TL_REQUIRE(p.row_shift == -2, "wino43v_nt: input gradient needs row_shift -2");
@@ -1181,6 +1346,18 @@ extern "C" int tl_conv3_wino43v_nt(const tl_nt_params* pp, void* stream) {
     return TL_EINVAL;
   }
   return check_launch("wino43v_nt");
+}
+
+extern "C" int tl_wino43_v_fixup(float* V, const float* vhalo, int64_t quads, int64_t tiles, int Tq, int C, int ldv, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(V && vhalo, "wino43_v_fixup: null pointer");
+  TL_REQUIRE(quads > 0 && tiles > 0 && Tq > 0 && Tq % 4 == 0, "wino43_v_fixup: quads, tiles > 0 and Tq %% 4 == 0 needed");
+  TL_REQUIRE(C > 0 && C % 4 == 0 && ldv >= C && ldv % 4 == 0, "wino43_v_fixup: C / ldv must be multiples of 4");
+  const long long n = (long long)tiles * (C / 4);
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino43_v_fixup: grid too large");
+  hipLaunchKernelGGL(wino43_v_fixup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, vhalo,
+                     (long long)quads, (long long)tiles, Tq, C, ldv);
+  return check_launch("wino43_v_fixup");
 }
 
 // weight gradient on V (a_form 1): A = V[quad][6][lda], A_rows = quads held by V (a whole number of 8-quad K-steps)

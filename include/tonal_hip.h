@@ -78,6 +78,12 @@ typedef struct {
    * * x[seq][2t + a + j] (j < c1kt taps) and [c1kt][col] = sum_rows G1 (bias), with a = arg-max bit
    * in c1bits (leading dimension ld_auxbits), x = c1x (S, c1T), rows valid for t < Tvalid.          */
   const float* c1x; const uint32_t* c1bits; float* c1partial; int c1T, c1kt;
+  /* epilogue 5 (tl_conv3_wino43v_nt only, round 4): POOL that also writes V = the F(4,3) input transform of its pooled
+   * OUTPUT for the next 3-tap stage: vout[vout_quads][6][ld_vout], quad Q' = pooled rows 4Q' .. 4Q'+5 of one sequence
+   * (Tp % 8 == 0).  `out` becomes optional (null: the raw pooled rows are never stored).  The last quad of every
+   * 512-row tile needs two rows of the next tile: it is left raw (rows 0..3 in its transform slots 0..3) and the tile
+   * stores its own first two pooled rows to vhalo[tile][2][N]; tl_wino43_v_fixup finishes those quads.                */
+  float* vout; float* vhalo; int64_t vout_quads; int ld_vout;
 } tl_nt_params;
 int tl_gemm_nt_window(const tl_nt_params* p, void* stream);
 
@@ -164,6 +170,10 @@ int tl_conv3_wino43_tn(const tl_tn_params* p, void* stream);
 int tl_wino43_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
 int tl_wino43_input_transform(const float* P, float* V, int64_t rows, int Tp, int C, int ldp, int ldv, void* stream);
 int tl_conv3_wino43v_nt(const tl_nt_params* p, void* stream);
+/* second half of epilogue 5: for every tile (64 output quads) of a tl_conv3_wino43v_nt launch that wrote V, the last quad
+ * Q' = 64 t + 63 (if < quads): rows 0..3 from its slots 0..3, rows 4, 5 from vhalo[t + 1] - or zeros where the quad ends
+ * its sequence (Tq = pooled rows per sequence) or is the last of the matrix - transformed in place.                     */
+int tl_wino43_v_fixup(float* V, const float* vhalo, int64_t quads, int64_t tiles, int Tq, int C, int ldv, void* stream);
 /* Vd[conv_rows / 4][6][ldv] of a pooled 3-tap stage from its output gradient G (g_rows pooled rows, ldg) and arg-max bits:
  * the F(4,3) input transform of the un-pooled dZ rows 4q-2 .. 4q+3 = the operand of tl_conv3_wino43v_nt with the MASK /
  * conv1-weight-gradient epilogue.  LDS-free and register-light: meant to run on a side stream beside the stage's

@@ -21,6 +21,9 @@ B = args.batch
 eng.fuse_c1 = False          # stage kernels in isolation: keep G1 as a tensor
 eng._alloc(B, dev)
 eng._alloc_bwd()
+for st in eng.stages:       # (a stage whose forward epilogue writes V for its successor keeps no raw pooled rows: give the
+    if st.idx not in eng.P:  # stand-alone transform of the next stage something to read when that stage is timed alone)
+        eng.P[st.idx] = torch.empty(eng.S * st.tp_out, st.cout, device=dev)
 g = torch.Generator(device=dev).manual_seed(1)
 for k in eng.P:
     eng.P[k].normal_(generator=g)

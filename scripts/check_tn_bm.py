@@ -23,6 +23,7 @@ bms = [int(b) for b in args.bms.split(",")]
 dev = torch.device("cuda:0")
 stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
 eng = CnnEngine(80, args.channels, args.timepoints, 6, 64, 0.0, 0.01, stages_def, [128, 128, 128, 128, 64])
+eng.wino_vout = False          # stage kernels one at a time: every stage reads P
 B = args.batch
 eng.fuse_c1 = False
 eng._alloc(B, dev)

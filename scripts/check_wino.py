@@ -18,6 +18,7 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
 eng = CnnEngine(80, args.channels, args.timepoints, 6, 64, 0.0, 0.01, stages_def, [128, 128, 128, 128, 64])
+eng.wino_vout = False          # stage kernels one at a time: every stage reads P
 B = args.batch
 eng.wino43 = args.f43
 eng.fuse_c1 = False          # stage kernels in isolation: keep G1 as a tensor

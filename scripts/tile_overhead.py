@@ -10,6 +10,7 @@ res = {}
 for c1 in (512, 256):
     defs = [(c1, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
     eng = CnnEngine(80, 128, 400, 6, 64, 0.0, 0.01, defs, [128, 128, 128, 128, 64])
+    eng.wino_vout = False          # stage kernels one at a time: every stage reads P
     eng.fuse_c1 = False
     eng._alloc(B, dev); eng._alloc_bwd()
     g = torch.Generator(device=dev).manual_seed(1)

@@ -615,6 +615,7 @@ def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
     for mode in ("0", "1", "4"):
         eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
         eng.wino, eng.wino43, eng.fuse_c1 = mode != "0", mode == "4", False
+        eng.wino_vout = False          # stage kernels one at a time on random inputs: every stage reads P
         eng._alloc(B, dev)
         eng._alloc_bwd()
         g.manual_seed(sum(widths))
@@ -649,6 +650,49 @@ def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
             assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(3, 5, 236, (128, 128, 64)), (2, 3, 400, (128, 256, 128)), (1, 1, 44, (128, 128, 128)),
+                                   (7, 3, 100, (64, 192, 64))])
+def test_forward_epilogue_writes_the_next_stage_operand(dev, shape):
+    """Round 4: the forward kernel of a pooled 3-tap stage writes V = the F(4,3) input transform of its own pooled output
+    (epilogue 5 + tl_wino43_v_fixup) instead of the raw rows.  With the raw rows stored as well (store_p1) the V it wrote
+    must be the transform of exactly those rows - including the quads that take rows from the next half-wave, the next
+    wave, the next tile (fix-up pass) and the quads that end a sequence - and rows / bits must equal the plain POOL launch."""
+    from decode_tonal_langauge_amd._cnn_engine import CnnEngine
+    from decode_tonal_langauge_amd._lib import check, ptr
+    B, C, T, (c1, c2, c3) = shape
+    defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
+    res = {}
+    for vout in (False, True):
+        eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
+        eng.fuse_c1, eng.wino_vout, eng.store_p1 = False, vout, True
+        eng._alloc(B, dev)
+        st = eng.stages[0]
+        assert eng._writes_v(st) == vout and st.tp_in % 8 == 0
+        g = torch.Generator(device=dev).manual_seed(11)
+        eng.P[1].normal_(generator=g)
+        eng.P[1].view(eng.S, st.tp_in, -1)[:, st.tin:, :] = 0
+        w = torch.randn(st.cout, st.cin, 3, 1, device=dev, generator=g) * 0.05
+        b = torch.randn(st.cout, device=dev, generator=g) * 0.1
+        eng._v_ready = {}
+        eng.stage_forward(st, w, b)
+        res[vout] = (eng.P[2].clone(), eng.bits[2].clone(), eng.sbits[2].clone())
+        if vout:
+            V = eng._v_ready[2]
+            nq = eng.S * st.tp_out // 4
+            Vref = torch.full_like(V, float("nan"))
+            check(eng.lib.tl_wino43_input_transform(ptr(eng.P[2]), ptr(Vref), eng.P[2].shape[0], st.tp_out, st.cout, st.cout,
+                                                    st.cout, torch.cuda.current_stream().cuda_stream), "tl_wino43_input_transform")
+            assert bool(torch.isfinite(V).all())
+            assert torch.allclose(V[:nq], Vref[:nq], rtol=1e-6, atol=1e-6), float((V[:nq] - Vref[:nq]).abs().max())
+            assert float(V[nq:].abs().max()) == 0.0 if V.shape[0] > nq else True
+            # a second launch into the same buffers: the raw rows the fix-up pass consumed are rewritten, not re-transformed
+            eng._v_ready = {}
+            eng.stage_forward(st, w, b)
+            assert torch.equal(eng._v_ready[2], V)
+    for a, b_ in zip(res[False], res[True]):
+        assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("shape", [(3, 5, 236, (128, 128, 64)), (2, 3, 400, (128, 256, 128)), (1, 1, 44, (128, 128, 128))])
 def test_weight_gradient_tilings_agree_bit_for_bit(dev, shape):
     """The three V-form F(4,3) weight-gradient kernels (64-wide C_in tile; 128-wide with Y staged through registers; 128-wide
@@ -660,6 +704,7 @@ def test_weight_gradient_tilings_agree_bit_for_bit(dev, shape):
     defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
     eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
     eng.fuse_c1 = False
+    eng.wino_vout = False
     eng._alloc(B, dev)
     eng._alloc_bwd()
     g = torch.Generator(device=dev).manual_seed(7)
