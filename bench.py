@@ -27,8 +27,13 @@ Objects on the JSON line beside the contract fields:
                all MFMA FLOPs issued in one step / step time / peak.  ``traffic`` = HBM bytes per
                launch from the rocprofv3 PMC passes committed under profiles/ (static file, named).
   cpu_baseline the CPU oracle (oracle/synthesis_oracle.py, PyTorch-CPU fp32 restatement of the
-               reference) timed on this box's host cores: 1 warm-up + 3 timed steps of the same model
-               at a bounded micro-batch; median, spread, threads and host RAM are reported.
+               reference) timed on this box's host cores at two micro-batches inside --cpu-budget seconds.
+               ``value`` is MEASURED (largest micro-batch / its median step time); the rate at the metric's
+               batch of 256 is an extrapolation and sits in ``extrapolated_to_batch_256``.
+  gpu_state    shader clock / power cap / power draw of the card read from sysfs before and after the
+               timed region (boxes of the pool differ by more than most per-kernel leads).
+The timed region carries no instrumentation: the per-kernel HIP-event timers behind ``roofline`` are
+collected in a second, untimed pass (--timer-steps, default 3).
   c2_lite      BASELINE config C2 (SynthesisLite 32 ch x 200, batch 64) on the same GPU.
   signal_c5    the preprocess/signal stage of config C5 (256 ch x 24 000 samples @ 400 Hz): Hilbert
                envelope, filtfilt, FIR - kernel time by HIP events, algorithmic GB/s against the HBM
@@ -66,7 +71,15 @@ def parse_args(argv=None):
     ap.add_argument("--timepoints", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="micro-batch of the CPU-oracle leg")
-    ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=100.0,
+                    help="seconds of host time the CPU-oracle leg may spend (default 100: two micro-batches of 4 and 12, "
+                         "2-3 timed steps each); >= 400 times micro-batches 32 and 64 directly with >= 5 steps each")
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="skip the untimed second pass that collects the per-kernel HIP-event timers")
+    ap.add_argument("--timer-steps", type=int, default=3, help="steps of that second pass")
+    ap.add_argument("--init", choices=["auto", "each", "broadcast"], default="auto",
+                    help="initial weights under data parallelism: every rank draws all 1.38 G of them (each), or rank 0 "
+                         "draws and broadcasts (broadcast; auto = broadcast when more than one rank) - same bits either way")
     ap.add_argument("--no-extras", action="store_true", help="skip the c2_lite / signal_c5 sub-results")
     ap.add_argument("--dropout", type=float, default=None, help="default: the model's own default (0.5 / 0.3)")
     ap.add_argument("--model", choices=["full", "lite"], default="full",
@@ -148,6 +161,33 @@ def host_threads() -> int:
     return int(os.environ.get("TL_BENCH_CPU_THREADS", min(n, 32)))
 
 
+def gpu_state(index: int = 0) -> dict:
+    """Shader clock and power cap of the card as sysfs shows them (one read; the box-to-box spread of this pool is larger
+    than most per-kernel leads, so a driver-run regression must be tellable from a slow box).  Best effort: absent files
+    give an empty dict.  (The in-kernel clock of an MFMA-dense loop can read up to ~10 % below pp_dpm_sclk:
+    MI355X_MICROARCH.md, DVFS give-back item 6.)"""
+    import glob
+    out = {}
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if not cards:
+        return out
+    dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+    try:
+        for ln in open(os.path.join(dev, "pp_dpm_sclk")):
+            if "*" in ln:
+                out["sclk_mhz"] = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+    except (OSError, ValueError, IndexError):
+        pass
+    for name, key, scale in (("power1_cap", "power_cap_w", 1e-6), ("power1_average", "power_avg_w", 1e-6),
+                             ("power1_input", "power_input_w", 1e-6)):
+        for p in glob.glob(os.path.join(dev, "hwmon", "hwmon*", name)):
+            try:
+                out[key] = round(int(open(p).read().strip()) * scale, 1)
+            except (OSError, ValueError):
+                pass
+    return out
+
+
 def host_ram_gb() -> float:
     """Memory this process may use: cgroup limit if set, else MemTotal."""
     try:
@@ -177,6 +217,9 @@ def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0
     from oracle import synthesis_oracle as so
     threads = host_threads()
     torch.set_num_threads(threads)
+    min_steps = 2
+    if budget_s >= 400.0 and not B_big:        # opt-in (--cpu-budget): larger micro-batches, >= 5 timed steps each
+        B_cpu, B_big, min_steps = 32, 64, 5
     B_big = B_big or 3 * B_cpu
     params = {k: v.detach().to("cpu", copy=True) for k, v in model.named_parameters()}
     state = so.NAdamState(params)
@@ -201,15 +244,19 @@ def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0
             times[Bc].append(one(Bc))
         spent = time.perf_counter() - t_begin
         per_round = (times[B_cpu][-1] + times[B_big][-1])
-        if spent + per_round > budget_s or len(times[B_cpu]) >= 5:
+        if (spent + per_round > budget_s and len(times[B_cpu]) >= min_steps) or len(times[B_cpu]) >= max(5, min_steps):
             break
     m_small, m_big = statistics.median(times[B_cpu]), statistics.median(times[B_big])
     b = max((m_big - m_small) / (B_big - B_cpu), 1e-9)
     a = max(m_small - b * B_cpu, 0.0)
     s256 = a + 256 * b
-    return {"value": 256 / s256, "unit": "mel-frames/s", "cores": threads, "kind": "port",
-            "value_is": "extrapolated to the metric's batch of 256 from s/step = a + b*B fitted on the two micro-batches",
-            "fit_a_s": round(a, 3), "fit_b_s_per_window": round(b, 4), "s_per_step_at_256_extrapolated": round(s256, 1),
+    return {"value": round(B_big / m_big, 4), "unit": "mel-frames/s", "cores": threads, "kind": "port",
+            "value_is": f"MEASURED: micro-batch {B_big} / median step time (the largest batch timed); the rate at the "
+                        "metric's batch of 256 is an extrapolation and is reported apart",
+            "extrapolated_to_batch_256": {"value": round(256 / s256, 3), "unit": "mel-frames/s",
+                                          "from": "s/step = a + b*B through the two micro-batch medians (two points: no residual)",
+                                          "fit_a_s": round(a, 3), "fit_b_s_per_window": round(b, 4),
+                                          "s_per_step_at_256": round(s256, 1)},
             "micro_batches": {str(k): {"timed_steps": len(v), "s_per_step_median": round(statistics.median(v), 3),
                                        "s_per_step_min": round(min(v), 3), "s_per_step_max": round(max(v), 3),
                                        "mel_frames_per_s": round(k / statistics.median(v), 3)} for k, v in times.items()},
@@ -219,8 +266,8 @@ def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0
                       f"step, then {len(times[B_cpu])} timed steps each at micro-batch {B_cpu} and {B_big}, bounded by a "
                       f"{budget_s:.0f} s budget (a full batch of 256 needs ~190 GB of eager activations and minutes per "
                       f"step; the default bench run has to finish within minutes).  A step costs a = {a:.1f} s that does not "
-                      f"depend on the batch (LSTM weight + NAdam traffic) plus b = {b:.2f} s per window, so the raw "
-                      f"micro-batch rates understate the CPU at batch 256; `value` uses the fit"}
+                      f"depend on the batch (LSTM weight + NAdam traffic) plus b = {b:.2f} s per window, so the measured "
+                      f"micro-batch rate understates the CPU at batch 256 (see extrapolated_to_batch_256)"}
 
 
 def event_ms(fn, iters: int, warm: int = 2):
@@ -395,18 +442,24 @@ def main():
         GB = args.batch * world
     B = len(range(*parallel.shard_rows(GB, rank, world).indices(GB)))       # rows of this rank
 
-    # every rank draws the same 1.38 G initial weights on the host: share the cores between ranks
-    torch.set_num_threads(max(1, host_threads() // max(world, 1)))
+    # initial weights: every rank draws the same 1.38 G values on the host (sharing its cores), or rank 0 draws with all
+    # cores and broadcasts after the move to the GPU (5.5 GB over xGMI) - 8 x 40 s of host RNG become one
+    bcast_init = world > 1 and args.init in ("auto", "broadcast")
+    torch.set_num_threads(host_threads() if (bcast_init and rank == 0) else max(1, host_threads() // max(world, 1)))
     torch.manual_seed(1234)
-    if args.model == "lite":
-        args.no_cpu_baseline = True
-        model = SynthesisLite(D, C, T, **({} if args.dropout is None else {"dropout": args.dropout}))
-    else:
-        model = SynthesisModelCNN(D, C, T, **({} if args.dropout is None else {"dropout": args.dropout}))
+    import contextlib
+    with (parallel.skip_param_init() if (bcast_init and rank != 0) else contextlib.nullcontext()):
+        if args.model == "lite":
+            args.no_cpu_baseline = True
+            model = SynthesisLite(D, C, T, **({} if args.dropout is None else {"dropout": args.dropout}))
+        else:
+            model = SynthesisModelCNN(D, C, T, **({} if args.dropout is None else {"dropout": args.dropout}))
     drop = args.dropout if args.dropout is not None else (0.3 if args.model == "lite" else 0.5)
     tone_m = LogisticRegressionClassifier(8 * T, 4)
     syl_m = LogisticRegressionClassifier(8 * T, 2)
     trainer = SynthesisTrainer(model, tone_m, syl_m, TONE_MAP, device=dev, verbose=False)
+    if bcast_init:
+        parallel.broadcast_parameters_(model, src=0)
     eng = model._engine
 
     # synthetic data, resident in HBM: every rank builds the same global batches and takes its shard
@@ -427,28 +480,39 @@ def main():
 
     for i in range(args.warmup):
         trainer.train_step(*data[i % nb])
-    if not args.no_kernel_timers and args.model == "full":
-        eng.enable_timers(True)
     if world > 1:
         trainer.exchange_events = []
+        trainer.exchange_wait_events = []
+    state0 = gpu_state(local if world > 1 else 0)
     sync()
+    # ---- the timed region: exactly args.steps train steps, nothing else (no per-kernel instrumentation) ----
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.train_step(*data[(args.warmup + i) % nb])
     sync()
     dt = time.perf_counter() - t0
-    tsum = eng.timer_summary() if getattr(eng, "timers", None) is not None else {}
-    if hasattr(eng, "enable_timers"):
-        eng.enable_timers(False)
-    exch_ms = None
+    state1 = gpu_state(local if world > 1 else 0)
+    exch_ms = exposed_ms = None
     if world > 1:
         ev = trainer.exchange_events
         trainer.exchange_events = None
         exch_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+        wev = getattr(trainer, "exchange_wait_events", None) or []
+        trainer.exchange_wait_events = None
+        exposed_ms = sum(a.elapsed_time(b) for a, b in wev) / max(args.steps, 1) if wev else None
+    # ---- second, UNTIMED pass: per-launch HIP-event timers of the conv kernels (roofline / families) ----
+    tsum = {}
+    if not args.no_kernel_timers and args.model == "full":
+        eng.enable_timers(True)
+        for i in range(max(1, args.timer_steps)):
+            trainer.train_step(*data[(args.warmup + args.steps + i) % nb])
+        tsum = eng.timer_summary()
+        eng.enable_timers(False)
     if dist.is_initialized():
-        tt = torch.tensor([dt, exch_ms or 0.0], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt, exch_ms or 0.0, exposed_ms or 0.0], device=dev, dtype=torch.float64)
         parallel.all_reduce_(tt, op=dist.ReduceOp.MAX)
         dt, exch_ms = float(tt[0].item()), float(tt[1].item())
+        exposed_ms = float(tt[2].item()) if exposed_ms is not None else None
     ms_per_step = dt / args.steps * 1e3
     value = GB * args.steps / dt
 
@@ -530,7 +594,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the 1-GPU run only
             try:
-                cpu = cpu_baseline(model, args.cpu_batch, C, T, D)
+                cpu = cpu_baseline(model, args.cpu_batch, C, T, D, budget_s=args.cpu_budget)
             except Exception as e:      # noqa: BLE001 - the baseline leg must not kill the bench line
                 cpu = {"value": None, "error": repr(e)}
         line = {
@@ -544,9 +608,15 @@ def main():
                                    f"NAdam, {model.get_nparams():,} params",
                        "per_gpu_batch": B, "global_batch": GB, "parallelism": f"dp{world}",
                        "backend": (dist.get_backend() if dist.is_initialized() else None),
-                       "exchange_ms_per_step": None if exch_ms is None else round(exch_ms, 3)},
+                       "exchange_ms_per_step": None if exch_ms is None else round(exch_ms, 3),
+                       "exchange_exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 3),
+                       "init": ("broadcast from rank 0" if bcast_init else "drawn on every rank")},
+            "gpu_state": {"before_timed_region": state0, "after_timed_region": state1,
+                          "note": "sysfs pp_dpm_sclk / hwmon power of this rank's card, one read each"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if roof is not None:
+            roof["timers_from"] = f"a second, untimed pass of {max(1, args.timer_steps)} steps (the timed region carries no instrumentation)"
         line.update(extras)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():

@@ -881,8 +881,20 @@ class CnnEngine:
             on_factors()
 
     # ------------------------------------------------------------------ backward
+    def grad_order(self) -> List[str]:
+        """Parameter names in the order ``backward`` finishes their gradients (the layout of a flat gradient buffer whose
+        exchange buckets are contiguous slices): output layer, 1x1 stack last to first, label LSTM, ecog stages 5..1."""
+        order = ["output_layer.weight", "output_layer.bias"]
+        for i in range(len(self.concat_dims) - 1, -1, -1):
+            order += [f"concat_conv_block.{2 * i}.weight", f"concat_conv_block.{2 * i}.bias"]
+        order += ["label_lstm.weight_ih_l0", "label_lstm.bias_ih_l0", "label_lstm.bias_hh_l0"]
+        for st in reversed(self.stages):
+            order += [self.STAGE_NAMES[st.idx] + ".weight", self.STAGE_NAMES[st.idx] + ".bias"]
+        order += ["ecog_conv_block.0.weight", "ecog_conv_block.0.bias"]
+        return order
+
     def backward(self, prm: Dict[str, torch.Tensor], dout: torch.Tensor, grads: Dict[str, torch.Tensor],
-                 gather_whh=None, whh_factors: bool = False, reduce_rows=None, on_factors=None) -> None:
+                 gather_whh=None, whh_factors: bool = False, reduce_rows=None, on_factors=None, on_grad_ready=None) -> None:
         """dout: (B, ldd) gradient of the loss w.r.t. the output (pad columns zero).
         Fills ``grads[name]`` (torch layouts) for every parameter.  ``gather_whh(dg, h)`` may
         return the low-rank factors of every data-parallel rank (parallel.gather_lowrank): the
@@ -912,6 +924,8 @@ class CnnEngine:
         self._permute(slab, gw, (self.out_dim, self.Cc, self.lat, self.C),
                       (self.kflat, 1, self.ldy5, self.tp5 * self.ldy5))
         colsum(dout, B, self.out_dim, self.ldd, 1, 1, grads["output_layer.bias"])
+        if on_grad_ready is not None:
+            on_grad_ready("output_layer")           # both gradients of the Linear layer are final (enqueued) from here on
         # dY5 = dout . Wp_out, masked by lrelu'(Y5)
         wpt = torch.empty(self.kflat, self.ldd, **f32)
         self._permute(prm["output_layer.weight"], wpt, (self.C, self.tp5, self.ldy5, self.ldd),

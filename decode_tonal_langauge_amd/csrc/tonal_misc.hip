@@ -1032,7 +1032,8 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
 }
 
 // arg-max of both classifiers' scores + the gather above + the (tone, syllable) pair id, one thread per window: the label pass
-// of a train step in one launch (five ATen kernels + tone_dynamics_kernel otherwise).  First maximum wins, as torch.argmax.
+// of a train step in one launch (five ATen kernels + tone_dynamics_kernel otherwise).  First maximum wins and a NaN counts as the
+// maximum (the first NaN wins), as torch.argmax - a diverged classifier labels a window the same way on both paths.
 __global__ void labels_from_scores_kernel(const float* __restrict__ st, const float* __restrict__ ss, const float* __restrict__ table,
                                           float* __restrict__ labels, long long* __restrict__ tone, long long* __restrict__ syl,
                                           int32_t* __restrict__ pair, int32_t* err, int B, int nt, int ns, int n_rows, int n_syl,
@@ -1043,12 +1044,12 @@ __global__ void labels_from_scores_kernel(const float* __restrict__ st, const fl
   float best = st[(long long)b * nt];
   for (int i = 1; i < nt; ++i) {
     const float v = st[(long long)b * nt + i];
-    if (v > best) { best = v; t = i; }
+    if (v > best || (v != v && best == best)) { best = v; t = i; }
   }
   best = ss[(long long)b * ns];
   for (int i = 1; i < ns; ++i) {
     const float v = ss[(long long)b * ns + i];
-    if (v > best) { best = v; y = i; }
+    if (v > best || (v != v && best == best)) { best = v; y = i; }
   }
   tone[b] = t;
   syl[b] = y;

@@ -158,12 +158,12 @@ __device__ __forceinline__ double ols_sqrt(double v) {
   return yv;
 }
 
-template <bool INV>
-__device__ __forceinline__ void ols_bfly(const double (&xr)[4], const double (&xi)[4], double (&yr)[4], double (&yi)[4]) {
-  const double t0r = xr[0] + xr[2], t0i = xi[0] + xi[2], t1r = xr[0] - xr[2], t1i = xi[0] - xi[2];
-  const double t2r = xr[1] + xr[3], t2i = xi[1] + xi[3];
-  const double dr = xr[1] - xr[3], di = xi[1] - xi[3];
-  const double t3r = INV ? -di : di, t3i = INV ? dr : -dr;    // (a1 - a3) * (-i) forward, (+i) inverse
+template <bool INV, typename R = double>
+__device__ __forceinline__ void ols_bfly(const R (&xr)[4], const R (&xi)[4], R (&yr)[4], R (&yi)[4]) {
+  const R t0r = xr[0] + xr[2], t0i = xi[0] + xi[2], t1r = xr[0] - xr[2], t1i = xi[0] - xi[2];
+  const R t2r = xr[1] + xr[3], t2i = xi[1] + xi[3];
+  const R dr = xr[1] - xr[3], di = xi[1] - xi[3];
+  const R t3r = INV ? -di : di, t3i = INV ? dr : -dr;    // (a1 - a3) * (-i) forward, (+i) inverse
   yr[0] = t0r + t2r; yi[0] = t0i + t2i;
   yr[1] = t1r + t3r; yi[1] = t1i + t3i;
   yr[2] = t0r - t2r; yi[2] = t0i - t2i;
@@ -349,26 +349,40 @@ __device__ __forceinline__ void ols_lane_swap(double& a, double& b) {
   a = __hiloint2double((int)r1[0], (int)r0[0]);
   b = __hiloint2double((int)r1[1], (int)r0[1]);
 }
-__device__ __forceinline__ void ols_lane_transpose(double (&v)[4]) {
+template <bool S32>
+__device__ __forceinline__ void ols_lane_swap(float& a, float& b) {
+  const unsigned a0 = __float_as_uint(a), b0 = __float_as_uint(b);
+  const auto r0 = S32 ? __builtin_amdgcn_permlane32_swap(a0, b0, false, false) : __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+  a = __uint_as_float(r0[0]);
+  b = __uint_as_float(r0[1]);
+}
+template <typename R>
+__device__ __forceinline__ void ols_lane_transpose(R (&v)[4]) {
   ols_lane_swap<true>(v[0], v[2]);
   ols_lane_swap<true>(v[1], v[3]);
   ols_lane_swap<false>(v[0], v[1]);
   ols_lane_swap<false>(v[2], v[3]);
 }
-template <bool INV>
-__device__ __forceinline__ void ols_twiddle(double (&xr)[4], double (&xi)[4], const double (&tc)[3], const double (&ts)[3]) {
+template <bool INV, typename R>
+__device__ __forceinline__ void ols_twiddle(R (&xr)[4], R (&xi)[4], const R (&tc)[3], const R (&ts)[3]) {
 #pragma unroll
   for (int r = 1; r < 4; ++r) {
-    const double c = tc[r - 1], sn = INV ? -ts[r - 1] : ts[r - 1];
-    const double tr = fma(-xi[r], sn, xr[r] * c), ti = fma(xr[r], sn, xi[r] * c);
+    const R c = tc[r - 1], sn = INV ? -ts[r - 1] : ts[r - 1];
+    const R tr = fma(-xi[r], sn, xr[r] * c), ti = fma(xr[r], sn, xi[r] * c);
     xr[r] = tr;
     xi[r] = ti;
   }
 }
-template <bool INV>
-__device__ __forceinline__ void ols_fft256_wave(double (&vr)[4], double (&vi)[4], ols_d2* __restrict__ buf, const double (&tc)[3][3],
-                                                const double (&ts)[3][3], int l) {
-  double xr[4], xi[4], yr[4], yi[4];
+// (re, im) pair of the transform's working precision: fp64 for float64 recordings; fp32 for float32 ones - the reference's
+// own arithmetic there (scipy.fft keeps single precision: complex64, preprocess/signal/frequency_filter.py:167-181)
+template <typename R>
+using ols_r2 = R __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ols_sqrt(float v) { return __builtin_sqrtf(v); }
+template <bool INV, typename R>
+__device__ __forceinline__ void ols_fft256_wave(R (&vr)[4], R (&vi)[4], ols_r2<R>* __restrict__ buf, const R (&tc)[3][3],
+                                                const R (&ts)[3][3], int l) {
+  using ols_d2 = ols_r2<R>;
+  R xr[4], xi[4], yr[4], yi[4];
   ols_bfly<INV>(vr, vi, yr, yi);                              // stage 0: outputs 4 l + r, stored digit-major (stride 68)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -412,15 +426,17 @@ __device__ __forceinline__ void ols_fft256_wave(double (&vr)[4], double (&vi)[4]
   ols_wave_sync();                                            // the next transform's stores stay behind this one's loads
 }
 
-template <typename TIN, int NBT>
+// R: working precision (see ols_r2).  The kernel-spectrum and twiddle tables stay fp64 in memory and are rounded on load.
+template <typename TIN, int NBT, typename R>
 __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restrict__ x, const ols_d2* __restrict__ Gp,
                                                             const int* __restrict__ k0s, const ols_d2* __restrict__ tw,
                                                             double* __restrict__ y, long long T, int nb, int lead, int skip,
                                                             int envelope) {
   const int NB = NBT ? NBT : nb;
   // region A: the forward transform's exchange [q][t], then the spectrum, bin 4 k + q at q x OLS_XS + k; region B: the waves' planes
-  __shared__ __attribute__((aligned(16))) ols_d2 ldsA[4 * OLS_XS];
-  __shared__ __attribute__((aligned(16))) ols_d2 ldsB[4 * OLS_WPL];
+  using r2 = ols_r2<R>;
+  __shared__ __attribute__((aligned(16))) r2 ldsA[4 * OLS_XS];
+  __shared__ __attribute__((aligned(16))) r2 ldsB[4 * OLS_WPL];
   const int tid = threadIdx.x, c = blockIdx.y;
   const int w = tid >> 6, l = tid & 63;
   const int Lv = OLS_N - skip;
@@ -428,25 +444,25 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
   long long base = t0 - lead;                                 // in (-T, 2 T): T >= 1024 >= lead, t0 < T + 1024
   if (base < 0) base += T;
   if (base >= T) base -= T;
-  double vr[4], vi[4], acc[4];
+  R vr[4], vi[4], acc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     long long ti = base + tid + r * OLS_Q;                    // < 2 T (the host requires T >= 1024): no 64-bit division
     if (ti >= T) ti -= T;
-    vr[r] = ld_as_f64<TIN>(x, (long long)c * T + ti);
-    vi[r] = 0.0;
-    acc[r] = 0.0;
+    vr[r] = (R)ld_as_f64<TIN>(x, (long long)c * T + ti);
+    vi[r] = (R)0;
+    acc[r] = (R)0;
   }
-  ols_d2* wbuf = ldsB + w * OLS_WPL;
-  double tc[3][3], ts[3][3];                                  // W_{4 Ns}^{r k}, k = l % Ns, as W_1024^{r k 256 / Ns}
+  r2* wbuf = ldsB + w * OLS_WPL;
+  R tc[3][3], ts[3][3];                                  // W_{4 Ns}^{r k}, k = l % Ns, as W_1024^{r k 256 / Ns}
 #pragma unroll
   for (int st = 1; st < 4; ++st) {
     const int step = (l & ((1 << (2 * st)) - 1)) * (OLS_WQ >> (2 * st));
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
       const ols_d2 t = tw[r * step];
-      tc[st - 1][r - 1] = t[0];
-      ts[st - 1][r - 1] = t[1];
+      tc[st - 1][r - 1] = (R)t[0];
+      ts[st - 1][r - 1] = (R)t[1];
     }
   }
   // Forward transform, the same way round: X[4 k + q] = DFT_256_t( W_1024^{t q} . sum_r x[t + 256 r] W_4^{r q} )[k] - the
@@ -454,18 +470,18 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
   // wave q (lane l takes t = l + 64 j), then the wave-private 256-point transform.  Three barriers up to the band loop
   // instead of the five of the 1024-point Stockham (ols_fft).
   {
-    double yr[4], yi[4], c3[3], s3[3];
+    R yr[4], yi[4], c3[3], s3[3];
 #pragma unroll
     for (int q = 1; q < 4; ++q) {
       const ols_d2 t = tw[tid * q];
-      c3[q - 1] = t[0];
-      s3[q - 1] = t[1];
+      c3[q - 1] = (R)t[0];
+      s3[q - 1] = (R)t[1];
     }
     ols_bfly<false>(vr, vi, yr, yi);
     ols_twiddle<false>(yr, yi, c3, s3);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      ols_d2 t;
+      r2 t;
       t[0] = yr[q];
       t[1] = yi[q];
       ldsA[q * OLS_Q + tid] = t;
@@ -473,7 +489,7 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const ols_d2 t = ldsA[w * OLS_Q + l + 64 * j];
+      const r2 t = ldsA[w * OLS_Q + l + 64 * j];
       vr[j] = t[0];
       vi[j] = t[1];
     }
@@ -481,25 +497,32 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
     ols_fft256_wave<false>(vr, vi, wbuf, tc, ts, l);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                             // bin 4 (l + 64 j) + w
-      ols_d2 t;
+      r2 t;
       t[0] = vr[j];
       t[1] = vi[j];
       ldsA[w * OLS_XS + l + 64 * j] = t;
     }
   }
-  const ols_d2* Xs = ldsA;
-  ols_d2 g[4], gn[4];
+  const r2* Xs = ldsA;
+  auto ldg = [&](long long i) -> r2 {
+    const ols_d2 t = Gp[i];
+    r2 o;
+    o[0] = (R)t[0];
+    o[1] = (R)t[1];
+    return o;
+  };
+  r2 g[4], gn[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) g[r] = Gp[w * OLS_WQ + l + 64 * r];
+  for (int r = 0; r < 4; ++r) g[r] = ldg(w * OLS_WQ + l + 64 * r);
   __syncthreads();
   for (int b = 0; b < NB; ++b) {
     const int bn = b + 1 < NB ? b + 1 : b;
     const int k0 = k0s[b];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      gn[r] = Gp[(long long)(bn * 4 + w) * OLS_WQ + l + 64 * r];
+      gn[r] = ldg((long long)(bn * 4 + w) * OLS_WQ + l + 64 * r);
       const int bin = (k0 + l + 64 * r) & (OLS_N - 1);
-      const ols_d2 X = Xs[(bin & 3) * OLS_XS + (bin >> 2)];
+      const r2 X = Xs[(bin & 3) * OLS_XS + (bin >> 2)];
       vr[r] = fma(-X[1], g[r][1], X[0] * g[r][0]);
       vi[r] = fma(X[0], g[r][1], X[1] * g[r][0]);
     }
@@ -511,7 +534,7 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {                           // Re(z W^{-k0 n}), n = 4 (l + 64 r) + w
         const ols_d2 e = tw[(k0 * (4 * (l + 64 * r) + w)) & (OLS_N - 1)];
-        acc[r] += fma(vi[r], e[1], vr[r] * e[0]);
+        acc[r] += fma(vi[r], (R)e[1], vr[r] * (R)e[0]);
       }
     }
 #pragma unroll
@@ -519,7 +542,7 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
     ols_wave_sync();
   }
   __syncthreads();                                            // every wave is done with the spectrum: its region takes the outputs
-  double* lds = reinterpret_cast<double*>(ldsA);
+  R* lds = reinterpret_cast<R*>(ldsA);
 #pragma unroll
   for (int r = 0; r < 4; ++r) lds[l + 72 * w + 288 * r] = acc[r];   // sample 4 l + w + 256 r, residue-major
   __syncthreads();
@@ -527,7 +550,7 @@ __global__ __launch_bounds__(OLS_Q) void ols_bank_bl_kernel(const void* __restri
   for (int r = 0; r < 4; ++r) {
     const int i = tid + r * OLS_Q;
     const long long t = t0 + i - skip;
-    if (i >= skip && t < T) y[(long long)c * T + t] = lds[(tid >> 2) + 72 * (tid & 3) + 288 * r] / NB;
+    if (i >= skip && t < T) y[(long long)c * T + t] = (double)(lds[(tid >> 2) + 72 * (tid & 3) + 288 * r] / (R)NB);
   }
 }
 
@@ -909,12 +932,17 @@ extern "C" int tl_hilbert_ols_bl(const void* x, int x_is_f64, const double* Gp, 
   hipStream_t st = (hipStream_t)stream;
   const ols_d2* g2 = reinterpret_cast<const ols_d2*>(Gp);
   const ols_d2* t2 = reinterpret_cast<const ols_d2*>(tw);
-  if (x_is_f64)
-    if (nb == 8) hipLaunchKernelGGL((ols_bank_bl_kernel<double, 8>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
-    else hipLaunchKernelGGL((ols_bank_bl_kernel<double, 0>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+  // x_is_f64: 1 float64 recording, fp64 transforms; 0 float32 recording, fp32 transforms (the reference's own precision for
+  // that dtype: scipy.fft stays in complex64); 2 float32 recording, fp64 transforms (round 3's behaviour)
+  const bool f32_math = x_is_f64 == 0;
+  if (x_is_f64 == 1)
+    if (nb == 8) hipLaunchKernelGGL((ols_bank_bl_kernel<double, 8, double>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+    else hipLaunchKernelGGL((ols_bank_bl_kernel<double, 0, double>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
   else
-    if (nb == 8) hipLaunchKernelGGL((ols_bank_bl_kernel<float, 8>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
-    else hipLaunchKernelGGL((ols_bank_bl_kernel<float, 0>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+    if (f32_math && nb == 8) hipLaunchKernelGGL((ols_bank_bl_kernel<float, 8, float>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+    else if (f32_math) hipLaunchKernelGGL((ols_bank_bl_kernel<float, 0, float>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+    else if (nb == 8) hipLaunchKernelGGL((ols_bank_bl_kernel<float, 8, double>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
+    else hipLaunchKernelGGL((ols_bank_bl_kernel<float, 0, double>), grid, dim3(OLS_Q), 0, st, x, g2, k0, t2, y, (long long)T, nb, half, 2 * half, envelope);
   return check_launch("hilbert_ols_bl");
 }
 

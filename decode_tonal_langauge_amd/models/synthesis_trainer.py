@@ -121,7 +121,18 @@ class SynthesisTrainer:
             # re-assemble it, but `train_step` is public: anything that reads the whole model (state_dict -> checkpoints)
             # first runs the collective, on every rank (a collective: all ranks must call state_dict together).  The
             # NAdam moments of that parameter stay per-rank shards: optimizer state under data parallelism is per rank.
-            self.model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.sync_parameters())
+            self.model.register_state_dict_pre_hook(self._state_dict_guard)
+
+    def _state_dict_guard(self, module, prefix, keep_vars) -> None:
+        """``state_dict()`` of the model while its label LSTM is row-sharded and out of date.  Re-assembling the weight is a
+        collective: hidden inside ``state_dict`` it would deadlock the usual ``if rank == 0: torch.save(model.state_dict())``
+        (and fire again for every nested / partial call).  So this raises; ``train`` / ``evaluate`` synchronise themselves,
+        after a bare ``train_step`` call ``sync_parameters()`` (or ``model_state_dict()``) on EVERY rank first."""
+        if self._whh_dirty:
+            raise RuntimeError(
+                "SynthesisTrainer: label_lstm.weight_hh_l0 is row-sharded over the data-parallel ranks and this rank only "
+                "holds current values for its own rows.  Call trainer.sync_parameters() (or trainer.model_state_dict()) on "
+                "every rank before model.state_dict() - it is a collective and is therefore not run implicitly here.")
 
     # ------------------------------------------------------------------ helpers
     def _labels(self, inputs_tone, inputs_syllable) -> torch.Tensor:
@@ -229,7 +240,16 @@ class SynthesisTrainer:
         if self._grads is None:
             # the low-rank parameter's gradient (5.4 GB at the north-star shape) is only materialised
             # if its rank exceeds what the fused optimiser kernel takes (the engine then allocates it)
-            self._grads = {k: torch.empty_like(v) for k, v in prm.items() if k != skip}
+            if self.dp and hasattr(eng, "grad_order"):
+                # data parallel: ONE flat buffer in the order the backward pass finishes the gradients - a bucket of the
+                # exchange step is a contiguous slice (no torch.cat in front of the collective, no copy back behind it)
+                sharded = getattr(eng, "lstm_shard", None) is not None and self._pair_table is not None
+                local_only = ("label_lstm.weight_ih_l0", "label_lstm.bias_ih_l0", "label_lstm.bias_hh_l0") if sharded else ()
+                self._flat = parallel.FlatGrads({k: v.shape for k, v in prm.items() if k != skip}, eng.grad_order(),
+                                                prm[names[0]].device, local=local_only)
+                self._grads = self._flat.views
+            else:
+                self._grads = {k: torch.empty_like(v) for k, v in prm.items() if k != skip}
         prm.update(model._engine_buffers())
         kw = {}
         ids = getattr(self, "_pair_ids", None)
@@ -256,15 +276,35 @@ class SynthesisTrainer:
             if factors is not None and not self.dp:
                 self.optimizer.step_lowrank({params[skip]: factors}, grad_scale=scale)
                 early.append(params[skip])
+        flat = getattr(self, "_flat", None) if self.dp else None
+        pending = []
+
+        def on_grad_ready(group):
+            # Data parallel: the gradients of the output layer (63 MB of the 72 MB that are exchanged at the north-star
+            # shape) are final before the convolution backward starts - their all-reduce is started here and runs beside
+            # that backward pass ("launched as soon as each grad is final"); the optimiser waits for it below
+            if flat is not None and group == "output_layer":
+                pending.append(self._timed(parallel.all_reduce_async)(flat.span(["output_layer.weight", "output_layer.bias"])))
+        bkw = dict(on_grad_ready=on_grad_ready) if flat is not None else {}
         eng.backward(prm, dout, self._grads, gather_whh=gather, whh_factors=skip is not None, reduce_rows=reduce_rows,
-                     on_factors=on_factors if skip is not None else None)
+                     on_factors=on_factors if skip is not None else None, **bkw)
         if self.dp:
             sharded = getattr(eng, "_sh", None) is not None
             # with the row-sharded LSTM its dgates - hence the W_ih / bias gradients - already belong to the global
             # batch on every rank: they stay out of the all-reduce
             local_only = ("label_lstm.weight_ih_l0", "label_lstm.bias_ih_l0", "label_lstm.bias_hh_l0") if sharded else ()
-            self._timed(parallel.allreduce_bucketed)([g for k, g in self._grads.items()
-                                                      if k != skip and k not in local_only])
+            if flat is not None and tuple(local_only) == tuple(flat.local):
+                rest = [k for k in flat.offsets if k not in ("output_layer.weight", "output_layer.bias") and k not in local_only]
+                if not pending:                              # (an engine that never reported the early group)
+                    rest = [k for k in flat.offsets if k not in local_only]
+                if rest:
+                    pending.append(self._timed(parallel.all_reduce_async)(flat.span(rest)))
+                wait_events = getattr(self, "exchange_wait_events", None)
+                for h in pending:
+                    h.wait(wait_events)
+            else:
+                self._timed(parallel.allreduce_bucketed)([g for k, g in self._grads.items()
+                                                          if k != skip and k not in local_only])
             self._whh_dirty = self._whh_dirty or sharded
         factors = getattr(eng, "whh_factors", None)
         if graph:            # scalars of the step from device memory (advanced by the caller per replay)
@@ -348,12 +388,38 @@ class SynthesisTrainer:
         return (self._graph_enabled and eng is not None and hasattr(eng, "seed_dev") and not self.dp
                 and not self.train_classifiers and not self._need_check and self.model.training)
 
+    def _graph_fingerprint(self) -> tuple:
+        """Everything a captured step has frozen into its kernel arguments besides the batch: storage of the parameters,
+        of their gradients and NAdam moments, the optimiser's hyper-parameters, the dropout rate and the classifiers'
+        weights (their packed copies are rebuilt when a weight's version changes).  A replay is only valid while this tuple
+        is what it was at capture: ``optimizer.load_state_dict`` (new moment tensors), an edited ``param_groups`` entry, a
+        re-loaded classifier or a re-assigned ``.data`` would otherwise leave the graph reading freed or stale buffers."""
+        opt = self.optimizer
+        fp = []
+        for group in opt.param_groups:
+            fp.append((tuple(group["betas"]), group["eps"], group["weight_decay"], group["momentum_decay"]))
+            for p in group["params"]:
+                st = opt.state.get(p) or {}
+                g = (self._grads or {}).get(p)
+                fp.append((p.data_ptr(), None if g is None else g.data_ptr(),
+                           None if "exp_avg" not in st else st["exp_avg"].data_ptr(),
+                           None if "exp_avg_sq" not in st else st["exp_avg_sq"].data_ptr()))
+        eng = getattr(self.model, "_engine", None)
+        fp.append((getattr(eng, "p_drop", None), getattr(self.model, "training", None)))
+        for clf in (self.tone_model, self.syllable_model):
+            fp.append(tuple((q.data_ptr(), q._version) for q in clf.parameters()) + (clf.training,))
+        return tuple(fp)
+
     def _graph_step(self, inputs_non, inputs_syllable, inputs_tone, targets) -> bool:
         key = (tuple(inputs_non.shape), tuple(inputs_syllable.shape), tuple(inputs_tone.shape), tuple(targets.shape),
                inputs_non.dtype, inputs_syllable.dtype, inputs_tone.dtype)
         st = self._graphs.get(key)
         if st is None:
             st = self._graphs[key] = {"warm": 0, "graph": None}
+        if st["graph"] is not None and st["fingerprint"] != self._graph_fingerprint():
+            # something the capture had frozen was replaced: drop the graph (and the NAdam entry table it pinned), warm
+            # up eagerly again and recapture - never replay onto freed or stale buffers
+            st.update(graph=None, warm=0, params=None, keep=None, fingerprint=None)
         if st["graph"] is None:
             if st["warm"] < 3 or len([v for v in self._graphs.values() if v["graph"] is not None]) >= 2:
                 st["warm"] += 1
@@ -382,6 +448,10 @@ class SynthesisTrainer:
                 return False            # nothing was executed during the failed capture: run this step eagerly
             eng.seed_dev = None                      # eager steps (other shapes) keep passing the seed by value
             st["graph"], st["params"] = g, set(params)
+            # the graph holds raw pointers into the optimiser's entry tables: keep those tensors alive with it (the
+            # optimiser's own cache is cleared when it grows), and remember what the capture froze
+            st["keep"] = list(self.optimizer._tables.values())
+            st["fingerprint"] = self._graph_fingerprint()
             staged = ()
         else:
             staged = tuple(zip(st["in"], (inputs_non, inputs_syllable, inputs_tone, targets)))

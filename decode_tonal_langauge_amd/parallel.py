@@ -150,6 +150,102 @@ def allreduce_bucketed(tensors: List[torch.Tensor], bucket_bytes: int = 64 << 20
     flush()
 
 
+class FlatGrads:
+    """Gradient storage of a model as ONE flat buffer with per-parameter views, laid out in the order the backward pass
+    finishes them, so that a bucket of the exchange step is a contiguous slice: no ``torch.cat`` staging copy in front of
+    a collective and no copy back behind it (round 3 had both).  ``order``: parameter names, first-finished first;
+    ``local`` names (gradients that already belong to the global batch on every rank) go behind the reduced range."""
+
+    def __init__(self, shapes: Dict[str, torch.Size], order: List[str], device, local=()):
+        names = [k for k in order if k in shapes and k not in local] + [k for k in shapes if k not in order and k not in local]
+        names += [k for k in shapes if k in local]
+        self.offsets, ofs = {}, 0
+        for k in names:
+            n = 1
+            for d in shapes[k]:
+                n *= int(d)
+            self.offsets[k] = (ofs, n)
+            ofs += (n + 3) // 4 * 4                      # 16-byte aligned views (the fused NAdam kernel's requirement)
+        self.flat = torch.zeros(ofs, dtype=torch.float32, device=device)
+        self.views = {k: self.flat[o:o + n].view(shapes[k]) for k, (o, n) in self.offsets.items()}
+        self.local = tuple(local)
+
+    def span(self, names) -> torch.Tensor:
+        """The contiguous slice that covers ``names`` (which must be adjacent in the layout)."""
+        lo = min(self.offsets[k][0] for k in names)
+        hi = max((self.offsets[k][0] + self.offsets[k][1] + 3) // 4 * 4 for k in names)
+        return self.flat[lo:hi]
+
+
+class _Pending:
+    """An all-reduce in flight.  ``wait()`` makes torch's current stream wait for it; with ``wait_events`` (a list) the
+    time that stream actually spends blocked is measured by a pair of HIP events around the wait."""
+
+    def __init__(self, work, tensor, host=None):
+        self.work, self.tensor, self.host = work, tensor, host
+
+    def wait(self, wait_events=None) -> None:
+        if self.work is None:
+            return
+        if wait_events is not None and self.tensor.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.work.wait()
+            e1.record()
+            wait_events.append((e0, e1))
+        else:
+            self.work.wait()
+        self.work = None
+
+
+def all_reduce_async(t: torch.Tensor) -> _Pending:
+    """Start a sum-all-reduce of ``t`` (in place) and return at once.  RCCL ("nccl"): the collective runs on the process
+    group's own stream, ordered behind everything already enqueued on torch's current stream - i.e. behind the kernel
+    that produced ``t`` - and BESIDE whatever the caller enqueues next (the rest of the backward pass).  gloo (tests: two
+    ranks sharing one GPU, collectives staged through host memory): done synchronously."""
+    if not active():
+        return _Pending(None, t)
+    if t.is_cuda and _staged():
+        all_reduce_(t)
+        return _Pending(None, t)
+    return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t)
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def skip_param_init():
+    """Construct modules WITHOUT drawing their initial weights (``torch.nn.init`` draws become no-ops): for the ranks
+    that receive rank 0's weights by ``broadcast_parameters_`` - at the north-star shape every rank would otherwise spend
+    ~40 s of host RNG on 1.38 G values it is about to overwrite."""
+    import torch.nn.init as init
+    names = [n for n in ("uniform_", "normal_", "kaiming_uniform_", "kaiming_normal_", "xavier_uniform_", "xavier_normal_",
+                         "trunc_normal_", "orthogonal_") if hasattr(init, n)]
+    saved = {n: getattr(init, n) for n in names}
+    try:
+        for n in names:
+            setattr(init, n, lambda tensor, *a, **k: tensor)
+        yield
+    finally:
+        for n, fn in saved.items():
+            setattr(init, n, fn)
+
+
+def broadcast_parameters_(module: torch.nn.Module, src: int = 0) -> None:
+    """Every parameter and buffer of ``module`` <- rank ``src``'s (in place; a collective)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.is_cuda and _staged():
+                h = t.detach().cpu()
+                dist.broadcast(h, src=src)
+                t.copy_(h)
+            else:
+                dist.broadcast(t.data, src=src)
+
+
 def gather_lowrank(dg: torch.Tensor, h: torch.Tensor, keys: Optional[torch.Tensor] = None
                    ) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather the factors of the W_hh gradient: dg (k, 4H), h (k, H) with a per-rank k.

@@ -43,7 +43,19 @@ def resolve_step_module(name: str):
     return importlib.import_module(name)
 
 
-_MIXES_CHANNELS = ("car_rereference",)                  # steps whose output rows depend on other rows
+# Steps of this package whose output row r depends on input row r only (they may stack band entries along the rows): these
+# run on a rank's shard with no communication.  Everything else - car_rereference (the mean over channels at every
+# sample) and ANY module this package does not know (the plugin ABI lets a pipeline YAML name arbitrary modules: a user
+# step may mix rows or select channels) - runs on the gathered, whole array on every rank and is cut again.  A foreign
+# module can opt in by defining ``CHANNEL_LOCAL = True`` at module level.
+_CHANNEL_LOCAL = ("downsample", "frequency_filter", "channel_zscore", "rolling_zscore", "zscore_rereference")
+
+
+def _is_channel_local(module, module_name: str) -> bool:
+    flag = getattr(module, "CHANNEL_LOCAL", None)
+    if flag is not None:
+        return bool(flag)
+    return module.__name__.startswith(_PKG + ".signal.") and module_name.rsplit(".", 1)[-1] in _CHANNEL_LOCAL
 
 
 class _ChannelShards:
@@ -68,7 +80,11 @@ class _ChannelShards:
         out = torch.zeros(self.groups, self.per, full.shape[-1], dtype=full.dtype, device=full.device)
         out[:, : self.hi - self.lo] = g[:, self.lo:self.hi]
         if self.hi - self.lo < self.per:
-            out[:, self.hi - self.lo:] = 1.0                         # padding rows: a harmless constant, dropped on gather
+            # padding rows (dropped on gather): a copy of the shard's last real row (or of the recording's last row when the
+            # shard is empty), so that per-row statistics of the channel-local steps stay finite (a constant row is 0 / 0
+            # in the z-score kernels)
+            fill = g[:, self.hi - 1:self.hi] if self.hi > self.lo else g[:, self.C - 1:self.C]
+            out[:, self.hi - self.lo:] = fill
         return out.reshape(self.groups * self.per, full.shape[-1])
 
     def gather(self, local):
@@ -109,13 +125,22 @@ def preprocess_signal(data, steps: List[Dict], block_params: Namespace, figure_d
             setattr(block_params, key, value)
         before_freq = block_params.signal_freq
         before = data if figure_dir is None else (data.copy() if isinstance(data, np.ndarray) else data.clone())
-        tail = module_name.rsplit(".", 1)[-1]
-        if shards is not None and tail in _MIXES_CHANNELS:
-            data = shards.cut(resolve_step_module(module_name).run(shards.gather(data), block_params))
+        module = resolve_step_module(module_name)
+        if shards is not None and not _is_channel_local(module, module_name):
+            whole = module.run(shards.gather(data), block_params)
+            if whole.shape[0] % (shards.groups * shards.C) == 0:
+                shards.groups *= whole.shape[0] // (shards.groups * shards.C)
+            else:                                                      # the step changed the channel count: shard anew
+                shards = _ChannelShards(whole.shape[0])
+            data = shards.cut(whole)
         else:
             rows = data.shape[0]
-            data = resolve_step_module(module_name).run(data, block_params)
+            data = module.run(data, block_params)
             if shards is not None and data.shape[0] != rows:           # band entries stacked along the rows
+                if data.shape[0] % rows:
+                    raise ValueError(f"preprocess_signal(shard_channels=True): step '{module_name}' turned {rows} rows into "
+                                     f"{data.shape[0]} - not a whole number of entries per channel; a channel-local step must "
+                                     "keep or multiply the rows")
                 shards.groups *= data.shape[0] // rows
         if figure_dir and getattr(data, "ndim", 0) == 2:
             _plot_step(before, before_freq, data, block_params.signal_freq, figure_dir, i, module_name,

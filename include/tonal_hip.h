@@ -379,7 +379,10 @@ int tl_hilbert_ols(const void* x, int x_is_f64, const double* G, const double* t
 /* tl_hilbert_ols for band-limited kernels (the Gaussian bank: frequency_filter.py:155-175): when every |G_b| outside a window
  * of nfft / 4 bins [k0_b, k0_b + nfft / 4) is negligible (the caller checks: < 1e-10 of the peak in sum), band b's inverse
  * transform is four independent (nfft / 4)-point transforms, one wave each, with no workgroup barrier in the band loop.
- * Gp (nb, 4, nfft / 4, 2) = G_b[(k0_b + k) % nfft] . exp(+2 pi i k r / nfft), r < 4; k0 (nb) int32, device memory.     */
+ * Gp (nb, 4, nfft / 4, 2) = G_b[(k0_b + k) % nfft] . exp(+2 pi i k r / nfft), r < 4; k0 (nb) int32, device memory.
+ * x_is_f64: 1 = float64 recording, fp64 transforms; 0 = float32 recording, fp32 transforms - the reference's own arithmetic
+ * for that dtype (scipy.fft keeps single precision: complex64, frequency_filter.py:167-181); 2 = float32 recording, fp64
+ * transforms (round 3's behaviour).  The output is float64 either way, as the reference returns it.                    */
 int tl_hilbert_ols_bl(const void* x, int x_is_f64, const double* Gp, const int* k0, const double* tw, double* y, int C,
                       int64_t T, int nb, int half, int nfft, int envelope, void* stream);
 /* The same bank evaluated in the DFT domain exactly as the reference writes it (frequency_filter.py:155-184):

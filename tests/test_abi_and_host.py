@@ -305,3 +305,17 @@ def test_bench_launcher_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(n, 2))], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+
+
+def test_state_dict_of_a_row_sharded_model_raises_instead_of_hiding_a_collective():
+    """with the row-sharded label LSTM a rank holds current values only for its own rows of W_hh between
+    steps.  ``model.state_dict()`` must not run the all-gather implicitly (``if rank == 0: torch.save(model.state_dict())``
+    would deadlock): the pre-hook raises and names ``sync_parameters()`` / ``model_state_dict()``."""
+    import types
+    import pytest
+    from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
+    fake = types.SimpleNamespace(_whh_dirty=True)
+    with pytest.raises(RuntimeError, match="sync_parameters"):
+        SynthesisTrainer._state_dict_guard(fake, None, "", False)
+    fake._whh_dirty = False
+    SynthesisTrainer._state_dict_guard(fake, None, "", False)      # in sync: nothing to do

@@ -59,6 +59,37 @@ def _worker(rank, world, port, q):
     ok = ok and torch.equal(mine_p, full)
     sl = parallel.shard_rows(10, rank, world)
     ok = ok and (sl.stop - sl.start == 5)
+    # round 4: gradients in ONE flat buffer in completion order; the exchange buckets are contiguous slices of it, started
+    # asynchronously as soon as their last gradient is final; "local" gradients stay out of the reduced range
+    shapes = {"a.weight": torch.Size([5, 3]), "a.bias": torch.Size([5]), "b.weight": torch.Size([7, 2]), "c.bias": torch.Size([3]),
+              "lstm.bias": torch.Size([6])}
+    fg = parallel.FlatGrads(shapes, ["b.weight", "a.weight", "a.bias"], "cpu", local=("lstm.bias",))
+    ok = ok and list(fg.offsets) == ["b.weight", "a.weight", "a.bias", "c.bias", "lstm.bias"]
+    ok = ok and all(o % 4 == 0 for o, _ in fg.offsets.values())
+    torch.manual_seed(11)
+    ref = {k: torch.randn(v) for k, v in shapes.items()}
+    for k, v in fg.views.items():
+        v.copy_(ref[k] * (rank + 1))
+    first = parallel.all_reduce_async(fg.span(["b.weight"]))            # "final" early: starts while the rest is computed
+    second = parallel.all_reduce_async(fg.span(["a.weight", "a.bias", "c.bias"]))
+    waits = []
+    first.wait(waits)
+    second.wait(waits)
+    for k in shapes:
+        want = ref[k] * (3.0 if k != "lstm.bias" else (rank + 1))        # the local gradient was not exchanged
+        ok = ok and torch.allclose(fg.views[k], want, rtol=1e-6, atol=1e-6)
+    # initial weights: rank 0 draws, the others skip their draws and receive the broadcast - the same bits as drawing everywhere
+    torch.manual_seed(1234)
+    everywhere = torch.nn.Sequential(torch.nn.Conv2d(1, 4, (3, 1)), torch.nn.LSTM(2, 8, batch_first=True), torch.nn.Linear(8, 3))
+    torch.manual_seed(1234)
+    import contextlib
+    with (parallel.skip_param_init() if rank != 0 else contextlib.nullcontext()):
+        net = torch.nn.Sequential(torch.nn.Conv2d(1, 4, (3, 1)), torch.nn.LSTM(2, 8, batch_first=True), torch.nn.Linear(8, 3))
+    if rank != 0:
+        ok = ok and not all(torch.equal(a, b) for a, b in zip(net.parameters(), everywhere.parameters()))   # really skipped
+    parallel.broadcast_parameters_(net, src=0)
+    ok = ok and all(torch.equal(a, b) for a, b in zip(net.parameters(), everywhere.parameters()))
+    ok = ok and torch.nn.init.uniform_ is not None and torch.nn.init.uniform_(torch.zeros(4)).abs().sum() > 0   # patch undone
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
