@@ -199,6 +199,14 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_dst, 16, voff, soff, 0, 0);
 }
+// the same with the non-temporal cache policy (aux = 2): for a stream every CU reads once or eight times within a few
+// microseconds (the V operand of the NT kernels) and that should not push a re-used operand (the taps) out of the L2
+__device__ __forceinline__ void dma16_nt(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_dst, 16, voff, soff, 0, 2);
+}
+#ifndef V4_NT
+#define V4_NT 0           // cache policy experiment of the NT kernel: 1 = V (streaming operand) non-temporal, 2 = taps non-temporal
+#endif
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p) {
@@ -282,11 +290,17 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
     const unsigned soff = (unsigned)step * (V4_BK * 4);
     if (!(V4_ABL & 64) || step < 2) {
 #pragma unroll
-      for (int t = 0; t < 6; ++t) dma16(tl_.rsA, base + adst[t], tl_.avoff[t], soff);
+      for (int t = 0; t < 6; ++t) {
+        if (V4_NT & 1) dma16_nt(tl_.rsA, base + adst[t], tl_.avoff[t], soff);
+        else dma16(tl_.rsA, base + adst[t], tl_.avoff[t], soff);
+      }
     }
     if (!(V4_ABL & 128) || step < 2) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t) dma16(rsB, base + bdst[t], tl_.bvoff[t], soff);
+      for (int t = 0; t < 3; ++t) {
+        if (V4_NT & 2) dma16_nt(rsB, base + bdst[t], tl_.bvoff[t], soff);
+        else dma16(rsB, base + bdst[t], tl_.bvoff[t], soff);
+      }
     }
   };
 

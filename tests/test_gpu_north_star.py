@@ -200,8 +200,9 @@ def test_c3_shape_three_steps_follow_reference_golden(dev, c3):
         ref, stride, _ = _sampled(g, "final.", k)
         err = gi.update_rel_l2(_take(p.detach(), stride), ref.reshape(-1), g["init." + k].reshape(-1).astype(np.float64))
         worst["upd." + k] = err
-        tol = 5e-2 if k in ("ecog_conv_block.9.bias", "concat_conv_block.4.bias") else 2e-2
-        assert err < tol, (k, err)
+        # observed on MI355X (round 4): the largest three-step update deviation is 8.7e-4 (ecog_conv_block.3.bias), every
+        # other tensor below 6e-4 - the bound is ~2.5 x that, not the 2e-2 / 5e-2 the one-step test had to allow in round 2
+        assert err < 2.5e-3, (k, err)
     print("G11b observed deviations (largest):", {k: f"{v:.2e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:10]})
     _pristine(model, dev)
 
