@@ -396,6 +396,12 @@ class CnnEngine:
                         extra[vdn] = ["conv2_wgrad_vd", "conv3_wgrad_vd"]
                         self._fam_share = {tn: (ntm - 1) / ntm, vdn: 1.0 / ntm}
         fams = {fwd: ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}
+        if self.wino_v and self._writes_v(self.stages[0]) and all(self._use_wino_v(st) for st in self.stages[:2]):
+            # round 4: stage 2's forward launch also writes V of its output for stage 3 (epilogue 5): its own kernel name
+            del fams[fwd]
+            fams["wino43v_nt_kernel<POOLV> (conv2 forward, Winograd F(4,3) on V, LDS-DMA; writes V of its pooled output for "
+                 "conv3 instead of the raw rows)"] = ["conv2_fwd"]
+            fams["wino43v_nt_kernel<POOL> (conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)"] = ["conv3_fwd"]
         fams.update(extra)
         if all(self._use_wino_vd(st) for st in self.stages[:2]):
             nt = "wino43v_nt_kernel"

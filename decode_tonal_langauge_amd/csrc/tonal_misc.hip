@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_v4_kernel(const float* __restri
 // next stage's forward / weight-gradient GEMMs read V by LDS-DMA and the 13 GB of P1 need not exist at all (P is
 // optional: tests and the direct-form kernels want it).  Thread = 4 channels x one quad; the two halo rows of a quad
 // are recomputed (3 MACs per element from the LDS-resident signal) rather than exchanged.  HBM-write bound.
+#ifndef CONV1_NT
+#define CONV1_NT 1      // same-box A/B under rocprofv3: 4.79 -> 4.65 ms per launch (20 GB written once, read by the next kernel)
+#endif
 __global__ __launch_bounds__(256) void conv1_fwd_vq_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, float* __restrict__ P,
                                                            float* __restrict__ V, uint32_t* __restrict__ bits,
@@ -224,12 +227,20 @@ __global__ __launch_bounds__(256) void conv1_fwd_vq_kernel(const float* __restri
       }
       const f32x4 s1 = d[4] - 4.f * d[2], s2 = d[3] - 4.f * d[1], s3 = d[4] - d[2], t = d[3] - d[1];
       float* dst = V + (seq * Tq + q) * 6LL * C1 + o;
-      *reinterpret_cast<f32x4*>(dst) = 4.f * d[0] + (d[4] - 5.f * d[2]);
-      *reinterpret_cast<f32x4*>(dst + C1) = s1 + s2;
-      *reinterpret_cast<f32x4*>(dst + 2LL * C1) = s1 - s2;
-      *reinterpret_cast<f32x4*>(dst + 3LL * C1) = s3 + 2.f * t;
-      *reinterpret_cast<f32x4*>(dst + 4LL * C1) = s3 - 2.f * t;
-      *reinterpret_cast<f32x4*>(dst + 5LL * C1) = (4.f * d[1] - 5.f * d[3]) + d[5];
+      // V1 (20 GB at the north-star shape) is written once and read by a later kernel: CONV1_NT streams it past the L2
+      auto stv = [](float* p_, const f32x4 v) {
+#if CONV1_NT
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p_));
+#else
+        *reinterpret_cast<f32x4*>(p_) = v;
+#endif
+      };
+      stv(dst, 4.f * d[0] + (d[4] - 5.f * d[2]));
+      stv(dst + C1, s1 + s2);
+      stv(dst + 2LL * C1, s1 - s2);
+      stv(dst + 3LL * C1, s3 + 2.f * t);
+      stv(dst + 4LL * C1, s3 - 2.f * t);
+      stv(dst + 5LL * C1, (4.f * d[1] - 5.f * d[3]) + d[5]);
     }
     d[0] = d[4]; d[1] = d[5];
     wb[0] = wb[4]; wb[1] = wb[5];

@@ -285,6 +285,51 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
     return t;
   };
   tile_t cur = setup(blockIdx.x);
+#if V4_LEAN
+  // Next tile of this workgroup WITHOUT the divisions of setup(): with a persistent launch of 8 k workgroups the XCD-aware
+  // remap sends tile sequence blockIdx.x + j gridDim.x to b' + j gridDim.x / 8, so (tm, tn) advance by a fixed (dq, dr) with
+  // a carry; the V quads of a tile always exist (host-checked: V holds whole 128-quad tiles), so the per-lane source
+  // offsets of the A pieces never change and those of the B pieces move with the column tile.  (setup() costs ~250
+  // scalar / vector instructions per tile; a wave issues at most one instruction of ANY kind per ~4 cycles, and with
+  // the matrix pipe idle between two tiles every one of them is exposed.)
+  const int walk = (int)(gridDim.x >> 3), walk_q = walk / ntn, walk_r = walk - walk_q * ntn;
+  const long long a_tile_bytes = (long long)V4_BQ * 6 * p.lda * 4, a_total_bytes = p.A_rows * 6LL * p.lda * 4;
+  unsigned bv_lane[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int pb = wave * 3 + k;
+    bv_lane[k] = (unsigned)((((long long)(pb >> 2) * p.N + (pb & 3) * 16 + prow) * p.ldb + src_chunk * 4) * 4);
+  }
+  auto advance = [&](const tile_t& c) -> tile_t {
+    tile_t t = c;
+    int tn = c.n0 / V4_BN + walk_r;
+    long long tm = c.tm + walk_q;
+    if (tn >= ntn) {
+      tn -= ntn;
+      ++tm;
+    }
+    t.tm = tm;
+    t.R0 = tm * (4 * V4_BQ);
+    t.n0 = tn * V4_BN;
+    const long long ab = tm * a_tile_bytes, left = a_total_bytes - ab;
+    t.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) + ab), 0,
+                                              (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+    if (t.n0 + V4_BN <= p.N) {
+      const unsigned nb4 = (unsigned)t.n0 * (unsigned)p.ldb * 4u;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t.bvoff[k] = bv_lane[k] + nb4;
+    } else {                                               // column tile past the edge: clamped columns (masked by the epilogue)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int pb = wave * 3 + k;
+        int n = t.n0 + (pb & 3) * 16 + prow;
+        if (n > p.N - 1) n = p.N - 1;
+        t.bvoff[k] = (unsigned)((((long long)(pb >> 2) * p.N + n) * p.ldb + src_chunk * 4) * 4);
+      }
+    }
+    return t;
+  };
+#endif
   auto issue = [&](const tile_t& tl_, int step) {
     char* base = lds + (step & 1) * V4_STAGE;
     const unsigned soff = (unsigned)step * (V4_BK * 4);
@@ -485,7 +530,11 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
 #endif
     if (V4_PERSIST && nb < nwg) {
       if (nsteps & 1) __syncthreads();
+#if V4_LEAN
+      cur = advance(cur);
+#else
       cur = setup(nb);
+#endif
       issue(cur, 0);
     }
 #if V4_LEAN
@@ -495,12 +544,18 @@ __global__ __launch_bounds__(512, 2) void wino43v_nt_kernel(const tl_nt_params p
 #if !(V4_ABL & 2)
     float* scratch = reinterpret_cast<float*>(lds + ((nsteps - 1) & 1) * V4_STAGE);
     (void)scratch;
+    // (workgroup-uniform) interior tile: every row / column / output quad exists - the in-matrix masks of the stores fold away
+    const bool full = done.R0 + 4 * V4_BQ <= p.M && done.n0 + V4_BN <= p.N;
     if constexpr (EPI == W_EPI_POOL) {
-      v5_epilogue_pool<false>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      if (full) v5_epilogue_pool<false, true>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      else v5_epilogue_pool<false, false>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm);
     } else if constexpr (EPI == W_EPI_POOLV) {
-      v5_epilogue_pool<true>(p, acc, pre, reinterpret_cast<float*>(lds + 2 * V4_STAGE), done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      float* xch = reinterpret_cast<float*>(lds + 2 * V4_STAGE);
+      if (full) v5_epilogue_pool<true, true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      else v5_epilogue_pool<true, false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
     } else if constexpr (EPI == W_EPI_MASK) {
-      v5_epilogue_mask(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
+      if (full) v5_epilogue_mask<true>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
+      else v5_epilogue_mask<false>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
     } else {
       // (the reduction takes the LAST step's stage as its scratch, behind a barrier: slower waves may still be reading it)
       v5_epilogue_c1w(p, acc, pre, reinterpret_cast<float*>(lds + 2 * V4_STAGE) + wave * 512, scratch, done.R0, done.n0, wm, wn,
@@ -1321,6 +1376,7 @@ extern "C" int tl_conv3_wino43v_nt(const tl_nt_params* pp, void* stream) {
   // (the epilogues of tonal_wino43v_epi.h: a wave's 32 columns are in or out of the matrix together; 32-bit row arithmetic)
   TL_REQUIRE(p.N % 32 == 0 && p.M + 4 * V4_BQ < (1LL << 31), "wino43v_nt: N %% 32 == 0 and M < 2^31 - 512 needed");
   TL_REQUIRE(p.slope >= 0.f && p.slope <= 1.f, "wino43v_nt: LeakyReLU slope must lie in [0, 1]");
+  TL_REQUIRE(p.A_rows >= ((p.M + 4 * V4_BQ - 1) / (4 * V4_BQ)) * V4_BQ, "wino43v_nt: V must hold whole 128-quad tiles (pad it with zero quads)");
 #endif
   hipStream_t st = (hipStream_t)stream;
 #if V4_PERSIST

@@ -154,7 +154,7 @@ __device__ __forceinline__ v5_pre_pool v5_prefetch_pool(const tl_nt_params& p, i
   r.bv = (colbase < p.N && p.bias) ? p.bias[colbase + lr] : 0.f;
   return r;
 }
-template <bool VOUT>
+template <bool VOUT, bool FULL>
 __device__ __forceinline__ void v5_epilogue_pool(const tl_nt_params& p, const f32x16 (&acc)[6], const v5_pre_pool& pre, float* xch,
                                                  long long R0, int n0, int wm, int wn, int lr, int lh, long long tm) {
   const int colbase = n0 + wn * 32;
@@ -177,7 +177,8 @@ __device__ __forceinline__ void v5_epilogue_pool(const tl_nt_params& p, const f3
   const unsigned ovoff = colok ? (lane_row * (unsigned)p.ldo + (unsigned)col) * 4u : V5_OOB;
   const unsigned ldo4 = (unsigned)p.ldo * 4u;
   // rows of the matrix (not: valid time) - the old epilogue stores zeros into the pad rows of a sequence
-  const uint32_t inA = (uint32_t)v5_in_bits<32, 2>(4 * Qw, p.M), inB = (uint32_t)v5_in_bits<32, 2>(4 * Qw + 64, p.M);
+  // (FULL: an interior tile - the masks are constants and the per-store selects fold away)
+  const uint32_t inA = FULL ? ~0u : (uint32_t)v5_in_bits<32, 2>(4 * Qw, p.M), inB = FULL ? ~0u : (uint32_t)v5_in_bits<32, 2>(4 * Qw + 64, p.M);
   float pv[32];
   uint32_t wbits = 0, wsign = 0;
   static_for<0, 16>([&](auto E) {
@@ -192,8 +193,8 @@ __device__ __forceinline__ void v5_epilogue_pool(const tl_nt_params& p, const f3
       const float o = valid ? (gt ? y1 : y0) : 0.f;
       pv[j] = o;
       // the lane's own column: one bit per pooled row, row j in bit 31 - j until the reversal below
-      wbits = (wbits << 1) | (uint32_t)gt;
-      wsign = (wsign << 1) | (uint32_t)(o > 0.f);
+      wbits = wbits + wbits + (uint32_t)gt;                 // (shift in: v_addc with the compare as carry)
+      wsign = wsign + wsign + (uint32_t)(o > 0.f);
       if constexpr (!VOUT) {
         const unsigned vo = selmu(mask2(inA, inB, j), ovoff, V5_OOB);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsO, vo, (unsigned)j * ldo4, 0);
@@ -247,8 +248,8 @@ __device__ __forceinline__ void v5_epilogue_pool(const tl_nt_params& p, const f3
       for (int k = 0; k < 8; ++k) {
         seA |= (uint32_t)(ta == Tq - 4) << k;
         seB |= (uint32_t)(tb == Tq - 4) << k;
-        nvA |= (uint32_t)(qa + k < p.vout_quads) << k;
-        nvB |= (uint32_t)(qb + k < p.vout_quads) << k;
+        nvA |= (uint32_t)(FULL || qa + k < p.vout_quads) << k;
+        nvB |= (uint32_t)(FULL || qb + k < p.vout_quads) << k;
         ta += 4;
         if (ta >= Tq) ta -= Tq;
         tb += 4;
@@ -319,6 +320,7 @@ __device__ __forceinline__ v5_pre_mask v5_prefetch_mask(const tl_nt_params& p, l
   if (colbase < p.N && rb < p.M) r.sB = p.auxbits[rb * (long long)p.ld_auxbits + (colbase >> 5)];
   return r;
 }
+template <bool FULL>
 __device__ __forceinline__ void v5_epilogue_mask(const tl_nt_params& p, const f32x16 (&acc)[6], const v5_pre_mask& pre, long long R0,
                                                  int n0, int wm, int wn, int lr, int lh) {
   const int colbase = n0 + wn * 32;
@@ -330,7 +332,7 @@ __device__ __forceinline__ void v5_epilogue_mask(const tl_nt_params& p, const f3
   const __amdgpu_buffer_rsrc_t rsO = rsrc_of(p.out + Rw * (long long)p.ldo, (p.M - Rw) * (long long)p.ldo * 4);
   const unsigned ovoff = colok ? ((unsigned)(64 * lh) * (unsigned)p.ldo + (unsigned)col) * 4u : V5_OOB;
   const unsigned ldo4 = (unsigned)p.ldo * 4u;
-  const unsigned long long inA = v5_in_bits<64, 1>(Rw, p.M), inB = v5_in_bits<64, 1>(Rw + 64, p.M);
+  const unsigned long long inA = FULL ? ~0ull : v5_in_bits<64, 1>(Rw, p.M), inB = FULL ? ~0ull : v5_in_bits<64, 1>(Rw + 64, p.M);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     float y[4];

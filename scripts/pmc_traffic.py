@@ -14,7 +14,8 @@ from collections import defaultdict
 # round 3: the V-form kernels (tonal_wino43v.hip); names as Engine.kernel_families() / rocprofv3 give them.  A weight-
 # gradient op is two launches (the Vd-writing first C_in tile, then the other tiles), listed apart.
 FAMILIES = {
-    "wino43v_nt_kernel<2>": "wino43v_nt_kernel<POOL> (conv2/conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)",
+    "wino43v_nt_kernel<5>": "wino43v_nt_kernel<POOLV> (conv2 forward, Winograd F(4,3) on V, LDS-DMA; writes V of its pooled output for conv3 instead of the raw rows)",
+    "wino43v_nt_kernel<2>": "wino43v_nt_kernel<POOL> (conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)",
     "wino43v_nt_kernel<4>": "wino43v_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd F(4,3) on the pre-transformed dZ, LDS-DMA)",
     "wino43v_nt_kernel<3>": "wino43v_nt_kernel<UNPOOL,MASK> (conv3 input gradient, Winograd F(4,3) on the pre-transformed dZ, LDS-DMA)",
     "wino43v_tn8_kernel<true>": "wino43v_tn8_kernel<true> (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA; also writes Vd for the input gradient)",
