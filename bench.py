@@ -394,7 +394,9 @@ def step_issued_flops(eng, B: int, U: int, L: int) -> float:
     tot = 0.0
     for st in eng.stages:
         alg = conv_flops(eng, st.idx, B)
-        if eng._use_wino43(st):
+        if getattr(eng, "wino63", False) and eng._f63(st):
+            f_nt = eng.f63_issue_factor(st)
+        elif eng._use_wino43(st):
             f_nt = 0.5
         elif eng._use_wino(st):
             f_nt = 2.0 / 3.0

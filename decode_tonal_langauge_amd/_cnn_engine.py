@@ -66,12 +66,22 @@ class CnnEngine:
             raise ValueError("first stage must pool")
         align = 1 << npool_after
         self.tp1 = max(align, (self.tout1 + align - 1) // align * align)
+        # TONAL_WINO=6: Winograd F(6,3) on pre-transformed operands for stages 2 and 3 (csrc/tonal_wino63.hip; 8 products per
+        # 6 conv rows).  A sequence of stage 2 holds a multiple of 12 rows (hexes of 6 rows, pooled into hexes of stage 3);
+        # the pooled output of stage 3 keeps the row stride of the default geometry (tl_nt_params.out_tp), so everything from
+        # stage 4 on is unchanged.  Shapes the form does not cover fall back to TONAL_WINO=4 as a whole.
+        self.wino63 = os.environ.get("TONAL_WINO", "4") == "6" and self._f63_covers(stage_defs, n_timepoints)
+        tp1_default = self.tp1
+        if self.wino63:
+            self.tp1 = (self.tout1 + 11) // 12 * 12
         self.stages: List[_Stage] = []
         cin, tin, tp = self.c1, self.tout1, self.tp1
         for i, (cout, k, pool) in enumerate(stage_defs[1:], start=2):
             st = _Stage(i, cin, cout, k, pool, tin, tp)
             if st.tout < 1:
                 raise ValueError("n_timepoints too small for the conv stack")
+            if self.wino63 and i == 3:
+                st.tp_out = tp1_default // 4               # the default geometry's rows per sequence behind stage 3
             self.stages.append(st)
             cin, tin, tp = cout, st.tout, st.tp_out
         self.lat = tin
@@ -102,6 +112,8 @@ class CnnEngine:
         #      reference golden all three forms sit at the same noise floor (scripts/update_parity.py,
         #      DESIGN.md section 6)
         mode = os.environ.get("TONAL_WINO", "4")
+        if mode == "6":
+            mode = "4"                          # (the F(4,3) predicates describe the fallback; wino63 overrides stages 2, 3)
         self.wino = mode != "0"
         self.wino43 = mode == "4"
         # weight gradient: F(4,3) with the transforms applied at LDS-staging time (tonal_wino43_tn.hip; half
@@ -146,14 +158,14 @@ class CnnEngine:
         zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
         self._v_ready = {}     # V tensors already written by the producing kernel in this forward
         self.P = {}
-        if not self._conv1_writes_v() or self.store_p1:
+        if not (self.wino63 or self._conv1_writes_v()) or self.store_p1:
             self.P[1] = z(S * self.tp1, self.c1)
         self.bits = {1: zi(S * self.tp1, self.c1 // 32)}
         self.sbits = {1: zi(S * self.tp1, self.c1 // 32)}      # "pooled output > 0": the LeakyReLU' mask of backward
         for st in self.stages:
             rows = S * st.tp_out
             ld = st.cout if st.pool else self.ld5
-            if not self._writes_v(st) or self.store_p1:
+            if not (self._writes_v(st) or (self.wino63 and st.idx == 2)) or self.store_p1:
                 self.P[st.idx] = z(rows, ld)
             if st.pool:
                 self.bits[st.idx] = zi(rows, st.cout // 32)
@@ -176,7 +188,7 @@ class CnnEngine:
         z = lambda *s: torch.zeros(*s, **f32)
         S = self.S
         self.G = {}
-        if not (self.fuse_c1 and self._c1_fusable() and self._use_wino(self.stages[0])):
+        if not self.wino63 and not (self.fuse_c1 and self._c1_fusable() and self._use_wino(self.stages[0])):
             self.G[1] = z(S * self.tp1, self.c1)      # otherwise G1 never leaves the stage-2 epilogue
         for st in self.stages:
             self.G[st.idx] = z(S * st.tp_out, st.cout if st.pool else self.ld5)
@@ -280,6 +292,120 @@ class CnnEngine:
         return dst
 
 
+    @staticmethod
+    def _f63_covers(stage_defs, T) -> bool:
+        """The F(6,3) kernels cover the stack: stages 2 and 3 are pooled 3-tap convolutions with C_in % 128 == 0 and
+        C_out % 64 == 0, the first stage has 1..3 taps, one input channel and a width tl_conv1_fwd_v6 takes, and the fused
+        first-stage weight gradient can read its sample windows."""
+        if len(stage_defs) < 4 or os.environ.get("TONAL_FUSE_C1", "1") == "0":
+            return False
+        (c1, k1, p1), (c2, k2, p2), (c3, k3, p3) = stage_defs[0], stage_defs[1], stage_defs[2]
+        tout1 = (T - k1 + 1) // 2
+        tout2 = (tout1 - 2) // 2
+        tout3 = (tout2 - 2) // 2
+        return (p1 and p2 and p3 and k2 == 3 and k3 == 3 and 1 <= k1 <= 3 and c1 in (128, 256, 512, 1024)
+                and c2 % 128 == 0 and c3 % 64 == 0 and tout3 >= 1 and T >= 2 * tout1 + 2)
+
+    def _f63(self, st) -> bool:
+        return self.wino63 and st.idx in (2, 3)
+
+    def _v_hex_buffer(self, store, idx, rows, cin):
+        """V / Vd of a stage input in hex form: rows / 6 hexes, padded with zero hexes to whole 128-hex tiles."""
+        nh = rows // 6
+        nh_pad = (nh + 127) // 128 * 128
+        V = store.get(idx)
+        if V is None or V.shape[0] != nh_pad or V.shape[1] != 8 or V.shape[2] != cin:
+            V = store[idx] = torch.zeros(nh_pad, 8, cin, dtype=torch.float32, device=self._dev)
+        return V
+
+    def _pack_wino63(self, w, forward: bool):
+        O, I = w.shape[0], w.shape[1]
+        dst = torch.empty(8, O, I, dtype=torch.float32, device=w.device) if forward else \
+            torch.empty(8, I, O, dtype=torch.float32, device=w.device)
+        check(self.lib.tl_wino63_weights(ptr(w), ptr(dst) if forward else None, None if forward else ptr(dst), O, I, I, O,
+                                         self._stream()), "tl_wino63_weights")
+        return dst
+
+    def f63_issue_factor(self, st) -> float:
+        """MFMA FLOPs the F(6,3) kernels issue per direct-convolution FLOP of the stage (8 products per hex, hexes padded
+        to whole sequences, against 3 MACs per valid conv row)."""
+        return (st.tp_in // 6) * 8.0 / (st.tc * 3.0)
+
+    def _stage_forward63(self, st, w, bia) -> None:
+        S = self.S
+        wp = self._pack_wino63(w, True)
+        V = self._v_ready[st.idx - 1]
+        Pout = self.P.get(st.idx)
+        kw = dict(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], loader=LOAD_V, Bw=ptr(wp), bias=ptr(bia), out=ptr(Pout),
+                  M=S * st.tp_in, N=st.cout, K=st.cin, ldb=st.cin, ldo=Pout.shape[1] if Pout is not None else st.cout, J=3,
+                  row_shift=0, Tp=st.tp_in, slope=self.slope, obits=ptr(self.bits[st.idx]), osign=ptr(self.sbits[st.idx]),
+                  ld_obits=st.cout // 32, Tvalid=2 * st.tout)
+        if st.idx == 2:
+            rows_out = S * st.tp_out
+            Vn = self._v_hex_buffer(self.V, 2, rows_out, st.cout)
+            ntm = (S * st.tp_in + 767) // 768
+            if not hasattr(self, "_vhalo"):
+                self._vhalo = {}
+            halo = self._vhalo.get(2)
+            if halo is None or halo.shape[0] != ntm or halo.shape[2] != st.cout:
+                halo = self._vhalo[2] = torch.zeros(ntm, 2, st.cout, dtype=torch.float32, device=self._dev)
+            kw.update(epilogue=EPI_POOLV, vout=ptr(Vn), vhalo=ptr(halo), vout_quads=Vn.shape[0], ld_vout=Vn.shape[2])
+            self._nt(tag="conv2_fwd", fn="tl_conv3_wino63v_nt", **kw)
+            check(self.lib.tl_wino63_v_fixup(ptr(Vn), ptr(halo), rows_out // 6, ntm, st.tp_out, st.cout, Vn.shape[2],
+                                             self._stream()), "tl_wino63_v_fixup")
+            self._v_ready[2] = Vn
+        else:
+            kw.update(epilogue=EPI_POOL, out_tp=st.tp_out)
+            self._nt(tag="conv3_fwd", fn="tl_conv3_wino63v_nt", **kw)
+
+    def _stage_wgrad63(self, st, gw, gb) -> None:
+        S = self.S
+        f32 = dict(dtype=torch.float32, device=self._dev)
+        Gs = self.G[st.idx]
+        rows_in = S * st.tp_in
+        ldg = Gs.shape[1]
+        nd = st.cout
+        V = self._v_ready[st.idx - 1]
+        tiles = (st.cin // 64) * (nd // 64)
+        sk = self._splitk(tiles, (rows_in + 35) // 36, int(os.environ.get("TONAL_TN_TARGET", "4096")))
+        slab = torch.empty(sk, 8 * st.cin, ldg, **f32)
+        bias_part = torch.empty(sk, nd, **f32)
+        Vd = self._v_hex_buffer(self.Vd, st.idx, rows_in, nd)
+        self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino63v_tn", A=ptr(V), B=ptr(Gs), slab=ptr(slab), Krows=rows_in,
+                 A_rows=V.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=V.shape[2], ldb=ldg, ldc=ldg, J=3,
+                 Tp=st.tp_in, splitk=sk, slab_stride=8 * st.cin * ldg, loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]),
+                 ld_bbits=st.cout // 32, Tvalid=2 * st.tout, colsum=ptr(bias_part), vd=ptr(Vd), ld_vd=nd, g_tp=st.tp_out)
+        self._vd_ready[st.idx] = self.generation
+        if sk > 1:
+            red = torch.empty(8 * st.cin, ldg, **f32)
+            n = 8 * st.cin * ldg
+            self._permute(slab, red, (1, 1, 1, n), (0, 0, 0, 1), nz=sk, zs=n)
+        else:
+            red = slab
+        check(self.lib.tl_wino63_wgrad_finalize(ptr(red), ptr(gw), st.cout, st.cin, ldg, self._stream()),
+              "tl_wino63_wgrad_finalize")
+        self._permute(bias_part, gb, (1, 1, 1, st.cout), (0, 0, 0, 1), nz=sk, zs=nd)
+
+    def _stage_dgrad63(self, st, w):
+        S = self.S
+        rows_in = S * st.tp_in
+        if self._vd_ready.get(st.idx) != self.generation:
+            raise RuntimeError("F(6,3) input gradient: the stage's weight-gradient pass (which writes Vd) must run first")
+        self._vd_ready[st.idx] = -1
+        Vd = self.Vd[st.idx]
+        wd = self._pack_wino63(w, False)                   # [8][cin][cout]
+        kw = dict(A=ptr(Vd), A_rows=Vd.shape[0], lda=Vd.shape[2], loader=LOAD_V, Bw=ptr(wd), M=rows_in, N=st.cin,
+                  K=st.cout, ldb=st.cout, ldo=st.cin, J=3, row_shift=-2, Tp=st.tp_in, slope=self.slope,
+                  auxbits=ptr(self.sbits[st.idx - 1]), ld_auxbits=self.sbits[st.idx - 1].shape[1])
+        if st.idx == 3:
+            self._nt(tag="conv3_dgrad", fn="tl_conv3_wino63v_nt", epilogue=EPI_MASK, out=ptr(self.G[2]), **kw)
+            return None
+        ntm = (rows_in + 767) // 768
+        part = torch.empty(ntm, (self.k1 + 1) * self.c1, dtype=torch.float32, device=self._dev)
+        self._nt(tag="conv2_dgrad", fn="tl_conv3_wino63v_nt", epilogue=EPI_C1WGRAD, out=None, c1x=ptr(self._x),
+                 c1bits=ptr(self.bits[1]), c1partial=ptr(part), c1T=self.T, c1kt=self.k1, Tvalid=self.tout1, **kw)
+        return part
+
     def _use_wino(self, st) -> bool:
         return (self.wino and st.k == 3 and st.pool and st.cin % 32 == 0 and st.cout % 32 == 0
                 and st.tp_in % 2 == 0)
@@ -357,6 +483,8 @@ class CnnEngine:
 
     def wgrad_issue_factor(self, st) -> float:
         """MFMA FLOPs the weight-gradient kernel of a stage issues per direct-convolution FLOP."""
+        if self._f63(st):
+            return self.f63_issue_factor(st)
         if self._use_wino43_tn(st):
             return 0.5
         return 2.0 / 3.0 if self._use_wino(st) else 1.0
@@ -364,6 +492,18 @@ class CnnEngine:
     def kernel_families(self):
         """({rocprofv3 kernel family: [timer tags]}, {family: MFMA FLOPs issued per algorithmic FLOP})
         for the conv stages - bench.py prices the HIP-event timers of ``enable_timers`` with it."""
+        if self.wino63:
+            self._fam_share = {}
+            st2, st3 = self.stages[0], self.stages[1]
+            f6 = "Winograd F(6,3) on pre-transformed operands, LDS-DMA"
+            fams = {f"wino63v_nt_kernel<POOLV> (conv2 forward, {f6}; writes V of its pooled output for conv3)": ["conv2_fwd"],
+                    f"wino63v_nt_kernel<POOL> (conv3 forward, {f6})": ["conv3_fwd"],
+                    f"wino63v_nt_kernel<C1WGRAD> (conv2 input gradient + conv1 weight gradient, {f6})": ["conv2_dgrad"],
+                    f"wino63v_nt_kernel<MASK> (conv3 input gradient, {f6})": ["conv3_dgrad"],
+                    f"wino63v_tn_kernel<true> (conv2 weight gradient, {f6}; also writes Vd)": ["conv2_wgrad"],
+                    f"wino63v_tn_kernel<true> (conv3 weight gradient, {f6}; also writes Vd)": ["conv3_wgrad"]}
+            issued = {k: self.f63_issue_factor(st2 if "conv2" in k else st3) for k in fams}
+            return fams, issued
         if not self.wino:
             fams = {"nt_window_kernel<128,UNPOOL,MASK> (conv input-gradient)": ["conv2_dgrad", "conv3_dgrad", "conv4_dgrad"],
                     "nt_window_kernel<128,DIRECT,POOL> (conv forward)": ["conv2_fwd", "conv3_fwd", "conv4_fwd"],
@@ -431,6 +571,8 @@ class CnnEngine:
 
     def stage_forward(self, st: _Stage, w: torch.Tensor, bia: torch.Tensor) -> None:
         """conv (k,1) + bias + LeakyReLU (+ max-pool, arg-max bits): P[idx-1] -> P[idx]."""
+        if self._f63(st):
+            return self._stage_forward63(st, w, bia)
         S = self.S
         wino = self._use_wino(st)
         f43 = self._use_wino43(st)
@@ -484,6 +626,8 @@ class CnnEngine:
 
     def stage_wgrad(self, st: _Stage, gw: torch.Tensor, gb: torch.Tensor) -> None:
         """dW, db of one stage from its input P[idx-1] and G[idx] (pooled gradient + arg-max bits)."""
+        if self._f63(st):
+            return self._stage_wgrad63(st, gw, gb)
         S = self.S
         f32 = dict(dtype=torch.float32, device=self._dev)
         Xin = self._pin(st)
@@ -603,6 +747,8 @@ class CnnEngine:
         For stage 2 on the Winograd kernels G[1] is not stored: the epilogue contracts it with the raw
         signal into per-row-tile partial sums of the first stage's weight / bias gradient, which are
         returned (shape (tiles, (k1 + 1) * c1), layout of ``tl_conv1_wgrad``'s partials)."""
+        if self._f63(st):
+            return self._stage_dgrad63(st, w)
         S = self.S
         Xin = self._pin(st)
         Gs = self.G[st.idx]
@@ -720,7 +866,13 @@ class CnnEngine:
         self._v_ready = {}
         # ---- stage 1 (C_in = 1) ----
         w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
-        if self._conv1_writes_v():
+        if self.wino63:
+            V1 = self._v_hex_buffer(self.V, 1, S * self.tp1, self.c1)
+            check(lib.tl_conv1_fwd_v6(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]),
+                                      ptr(self.P[1]) if self.store_p1 else None, ptr(V1), ptr(self.bits[1]), ptr(self.sbits[1]),
+                                      S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd_v6")
+            self._v_ready[1] = V1
+        elif self._conv1_writes_v():
             if self.store_p1 and 1 not in self.P:
                 self.P[1] = torch.zeros(S * self.tp1, self.c1, dtype=torch.float32, device=dev)
             V1 = self._v_buffer(1, S * self.tp1, self.c1)

@@ -35,6 +35,7 @@ class NtParams(C.Structure):
         ("osign", C.c_void_p), ("auxbits", C.c_void_p), ("ld_auxbits", C.c_int),
         ("c1x", C.c_void_p), ("c1bits", C.c_void_p), ("c1partial", C.c_void_p), ("c1T", C.c_int), ("c1kt", C.c_int),
         ("vout", C.c_void_p), ("vhalo", C.c_void_p), ("vout_quads", C.c_int64), ("ld_vout", C.c_int),
+        ("out_tp", C.c_int),
     ]
 
 
@@ -47,7 +48,7 @@ class TnParams(C.Structure):
         ("J", C.c_int), ("Tp", C.c_int), ("Tvalid", C.c_int), ("loader", C.c_int),
         ("splitk", C.c_int), ("slab_stride", C.c_int64),
         ("colsum", C.c_void_p),
-        ("vd", C.c_void_p), ("ld_vd", C.c_int), ("part", C.c_int), ("bm", C.c_int),
+        ("vd", C.c_void_p), ("ld_vd", C.c_int), ("part", C.c_int), ("bm", C.c_int), ("g_tp", C.c_int),
     ]
 
 
@@ -78,6 +79,12 @@ SIGNATURES = {
     "tl_wino43_v_fixup": (_I, [_P, _P, _L, _L, _I, _I, _I, _P]),
     "tl_wino43_unpool_transform": (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P]),
     "tl_conv3_wino43v_tn": (_I, [C.POINTER(TnParams), _P]),
+    "tl_wino63_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "tl_conv3_wino63v_nt": (_I, [C.POINTER(NtParams), _P]),
+    "tl_wino63_v_fixup": (_I, [_P, _P, _L, _L, _I, _I, _I, _P]),
+    "tl_conv3_wino63v_tn": (_I, [C.POINTER(TnParams), _P]),
+    "tl_wino63_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
+    "tl_conv1_fwd_v6": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
     "tl_sizeof_nt_params": (_I, []),
     "tl_sizeof_tn_params": (_I, []),
     "tl_conv1_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),

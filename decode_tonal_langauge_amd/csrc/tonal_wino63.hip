@@ -1,0 +1,1032 @@
+// Winograd F(6,3) on pre-transformed operands (round 4): the V-form kernels of tonal_wino43v.hip with HEXES in place of
+// quads - 8 products per 6 conv rows instead of 6 per 4 (0.444 of the direct convolution's multiplies against 0.5).
+//
+// conv2 / conv3 of the ECoG stack (models/synthesis_models.py:91-97) and their backward are 80 % of the train step and
+// run on the fp32 matrix pipe at 0.77 - 0.83 of its peak: what is left is the amount of matrix work itself.  The numerics
+// of the form were cleared first (oracle/winograd_f63_gate.py: per stage 8.5e-7 relative L2 against fp64, the 30-step
+// trajectory of golden G14 1.9e-6 from the reference's - the same noise floor as F(4,3)).  Interpolation points
+// 0, +-1, +-2, +-1/2, inf; the matrices are the exact Cook-Toom construction of that script.
+//
+// Layouts.  A sequence holds Tp rows, Tp a multiple of 6 (of 12 where the pooled output feeds another F(6,3) stage).
+// V[hex][8][ldv]: hex H of a sequence = its rows 6 H .. 6 H + 7 (rows past the sequence taken as zero), eight transforms,
+// channels last; zero hexes appended to whole 128-hex tiles.  Vd the same for the un-pooled dZ rows 6 H - 2 .. 6 H + 5.
+//
+//   tl_wino63_weights       w (O, I, 3, 1) -> forward taps [8][O][ld_f], input-gradient taps [8][I][ld_d] (flipped)
+//   tl_conv3_wino63v_nt     M_i[hex][n] = sum_k V_i[hex][k] U_i[n][k], i < 8: batched NT GEMM, both operands by LDS-DMA
+//                           into three 8-deep stages, epilogues of tonal_wino63_epi.h
+//   tl_wino63_v_fixup       second half of the V-writing forward epilogue
+//   tl_conv3_wino63v_tn     weight gradient slab_i[c_in][c_out] = sum_hexes V_i (x) Y_i, Y = A dy; also writes Vd
+//   tl_wino63_wgrad_finalize  dW = G^T (sum of slabs)
+//   tl_conv1_fwd_v6         first stage (C_in = 1) writing V of its pooled output in hex form
+#include "tonal_common.h"
+#include "tonal_wino43_epi.h"
+#include "tonal_wino43v_epi.h"
+#include "tonal_wino63_epi.h"
+#include <type_traits>
+
+namespace tl {
+
+typedef __attribute__((address_space(3))) void lds_void6_t;
+__device__ __forceinline__ void dma16h(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void6_t*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Tap transforms U = G g,  G = [-1 0 0; -2/9 (1 1 1); -2/9 (1 -1 1); 1/90 (1 2 4); 1/90 (1 -2 4); 1/45 (32 16 8);
+// 1/45 (32 -16 8); 0 0 1]
+// ------------------------------------------------------------------------------------------
+__global__ void wino63_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ dgr, int O,
+                                      int I, int ld_f, int ld_d) {
+  const long long n_f = (long long)O * ld_f, n_d = (long long)I * ld_d;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  auto emit = [](float* dst, long long n, long long at, float g0, float g1, float g2) {
+    const float s = g0 + g2;
+    dst[at] = -g0;
+    dst[n + at] = (-2.f / 9.f) * (s + g1);
+    dst[2 * n + at] = (-2.f / 9.f) * (s - g1);
+    const float a = fmaf(4.f, g2, g0), b = 2.f * g1;
+    dst[3 * n + at] = (1.f / 90.f) * (a + b);
+    dst[4 * n + at] = (1.f / 90.f) * (a - b);
+    const float c = fmaf(4.f, g0, g2), d = 2.f * g1;
+    dst[5 * n + at] = (8.f / 45.f) * (c + d);
+    dst[6 * n + at] = (8.f / 45.f) * (c - d);
+    dst[7 * n + at] = g2;
+  };
+  if (fwd != nullptr && idx < n_f) {
+    const int o = (int)(idx / ld_f), i = (int)(idx % ld_f);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (i < I) {
+      const float* s = w + ((long long)o * I + i) * 3;
+      g0 = s[0], g1 = s[1], g2 = s[2];
+    }
+    emit(fwd, n_f, idx, g0, g1, g2);
+  }
+  if (dgr != nullptr && idx < n_d) {
+    const int i = (int)(idx / ld_d), o = (int)(idx % ld_d);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (o < O) {
+      const float* s = w + ((long long)o * I + i) * 3;
+      g0 = s[2], g1 = s[1], g2 = s[0];          // flipped taps
+    }
+    emit(dgr, n_d, idx, g0, g1, g2);
+  }
+}
+
+// dW (O, I, 3) = G^T M from the reduced transforms red[8][I][ld]
+__global__ void wino63_wgrad_finalize_kernel(const float* __restrict__ red, float* __restrict__ gw, int O, int I, int ld) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)O * I) return;
+  const int i = (int)(idx / O), o = (int)(idx % O);
+  const long long plane = (long long)I * ld;
+  const float* s = red + (long long)i * ld + o;
+  float m[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) m[t] = s[t * plane];
+  const float a12 = m[1] + m[2], s12 = m[1] - m[2], a34 = m[3] + m[4], s34 = m[3] - m[4], a56 = m[5] + m[6], s56 = m[5] - m[6];
+  float* d = gw + ((long long)o * I + i) * 3;
+  d[0] = -m[0] - (2.f / 9.f) * a12 + (1.f / 90.f) * a34 + (32.f / 45.f) * a56;
+  d[1] = -(2.f / 9.f) * s12 + (1.f / 45.f) * s34 + (16.f / 45.f) * s56;
+  d[2] = -(2.f / 9.f) * a12 + (2.f / 45.f) * a34 + (8.f / 45.f) * a56 + m[7];
+}
+
+// ------------------------------------------------------------------------------------------
+// Second half of the V-writing forward epilogue (tonal_wino63_epi.h, POOLV): the last output hex of every 128-hex tile
+// (64 next-stage hexes) needs pooled rows 6, 7 from the next tile.  The tile left rows 0..5 raw in the hex's transform
+// slots 0..5 and every tile stored its first two pooled rows to vhalo; thread = (tile, 4 channels).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void wino63_v_fixup_kernel(float* __restrict__ V, const float* __restrict__ halo, long long hexes,
+                                                              long long tiles, int Tq, int C, int ldv) {
+  const int c4n = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tiles * c4n) return;
+  const long long t = idx / c4n;
+  const int c = (int)(idx - t * c4n) * 4;
+  const long long q = t * 64 + 63;
+  if (q >= hexes) return;
+  float* v = V + q * 8 * (long long)ldv + c;
+  f32x4 d[8];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) d[j] = *reinterpret_cast<const f32x4*>(v + (long long)j * ldv);
+  const int tq = (int)((6 * q) % Tq);
+  if (tq + 6 < Tq && t + 1 < tiles) {
+    d[6] = *reinterpret_cast<const f32x4*>(halo + ((t + 1) * 2) * (long long)C + c);
+    d[7] = *reinterpret_cast<const f32x4*>(halo + ((t + 1) * 2 + 1) * (long long)C + c);
+  } else {
+    d[6] = d[7] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 o[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float dd[8], vv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dd[j] = d[j][k];
+    wino63_bt(dd, vv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j][k] = vv[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(v + (long long)j * ldv) = o[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel on V.  Workgroup: 8 waves as 4 (hexes) x 2 (columns); block tile 128 hexes (768 conv rows) x 64 columns;
+// wave tile 32 hexes x 32 columns x 8 transforms = 128 accumulator registers.  A K-step is 8 channels: A stage
+// [8][128 hexes][32 B] = 32 KB, B stage [8][64 columns][32 B] = 16 KB; THREE stages = 144 KB (a 16-deep stage would be 96 KB:
+// two do not fit), filled two steps ahead by 48 LDS-DMA pieces (32 rows x 32 B each), 6 per wave - the same 0.19 pieces
+// per MFMA as the F(4,3) kernel.  Per wave and K-step: 16 ds_read_b128 + 32 MFMAs; the fragments are held as two half-sets
+// (transforms 0-3, 4-7: 32 registers each), the second one carried across the closing barrier.
+// LDS rows are 32 B: bank conflicts of the fragment reads are removed by swapping the two 16-byte chunks of the rows with
+// bit 3 set (applied to the per-lane SOURCE address of the LDS-DMA and to the fragment read).
+// ------------------------------------------------------------------------------------------
+constexpr int V6_BH = 128, V6_BN = 64, V6_BK = 8;
+constexpr int V6_ROWB = V6_BK * 4;                       // bytes per LDS row (32)
+constexpr int V6_A_BYTES = 8 * V6_BH * V6_ROWB;          // 32768
+constexpr int V6_B_BYTES = 8 * V6_BN * V6_ROWB;          // 16384
+constexpr int V6_STAGE = V6_A_BYTES + V6_B_BYTES;        // 49152
+constexpr int V6_ROWS = 6 * V6_BH;                       // conv rows per tile (768)
+#ifndef V6_ABL
+#define V6_ABL 0          // timing-only build variants: 1 no steady-state DMA, 2 no epilogue, 4 no barrier
+#endif
+
+enum { KS_NORMAL = 0, KS_PRELAST = 1, KS_LAST = 2 };
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p) {
+  __shared__ __attribute__((aligned(1024))) char lds[3 * V6_STAGE + (EPI == W_EPI_POOLV ? 4096 : EPI == W_EPI_C1W ? 16384 : 0)];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  const int ntn = (p.N + V6_BN - 1) / V6_BN;
+  const long long ntm = (p.M + V6_ROWS - 1) / V6_ROWS;
+  const long long nwg = ntm * ntn;
+  const int nsteps = p.K / V6_BK;                          // host-checked: K % 8 == 0, K >= 24
+  f32x16 acc[8];
+
+  // ---- LDS-DMA plan.  Piece = 32 rows x 32 B; lane -> (row = lane >> 1, physical chunk = lane & 1); the source chunk
+  // is the swizzled one, chunk ^ ((row >> 3) & 1).  Wave w fetches transform w: its four 32-hex blocks of A and its two
+  // 32-column blocks of B.
+  const int prow = lane >> 1;
+  const int src_chunk = (lane & 1) ^ ((lane >> 4) & 1);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw, 0, (int)(8LL * p.N * p.ldb * 4), 0x00020000);
+  unsigned adst[4], bdst[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) adst[t] = (unsigned)((wave * V6_BH + t * 32) * V6_ROWB);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bdst[t] = (unsigned)(V6_A_BYTES + (wave * V6_BN + t * 32) * V6_ROWB);
+  // LDS row rho = 8 g + 4 lh' + j' of a wave's 32 (the MFMA row whose results lane half lh' holds in accumulator elements
+  // 4 g + j') takes hex 16 lh' + 4 g + j': a lane owns 16 consecutive hexes (tonal_wino63_epi.h)
+  const int hex_of_row = (prow & 3) | ((prow >> 3) << 2) | (((prow >> 2) & 1) << 4);
+  unsigned avoff[4], bv_lane[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) avoff[t] = (unsigned)((((long long)(t * 32 + hex_of_row) * 8 + wave) * p.lda + src_chunk * 4) * 4);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) bv_lane[t] = (unsigned)((((long long)wave * p.N + t * 32 + prow) * p.ldb + src_chunk * 4) * 4);
+
+  // A workgroup walks the tiles blockIdx.x, + gridDim.x, ... (one workgroup per CU, a multiple of 8: a tile sequence stays
+  // on one XCD).  V holds whole 128-hex tiles (host-checked): the per-lane source offsets of the A pieces never change.
+  struct tile_t {
+    long long tm, R0;
+    int n0;
+    __amdgpu_buffer_rsrc_t rsA;
+    unsigned bvoff[2];
+  };
+  const long long a_tile_bytes = (long long)V6_BH * 8 * p.lda * 4, a_total_bytes = p.A_rows * 8LL * p.lda * 4;
+  auto place = [&](tile_t& t, long long tm, int tn) {
+    t.tm = tm;
+    t.R0 = tm * V6_ROWS;
+    t.n0 = tn * V6_BN;
+    const long long ab = tm * a_tile_bytes, left = a_total_bytes - ab;
+    t.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) + ab), 0,
+                                              (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+    if (t.n0 + V6_BN <= p.N) {
+      const unsigned nb4 = (unsigned)t.n0 * (unsigned)p.ldb * 4u;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) t.bvoff[k] = bv_lane[k] + nb4;
+    } else {                                               // column tile past the edge: clamped columns (masked by the epilogue)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int n = t.n0 + k * 32 + prow;
+        if (n > p.N - 1) n = p.N - 1;
+        t.bvoff[k] = (unsigned)((((long long)wave * p.N + n) * p.ldb + src_chunk * 4) * 4);
+      }
+    }
+  };
+  tile_t cur;
+  {
+    long long bid = blockIdx.x;
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    place(cur, bid / ntn, (int)(bid % ntn));
+  }
+  // next tile without divisions: with a persistent launch of 8 k workgroups the XCD-aware remap sends tile sequence
+  // blockIdx.x + j gridDim.x to b' + j gridDim.x / 8, so (tm, tn) advance by a fixed pair with a carry
+  const int walk = (int)(gridDim.x >> 3), walk_q = walk / ntn, walk_r = walk - walk_q * ntn;
+  auto advance = [&](const tile_t& c) -> tile_t {
+    tile_t t = c;
+    int tn = c.n0 / V6_BN + walk_r;
+    long long tm = c.tm + walk_q;
+    if (tn >= ntn) {
+      tn -= ntn;
+      ++tm;
+    }
+    place(t, tm, tn);
+    return t;
+  };
+  auto issue = [&](const tile_t& tl_, int step, int stage) {
+    char* base = lds + stage * V6_STAGE;
+    const unsigned soff = (unsigned)step * (V6_BK * 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dma16h(tl_.rsA, base + adst[t], avoff[t], soff);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dma16h(rsB, base + bdst[t], tl_.bvoff[t], soff);
+  };
+  auto next3 = [](int s) { return s == 2 ? 0 : s + 1; };
+
+  // ---- fragment reads: row r of a plane, logical chunk lh -> r * 32 + ((lh ^ ((r >> 3) & 1)) << 4)
+  const int cphys = (lh ^ ((lr >> 3) & 1)) << 4;
+  const int a_row = (wm * 32 + lr) * V6_ROWB + cphys, b_row = V6_A_BYTES + (wn * 32 + lr) * V6_ROWB + cphys;
+  f32x4 faL[4], fbL[4], faH[4], fbH[4];
+  auto load_half = [&](f32x4 (&fa)[4], f32x4 (&fb)[4], int stage, int i0) {
+    const char* a_s = lds + stage * V6_STAGE + a_row + i0 * (V6_BH * V6_ROWB);
+    const char* b_s = lds + stage * V6_STAGE + b_row + i0 * (V6_BN * V6_ROWB);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * (V6_BH * V6_ROWB));
+      fb[i] = *reinterpret_cast<const f32x4*>(b_s + i * (V6_BN * V6_ROWB));
+    }
+  };
+  // 16 MFMAs of one half-set (ZERO: the accumulators start from the zero constant of the first MFMA of each)
+  auto mfma_half = [&](auto ZERO, const f32x4 (&fa)[4], const f32x4 (&fb)[4], int i0) {
+    if constexpr (decltype(ZERO)::value) {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][0], fb[i][0], zero, 0, 0, 0);
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[i][q], acc[i0 + i], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[i][q], acc[i0 + i], 0, 0, 0);
+    }
+  };
+  using Y = std::true_type;
+  using N = std::false_type;
+  int stg = 0;                                             // stage of the K-step about to run (rolls on across tiles)
+  // One K-step s >= 1 of the current tile: the first half-set of stage stg is read behind the barrier that opened the step,
+  // the carried half-set H(s - 1) runs, the pieces of step s + 2 go out (one per two MFMAs), the second half-set is read
+  // between the MFMAs of the first.  Closing wait: the pieces of step s + 1 have landed, those of step s + 2 may fly.
+  auto kstep = [&](auto MODE, auto ZH, int s) {
+    constexpr int mode = decltype(MODE)::value;
+    load_half(faL, fbL, stg, 0);
+    if constexpr (mode == KS_NORMAL) {
+      if (!(V6_ABL & 1)) issue(cur, s + 2, stg == 0 ? 2 : stg - 1);       // (stg + 2) % 3: released at the last barrier
+    }
+    mfma_half(ZH, faH, fbH, 4);                             // half-set H of the previous step (registers)
+    load_half(faH, fbH, stg, 4);
+    mfma_half(N{}, faL, fbL, 0);
+    // issue order (sched_group_barrier: 0x008 MFMA, 0x010 vector memory, 0x100 LDS read): the 8 reads of L first, then
+    // the carried MFMAs with one LDS-DMA piece per two of them, then the MFMAs of L with one read of H per two
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    if constexpr (mode == KS_NORMAL) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    if constexpr (mode != KS_LAST) {
+      // (the builtin, not inline asm: the compiler's own wait-count bookkeeping sees the drained counters)
+      if constexpr (mode == KS_NORMAL) __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(0x0070);                                // vmcnt(0) lgkmcnt(0)
+#if !(V6_ABL & 4)
+      __builtin_amdgcn_s_barrier();
+#endif
+      asm volatile("" ::: "memory");
+    }
+    stg = next3(stg);
+  };
+  // First K-step of a tile: no carried half-set.  The pieces of step 1 were issued in front of the previous tile's
+  // epilogue; between them and this step's pieces (step 2) sit that epilogue's stores: the closing wait leaves both in flight.
+  auto kstep_first = [&](auto EPIN) {
+    load_half(faL, fbL, stg, 0);
+    if (!(V6_ABL & 1) || true) issue(cur, 2, stg == 0 ? 2 : stg - 1);
+    load_half(faH, fbH, stg, 4);
+    mfma_half(Y{}, faL, fbL, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (t < 6) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+    {
+      constexpr int n = decltype(EPIN)::value + 6 > 63 ? 63 : decltype(EPIN)::value + 6;
+      __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (0 << 8) | ((n >> 4) << 14));     // vmcnt(n) lgkmcnt(0)
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stg = next3(stg);
+  };
+
+  // the first tile's first two stages
+  issue(cur, 0, 0);
+  issue(cur, 1, 1);
+  __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0)
+  for (long long vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    // stage stg of this tile has landed (waited for at the end of the tile in front), every wave is past that epilogue
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // What the epilogue reads from global memory is requested in front of the LAST K-step (tonal_wino43v.hip)
+    auto prefetch = [&] {
+      if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_POOLV) return v5_prefetch_pool(p, cur.n0, wn, lr);
+      else if constexpr (EPI == W_EPI_MASK) return v6_prefetch_mask(p, cur.R0, cur.n0, wm, wn, lr, lh);
+      else return v6_prefetch_c1w(p, cur.R0, cur.n0, wm, wn, lr, lh);
+    };
+    decltype(prefetch()) pre;
+    constexpr int NST = v6_stores<EPI>();
+    kstep_first(std::integral_constant<int, NST>{});
+    if (nsteps > 3) {
+      kstep(std::integral_constant<int, KS_NORMAL>{}, Y{}, 1);
+      for (int s = 2; s + 2 < nsteps; ++s) kstep(std::integral_constant<int, KS_NORMAL>{}, N{}, s);
+      kstep(std::integral_constant<int, KS_PRELAST>{}, N{}, nsteps - 2);
+    } else {
+      kstep(std::integral_constant<int, KS_PRELAST>{}, Y{}, 1);
+    }
+    pre = prefetch();
+    __builtin_amdgcn_sched_barrier(0);
+    kstep(std::integral_constant<int, KS_LAST>{}, N{}, nsteps - 1);
+    mfma_half(N{}, faH, fbH, 4);
+
+#if V6_ABL & 2
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[i][e];
+      if (t == 12345.678f) p.out[tid] = t;
+    }
+#endif
+    // The first two K-steps of the next tile go into the two stages that are NOT the last step's: stg (read in step
+    // nsteps - 3) and stg + 1 (step nsteps - 2) - every wave is past the barrier that closed step nsteps - 2.  The last
+    // step's stage (stg + 2) is still being read by slower waves; it is the epilogue's scratch behind a barrier.
+    const tile_t done = cur;
+    const long long nb = vb + gridDim.x;
+    const int last_stage = stg == 0 ? 2 : stg - 1;
+    // the prefetched words have landed (requested a K-step ago; nothing else is in flight)
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (nb < nwg) {
+      cur = advance(cur);
+      issue(cur, 0, stg);
+      issue(cur, 1, next3(stg));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#if !(V6_ABL & 2)
+    float* scratch = reinterpret_cast<float*>(lds + last_stage * V6_STAGE);
+    (void)scratch;
+    const bool full = done.R0 + V6_ROWS <= p.M && done.n0 + V6_BN <= p.N;
+    if constexpr (EPI == W_EPI_POOL) {
+      if (full) v6_epilogue_pool<false, true>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      else v6_epilogue_pool<false, false>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+    } else if constexpr (EPI == W_EPI_POOLV) {
+      float* xch = reinterpret_cast<float*>(lds + 3 * V6_STAGE);
+      if (full) v6_epilogue_pool<true, true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      else v6_epilogue_pool<true, false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+    } else if constexpr (EPI == W_EPI_MASK) {
+      if (full) v6_epilogue_mask<true>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
+      else v6_epilogue_mask<false>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
+    } else {
+      v6_epilogue_c1w(p, acc, pre, reinterpret_cast<float*>(lds + 3 * V6_STAGE) + wave * 384, scratch, done.R0, done.n0, wm, wn,
+                      lr, lh, done.tm);
+    }
+#endif
+    {
+      // The next tile's first stage (issued in front of the epilogue) has landed; its second stage and the epilogue's own
+      // stores need not: vmcnt counts in issue order (6 bits)
+      constexpr int n = NST + 6 > 63 ? 63 : NST + 6;
+      __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14));
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient on V, 128 (C_in) x 64 (C_out) tile, 8 waves, one workgroup per CU: wino43v_tn8_kernel with hexes.
+// A K-step is SIX hexes (36 conv rows; three k-slices of two hexes): the V tile [8][6 hexes][64 channels] is exactly the
+// 12 KB of the F(4,3) kernel's [6][8 quads][64], so ring, pieces (3 per wave), swizzle and fragment reads keep their
+// shape; 24 MFMAs per wave and K-step as before, for 36 rows instead of 32.
+//   * V: LDS-DMA, 4-slot ring, three steps ahead;
+//   * the pooled gradient rows of a hex (3 h .. 3 h + 3: its own three and the first of the next hex - the row in front of
+//     a hex, which Vd needs, is row 2 of the piece in front) by LDS-DMA, waves 0-5 one hex each, four steps ahead, 6-slot
+//     ring; their arg-max words as one 4-byte-per-lane piece (waves 6, 7: the same one).  The gradient and its words live
+//     in the row layout [seq * g_tp + t'] of the stage's OUTPUT (tl_tn_params.g_tp; 0: Tp / 2): a lane follows its hex
+//     through the sequences with two counters;
+//   * Y side: wave w < 6 owns hex w of the step, a lane one channel; the word pair of a pooled row is the lane mask of
+//     the un-pool select; Y = A dy (8 values) to LDS, Vd = B^T (dZ rows 6 h - 2 .. 6 h + 5) transposed over groups of four
+//     lanes and stored as two 16-byte buffer stores per lane, the C_in-tile workgroups of a (split, C_out tile) taking turns.
+// ------------------------------------------------------------------------------------------
+constexpr int T6_BN = 64, T6_H = 6;
+constexpr int T6_PLANE = T6_H * 64;                       // floats per transform plane (384)
+constexpr int T6_TILE = 8 * T6_PLANE;                     // floats per operand tile (12 KB)
+constexpr int T6_NA = 4, T6_NG = 6;
+constexpr int T6_GW = T6_H * 4 * 64;                      // floats of gradient rows per raw slot (6 hexes x 4 rows x 64)
+constexpr int T6_GT = T6_GW + 64;                         // + 6 x 4 rows x 2 words (48 of 64 four-byte lanes)
+#ifndef T6_ABL
+#define T6_ABL 0           // timing-only: 1 no V pieces, 2 no G piece, 4 no Vd stores, 8 no transform, 16 no barrier
+#endif
+
+template <bool WVD>
+__global__ __launch_bounds__(512, 1) void wino63v_tn_kernel(const tl_tn_params p, int mtn) {
+  constexpr int NA = T6_NA, NG = T6_NG, GW = T6_GW, GT = T6_GT;
+  __shared__ __attribute__((aligned(1024))) float lds[(NA * 2 + 2) * T6_TILE + NG * GT];
+  float* As = lds;                               // [4][2][8][6][64]  V ring (two 64-channel half-tiles)
+  float* Bs = lds + NA * 2 * T6_TILE;            // [2][8][6][64]     Y
+  float* Gs = Bs + 2 * T6_TILE;                  // [6]{[6 hexes][4 rows][64], [6][4][2 words]}
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int ntn = p.Ndim / T6_BN;
+  const long long tiles = (long long)mtn * ntn;
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int z = __builtin_amdgcn_readfirstlane((int)(bid / tiles));
+  const int tt = __builtin_amdgcn_readfirstlane((int)(bid % tiles));
+  const int mi = __builtin_amdgcn_readfirstlane(tt / ntn);                          // C_in tile of this workgroup
+  const int m0 = mi * 128, n0 = __builtin_amdgcn_readfirstlane((tt % ntn) * T6_BN);
+
+  const long long hexes_all = p.Krows / 6;
+  const long long ksteps_all = (hexes_all + T6_H - 1) / T6_H;
+  const long long per = __builtin_amdgcn_readfirstlane((int)((ksteps_all + p.splitk - 1) / p.splitk));
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const int nsteps = ks_end > ks_begin ? (int)(ks_end - ks_begin) : 0;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // ---- V by LDS-DMA: piece 3 wave + t -> half-tile pc / 12, rows 4 (pc % 12) .. + 3 of its 48 ([transform][hex] order);
+  // lane -> (row offset lane >> 4, physical 16-byte chunk lane & 15); odd hexes: halves swapped = source chunk ^ 8
+  const long long v_h0 = ks_begin * T6_H;                           // first hex of this split
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + v_h0 * 8 * (long long)p.lda + m0), 0, clip31((p.A_rows - v_h0) * 8 * (long long)p.lda * 4 - (long long)m0 * 4),
+      0x00020000);
+  unsigned vvoff[3], vdst[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int half = (wave * 3 + t) / 12, pc = (wave * 3 + t) % 12;
+    const int rho = 4 * pc + (lane >> 4), i = rho / 6, hx = rho % 6;
+    const int chunk = (lane & 15) ^ ((hx & 1) << 3);
+    vvoff[t] = (unsigned)((((long long)hx * 8 + i) * p.lda + half * 64 + chunk * 4) * 4);
+    vdst[t] = (unsigned)((half * T6_TILE + pc * 256) * 4);
+  }
+  const unsigned v_step = (unsigned)(T6_H * 8 * p.lda * 4);         // bytes per K-step (host-checked to fit)
+  auto issue_v = [&](int step) {
+    char* base = reinterpret_cast<char*>(As) + (step & (NA - 1)) * (2 * T6_TILE * 4);
+    const unsigned soff = (unsigned)step * v_step;          // (in the per-lane offset: that one is range-checked)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dma16h(rsV, base + vdst[t], vvoff[t] + soff, 0u);
+  };
+  // ---- raw pooled gradient rows and arg-max words by LDS-DMA.  A lane follows ITS hex of the step (waves 0-5: hex `wave`;
+  // waves 6, 7: hex lane >> 3 for the word piece) through the G row layout: hs = hex index inside its sequence, goff = G
+  // row of the hex's first pooled row relative to the first hex of the split.
+  const int Tq = p.Tp >> 1, hps = p.Tp / 6;                        // pooled rows / hexes per sequence (hex layout)
+  const int g_tp = p.g_tp > 0 ? p.g_tp : Tq;
+  const bool wpiece = wave >= 6;
+  const int myhex = wpiece ? (lane >> 3) : wave;                    // (lanes >= 48 of a word piece: never fetched)
+  const long long seq0 = v_h0 / hps;
+  const int hs0 = (int)(v_h0 - seq0 * hps);
+  const long long g_r0 = seq0 * g_tp + 3LL * hs0;                   // G row of the split's first hex
+  int g_hs = hs0 + myhex, g_off = 3 * myhex;
+  while (g_hs >= hps) {
+    g_hs -= hps;
+    g_off += g_tp - Tq;
+  }
+  const int ldw4 = p.ld_bbits * 4;
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+      wpiece ? (void*)(p.bbits + g_r0 * (long long)p.ld_bbits + (n0 >> 5)) : (void*)(p.B + g_r0 * (long long)p.ldb + n0), 0,
+      wpiece ? clip31((p.B_rows - g_r0) * (long long)ldw4 - (long long)(n0 >> 5) * 4)
+             : clip31((p.B_rows - g_r0) * (long long)p.ldb * 4 - (long long)n0 * 4),
+      0x00020000);
+  const unsigned g_lane = wpiece ? (unsigned)(((lane >> 1) & 3) * ldw4 + (lane & 1) * 4)
+                                 : (unsigned)(((lane >> 4) * (long long)p.ldb + (lane & 15) * 4) * 4);
+  const unsigned g_row4 = wpiece ? (unsigned)ldw4 : (unsigned)(p.ldb * 4);
+  const unsigned gdst = wpiece ? (unsigned)(GW * 4) : (unsigned)(wave * 256 * 4);
+  const bool g_live = !wpiece || lane < 48;
+  auto issue_g = [&](int slot) {                                    // the piece of the NEXT step in line; advances the counters
+    const unsigned voff = g_live ? (unsigned)g_off * g_row4 + g_lane : 0xfffffff0u;
+    if (wpiece) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_void6_t*)(reinterpret_cast<char*>(Gs) + slot * (GT * 4) + gdst), 4, voff, 0u, 0, 0);
+    else dma16h(rsG, reinterpret_cast<char*>(Gs) + slot * (GT * 4) + gdst, voff, 0u);
+    g_hs += T6_H;
+    g_off += 3 * T6_H;
+    while (g_hs >= hps) {
+      g_hs -= hps;
+      g_off += g_tp - Tq;
+    }
+  };
+  auto next6 = [](int v) { return v == NG - 1 ? 0 : v + 1; };
+
+  // ---- Y side: wave w < 6 = hex w of the K-step, lane = channel ----
+  constexpr bool write_vd = WVD;
+  const bool ywave = wave < T6_H;
+  const int sw = lane ^ ((wave & 1) << 5);                  // swizzled channel position inside the 64-wide row
+  int tq = __builtin_amdgcn_readfirstlane((int)((6 * (v_h0 + (ywave ? wave : 0))) % p.Tp));   // first conv row of the NEXT hex to transform
+  const int dstep = __builtin_amdgcn_readfirstlane((6 * T6_H) % p.Tp);
+  float bsum = 0.f;
+  const unsigned vd_hstride = (unsigned)(8 * p.ld_vd * 4);
+  const __amdgpu_buffer_rsrc_t rsVd = __builtin_amdgcn_make_buffer_rsrc(
+      write_vd ? (void*)(p.vd + v_h0 * 8 * (long long)p.ld_vd + n0) : (void*)p.slab, 0,
+      write_vd ? clip31((hexes_all - v_h0) * 8 * (long long)p.ld_vd * 4 - (long long)n0 * 4) : 0, 0x00020000);
+  const unsigned vdA_lane = (unsigned)((lane & 3) * p.ld_vd * 4 + (lane & ~3) * 4);
+  const unsigned vdB_lane = (unsigned)((4 + (lane & 3)) * p.ld_vd * 4 + (lane & ~3) * 4);
+  const int nhex = (int)hexes_all, h_first = (int)v_h0;
+  const int h_end = h_first + nsteps * T6_H;
+  const int hs_lim = nhex < h_end ? nhex : h_end;           // hexes of this split that exist
+  struct y_in {
+    float g[3];
+    unsigned long long mo[3], me[3];
+    int tq;               // time index of the hex's first conv row
+  };
+  struct y_out {
+    float d[6];           // dZ rows 6 h .. 6 h + 5
+  };
+  auto uni = [](unsigned long long v) -> unsigned long long {   // a wave-uniform value out of vector registers
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+  };
+  const int wy = ywave ? wave : 0;                          // (waves 6, 7 run the same code on hex 0's data with all-zero masks)
+  auto fetch_y = [&](int sd, int slot, y_in& y) {
+    const int h = h_first + sd * T6_H + wy;
+    const int live = ywave & (h < hs_lim);
+    const float* gs = Gs + slot * GT;
+    const unsigned long long* ws = reinterpret_cast<const unsigned long long*>(gs + GW) + wy * 4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      y.g[r] = gs[wy * 256 + r * 64 + lane];
+      const unsigned long long w = uni(ws[r]);
+      const int v = live & (tq + 2 * r < p.Tvalid);
+      y.mo[r] = v ? w : 0ull;
+      y.me[r] = v ? ~w : 0ull;
+    }
+    y.tq = tq;
+    tq += dstep;
+    if (tq >= p.Tp) tq -= p.Tp;
+  };
+  auto compute_y = [&](int sd, const y_in& y) -> y_out {
+    y_out u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      u.d[2 * r] = selm0(y.me[r], y.g[r]);
+      u.d[2 * r + 1] = selm0(y.mo[r], y.g[r]);
+    }
+    const float ev1 = (u.d[0] + u.d[2]) + u.d[4], od1 = (u.d[1] + u.d[3]) + u.d[5];
+    const float ev2 = fmaf(16.f, u.d[4], fmaf(4.f, u.d[2], u.d[0])), od2 = fmaf(32.f, u.d[5], fmaf(8.f, u.d[3], 2.f * u.d[1]));
+    const float ev3 = fmaf(0.0625f, u.d[4], fmaf(0.25f, u.d[2], u.d[0])), od3 = fmaf(0.03125f, u.d[5], fmaf(0.125f, u.d[3], 0.5f * u.d[1]));
+    float o[8];
+    o[0] = u.d[0];
+    o[1] = ev1 + od1;
+    o[2] = ev1 - od1;
+    o[3] = ev2 + od2;
+    o[4] = ev2 - od2;
+    o[5] = ev3 + od3;
+    o[6] = ev3 - od3;
+    o[7] = u.d[5];
+    bsum += o[1];
+    if (ywave) {
+      float* dst = Bs + (sd & 1) * T6_TILE + wave * 64 + sw;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i * T6_PLANE] = o[i];
+    }
+    return u;
+  };
+  typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+  // Vd of the hexes of step sd.  gp / wp: the pooled row in front of the hex (conv rows 6 h - 2, 6 h - 1) and its word pair
+  auto vd_part = [&](int sd, int tqc, const y_out& u, float gp, unsigned long long wp) {
+    const int h = h_first + sd * T6_H + wy;
+    const int vp = ywave & (tqc >= 2) & (tqc - 2 < p.Tvalid) & (h < hs_lim);
+    float d[8], v[8];
+    d[1] = selm0(vp ? wp : 0ull, gp);
+    d[0] = selm0(vp ? ~wp : 0ull, gp);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[2 + k] = u.d[k];
+    wino63_bt(d, v);
+    // two 4 x 4 transposes over the lanes of a group (register n of lane r <- register r of lane n)
+    const bool odd = lane & 1, hi = lane & 2;
+    auto xch = [](float x, auto CTRL) -> float {
+      return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(CTRL)::value, 0xf, 0xf, true));
+    };
+    using X1 = std::integral_constant<int, 0xB1>;         // quad_perm [1,0,3,2]
+    using X2 = std::integral_constant<int, 0x4E>;         // quad_perm [2,3,0,1]
+    auto stage = [&](float& a, float& b, bool up, auto CTRL) {
+      const float r = xch(up ? a : b, CTRL);
+      a = up ? r : a;
+      b = up ? b : r;
+    };
+#pragma unroll
+    for (int g4 = 0; g4 < 8; g4 += 4) {
+      stage(v[g4 + 0], v[g4 + 1], odd, X1{});
+      stage(v[g4 + 2], v[g4 + 3], odd, X1{});
+      stage(v[g4 + 0], v[g4 + 2], hi, X2{});
+      stage(v[g4 + 1], v[g4 + 3], hi, X2{});
+    }
+    const f32x4 va4 = {v[0], v[1], v[2], v[3]};
+    const f32x4 vb4 = {v[4], v[5], v[6], v[7]};
+    const bool ok = ywave && h < hs_lim;
+    const unsigned hoff = (unsigned)(h - h_first) * vd_hstride;
+    if (!(T6_ABL & 4)) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, va4), rsVd, ok ? hoff + vdA_lane : 0xfffffff0u, 0u, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, vb4), rsVd, ok ? hoff + vdB_lane : 0xfffffff0u, 0u, 2);
+    }
+  };
+  // the row in front of this wave's hex at step sd: row 2 of the piece in front (hex wave - 1; for wave 0 the last hex
+  // of the previous step, still in the ring)
+  auto front_row = [&](int slot, int pslot, float& gp, unsigned long long& wp) {
+    const int s_ = wy > 0 ? slot : pslot, hx = wy > 0 ? wy - 1 : T6_H - 1;
+    gp = Gs[s_ * GT + hx * 256 + 128 + lane];
+    wp = uni(reinterpret_cast<const unsigned long long*>(Gs + s_ * GT + GW)[hx * 4 + 2]);
+  };
+
+  // ---- MFMA side: k-slice sl of a K-step = hexes 2 sl (lanes 0-31) and 2 sl + 1 (lanes 32-63) ----
+  const int a_off = (wm >> 1) * T6_TILE + lh * 64 + (((wm & 1) * 32 + lr) ^ (lh << 5));
+  const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
+  float fa0[8], fb0[8], fa1[8], fb1[8], fac[8], fbc[8];     // slices 0, 1 of a step; slice 2, carried
+  auto load_frag = [&](float (&fa)[8], float (&fb)[8], int abuf, int bbuf, int sl) {
+    const float* a_s = As + abuf * (2 * T6_TILE) + sl * 128 + a_off;
+    const float* b_s = Bs + bbuf * T6_TILE + sl * 128 + b_off;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      fa[i] = a_s[i * T6_PLANE];
+      fb[i] = b_s[i * T6_PLANE];
+    }
+  };
+  auto mfma8 = [&](const float (&fa)[8], const float (&fb)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc[i], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fac[i] = fbc[i] = 0.f;
+
+  {   // (also for an empty split: every access is clamped by its resource, the masks are all zero)
+    issue_v(0);
+    issue_v(1);
+    issue_v(2);
+    issue_g(0);
+    issue_g(1);
+    issue_g(2);
+    issue_g(3);
+    // the pooled row in front of the split's first hex (wave 0 only needs it, for Vd; everyone loads it - uniform code)
+    float gp0 = 0.f;
+    unsigned long long wp0 = 0ull;
+    if (write_vd && hs0 > 0) {
+      const long long pr = g_r0 - 1;                          // same sequence as the first hex (hs0 > 0)
+      if (pr < p.B_rows) {
+        gp0 = p.B[pr * (long long)p.ldb + n0 + lane];
+        const uint32_t* wsrc = p.bbits + pr * (long long)p.ld_bbits + (n0 >> 5);
+        wp0 = (unsigned long long)wsrc[0] | ((unsigned long long)wsrc[1] << 32);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      y_in y0;
+      fetch_y(0, 0, y0);
+      const y_out u0 = compute_y(0, y0);
+      if (write_vd && mi == 0) {
+        float gp;
+        unsigned long long wp;
+        front_row(0, NG - 1, gp, wp);                         // (wave 0 reads an unwritten slot here: replaced below)
+        if (wave == 0) {
+          gp = gp0;
+          wp = uni(wp0);
+        }
+        vd_part(0, y0.tq, u0, gp, wp);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  int slot1 = 1, slot4 = 4;                                 // ring slots of steps s + 1 and s + 4
+  int turn = mtn > 1 ? 1 : 0;                               // (s + 1) % mtn: whose turn it is to write Vd for step s + 1
+  for (int s = 0; s < nsteps; ++s) {
+    const int abuf = s & (NA - 1), bbuf = s & 1;
+    const int slot0 = slot1 == 0 ? NG - 1 : slot1 - 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(T6_ABL & 1)) issue_v(s + 3);
+    if (!(T6_ABL & 2)) issue_g(slot4);
+    load_frag(fa0, fb0, abuf, bbuf, 0);
+    mfma8(fac, fbc);                                        // slice 2 of the previous step
+    load_frag(fa1, fb1, abuf, bbuf, 1);
+    mfma8(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    // second half: the transform of step s + 1 beside the MFMAs of slice 1
+    y_in yn;
+    y_out un = {};
+    if (!(T6_ABL & 8)) fetch_y(s + 1, slot1, yn);
+    load_frag(fac, fbc, abuf, bbuf, 2);
+    if (!(T6_ABL & 8)) un = compute_y(s + 1, yn);
+    if constexpr (write_vd) {
+      if (turn == mi && s + 1 < nsteps && !(T6_ABL & 8)) {
+        float gp;
+        unsigned long long wp;
+        front_row(slot1, slot0, gp, wp);
+        vd_part(s + 1, yn.tq, un, gp, wp);
+      }
+      turn = turn + 1 == mtn ? 0 : turn + 1;
+    }
+    mfma8(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);                      // (the closing wait would be hoisted over these MFMAs)
+    // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2).  In flight: the 4 pieces of this step and of the
+    // one before (a Vd store among them only makes the wait reach further back)
+    __builtin_amdgcn_s_waitcnt(0x0078);                           // vmcnt(8) lgkmcnt(0)
+#if !(T6_ABL & 16)
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+    slot1 = next6(slot1);
+    slot4 = next6(slot4);
+  }
+  mfma8(fac, fbc);
+
+  if (p.colsum != nullptr && m0 == 0) {
+    __syncthreads();
+    float* red = lds;
+    red[wave * 64 + lane] = ywave ? bsum : 0.f;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < T6_H; ++q) t += red[q * 64 + tid];
+      p.colsum[(long long)z * p.Ndim + n0 + tid] = t;
+    }
+  }
+  float* out = p.slab + (long long)z * p.slab_stride;
+  const int col = n0 + wn * 32 + lr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      out[((long long)i * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 (C_in = 1) + LeakyReLU + max-pool writing V of its pooled output in HEX form (conv1_fwd_vq_kernel of
+// tonal_misc.hip with six rows per unit): thread = 4 channels x consecutive hexes of one sequence, the two halo rows of a
+// hex are rows 0, 1 of the next.  HBM-write bound.
+// ------------------------------------------------------------------------------------------
+constexpr int C1_MAXKT = 8;
+__global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ P,
+                                                           float* __restrict__ V, uint32_t* __restrict__ bits,
+                                                           uint32_t* __restrict__ sign, long long S, int T, int kt, int C1,
+                                                           int Tp, int Tout, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  const long long seq = blockIdx.x;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
+  __syncthreads();
+  const int groups = C1 >> 2;                    // threads per hex (<= 256, a multiple of 32)
+  const int hpp = 256 / groups;                  // hexes per pass
+  const int g = threadIdx.x % groups, hsub = threadIdx.x / groups;
+  const int o = 4 * g;
+  float wv[4][C1_MAXKT], bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bv[c] = b[o + c];
+#pragma unroll
+    for (int j = 0; j < C1_MAXKT; ++j) wv[c][j] = j < kt ? w[(o + c) * kt + j] : 0.f;
+  }
+  const int sh = 4 * (threadIdx.x & 7);
+  const int Th = Tp / 6;
+  auto row = [&](int pr, bool live, f32x4& out, uint32_t& wb, uint32_t& ws) {
+    out = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint32_t nib = 0, nsg = 0;
+    if (live && pr < Tout) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < C1_MAXKT; ++jj)
+          if (jj < kt) {
+            z0 = fmaf(wv[c][jj], xs[2 * pr + jj], z0);
+            z1 = fmaf(wv[c][jj], xs[2 * pr + 1 + jj], z1);
+          }
+        const float y0 = lrelu(z0 + bv[c], slope), y1 = lrelu(z1 + bv[c], slope);
+        const bool sel = y1 > y0;
+        const float v = sel ? y1 : y0;
+        out[c] = v;
+        nib |= (sel ? 1u : 0u) << c;
+        nsg |= (v > 0.f ? 1u : 0u) << c;
+      }
+    }
+    uint32_t a = nib << sh, e = nsg << sh;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      a |= __shfl_xor(a, m);
+      e |= __shfl_xor(e, m);
+    }
+    wb = a;
+    ws = e;
+  };
+  const int per = (Th + hpp - 1) / hpp;
+  const int hb = hsub * per;
+  f32x4 d[8];
+  uint32_t wb[8], ws[8];
+  row(6 * hb, hb < Th, d[0], wb[0], ws[0]);
+  row(6 * hb + 1, hb < Th, d[1], wb[1], ws[1]);
+  for (int i = 0; i < per; ++i) {
+    const int q = hb + i;
+    const bool live = q < Th;
+#pragma unroll
+    for (int j = 2; j < 8; ++j) row(6 * q + j, live && 6 * q + j < Tp, d[j], wb[j], ws[j]);
+    if (live) {
+      const long long row0 = seq * Tp + 6 * q;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (P != nullptr) *reinterpret_cast<f32x4*>(P + (row0 + j) * C1 + o) = d[j];
+        if ((threadIdx.x & 7) == 0) {
+          bits[(row0 + j) * (C1 >> 5) + (o >> 5)] = wb[j];
+          if (sign != nullptr) sign[(row0 + j) * (C1 >> 5) + (o >> 5)] = ws[j];
+        }
+      }
+      f32x4 ov[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float dd[8], vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dd[j] = d[j][k];
+        wino63_bt(dd, vv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j][k] = vv[j];
+      }
+      float* dst = V + (seq * Th + q) * 8LL * C1 + o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) __builtin_nontemporal_store(ov[j], reinterpret_cast<f32x4*>(dst + (long long)j * C1));
+    }
+    d[0] = d[6]; d[1] = d[7];
+    wb[0] = wb[6]; wb[1] = wb[7];
+    ws[0] = ws[6]; ws[1] = ws[7];
+  }
+}
+
+}  // namespace tl
+
+extern "C" int tl_wino63_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(w != nullptr && (fwd != nullptr || dgr != nullptr), "wino63_weights: null pointer");
+  TL_REQUIRE(O > 0 && I > 0, "wino63_weights: bad sizes");
+  TL_REQUIRE((fwd == nullptr || ld_f >= I) && (dgr == nullptr || ld_d >= O), "wino63_weights: leading dimension too small");
+  const long long nf = (long long)O * ld_f, nd = (long long)I * ld_d;
+  const long long n = nf > nd ? nf : nd;
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_weights: too large");
+  hipLaunchKernelGGL(wino63_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, fwd, dgr, O,
+                     I, ld_f, ld_d);
+  return check_launch("wino63_weights");
+}
+
+extern "C" int tl_wino63_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(red && gw && O > 0 && I > 0 && ld >= O, "wino63_wgrad_finalize: bad arguments");
+  const long long n = (long long)O * I;
+  hipLaunchKernelGGL(wino63_wgrad_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, red, gw,
+                     O, I, ld);
+  return check_launch("wino63_wgrad_finalize");
+}
+
+extern "C" int tl_wino63_v_fixup(float* V, const float* vhalo, int64_t hexes, int64_t tiles, int Tq, int C, int ldv, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(V && vhalo, "wino63_v_fixup: null pointer");
+  TL_REQUIRE(hexes > 0 && tiles > 0 && Tq > 0 && Tq % 6 == 0, "wino63_v_fixup: hexes, tiles > 0 and Tq %% 6 == 0 needed");
+  TL_REQUIRE(C > 0 && C % 4 == 0 && ldv >= C && ldv % 4 == 0, "wino63_v_fixup: C / ldv must be multiples of 4");
+  const long long n = (long long)tiles * (C / 4);
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_v_fixup: grid too large");
+  hipLaunchKernelGGL(wino63_v_fixup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, vhalo,
+                     (long long)hexes, (long long)tiles, Tq, C, ldv);
+  return check_launch("wino63_v_fixup");
+}
+
+// NT passes on a pre-transformed operand: A = V[hex][8][lda], A_rows = hexes in V (whole 128-hex tiles), M = output rows
+// (6 per hex).  Forward: V of the stage input, POOL / POOLV epilogue.  Input gradient: Vd (written by tl_conv3_wino63v_tn),
+// taps = the flipped / transposed set, MASK or fused-conv1-weight-gradient epilogue.
+extern "C" int tl_conv3_wino63v_nt(const tl_nt_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "wino63v_nt: null params");
+  const tl_nt_params& p = *pp;
+  TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W || p.epilogue == W_EPI_POOLV), "wino63v_nt: null V/Bw/out");
+  TL_REQUIRE(p.loader == W_LOAD_V, "wino63v_nt: loader 2 (pre-transformed operand) only");
+  TL_REQUIRE(p.J == 3 && p.splitk <= 1, "wino63v_nt: 3 taps, no split-K");
+  TL_REQUIRE(p.M > 0 && p.M % 6 == 0 && p.N > 0 && p.K >= 24 && p.K % 8 == 0, "wino63v_nt: M %% 6, K %% 8, K >= 24 needed");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino63v_nt: bad leading dimensions");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 6 == 0 && p.M % p.Tp == 0, "wino63v_nt: Tp must be a positive multiple of 6, M whole sequences");
+  TL_REQUIRE(8LL * p.N * p.ldb * 4 < (1LL << 31), "wino63v_nt: tap set larger than a buffer resource");
+  TL_REQUIRE(128LL * 8 * p.lda * 4 + 4LL * p.K < (1LL << 31), "wino63v_nt: tile span too large");
+  const long long ntm = (p.M + V6_ROWS - 1) / V6_ROWS;
+  const long long nwg = ntm * ((p.N + V6_BN - 1) / V6_BN);
+  TL_REQUIRE(nwg < (1LL << 31), "wino63v_nt: grid too large");
+  TL_REQUIRE(p.N % 32 == 0 && p.M + V6_ROWS < (1LL << 31), "wino63v_nt: N %% 32 == 0 and M < 2^31 - 768 needed");
+  TL_REQUIRE(p.slope >= 0.f && p.slope <= 1.f, "wino63v_nt: LeakyReLU slope must lie in [0, 1]");
+  TL_REQUIRE(p.A_rows >= ntm * V6_BH, "wino63v_nt: V must hold whole 128-hex tiles (pad it with zero hexes)");
+  hipStream_t st = (hipStream_t)stream;
+  const long long ngrid = nwg < 256 ? nwg : 256;          // one workgroup per CU (144 - 160 KB of LDS each)
+  if (p.epilogue == W_EPI_POOL) {
+    TL_REQUIRE(p.row_shift == 0 && p.out && p.ldo >= p.N, "wino63v_nt: forward needs row_shift 0 and an output");
+    TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino63v_nt: POOL needs obits and an even Tvalid");
+    TL_REQUIRE(p.ld_obits * 32 >= p.N, "wino63v_nt: POOL: ld_obits too small");
+    TL_REQUIRE(p.out_tp >= 0 && (p.out_tp == 0 || 2 * p.out_tp >= p.Tvalid), "wino63v_nt: out_tp must cover the valid pooled rows");
+    const long long orows = (p.M / p.Tp) * (long long)(p.out_tp > 0 ? p.out_tp : p.Tp / 2);
+    TL_REQUIRE(orows * (long long)p.ldo * 4 < (1LL << 40), "wino63v_nt: output too large");
+    hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_POOL>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
+  } else if (p.epilogue == W_EPI_POOLV) {
+    TL_REQUIRE(p.row_shift == 0 && (p.out == nullptr || p.ldo >= p.N), "wino63v_nt: forward needs row_shift 0");
+    TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino63v_nt: POOLV needs obits and an even Tvalid");
+    TL_REQUIRE(p.ld_obits * 32 >= p.N && p.Tp % 12 == 0, "wino63v_nt: POOLV needs Tp %% 12 == 0 (output hexes inside one sequence)");
+    TL_REQUIRE(p.vout && p.vhalo && p.ld_vout >= p.N && p.vout_quads >= p.M / 12, "wino63v_nt: POOLV needs vout (>= M / 12 hexes) and vhalo");
+    TL_REQUIRE(64LL * 8 * p.ld_vout * 4 < (1LL << 31), "wino63v_nt: ld_vout too large");
+    hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_POOLV>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
+  } else if (p.epilogue == W_EPI_MASK) {
+    TL_REQUIRE(p.row_shift == -2 && p.ldo >= p.N, "wino63v_nt: input gradient needs row_shift -2");
+    TL_REQUIRE(p.auxbits != nullptr, "wino63v_nt: MASK needs auxbits (the sign bits of the stage input)");
+    hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_MASK>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
+  } else if (p.epilogue == W_EPI_C1W) {
+    TL_REQUIRE(p.row_shift == -2, "wino63v_nt: input gradient needs row_shift -2");
+    TL_REQUIRE(p.auxbits && p.c1x && p.c1bits && p.c1partial, "wino63v_nt: epilogue 4 needs auxbits, c1x, c1bits, c1partial");
+    TL_REQUIRE(p.c1kt >= 1 && p.c1kt <= 3 && p.c1T >= 2 * p.Tvalid + 2, "wino63v_nt: epilogue 4: 1..3 taps, c1T >= 2*Tvalid + 2");
+    hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_C1W>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
+  } else {
+    set_error("wino63v_nt: unsupported epilogue %d", p.epilogue);
+    return TL_EINVAL;
+  }
+  return check_launch("wino63v_nt");
+}
+
+// weight gradient on V: A = V[hex][8][lda], A_rows = hexes held by V (a whole number of 6-hex K-steps)
+extern "C" int tl_conv3_wino63v_tn(const tl_tn_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "wino63v_tn: null params");
+  tl_tn_params p = *pp;
+  if (p.splitk < 1) p.splitk = 1;
+  TL_REQUIRE(p.A && p.B && p.slab && p.bbits, "wino63v_tn: null V/B/bbits/slab");
+  TL_REQUIRE(p.J == 3 && p.loader == 1, "wino63v_tn: 3 taps, UNPOOL loader only");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 6 == 0 && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino63v_tn: Tp %% 6 == 0 and an even Tvalid <= Tp needed");
+  TL_REQUIRE(p.Krows > 0 && p.Krows % p.Tp == 0 && p.Mdim > 0 && p.Ndim > 0, "wino63v_tn: bad sizes (Krows must be whole sequences)");
+  TL_REQUIRE(p.Krows + 64 < (1LL << 31), "wino63v_tn: more than 2^31 reduction rows");
+  TL_REQUIRE(p.Mdim % 128 == 0 && p.Ndim % 64 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino63v_tn: Mdim %% 128, Ndim %% 64, ld %% 4 needed");
+  TL_REQUIRE(p.lda >= p.Mdim && p.ldb >= p.Ndim && p.ldc >= p.Ndim, "wino63v_tn: leading dimension too small");
+  TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim && p.ld_bbits % 2 == 0, "wino63v_tn: bbits row too short / odd");
+  TL_REQUIRE(p.splitk <= 65535, "wino63v_tn: splitk too large");
+  TL_REQUIRE(p.splitk == 1 || p.slab_stride >= 8LL * p.Mdim * p.ldc, "wino63v_tn: slab_stride smaller than 8*Mdim*ldc");
+  const int g_tp = p.g_tp > 0 ? p.g_tp : p.Tp / 2;
+  TL_REQUIRE(2 * g_tp >= p.Tvalid, "wino63v_tn: g_tp must cover the valid pooled rows");
+  TL_REQUIRE(p.B_rows >= (p.Krows / p.Tp) * (long long)g_tp && p.B_rows < (1LL << 30), "wino63v_tn: G holds fewer rows than sequences x g_tp");
+  const long long ksteps_all = (p.Krows / 6 + T6_H - 1) / T6_H;
+  TL_REQUIRE(p.A_rows >= (ksteps_all + 3) * T6_H, "wino63v_tn: V must hold whole 6-hex K-steps and three more (pad it with zero hexes)");
+  const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
+  TL_REQUIRE((per + 4) * (long long)T6_H * 8 * p.lda * 4 < (1LL << 31), "wino63v_tn: a reduction split spans more than 2 GB of V: raise splitk");
+  TL_REQUIRE((per + 6) * 3LL * T6_H * p.ldb * 4 < (1LL << 31), "wino63v_tn: a reduction split spans more than 2 GB of G: raise splitk");
+  TL_REQUIRE(p.vd == nullptr || (p.ld_vd >= p.Ndim && p.ld_vd % 4 == 0), "wino63v_tn: ld_vd must cover Ndim");
+  TL_REQUIRE(p.vd == nullptr || (per + 4) * (long long)T6_H * 8 * p.ld_vd * 4 < (1LL << 31), "wino63v_tn: a reduction split spans more than 2 GB of Vd: raise splitk");
+  const int ntm = p.Mdim / 128, ntn = p.Ndim / T6_BN;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(ntm * ntn), (unsigned)p.splitk, 1);
+  if (p.vd != nullptr) hipLaunchKernelGGL((wino63v_tn_kernel<true>), grid, dim3(512), 0, st, p, ntm);
+  else hipLaunchKernelGGL((wino63v_tn_kernel<false>), grid, dim3(512), 0, st, p, ntm);
+  return check_launch("wino63v_tn");
+}
+
+extern "C" int tl_conv1_fwd_v6(const float* x, const float* w, const float* b, float* P, float* V, uint32_t* bits, uint32_t* sign,
+                               int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(x && w && b && V && bits, "conv1_fwd_v6: null pointer");
+  TL_REQUIRE(S > 0 && S < (1LL << 31) && T > 0, "conv1_fwd_v6: bad sizes");
+  TL_REQUIRE(ktaps >= 1 && ktaps <= C1_MAXKT, "conv1_fwd_v6: ktaps must be 1..%d", C1_MAXKT);
+  TL_REQUIRE(C1 % 128 == 0 && C1 <= 1024 && (C1 & (C1 - 1)) == 0, "conv1_fwd_v6: C1 must be 128, 256, 512 or 1024");
+  TL_REQUIRE(Tp > 0 && Tp % 6 == 0, "conv1_fwd_v6: Tp must be a multiple of 6");
+  TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_fwd_v6: Tout/Tp/T inconsistent (%d,%d,%d)", Tout, Tp, T);
+  TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_fwd_v6: T too large for the LDS window");
+  hipLaunchKernelGGL(conv1_fwd_vh_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P, V, bits,
+                     sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+  return check_launch("conv1_fwd_v6");
+}

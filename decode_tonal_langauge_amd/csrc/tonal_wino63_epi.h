@@ -1,0 +1,415 @@
+// Epilogues of the V-form F(6,3) NT kernel (tonal_wino63.hip), round 4.  Same arithmetic contracts as tonal_wino43v_epi.h
+// (reference: models/synthesis_models.py:87-97 and their backward); the unit of work is a HEX: six conv rows from eight
+// Winograd products (points 0, +-1, +-2, +-1/2, inf - the set cleared by oracle/winograd_f63_gate.py).
+//
+// The kernel hands the matrix pipe the hexes of a wave in the permuted order of the F(4,3) kernel: a lane (lr, lh) owns ONE
+// column and SIXTEEN CONSECUTIVE hexes, accumulator element e = hex 16 lh + e of the wave's 32: 96 consecutive conv rows,
+// 48 consecutive pooled rows, 8 next-stage hexes.  Row logic is half-wave uniform and runs on the scalar ALU; 1-bit words
+// are lane masks; stores are buffer stores with scalar row offsets (tonal_wino43v_epi.h explains each of these).
+#pragma once
+#include "tonal_common.h"
+#include "tonal_wino43_epi.h"
+#include "tonal_wino43v_epi.h"
+
+namespace tl {
+
+constexpr unsigned V6_DROP = 0x80000000u;     // added to any in-range byte offset (< 2^31) it stays past every resource
+constexpr unsigned long long V6_HI = 0xffffffff00000000ull;
+
+// the six conv rows of a hex from its eight products: y = A^T m,
+//   A^T = [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 0; 0 1 1 4 4 1/4 1/4 0; 0 1 -1 8 -8 1/8 -1/8 0; 0 1 1 16 16 1/16 1/16 0;
+//          0 1 -1 32 -32 1/32 -1/32 1]
+__device__ __forceinline__ void wino63_rows(const f32x16 (&acc)[8], int e, float (&y)[6]) {
+  const float m1 = acc[1][e], m2 = acc[2][e], m3 = acc[3][e], m4 = acc[4][e], m5 = acc[5][e], m6 = acc[6][e];
+  const float a12 = m1 + m2, s12 = m1 - m2, a34 = m3 + m4, s34 = m3 - m4, a56 = m5 + m6, s56 = m5 - m6;
+  y[0] = ((acc[0][e] + a12) + a34) + a56;
+  y[1] = fmaf(0.5f, s56, fmaf(2.f, s34, s12));
+  y[2] = fmaf(0.25f, a56, fmaf(4.f, a34, a12));
+  y[3] = fmaf(0.125f, s56, fmaf(8.f, s34, s12));
+  y[4] = fmaf(0.0625f, a56, fmaf(16.f, a34, a12));
+  y[5] = fmaf(0.03125f, s56, fmaf(32.f, s34, s12)) + acc[7][e];
+}
+// V = B^T d of eight rows (the input transform of a hex),
+//   B^T = [-1 0 21/4 0 -21/4 0 1 0; 0 1 1 -17/4 -17/4 1 1 0; 0 -1 1 17/4 -17/4 -1 1 0; 0 1/2 1/4 -5/2 -5/4 2 1 0;
+//          0 -1/2 1/4 5/2 -5/4 -2 1 0; 0 2 4 -5/2 -5 1/2 1 0; 0 -2 4 5/2 -5 -1/2 1 0; 0 -1 0 21/4 0 -21/4 0 1]
+// every product fused (one rounding per fmaf): all writers of V / Vd agree bit for bit whatever vector width they use
+__device__ __forceinline__ void wino63_bt(const float (&d)[8], float (&v)[8]) {
+  v[0] = fmaf(5.25f, d[2] - d[4], d[6] - d[0]);
+  const float e1 = fmaf(-4.25f, d[4], d[2] + d[6]), o1 = fmaf(-4.25f, d[3], d[1] + d[5]);
+  v[1] = e1 + o1;
+  v[2] = e1 - o1;
+  const float e2 = fmaf(0.25f, d[2], fmaf(-1.25f, d[4], d[6])), o2 = fmaf(0.5f, d[1], fmaf(-2.5f, d[3], 2.f * d[5]));
+  v[3] = e2 + o2;
+  v[4] = e2 - o2;
+  const float e3 = fmaf(4.f, d[2], fmaf(-5.f, d[4], d[6])), o3 = fmaf(2.f, d[1], fmaf(-2.5f, d[3], 0.5f * d[5]));
+  v[5] = e3 + o3;
+  v[6] = e3 - o3;
+  v[7] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
+}
+
+// Row bookkeeping of one wave tile.  Hw: first hex of the wave; rows R = 6 Hw + 96 lh + r, r < 96.
+struct v6_rows {
+  int tA, tB;                 // time index of the first conv row of half 0 / half 1
+  long long seqA, seqB;       // their sequences
+};
+__device__ __forceinline__ v6_rows v6_rows_of(long long Hw, int Tp) {
+  v6_rows r;
+  const unsigned R = (unsigned)(6 * Hw);                    // host-checked: M < 2^31
+  const unsigned s = R / (unsigned)Tp;
+  r.seqA = (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)s);
+  r.tA = __builtin_amdgcn_readfirstlane((int)(R - s * (unsigned)Tp));
+  r.tB = r.tA + 96;
+  r.seqB = r.seqA;
+  while (r.tB >= Tp) {
+    r.tB -= Tp;
+    ++r.seqB;
+  }
+  return r;
+}
+// 96 half-wave-uniform row flags
+struct bits96 {
+  unsigned long long lo;      // rows 0..63
+  uint32_t hi;                // rows 64..95
+};
+// lane mask of row j (compile-time j after unrolling): bit j of a for lanes 0-31, of b for lanes 32-63
+__device__ __forceinline__ unsigned long long mask96(const bits96& a, const bits96& b, int j) {
+  return j < 64 ? mask2l(a.lo, b.lo, j) : mask2(a.hi, b.hi, j - 64);
+}
+__device__ __forceinline__ bits96 v6_in_bits96(long long R0h, long long M) {
+  bits96 r;
+  r.lo = v5_in_bits<64, 1>(R0h, M);
+  r.hi = (uint32_t)v5_in_bits<32, 1>(R0h + 64, M);
+  return r;
+}
+__device__ __forceinline__ bits96 v6_valid_bits96(int t0, int Tp, int tlim, long long R0h, long long M) {
+  bits96 r;
+  r.lo = v5_valid_bits<64, 1>(t0, Tp, tlim, R0h, M);
+  int t1 = t0 + 64;
+  while (t1 >= Tp) t1 -= Tp;
+  r.hi = (uint32_t)v5_valid_bits<32, 1>(t1, Tp, tlim, R0h + 64, M);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward: bias + LeakyReLU + max-pool (2,1) + arg-max / sign bits.
+//   VOUT false: pooled rows, arg-max and sign words go out in the layout [seq * out_tp + t'] (out_tp = p.out_tp, or Tp / 2
+//               when 0; rows t' >= out_tp are dropped): the row stride of the stage's OUTPUT is decoupled from the hex
+//               padding of its input (conv3 of the reference stack: Tp / 2 = 51 is odd, the next stage pools pairs).
+//   VOUT true:  V = B^T d of the pooled output for the next stage's F(6,3) kernels (next-stage hex H' of a sequence = its
+//               pooled rows 6 H' .. 6 H' + 7; Tp % 12 == 0), bits in the [seq * Tp / 2 + t'] layout; p.out optional (tests).
+// xch: 8 x 64 x 2 floats of LDS that nothing else uses; the function holds ONE workgroup barrier when VOUT.
+// ------------------------------------------------------------------------------------------
+template <bool VOUT, bool FULL>
+__device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f32x16 (&acc)[8], const v5_pre_pool& pre, float* xch,
+                                                 long long R0, int n0, int wm, int wn, int lr, int lh, long long tm) {
+  const int colbase = n0 + wn * 32;
+  const bool colok = colbase < p.N;                         // N % 32 == 0 (host-checked)
+  const int col = colbase + lr;
+  const long long Hw = tm * 128 + wm * 32;
+  const int Tp = p.Tp, Tq = Tp >> 1;
+  const v6_rows rw = v6_rows_of(Hw, Tp);
+  // pooled row j of a half (conv rows 2 j, 2 j + 1 of its 96) is an output row
+  const unsigned long long vA = v5_valid_bits<48, 2>(rw.tA, Tp, p.Tvalid, 6 * Hw, p.M);
+  const unsigned long long vB = v5_valid_bits<48, 2>(rw.tB, Tp, p.Tvalid, 6 * Hw + 96, p.M);
+  const float bv = pre.bv;
+  const long long P0 = 3 * Hw;                              // first pooled row of the wave (hex layout)
+  const long long prows = p.M >> 1;
+  const int out_tp = (!VOUT && p.out_tp > 0) ? p.out_tp : Tq;
+  const int tqa0 = rw.tA >> 1, tqb0 = rw.tB >> 1;
+  // rows that are stored: pooled time below out_tp, inside the matrix (pad rows below out_tp get zeros, as before)
+  const unsigned long long kA = v5_valid_bits<48, 1>(tqa0, Tq, out_tp, P0, prows);
+  const unsigned long long kB = v5_valid_bits<48, 1>(tqb0, Tq, out_tp, P0 + 48, prows);
+  const long long nseq = p.M / Tp;
+  const long long obase = rw.seqA * out_tp;                 // output row of (seqA, t' = 0): every offset below is >= 0
+  const __amdgpu_buffer_rsrc_t rsO = rsrc_of(!VOUT ? p.out + obase * (long long)p.ldo : nullptr,
+                                            !VOUT ? (nseq * out_tp - obase) * (long long)p.ldo * 4 : 0);
+  const unsigned ldo4 = (unsigned)p.ldo * 4u;
+  const unsigned col4 = colok ? (unsigned)col * 4u : V6_DROP;
+  int ta = tqa0, tb = tqb0;
+  unsigned ra = (unsigned)tqa0 * ldo4, rb = ((unsigned)(rw.seqB - rw.seqA) * (unsigned)out_tp + (unsigned)tqb0) * ldo4;
+  const unsigned seq_step = (unsigned)(out_tp - Tq) * ldo4;  // (wraps: added when a half enters its next sequence)
+  float pv[48];
+  uint32_t wb0 = 0, wb1 = 0, ws0 = 0, ws1 = 0;
+  static_for<0, 16>([&](auto E) {
+    constexpr int e = decltype(E)::value;
+    float y[6];
+    wino63_rows(acc, e, y);
+    unsigned vo_e = 0;
+    if constexpr (!VOUT) vo_e = selmu(V6_HI, rb, ra) + col4;
+    static_for<0, 3>([&](auto H) {
+      constexpr int h = decltype(H)::value, j = 3 * e + h;
+      const float y0 = lrelu01(y[2 * h] + bv, p.slope), y1 = lrelu01(y[2 * h + 1] + bv, p.slope);
+      const bool valid = __builtin_amdgcn_inverse_ballot_w64(mask2l(vA, vB, j));
+      const bool gt = (y1 > y0) && valid;
+      const float o = valid ? (gt ? y1 : y0) : 0.f;
+      pv[j] = o;
+      if constexpr (j < 32) {
+        wb0 = wb0 + wb0 + (uint32_t)gt;
+        ws0 = ws0 + ws0 + (uint32_t)(o > 0.f);
+      } else {
+        wb1 = wb1 + wb1 + (uint32_t)gt;
+        ws1 = ws1 + ws1 + (uint32_t)(o > 0.f);
+      }
+      if constexpr (!VOUT) {
+        const unsigned vo = selmu(mask2l(kA, kB, j), vo_e, V5_OOB);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsO, vo, (unsigned)h * ldo4, 0);
+      }
+    });
+    if constexpr (!VOUT) {
+      // the next hex of each half: three pooled rows on, into the next sequence where the time index wraps (selects, no
+      // branches: a branch per hex would cut the epilogue into basic blocks)
+      ta += 3;
+      ra += 3u * ldo4;
+      const bool wa = ta >= Tq;
+      ta -= wa ? Tq : 0;
+      ra += wa ? seq_step : 0u;
+      tb += 3;
+      rb += 3u * ldo4;
+      const bool wbb = tb >= Tq;
+      tb -= wbb ? Tq : 0;
+      rb += wbb ? seq_step : 0u;
+    }
+  });
+  {
+    // bit words: after the transposes lane lr of a half holds those of its pooled rows lr (block 0) and 32 + lr (block 1,
+    // lr < 16).  Buffer stores with a constant count per wave and tile (v6_stores below).
+    wb0 = bit_transpose32(__builtin_bitreverse32(wb0), lr);
+    ws0 = bit_transpose32(__builtin_bitreverse32(ws0), lr);
+    wb1 = bit_transpose32(__builtin_bitreverse32(wb1) >> 16, lr);
+    ws1 = bit_transpose32(__builtin_bitreverse32(ws1) >> 16, lr);
+    const long long wleft = (nseq * out_tp - obase) * (long long)p.ld_obits * 4;
+    const long long wbase = obase * (long long)p.ld_obits + (colbase >> 5);
+    const __amdgpu_buffer_rsrc_t rsB = rsrc_of(p.obits + wbase, wleft - (long long)(colbase >> 5) * 4);
+    const __amdgpu_buffer_rsrc_t rsS = rsrc_of(p.osign ? p.osign + wbase : nullptr, p.osign ? wleft - (long long)(colbase >> 5) * 4 : 0);
+    const unsigned t0h = (unsigned)(lh ? tqb0 : tqa0);
+    const unsigned s0h = lh ? (unsigned)(rw.seqB - rw.seqA) : 0u;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const unsigned r = 32u * b + (unsigned)lr;
+      unsigned t = t0h + r;
+      const unsigned c = t / (unsigned)Tq;
+      t -= c * (unsigned)Tq;
+      const bool keep = colok && r < 48u && t < (unsigned)out_tp && (P0 + 48 * lh + r) < prows;
+      const unsigned wo = keep ? ((s0h + c) * (unsigned)out_tp + t) * (unsigned)p.ld_obits * 4u : V5_OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(b ? wb1 : wb0, rsB, wo, 0u, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(b ? ws1 : ws0, rsS, wo, 0u, 0);
+    }
+  }
+  if constexpr (VOUT) {
+    if (p.out != nullptr) {                                 // (tests, TONAL_STORE_P1: the raw pooled rows as well, [seq * Tp / 2 + t'])
+      const __amdgpu_buffer_rsrc_t rsP = rsrc_of(p.out + P0 * (long long)p.ldo, (prows - P0) * (long long)p.ldo * 4);
+      const unsigned pvoff = colok ? ((unsigned)(48 * lh) * (unsigned)p.ldo + (unsigned)col) * 4u : V5_OOB;
+#pragma unroll
+      for (int j = 0; j < 48; ++j) {
+        const unsigned vo = selmu(mask2l(kA, kB, j), pvoff, V5_OOB);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[j]), rsP, vo, (unsigned)j * (unsigned)p.ldo * 4u, 0);
+      }
+    }
+    // ---- V of the pooled output: next-stage hex H' of a half = its pooled rows 6 H' .. 6 H' + 7 ----
+    const int slot = wm * 2 + lh;
+    {
+      float2 v2 = {pv[0], pv[1]};
+      *reinterpret_cast<float2*>(xch + (slot * 64 + wn * 32 + lr) * 2) = v2;
+    }
+    // (not __syncthreads(): its fence would also wait for the vector-memory operations in flight - the next tile's LDS-DMA)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float nb0 = 0.f, nb1 = 0.f;
+    if (slot < 7) {                                         // (the last half-wave of a tile: finished by the fix-up pass)
+      const float2 v2 = *reinterpret_cast<const float2*>(xch + ((slot + 1) * 64 + wn * 32 + lr) * 2);
+      nb0 = v2.x;
+      nb1 = v2.y;
+    }
+    // hex H' ends its sequence (rows 6, 7 belong to the next one: zero): pooled time of its first row == Tq - 6
+    uint32_t seA = 0, seB = 0, nvA = 0, nvB = 0;
+    {
+      int t_a = tqa0, t_b = tqb0;
+      const long long qa = (Hw >> 1), qb = (Hw >> 1) + 8;   // next-stage hex index of H' = 0
+      for (int k = 0; k < 8; ++k) {
+        seA |= (uint32_t)(t_a == Tq - 6) << k;
+        seB |= (uint32_t)(t_b == Tq - 6) << k;
+        nvA |= (uint32_t)(FULL || qa + k < p.vout_quads) << k;
+        nvB |= (uint32_t)(FULL || qb + k < p.vout_quads) << k;
+        t_a += 6;
+        if (t_a >= Tq) t_a -= Tq;
+        t_b += 6;
+        if (t_b >= Tq) t_b -= Tq;
+      }
+    }
+    const long long Hn = Hw >> 1;                           // first next-stage hex of the wave (Hw % 32 == 0)
+    const __amdgpu_buffer_rsrc_t rsV = rsrc_of(p.vout + Hn * 8 * (long long)p.ld_vout,
+                                              (p.vout_quads - Hn) * 8 * (long long)p.ld_vout * 4);
+    const unsigned vvoff = colok ? ((unsigned)(8 * lh * 8) * (unsigned)p.ld_vout + (unsigned)col) * 4u : V5_OOB;
+    const unsigned ldv4 = (unsigned)p.ld_vout * 4u;
+    const unsigned long long mraw = wm == 3 ? V6_HI : 0ull;   // H' = 7 of the tile's last half-wave
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned long long mend = mask2(seA, seB, q);
+      float d[8], v[8];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d[k] = pv[6 * q + k];
+      d[6] = selm(mend, 0.f, q < 7 ? pv[(6 * q + 6) % 48] : nb0);
+      d[7] = selm(mend, 0.f, q < 7 ? pv[(6 * q + 7) % 48] : nb1);
+      wino63_bt(d, v);
+      if (q == 7) {                                         // raw rows for tl_wino63_v_fixup (which owns rows 6, 7 of this hex)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = selm(mraw, d[k], v[k]);
+      }
+      const unsigned vo = selmu(mask2(nvA, nvB, q), vvoff, V5_OOB);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsV, vo, (unsigned)(q * 8 + i) * ldv4, 0);
+    }
+    // the tile's first two pooled rows: rows 6, 7 of the last hex of the tile in front (tl_wino63_v_fixup)
+    {
+      const bool hw = wm == 0 && p.vhalo != nullptr;
+      const __amdgpu_buffer_rsrc_t rsH = rsrc_of(hw ? p.vhalo + tm * 2 * (long long)p.N : nullptr, hw ? 2LL * p.N * 4 : 0);
+      const unsigned ho = (colok && lh == 0) ? (unsigned)col * 4u : V5_OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[0]), rsH, ho, 0u, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv[1]), rsH, ho, (unsigned)p.N * 4u, 0);
+    }
+  }
+}
+
+// Vector-memory stores every wave issues per tile (lower bound where a branch adds some), see v5_stores
+template <int EPI>
+constexpr int v6_stores() {
+  return EPI == W_EPI_POOL ? 52 : EPI == W_EPI_POOLV ? 70 : EPI == W_EPI_MASK ? 96 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Input gradient: out[R][col] = y * LeakyReLU'(stage input), the sign of the input from its 1-bit array (auxbits).
+// ------------------------------------------------------------------------------------------
+struct v6_pre_mask {
+  uint32_t s[3];               // sign words of the half's rows: lane lr holds those of rows lr, 32 + lr, 64 + lr
+};
+__device__ __forceinline__ v6_pre_mask v6_prefetch_mask(const tl_nt_params& p, long long R0, int n0, int wm, int wn, int lr, int lh) {
+  const int colbase = n0 + wn * 32;
+  const long long ra = R0 + wm * 192 + 96 * lh + lr;
+  v6_pre_mask r = {{0u, 0u, 0u}};
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (colbase < p.N && ra + 32 * k < p.M) r.s[k] = p.auxbits[(ra + 32 * k) * (long long)p.ld_auxbits + (colbase >> 5)];
+  return r;
+}
+template <bool FULL>
+__device__ __forceinline__ void v6_epilogue_mask(const tl_nt_params& p, const f32x16 (&acc)[8], const v6_pre_mask& pre, long long R0,
+                                                 int n0, int wm, int wn, int lr, int lh) {
+  const int colbase = n0 + wn * 32;
+  const bool colok = colbase < p.N;
+  const int col = colbase + lr;
+  const long long Rw = R0 + wm * 192;                       // first row of the wave; a half covers 96 rows
+  const __amdgpu_buffer_rsrc_t rsO = rsrc_of(p.out + Rw * (long long)p.ldo, (p.M - Rw) * (long long)p.ldo * 4);
+  const unsigned ovoff = colok ? ((unsigned)(96 * lh) * (unsigned)p.ldo + (unsigned)col) * 4u : V5_OOB;
+  const unsigned ldo4 = (unsigned)p.ldo * 4u;
+  bits96 inA = {~0ull, ~0u}, inB = inA;
+  if (!FULL) {
+    inA = v6_in_bits96(Rw, p.M);
+    inB = v6_in_bits96(Rw + 96, p.M);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float y[6];
+    wino63_rows(acc, e, y);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      const int r = 6 * e + h;
+      const unsigned long long mpos = words_as_mask(pre.s[r >> 5], r & 31);
+      const float o = selm(mpos, y[h], y[h] * p.slope);
+      const unsigned vo = FULL ? ovoff : selmu(mask96(inA, inB, r), ovoff, V5_OOB);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsO, vo, (unsigned)r * ldo4, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Input gradient of stage 2 with the fused first-stage weight gradient (tonal_wino43v_epi.h, v5_epilogue_c1w): G1 = y *
+// LeakyReLU'(sign bit) is contracted on the spot with the raw signal, dW1[o][j] = sum_rows G1[row][o] x[seq][2 t + a + j].
+// Prefetch: lane lr of a half requests the two bit words and the sample window x[seq][2 t .. 2 t + 3] of its rows lr,
+// 32 + lr, 64 + lr.  Body: two passes of 48 rows; the windows of a pass sit in a wave-private LDS table [half][48][4] and
+// come back per row as one ds_read_b128 at a half-wave-uniform address.  xw: 1.5 KB of LDS per wave that nothing else uses.
+// ------------------------------------------------------------------------------------------
+struct v6_pre_c1w {
+  uint32_t s[3], c[3];
+  f32x4 x[3];
+};
+__device__ __forceinline__ v6_pre_c1w v6_prefetch_c1w(const tl_nt_params& p, long long R0, int n0, int wm, int wn, int lr, int lh) {
+  const int colbase = n0 + wn * 32;
+  const long long ra = R0 + wm * 192 + 96 * lh + lr;
+  v6_pre_c1w r;
+  const int Tp = p.Tp;
+  const unsigned Ra = (unsigned)ra, sa = Ra / (unsigned)Tp;                  // M < 2^31 (host-checked)
+  unsigned sq = sa, tq = Ra - sa * (unsigned)Tp;
+  const long long nseq = p.M / Tp;
+  const unsigned s0 = (unsigned)(R0 / Tp);                   // first sequence of the tile (the resource starts there)
+  const __amdgpu_buffer_rsrc_t rsX = rsrc_of(p.c1x + (long long)s0 * p.c1T, (nseq - s0) * (long long)p.c1T * 4);
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    r.s[k] = r.c[k] = 0u;
+    const long long rk = ra + 32 * k;
+    if (colbase < p.N && rk < p.M) {
+      r.s[k] = p.auxbits[rk * (long long)p.ld_auxbits + (colbase >> 5)];
+      r.c[k] = p.c1bits[rk * (long long)p.ld_auxbits + (colbase >> 5)];
+    }
+    // sample windows (rows past the valid time / the matrix read whatever the resource still covers or zeros: their dz is 0)
+    r.x[k] = __builtin_bit_cast(f32x4, (v4u)__builtin_amdgcn_raw_buffer_load_b128(rsX, ((sq - s0) * (unsigned)p.c1T + 2u * tq) * 4u, 0u, 0));
+    tq += 32;
+    while (tq >= (unsigned)Tp) {
+      tq -= (unsigned)Tp;
+      ++sq;
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ void v6_epilogue_c1w(const tl_nt_params& p, const f32x16 (&acc)[8], const v6_pre_c1w& pre, float* xw,
+                                                float* red, long long R0, int n0, int wm, int wn, int lr, int lh, long long tm) {
+  const int colbase = n0 + wn * 32;
+  const bool colok = colbase < p.N;
+  const int col = colbase + lr;
+  const long long Hw = tm * 128 + wm * 32;
+  const long long Rw = 6 * Hw;
+  const int Tp = p.Tp;
+  const v6_rows rw = v6_rows_of(Hw, Tp);
+  // rows that count: time below Tvalid, inside the matrix
+  const bits96 okA = v6_valid_bits96(rw.tA, Tp, p.Tvalid, Rw, p.M);
+  const bits96 okB = v6_valid_bits96(rw.tB, Tp, p.Tvalid, Rw + 96, p.M);
+  float* xh = xw + lh * 192;                                 // this half's table: row r of the pass at xh + 4 r
+  c1w_acc ca;
+  ca.clear();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0) {
+      *reinterpret_cast<f32x4*>(xh + 4 * lr) = pre.x[0];                       // rows 0..31
+      if (lr < 16) *reinterpret_cast<f32x4*>(xh + 4 * (32 + lr)) = pre.x[1];   // rows 32..47
+    } else {
+      if (lr >= 16) *reinterpret_cast<f32x4*>(xh + 4 * (lr - 16)) = pre.x[1];  // rows 48..63
+      *reinterpret_cast<f32x4*>(xh + 4 * (16 + lr)) = pre.x[2];                // rows 64..95
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int e8 = 0; e8 < 8; ++e8) {
+      const int e = 8 * pass + e8;
+      float y[6];
+      wino63_rows(acc, e, y);
+#pragma unroll
+      for (int h = 0; h < 6; ++h) {
+        const int r = 6 * e + h;
+        const f32x4 xs = *reinterpret_cast<const f32x4*>(xh + 4 * (r - 48 * pass));
+        const unsigned long long mpos = words_as_mask(pre.s[r >> 5], r & 31);
+        const unsigned long long mam = words_as_mask(pre.c[r >> 5], r & 31);
+        const float dz = selm0(mask96(okA, okB, r), selm(mpos, y[h], y[h] * p.slope));
+        ca.s[0] = fmaf(dz, selm(mam, xs[1], xs[0]), ca.s[0]);
+        ca.s[1] = fmaf(dz, selm(mam, xs[2], xs[1]), ca.s[1]);
+        ca.s[2] = fmaf(dz, selm(mam, xs[3], xs[2]), ca.s[2]);
+        ca.b += dz;
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+  __syncthreads();                                          // `red` is a K-loop stage: every wave past its last fragment read
+  c1w_reduce_store<4, 64>(p, red, ca, wm, wn * 32 + lr, lh, tm, col, colok);
+}
+
+}  // namespace tl

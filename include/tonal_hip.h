@@ -84,6 +84,9 @@ typedef struct {
    * 512-row tile needs two rows of the next tile: it is left raw (rows 0..3 in its transform slots 0..3) and the tile
    * stores its own first two pooled rows to vhalo[tile][2][N]; tl_wino43_v_fixup finishes those quads.                */
   float* vout; float* vhalo; int64_t vout_quads; int ld_vout;
+  /* tl_conv3_wino63v_nt, POOL epilogue: rows per sequence of out / obits / osign, [seq * out_tp + t'] (pooled rows t' >=
+   * out_tp are dropped); 0: Tp / 2.  Decouples the row stride of a stage's output from the hex padding of its input.   */
+  int out_tp;
 } tl_nt_params;
 int tl_gemm_nt_window(const tl_nt_params* p, void* stream);
 
@@ -114,6 +117,7 @@ typedef struct {
   int part;           /* with vd: 0 both launches (the Vd-writing first C_in tile, then the other tiles), 1 / 2 only the
                          first / second of them (to put them on different streams)                                  */
   int bm;             /* tl_conv3_wino43v_tn: C_in tile, 0 = 128 when Mdim % 128 == 0 else 64; 64 / 128 force one   */
+  int g_tp;           /* tl_conv3_wino63v_tn: rows per sequence of B / bbits, [seq * g_tp + t']; 0: Tp / 2           */
 } tl_tn_params;
 int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
 
@@ -181,6 +185,30 @@ int tl_wino43_v_fixup(float* V, const float* vhalo, int64_t quads, int64_t tiles
 int tl_wino43_unpool_transform(const float* G, const uint32_t* bits, float* V, int64_t conv_rows, int64_t g_rows, int Tp,
                                int Tvalid, int C, int ldg, int ld_bits, int ldv, void* stream);
 int tl_conv3_wino43v_tn(const tl_tn_params* p, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * Round 4 - Winograd F(6,3) on pre-transformed operands (csrc/tonal_wino63.hip): the same three passes of conv2 / conv3
+ * (models/synthesis_models.py:91-97 and their backward in loss.backward(), models/synthesis_trainer.py:226) with HEXES:
+ * 8 channel contractions per 6 conv rows (0.444 of the direct form's multiplies; F(4,3): 0.5).  Points 0, +-1, +-2,
+ * +-1/2, inf (numerics: oracle/winograd_f63_gate.py).  A sequence holds Tp rows, Tp % 6 == 0 (% 12 where the pooled
+ * output feeds another F(6,3) stage); V[hex][8][ldv], hex H of a sequence = its rows 6H .. 6H+7 (rows past the sequence
+ * taken as zero), zero hexes appended to whole 128-hex tiles; Vd the same of the un-pooled dZ rows 6H-2 .. 6H+5.
+ *   tl_wino63_weights        w (O, I, 3, 1) -> forward taps [8][O][ld_f], input-gradient taps [8][I][ld_d] (flipped)
+ *   tl_conv3_wino63v_nt      tl_conv3_wino43v_nt with A = V in hex form (loader 2, A_rows = hexes, whole 128-hex tiles;
+ *                            M % 6 == 0, K % 8 == 0, K >= 24, N % 32 == 0); epilogues POOL (+ out_tp), POOLV (vout in
+ *                            hex form, vout_quads = hexes, Tp % 12 == 0), MASK, conv1-weight-gradient (4)
+ *   tl_wino63_v_fixup        second half of POOLV: the last hex of every 64 written by a tile (rows 6, 7 from vhalo)
+ *   tl_conv3_wino63v_tn      tl_conv3_wino43v_tn with hexes (Mdim % 128 == 0, Ndim % 64 == 0; slab[z][8][Mdim][ldc],
+ *                            slab_stride >= 8*Mdim*ldc; B / bbits rows [seq * g_tp + t']); vd optional: Vd[hex][8][ld_vd]
+ *   tl_wino63_wgrad_finalize red [8][I][ld] -> dW (O, I, 3, 1)
+ *   tl_conv1_fwd_v6          tl_conv1_fwd_v writing V[S * Tp / 6][8][C1] (Tp % 6 == 0)
+ * ------------------------------------------------------------------------------------------ */
+int tl_wino63_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
+int tl_conv3_wino63v_nt(const tl_nt_params* p, void* stream);
+int tl_wino63_v_fixup(float* V, const float* vhalo, int64_t hexes, int64_t tiles, int Tq, int C, int ldv, void* stream);
+int tl_conv3_wino63v_tn(const tl_tn_params* p, void* stream);
+int tl_wino63_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
+int tl_conv1_fwd_v6(const float* x, const float* w, const float* b, float* P, float* V, uint32_t* bits, uint32_t* sign,
+                    int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
 int tl_sizeof_nt_params(void);
 int tl_sizeof_tn_params(void);
