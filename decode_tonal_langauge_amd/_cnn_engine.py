@@ -310,9 +310,10 @@ class CnnEngine:
         return self.wino63 and st.idx in (2, 3)
 
     def _v_hex_buffer(self, store, idx, rows, cin):
-        """V / Vd of a stage input in hex form: rows / 6 hexes, padded with zero hexes to whole 128-hex tiles."""
+        """V / Vd of a stage input in hex form: rows / 6 hexes, padded with zero hexes to whole 128-hex tiles (and by at
+        least 24: the weight-gradient kernel prefetches three 6-hex K-steps past the last one it uses)."""
         nh = rows // 6
-        nh_pad = (nh + 127) // 128 * 128
+        nh_pad = (nh + 24 + 127) // 128 * 128
         V = store.get(idx)
         if V is None or V.shape[0] != nh_pad or V.shape[1] != 8 or V.shape[2] != cin:
             V = store[idx] = torch.zeros(nh_pad, 8, cin, dtype=torch.float32, device=self._dev)

@@ -8,8 +8,14 @@
 // 0, +-1, +-2, +-1/2, inf; the matrices are the exact Cook-Toom construction of that script.
 //
 // Layouts.  A sequence holds Tp rows, Tp a multiple of 6 (of 12 where the pooled output feeds another F(6,3) stage).
-// V[hex][8][ldv]: hex H of a sequence = its rows 6 H .. 6 H + 7 (rows past the sequence taken as zero), eight transforms,
-// channels last; zero hexes appended to whole 128-hex tiles.  Vd the same for the un-pooled dZ rows 6 H - 2 .. 6 H + 5.
+// Hex H of a sequence = its rows 6 H .. 6 H + 7 (rows past the sequence taken as zero), eight transforms, ldv channels
+// (a multiple of 8); zero hexes appended to whole 128-hex tiles.  Vd the same for the un-pooled dZ rows 6 H - 2 .. 6 H + 5.
+// V is stored in the PAIR layout V[hex / 2][ldv / 8][8 transforms][hex % 2][8 channels] (8 ldv floats per hex, like
+// [hex][8][ldv]): what one LDS-DMA piece of the NT kernel fetches - an 8-channel chunk of one transform of 32 hexes - is
+// then 16 runs of 64 B, and a piece of the weight-gradient kernel (64 channels of four (transform, hex) rows) 16 runs of
+// 64 B as well.  (With channels last an NT piece is 32 runs of 32 B, a quarter of a cache line each: measured 4.2 of 41.5
+// ms at conv2 forward - the 8-deep K-steps that three stages in 160 KB of LDS allow make the runs that short.)  The taps
+// are stored chunk-major for the same reason: U[K / 8][8 transforms][rows][8] - a piece is 1 KB contiguous.
 //
 //   tl_wino63_weights       w (O, I, 3, 1) -> forward taps [8][O][ld_f], input-gradient taps [8][I][ld_d] (flipped)
 //   tl_conv3_wino63v_nt     M_i[hex][n] = sum_k V_i[hex][k] U_i[n][k], i < 8: batched NT GEMM, both operands by LDS-DMA
@@ -31,6 +37,11 @@ __device__ __forceinline__ void dma16h(__amdgpu_buffer_rsrc_t rs, char* lds_dst,
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void6_t*)lds_dst, 16, voff, soff, 0, 0);
 }
 
+// float offset of (hex, transform i, channel c) in the pair layout; kc8 = ldv / 8
+__device__ __forceinline__ long long v6_at(long long hex, int i, int c, int kc8) {
+  return ((((hex >> 1) * kc8 + (c >> 3)) * 8 + i) * 2 + (hex & 1)) * 8 + (c & 7);
+}
+
 // ------------------------------------------------------------------------------------------
 // Tap transforms U = G g,  G = [-1 0 0; -2/9 (1 1 1); -2/9 (1 -1 1); 1/90 (1 2 4); 1/90 (1 -2 4); 1/45 (32 16 8);
 // 1/45 (32 -16 8); 0 0 1]
@@ -39,18 +50,21 @@ __global__ void wino63_weights_kernel(const float* __restrict__ w, float* __rest
                                       int I, int ld_f, int ld_d) {
   const long long n_f = (long long)O * ld_f, n_d = (long long)I * ld_d;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  auto emit = [](float* dst, long long n, long long at, float g0, float g1, float g2) {
+  // element (transform t, row r of R, reduction index k) of a chunk-major tap set: ((k / 8 * 8 + t) * R + r) * 8 + k % 8
+  auto emit = [](float* dst, int R, int r, int k, float g0, float g1, float g2) {
+    float* d0 = dst + (((long long)(k >> 3) * 8) * R + r) * 8 + (k & 7);
+    const long long n = (long long)R * 8;
     const float s = g0 + g2;
-    dst[at] = -g0;
-    dst[n + at] = (-2.f / 9.f) * (s + g1);
-    dst[2 * n + at] = (-2.f / 9.f) * (s - g1);
+    d0[0] = -g0;
+    d0[n] = (-2.f / 9.f) * (s + g1);
+    d0[2 * n] = (-2.f / 9.f) * (s - g1);
     const float a = fmaf(4.f, g2, g0), b = 2.f * g1;
-    dst[3 * n + at] = (1.f / 90.f) * (a + b);
-    dst[4 * n + at] = (1.f / 90.f) * (a - b);
+    d0[3 * n] = (1.f / 90.f) * (a + b);
+    d0[4 * n] = (1.f / 90.f) * (a - b);
     const float c = fmaf(4.f, g0, g2), d = 2.f * g1;
-    dst[5 * n + at] = (8.f / 45.f) * (c + d);
-    dst[6 * n + at] = (8.f / 45.f) * (c - d);
-    dst[7 * n + at] = g2;
+    d0[5 * n] = (8.f / 45.f) * (c + d);
+    d0[6 * n] = (8.f / 45.f) * (c - d);
+    d0[7 * n] = g2;
   };
   if (fwd != nullptr && idx < n_f) {
     const int o = (int)(idx / ld_f), i = (int)(idx % ld_f);
@@ -59,7 +73,7 @@ __global__ void wino63_weights_kernel(const float* __restrict__ w, float* __rest
       const float* s = w + ((long long)o * I + i) * 3;
       g0 = s[0], g1 = s[1], g2 = s[2];
     }
-    emit(fwd, n_f, idx, g0, g1, g2);
+    emit(fwd, O, o, i, g0, g1, g2);
   }
   if (dgr != nullptr && idx < n_d) {
     const int i = (int)(idx / ld_d), o = (int)(idx % ld_d);
@@ -68,7 +82,7 @@ __global__ void wino63_weights_kernel(const float* __restrict__ w, float* __rest
       const float* s = w + ((long long)o * I + i) * 3;
       g0 = s[2], g1 = s[1], g2 = s[0];          // flipped taps
     }
-    emit(dgr, n_d, idx, g0, g1, g2);
+    emit(dgr, I, i, o, g0, g1, g2);
   }
 }
 
@@ -103,10 +117,10 @@ __global__ __launch_bounds__(256, 4) void wino63_v_fixup_kernel(float* __restric
   const int c = (int)(idx - t * c4n) * 4;
   const long long q = t * 64 + 63;
   if (q >= hexes) return;
-  float* v = V + q * 8 * (long long)ldv + c;
+  float* v = V + v6_at(q, 0, c, ldv >> 3);                  // transform j of these four channels: v + 16 j
   f32x4 d[8];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) d[j] = *reinterpret_cast<const f32x4*>(v + (long long)j * ldv);
+  for (int j = 0; j < 6; ++j) d[j] = *reinterpret_cast<const f32x4*>(v + 16 * j);
   const int tq = (int)((6 * q) % Tq);
   if (tq + 6 < Tq && t + 1 < tiles) {
     d[6] = *reinterpret_cast<const f32x4*>(halo + ((t + 1) * 2) * (long long)C + c);
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(256, 4) void wino63_v_fixup_kernel(float* __restric
     for (int j = 0; j < 8; ++j) o[j][k] = vv[j];
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(v + (long long)j * ldv) = o[j];
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(v + 16 * j) = o[j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -179,11 +193,14 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   // LDS row rho = 8 g + 4 lh' + j' of a wave's 32 (the MFMA row whose results lane half lh' holds in accumulator elements
   // 4 g + j') takes hex 16 lh' + 4 g + j': a lane owns 16 consecutive hexes (tonal_wino63_epi.h)
   const int hex_of_row = (prow & 3) | ((prow >> 3) << 2) | (((prow >> 2) & 1) << 4);
+  // sources: V in the pair layout (K-step s = its 8-channel chunk s: + 512 B), taps chunk-major (+ 256 N bytes per step)
+  const int kc8 = p.lda >> 3;
   unsigned avoff[4], bv_lane[2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) avoff[t] = (unsigned)((((long long)(t * 32 + hex_of_row) * 8 + wave) * p.lda + src_chunk * 4) * 4);
+  for (int t = 0; t < 4; ++t) avoff[t] = (unsigned)(v6_at(t * 32 + hex_of_row, wave, src_chunk * 4, kc8) * 4);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) bv_lane[t] = (unsigned)((((long long)wave * p.N + t * 32 + prow) * p.ldb + src_chunk * 4) * 4);
+  for (int t = 0; t < 2; ++t) bv_lane[t] = (unsigned)((((long long)wave * p.N + t * 32 + prow) * 8 + src_chunk * 4) * 4);
+  const unsigned b_step = (unsigned)p.N * 256u;
 
   // A workgroup walks the tiles blockIdx.x, + gridDim.x, ... (one workgroup per CU, a multiple of 8: a tile sequence stays
   // on one XCD).  V holds whole 128-hex tiles (host-checked): the per-lane source offsets of the A pieces never change.
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     t.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) + ab), 0,
                                               (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
     if (t.n0 + V6_BN <= p.N) {
-      const unsigned nb4 = (unsigned)t.n0 * (unsigned)p.ldb * 4u;
+      const unsigned nb4 = (unsigned)t.n0 * 32u;
 #pragma unroll
       for (int k = 0; k < 2; ++k) t.bvoff[k] = bv_lane[k] + nb4;
     } else {                                               // column tile past the edge: clamped columns (masked by the epilogue)
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
       for (int k = 0; k < 2; ++k) {
         int n = t.n0 + k * 32 + prow;
         if (n > p.N - 1) n = p.N - 1;
-        t.bvoff[k] = (unsigned)((((long long)wave * p.N + n) * p.ldb + src_chunk * 4) * 4);
+        t.bvoff[k] = (unsigned)((((long long)wave * p.N + n) * 8 + src_chunk * 4) * 4);
       }
     }
   };
@@ -237,11 +254,22 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   };
   auto issue = [&](const tile_t& tl_, int step, int stage) {
     char* base = lds + stage * V6_STAGE;
-    const unsigned soff = (unsigned)step * (V6_BK * 4);
+    const unsigned soff = (unsigned)step * 512u, soff_b = (unsigned)step * b_step;
+#if V6_ABL & 8
+    // timing only: the A pieces of a step as 1 KB contiguous blocks of the tile's span (same bytes per tile, full lines)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dma16h(tl_.rsA, base + adst[t], (unsigned)(lane * 16 + (wave * 4 + t) * 1024), (unsigned)step * 32768u);
+#else
 #pragma unroll
     for (int t = 0; t < 4; ++t) dma16h(tl_.rsA, base + adst[t], avoff[t], soff);
+#endif
+#if V6_ABL & 16
 #pragma unroll
-    for (int t = 0; t < 2; ++t) dma16h(rsB, base + bdst[t], tl_.bvoff[t], soff);
+    for (int t = 0; t < 2; ++t) dma16h(rsB, base + bdst[t], (unsigned)(lane * 16 + (wave * 2 + t) * 1024 + (tl_.n0 / 64) * 1048576), (unsigned)step * 16384u);
+#else
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dma16h(rsB, base + bdst[t], tl_.bvoff[t], soff_b);
+#endif
   };
   auto next3 = [](int s) { return s == 2 ? 0 : s + 1; };
 
@@ -489,16 +517,17 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn_kernel(const tl_tn_params p
   // ---- V by LDS-DMA: piece 3 wave + t -> half-tile pc / 12, rows 4 (pc % 12) .. + 3 of its 48 ([transform][hex] order);
   // lane -> (row offset lane >> 4, physical 16-byte chunk lane & 15); odd hexes: halves swapped = source chunk ^ 8
   const long long v_h0 = ks_begin * T6_H;                           // first hex of this split
+  // (V in the pair layout: v_h0 is even, a K-step is three pairs; the channel tile enters through the chunk index)
+  const int kc8 = p.lda >> 3;
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.A + v_h0 * 8 * (long long)p.lda + m0), 0, clip31((p.A_rows - v_h0) * 8 * (long long)p.lda * 4 - (long long)m0 * 4),
-      0x00020000);
+      (void*)(p.A + v_h0 * 8 * (long long)p.lda), 0, clip31((p.A_rows - v_h0) * 8 * (long long)p.lda * 4), 0x00020000);
   unsigned vvoff[3], vdst[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int half = (wave * 3 + t) / 12, pc = (wave * 3 + t) % 12;
     const int rho = 4 * pc + (lane >> 4), i = rho / 6, hx = rho % 6;
     const int chunk = (lane & 15) ^ ((hx & 1) << 3);
-    vvoff[t] = (unsigned)((((long long)hx * 8 + i) * p.lda + half * 64 + chunk * 4) * 4);
+    vvoff[t] = (unsigned)(v6_at(hx, i, m0 + half * 64 + chunk * 4, kc8) * 4);
     vdst[t] = (unsigned)((half * T6_TILE + pc * 256) * 4);
   }
   const unsigned v_step = (unsigned)(T6_H * 8 * p.lda * 4);         // bytes per K-step (host-checked to fit)
@@ -554,12 +583,15 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn_kernel(const tl_tn_params p
   int tq = __builtin_amdgcn_readfirstlane((int)((6 * (v_h0 + (ywave ? wave : 0))) % p.Tp));   // first conv row of the NEXT hex to transform
   const int dstep = __builtin_amdgcn_readfirstlane((6 * T6_H) % p.Tp);
   float bsum = 0.f;
-  const unsigned vd_hstride = (unsigned)(8 * p.ld_vd * 4);
+  // Vd in the pair layout (ld_vd / 8 chunks): a lane stores four channels of transforms lane & 3 and 4 + (lane & 3)
+  const int kcd = write_vd ? (p.ld_vd >> 3) : 1;
+  const unsigned vd_pstride = (unsigned)(16 * p.ld_vd * 4);          // bytes per hex pair
+  const long long vd_hexes = ((hexes_all + 1) >> 1) << 1;
   const __amdgpu_buffer_rsrc_t rsVd = __builtin_amdgcn_make_buffer_rsrc(
-      write_vd ? (void*)(p.vd + v_h0 * 8 * (long long)p.ld_vd + n0) : (void*)p.slab, 0,
-      write_vd ? clip31((hexes_all - v_h0) * 8 * (long long)p.ld_vd * 4 - (long long)n0 * 4) : 0, 0x00020000);
-  const unsigned vdA_lane = (unsigned)((lane & 3) * p.ld_vd * 4 + (lane & ~3) * 4);
-  const unsigned vdB_lane = (unsigned)((4 + (lane & 3)) * p.ld_vd * 4 + (lane & ~3) * 4);
+      write_vd ? (void*)(p.vd + v_h0 * 8 * (long long)p.ld_vd) : (void*)p.slab, 0,
+      write_vd ? clip31((vd_hexes - v_h0) * 8 * (long long)p.ld_vd * 4) : 0, 0x00020000);
+  const unsigned vdA_lane = (unsigned)(v6_at(0, lane & 3, n0 + (lane & ~3), kcd) * 4);
+  const unsigned vdB_lane = vdA_lane + 4u * 64u;
   const int nhex = (int)hexes_all, h_first = (int)v_h0;
   const int h_end = h_first + nsteps * T6_H;
   const int hs_lim = nhex < h_end ? nhex : h_end;           // hexes of this split that exist
@@ -653,7 +685,7 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn_kernel(const tl_tn_params p
     const f32x4 va4 = {v[0], v[1], v[2], v[3]};
     const f32x4 vb4 = {v[4], v[5], v[6], v[7]};
     const bool ok = ywave && h < hs_lim;
-    const unsigned hoff = (unsigned)(h - h_first) * vd_hstride;
+    const unsigned hoff = (unsigned)((h - h_first) >> 1) * vd_pstride + (unsigned)((h - h_first) & 1) * 32u;
     if (!(T6_ABL & 4)) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, va4), rsVd, ok ? hoff + vdA_lane : 0xfffffff0u, 0u, 2);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, vb4), rsVd, ok ? hoff + vdB_lane : 0xfffffff0u, 0u, 2);
@@ -742,20 +774,21 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn_kernel(const tl_tn_params p
     mfma8(fa0, fb0);
     __builtin_amdgcn_sched_barrier(0);
     // second half: the transform of step s + 1 beside the MFMAs of slice 1
-    y_in yn;
-    y_out un = {};
-    if (!(T6_ABL & 8)) fetch_y(s + 1, slot1, yn);
     load_frag(fac, fbc, abuf, bbuf, 2);
-    if (!(T6_ABL & 8)) un = compute_y(s + 1, yn);
-    if constexpr (write_vd) {
-      if (turn == mi && s + 1 < nsteps && !(T6_ABL & 8)) {
-        float gp;
-        unsigned long long wp;
-        front_row(slot1, slot0, gp, wp);
-        vd_part(s + 1, yn.tq, un, gp, wp);
+    if (ywave && !(T6_ABL & 8)) {                           // (wave-uniform: waves 6, 7 own no hex)
+      y_in yn;
+      fetch_y(s + 1, slot1, yn);
+      const y_out un = compute_y(s + 1, yn);
+      if constexpr (write_vd) {
+        if (turn == mi && s + 1 < nsteps) {
+          float gp;
+          unsigned long long wp;
+          front_row(slot1, slot0, gp, wp);
+          vd_part(s + 1, yn.tq, un, gp, wp);
+        }
       }
-      turn = turn + 1 == mtn ? 0 : turn + 1;
     }
+    if constexpr (write_vd) turn = turn + 1 == mtn ? 0 : turn + 1;
     mfma8(fa1, fb1);
     __builtin_amdgcn_sched_barrier(0);                      // (the closing wait would be hoisted over these MFMAs)
     // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2).  In flight: the 4 pieces of this step and of the
@@ -882,9 +915,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j][k] = vv[j];
       }
-      float* dst = V + (seq * Th + q) * 8LL * C1 + o;
+      float* dst = V + v6_at(seq * Th + q, 0, o, C1 >> 3);      // (pair layout: transform j of these four channels at + 16 j)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) __builtin_nontemporal_store(ov[j], reinterpret_cast<f32x4*>(dst + (long long)j * C1));
+      for (int j = 0; j < 8; ++j) __builtin_nontemporal_store(ov[j], reinterpret_cast<f32x4*>(dst + 16 * j));
     }
     d[0] = d[6]; d[1] = d[7];
     wb[0] = wb[6]; wb[1] = wb[7];
@@ -898,7 +931,8 @@ extern "C" int tl_wino63_weights(const float* w, float* fwd, float* dgr, int O, 
   using namespace tl;
   TL_REQUIRE(w != nullptr && (fwd != nullptr || dgr != nullptr), "wino63_weights: null pointer");
   TL_REQUIRE(O > 0 && I > 0, "wino63_weights: bad sizes");
-  TL_REQUIRE((fwd == nullptr || ld_f >= I) && (dgr == nullptr || ld_d >= O), "wino63_weights: leading dimension too small");
+  TL_REQUIRE((fwd == nullptr || (ld_f >= I && ld_f % 8 == 0)) && (dgr == nullptr || (ld_d >= O && ld_d % 8 == 0)),
+             "wino63_weights: leading dimensions must cover the reduction length and be multiples of 8");
   const long long nf = (long long)O * ld_f, nd = (long long)I * ld_d;
   const long long n = nf > nd ? nf : nd;
   TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_weights: too large");
@@ -920,7 +954,7 @@ extern "C" int tl_wino63_v_fixup(float* V, const float* vhalo, int64_t hexes, in
   using namespace tl;
   TL_REQUIRE(V && vhalo, "wino63_v_fixup: null pointer");
   TL_REQUIRE(hexes > 0 && tiles > 0 && Tq > 0 && Tq % 6 == 0, "wino63_v_fixup: hexes, tiles > 0 and Tq %% 6 == 0 needed");
-  TL_REQUIRE(C > 0 && C % 4 == 0 && ldv >= C && ldv % 4 == 0, "wino63_v_fixup: C / ldv must be multiples of 4");
+  TL_REQUIRE(C > 0 && C % 4 == 0 && ldv >= C && ldv % 8 == 0 && hexes % 2 == 0, "wino63_v_fixup: C %% 4, ldv %% 8, whole hex pairs needed");
   const long long n = (long long)tiles * (C / 4);
   TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_v_fixup: grid too large");
   hipLaunchKernelGGL(wino63_v_fixup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, vhalo,
@@ -939,7 +973,8 @@ extern "C" int tl_conv3_wino63v_nt(const tl_nt_params* pp, void* stream) {
   TL_REQUIRE(p.loader == W_LOAD_V, "wino63v_nt: loader 2 (pre-transformed operand) only");
   TL_REQUIRE(p.J == 3 && p.splitk <= 1, "wino63v_nt: 3 taps, no split-K");
   TL_REQUIRE(p.M > 0 && p.M % 6 == 0 && p.N > 0 && p.K >= 24 && p.K % 8 == 0, "wino63v_nt: M %% 6, K %% 8, K >= 24 needed");
-  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino63v_nt: bad leading dimensions");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K && p.lda % 8 == 0 && p.ldb % 8 == 0, "wino63v_nt: bad leading dimensions (multiples of 8)");
+  TL_REQUIRE(p.A_rows % 2 == 0, "wino63v_nt: V holds hex pairs");
   TL_REQUIRE(p.Tp > 0 && p.Tp % 6 == 0 && p.M % p.Tp == 0, "wino63v_nt: Tp must be a positive multiple of 6, M whole sequences");
   TL_REQUIRE(8LL * p.N * p.ldb * 4 < (1LL << 31), "wino63v_nt: tap set larger than a buffer resource");
   TL_REQUIRE(128LL * 8 * p.lda * 4 + 4LL * p.K < (1LL << 31), "wino63v_nt: tile span too large");
@@ -963,7 +998,8 @@ extern "C" int tl_conv3_wino63v_nt(const tl_nt_params* pp, void* stream) {
     TL_REQUIRE(p.row_shift == 0 && (p.out == nullptr || p.ldo >= p.N), "wino63v_nt: forward needs row_shift 0");
     TL_REQUIRE(p.obits != nullptr && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino63v_nt: POOLV needs obits and an even Tvalid");
     TL_REQUIRE(p.ld_obits * 32 >= p.N && p.Tp % 12 == 0, "wino63v_nt: POOLV needs Tp %% 12 == 0 (output hexes inside one sequence)");
-    TL_REQUIRE(p.vout && p.vhalo && p.ld_vout >= p.N && p.vout_quads >= p.M / 12, "wino63v_nt: POOLV needs vout (>= M / 12 hexes) and vhalo");
+    TL_REQUIRE(p.vout && p.vhalo && p.ld_vout >= p.N && p.ld_vout % 8 == 0 && p.vout_quads >= p.M / 12 && p.vout_quads % 2 == 0,
+               "wino63v_nt: POOLV needs vout (>= M / 12 hexes, whole pairs, ld_vout %% 8 == 0) and vhalo");
     TL_REQUIRE(64LL * 8 * p.ld_vout * 4 < (1LL << 31), "wino63v_nt: ld_vout too large");
     hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_POOLV>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
   } else if (p.epilogue == W_EPI_MASK) {
@@ -993,7 +1029,8 @@ extern "C" int tl_conv3_wino63v_tn(const tl_tn_params* pp, void* stream) {
   TL_REQUIRE(p.Tp > 0 && p.Tp % 6 == 0 && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino63v_tn: Tp %% 6 == 0 and an even Tvalid <= Tp needed");
   TL_REQUIRE(p.Krows > 0 && p.Krows % p.Tp == 0 && p.Mdim > 0 && p.Ndim > 0, "wino63v_tn: bad sizes (Krows must be whole sequences)");
   TL_REQUIRE(p.Krows + 64 < (1LL << 31), "wino63v_tn: more than 2^31 reduction rows");
-  TL_REQUIRE(p.Mdim % 128 == 0 && p.Ndim % 64 == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0, "wino63v_tn: Mdim %% 128, Ndim %% 64, ld %% 4 needed");
+  TL_REQUIRE(p.Mdim % 128 == 0 && p.Ndim % 64 == 0 && p.lda % 8 == 0 && p.ldb % 4 == 0 && p.A_rows % 2 == 0,
+             "wino63v_tn: Mdim %% 128, Ndim %% 64, lda %% 8, ldb %% 4, whole hex pairs in V needed");
   TL_REQUIRE(p.lda >= p.Mdim && p.ldb >= p.Ndim && p.ldc >= p.Ndim, "wino63v_tn: leading dimension too small");
   TL_REQUIRE(p.ld_bbits * 32 >= p.Ndim && p.ld_bbits % 2 == 0, "wino63v_tn: bbits row too short / odd");
   TL_REQUIRE(p.splitk <= 65535, "wino63v_tn: splitk too large");
@@ -1006,7 +1043,7 @@ extern "C" int tl_conv3_wino63v_tn(const tl_tn_params* pp, void* stream) {
   const long long per = (ksteps_all + p.splitk - 1) / p.splitk;
   TL_REQUIRE((per + 4) * (long long)T6_H * 8 * p.lda * 4 < (1LL << 31), "wino63v_tn: a reduction split spans more than 2 GB of V: raise splitk");
   TL_REQUIRE((per + 6) * 3LL * T6_H * p.ldb * 4 < (1LL << 31), "wino63v_tn: a reduction split spans more than 2 GB of G: raise splitk");
-  TL_REQUIRE(p.vd == nullptr || (p.ld_vd >= p.Ndim && p.ld_vd % 4 == 0), "wino63v_tn: ld_vd must cover Ndim");
+  TL_REQUIRE(p.vd == nullptr || (p.ld_vd >= p.Ndim && p.ld_vd % 8 == 0), "wino63v_tn: ld_vd must cover Ndim (multiple of 8)");
   TL_REQUIRE(p.vd == nullptr || (per + 4) * (long long)T6_H * 8 * p.ld_vd * 4 < (1LL << 31), "wino63v_tn: a reduction split spans more than 2 GB of Vd: raise splitk");
   const int ntm = p.Mdim / 128, ntn = p.Ndim / T6_BN;
   hipStream_t st = (hipStream_t)stream;

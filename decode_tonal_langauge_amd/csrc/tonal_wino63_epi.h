@@ -238,10 +238,11 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
       }
     }
     const long long Hn = Hw >> 1;                           // first next-stage hex of the wave (Hw % 32 == 0)
+    // pair layout (tonal_wino63.hip): hex pair stride 16 ld_vout floats, 8-channel chunk 128, transform 16, hex % 2 8
     const __amdgpu_buffer_rsrc_t rsV = rsrc_of(p.vout + Hn * 8 * (long long)p.ld_vout,
                                               (p.vout_quads - Hn) * 8 * (long long)p.ld_vout * 4);
-    const unsigned vvoff = colok ? ((unsigned)(8 * lh * 8) * (unsigned)p.ld_vout + (unsigned)col) * 4u : V5_OOB;
-    const unsigned ldv4 = (unsigned)p.ld_vout * 4u;
+    const unsigned pair4 = (unsigned)p.ld_vout * 64u;        // bytes per hex pair
+    const unsigned vvoff = colok ? (unsigned)(4 * lh) * pair4 + ((unsigned)(col >> 3) * 128u + (unsigned)(col & 7)) * 4u : V5_OOB;
     const unsigned long long mraw = wm == 3 ? V6_HI : 0ull;   // H' = 7 of the tile's last half-wave
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -259,7 +260,8 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
       const unsigned vo = selmu(mask2(nvA, nvB, q), vvoff, V5_OOB);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsV, vo, (unsigned)(q * 8 + i) * ldv4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsV, vo,
+                                              (unsigned)(q >> 1) * pair4 + (unsigned)(i * 64 + (q & 1) * 32), 0);
     }
     // the tile's first two pooled rows: rows 6, 7 of the last hex of the tile in front (tl_wino63_v_fixup)
     {

@@ -1,0 +1,64 @@
+"""Isolated timing of the F(6,3) conv-stage kernels (TONAL_WINO=6) at the north-star geometry (no model, no LSTM).
+
+    TONAL_WINO=6 python scripts/bench_conv63.py [--batch 256] [--iters 5] [--passes fwd,wgrad,dgrad]
+Prints ms, algorithmic TFLOP/s (direct-convolution FLOPs of the valid rows) and the MFMA TFLOP/s issued.
+"""
+import argparse, os, sys
+os.environ["TONAL_WINO"] = "6"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from decode_tonal_langauge_amd._cnn_engine import CnnEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--passes", default="fwd,wgrad,dgrad")
+ap.add_argument("--stages", default="2,3")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
+eng = CnnEngine(80, 128, 400, 6, 64, 0.0, 0.01, stages_def, [128, 128, 128, 128, 64])
+assert eng.wino63
+B = args.batch
+eng._alloc(B, dev)
+eng._alloc_bwd()
+S = eng.S
+g = torch.Generator(device=dev).manual_seed(1)
+eng._x = torch.randn(B, 128, 400, device=dev, generator=g)
+eng.generation += 1
+V1 = eng._v_hex_buffer(eng.V, 1, S * eng.tp1, 512)
+V1.normal_(generator=g)
+eng._v_ready = {1: V1}
+for k in eng.G:
+    eng.G[k].normal_(generator=g)
+for k in eng.bits:
+    eng.bits[k].random_(-2**31, 2**31 - 1, generator=g)
+    eng.sbits[k].random_(-2**31, 2**31 - 1, generator=g)
+for si in [int(s) for s in args.stages.split(",")]:
+    st = eng.stages[si - 2]
+    if si == 3 and 2 not in eng._v_ready:
+        V2 = eng._v_hex_buffer(eng.V, 2, S * st.tp_in, 512)
+        V2.normal_(generator=g)
+        eng._v_ready[2] = V2
+    w = torch.randn(st.cout, st.cin, 3, 1, device=dev, generator=g) * 0.02
+    b = torch.randn(st.cout, device=dev, generator=g) * 0.1
+    gw, gb = torch.empty_like(w), torch.empty_like(b)
+    fl = 2.0 * B * eng.C * st.tc * 3 * st.cin * st.cout
+    iss = eng.f63_issue_factor(st)
+
+    def dgrad():
+        eng._vd_ready[st.idx] = eng.generation       # (Vd left by the last weight-gradient launch)
+        eng.stage_dgrad(st, w)
+    for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("wgrad", lambda: eng.stage_wgrad(st, gw, gb)), ("dgrad", dgrad)):
+        if name not in args.passes.split(","):
+            continue
+        if name == "dgrad" and st.idx not in eng.Vd:
+            eng.stage_wgrad(st, gw, gb)
+        fn(); torch.cuda.synchronize()
+        eng.enable_timers(True)
+        for _ in range(args.iters):
+            fn()
+        ts = eng.timer_summary(); eng.enable_timers(False)
+        ms = ts[f"conv{si}_{name}"][1]
+        print(f"F63 conv{si}_{name:6s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TFLOP/s algorithmic  {fl * iss / ms / 1e9:7.2f} issued "
+              f"({100 * fl * iss / ms / 1e9 / 157.3:.1f}% of fp32 MFMA peak)", flush=True)

@@ -37,6 +37,12 @@ def hex_transform(P, S, Tp, shift=0):
     return V.reshape(S * nh, 8, C)
 
 
+def logical(V):
+    """kernel V / Vd (pair layout [hex / 2][C / 8][8][hex % 2][8], stored as (hexes, 8, C)) -> (hexes, 8, C) channels last"""
+    nh, _, C = V.shape
+    return V.reshape(nh // 2, C // 8, 8, 2, 8).permute(0, 3, 2, 1, 4).reshape(nh, 8, C)
+
+
 def rel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / max(1e-30, float(b.abs().max())))
@@ -120,7 +126,7 @@ def run(shape, dev):
     note("conv1 raw rows", rel(rows(e6, e6.P[1], e6.tp1, tin2), rows(e0, e0.P[1], e0.tp1, tin2)), 1e-6)
     assert torch.equal(rows(e6, e6.bits[1], e6.tp1, tin2), rows(e0, e0.bits[1], e0.tp1, tin2))
     V1ref = hex_transform(e6.P[1], S, e6.tp1)
-    note("V1 == B^T P1", rel(e6.V[1][:V1ref.shape[0]], V1ref), 1e-6)
+    note("V1 == B^T P1", rel(logical(e6.V[1])[:V1ref.shape[0]], V1ref), 1e-6)
     assert float(e6.V[1][V1ref.shape[0]:].abs().max()) == 0.0 if e6.V[1].shape[0] > V1ref.shape[0] else True
 
     # ---- forward stages 2, 3 ----
@@ -140,7 +146,7 @@ def run(shape, dev):
         note(f"conv{si} sign word flips", float((fl != 0).sum()), 4)
         if si == 2:
             V2ref = hex_transform(e6.P[2], S, s6.tp_out)
-            note("V2 == B^T P2", rel(e6.V[2][:V2ref.shape[0]], V2ref), 1e-6)
+            note("V2 == B^T P2", rel(logical(e6.V[2])[:V2ref.shape[0]], V2ref), 1e-6)
             # the F(6,3) stage 3 must see the same input as the direct one: copy the direct rows where valid
     # ---- backward: random G3 into both engines ----
     s0, s6 = e0.stages[1], e6.stages[1]
@@ -171,7 +177,7 @@ def run(shape, dev):
         if 2 * s6.tp_out < s6.tp_in:
             dz = torch.nn.functional.pad(dz, (0, 0, 0, s6.tp_in - 2 * s6.tp_out))
         Vdref = hex_transform(dz[:, :s6.tp_in].reshape(-1, s6.cout), S, s6.tp_in, shift=-2)
-        note(f"Vd{si} == B^T dZ", rel(e6.Vd[si][:Vdref.shape[0]], Vdref), 1e-6)
+        note(f"Vd{si} == B^T dZ", rel(logical(e6.Vd[si])[:Vdref.shape[0]], Vdref), 1e-6)
         if si == 3:
             nin = s6.tin
             note("conv3 input gradient (rel L2)", rel_l2(rows(e6, e6.G[2], s6.tp_in, nin), rows(e0, e0.G[2], s0.tp_in, nin)), 1e-5)
