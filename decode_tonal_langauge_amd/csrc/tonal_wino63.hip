@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
       if (full) v6_epilogue_mask<true>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
       else v6_epilogue_mask<false>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
     } else {
-      v6_epilogue_c1w(p, acc, pre, reinterpret_cast<float*>(lds + 3 * V6_STAGE) + wave * 384, scratch, done.R0, done.n0, wm, wn,
+      v6_epilogue_c1w(p, acc, pre, reinterpret_cast<float*>(lds + 3 * V6_STAGE) + wave * 512, scratch, done.R0, done.n0, wm, wn,
                       lr, lh, done.tm);
     }
 #endif

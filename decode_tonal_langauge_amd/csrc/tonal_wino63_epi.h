@@ -47,6 +47,15 @@ __device__ __forceinline__ void wino63_bt(const float (&d)[8], float (&v)[8]) {
   v[7] = fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
 }
 
+// lane's bit j of w set ? a : b without a lane mask in scalar registers: sign-extended bit field + bit-field insert.  (The
+// epilogues below transpose the 1-bit words of their rows once per tile - bit_transpose32 - so that a lane holds the bits
+// of ITS column for 32 rows; the F(4,3) epilogues broadcast a row's word with two v_readlane per use, and with 96 rows per
+// lane those scalar masks spilled through v_writelane: ~400 of 2 100 instructions of the fused conv1 epilogue.)
+__device__ __forceinline__ float selbit(uint32_t w, int j, float a, float b) {
+  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)w, j, 1);
+  return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+}
+
 // Row bookkeeping of one wave tile.  Hw: first hex of the wave; rows R = 6 Hw + 96 lh + r, r < 96.
 struct v6_rows {
   int tA, tB;                 // time index of the first conv row of half 0 / half 1
@@ -101,7 +110,9 @@ __device__ __forceinline__ bits96 v6_valid_bits96(int t0, int Tp, int tlim, long
 // ------------------------------------------------------------------------------------------
 template <bool VOUT, bool FULL>
 __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f32x16 (&acc)[8], const v5_pre_pool& pre, float* xch,
-                                                 long long R0, int n0, int wm, int wn, int lr, int lh, long long tm) {
+                                                 long long R0, int n0, int wm, int wn, int lr_in, int lh, long long tm) {
+  int lr = lr_in;                                           // (opaque copy: see v6_epilogue_c1w)
+  asm volatile("" : "+v"(lr));
   const int colbase = n0 + wn * 32;
   const bool colok = colbase < p.N;                         // N % 32 == 0 (host-checked)
   const int col = colbase + lr;
@@ -297,7 +308,9 @@ __device__ __forceinline__ v6_pre_mask v6_prefetch_mask(const tl_nt_params& p, l
 }
 template <bool FULL>
 __device__ __forceinline__ void v6_epilogue_mask(const tl_nt_params& p, const f32x16 (&acc)[8], const v6_pre_mask& pre, long long R0,
-                                                 int n0, int wm, int wn, int lr, int lh) {
+                                                 int n0, int wm, int wn, int lr_in, int lh) {
+  int lr = lr_in;                                           // (opaque copy: see v6_epilogue_c1w)
+  asm volatile("" : "+v"(lr));
   const int colbase = n0 + wn * 32;
   const bool colok = colbase < p.N;
   const int col = colbase + lr;
@@ -310,6 +323,9 @@ __device__ __forceinline__ void v6_epilogue_mask(const tl_nt_params& p, const f3
     inA = v6_in_bits96(Rw, p.M);
     inB = v6_in_bits96(Rw + 96, p.M);
   }
+  uint32_t sT[3];                                           // bit j of sT[k]: sign of (row 32 k + j, this lane's column)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sT[k] = bit_transpose32(pre.s[k], lr);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     float y[6];
@@ -317,8 +333,7 @@ __device__ __forceinline__ void v6_epilogue_mask(const tl_nt_params& p, const f3
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
       const int r = 6 * e + h;
-      const unsigned long long mpos = words_as_mask(pre.s[r >> 5], r & 31);
-      const float o = selm(mpos, y[h], y[h] * p.slope);
+      const float o = y[h] * selbit(sT[r >> 5], r & 31, 1.f, p.slope);
       const unsigned vo = FULL ? ovoff : selmu(mask96(inA, inB, r), ovoff, V5_OOB);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsO, vo, (unsigned)r * ldo4, 0);
     }
@@ -334,15 +349,13 @@ __device__ __forceinline__ void v6_epilogue_mask(const tl_nt_params& p, const f3
 // ------------------------------------------------------------------------------------------
 struct v6_pre_c1w {
   uint32_t s[3], c[3];
-  f32x4 x[3];
+  f32x4 x[2];                  // samples x[seq][2 t .. 2 t + 7] of the lane's rows 3 lr, 3 lr + 1, 3 lr + 2 (windows of four, two apart)
 };
 __device__ __forceinline__ v6_pre_c1w v6_prefetch_c1w(const tl_nt_params& p, long long R0, int n0, int wm, int wn, int lr, int lh) {
   const int colbase = n0 + wn * 32;
-  const long long ra = R0 + wm * 192 + 96 * lh + lr;
+  const long long rh = R0 + wm * 192 + 96 * lh;             // first row of the half
   v6_pre_c1w r;
   const int Tp = p.Tp;
-  const unsigned Ra = (unsigned)ra, sa = Ra / (unsigned)Tp;                  // M < 2^31 (host-checked)
-  unsigned sq = sa, tq = Ra - sa * (unsigned)Tp;
   const long long nseq = p.M / Tp;
   const unsigned s0 = (unsigned)(R0 / Tp);                   // first sequence of the tile (the resource starts there)
   const __amdgpu_buffer_rsrc_t rsX = rsrc_of(p.c1x + (long long)s0 * p.c1T, (nseq - s0) * (long long)p.c1T * 4);
@@ -350,23 +363,26 @@ __device__ __forceinline__ v6_pre_c1w v6_prefetch_c1w(const tl_nt_params& p, lon
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     r.s[k] = r.c[k] = 0u;
-    const long long rk = ra + 32 * k;
+    const long long rk = rh + lr + 32 * k;
     if (colbase < p.N && rk < p.M) {
       r.s[k] = p.auxbits[rk * (long long)p.ld_auxbits + (colbase >> 5)];
       r.c[k] = p.c1bits[rk * (long long)p.ld_auxbits + (colbase >> 5)];
     }
-    // sample windows (rows past the valid time / the matrix read whatever the resource still covers or zeros: their dz is 0)
-    r.x[k] = __builtin_bit_cast(f32x4, (v4u)__builtin_amdgcn_raw_buffer_load_b128(rsX, ((sq - s0) * (unsigned)p.c1T + 2u * tq) * 4u, 0u, 0));
-    tq += 32;
-    while (tq >= (unsigned)Tp) {
-      tq -= (unsigned)Tp;
-      ++sq;
-    }
   }
+  // three rows = half a hex: inside one sequence (Tp % 6 == 0).  Rows past the valid time / the matrix read whatever the
+  // resource still covers or zeros: their dz is 0
+  const unsigned Rx = (unsigned)(rh + 3 * lr), sx = Rx / (unsigned)Tp, tx = Rx - sx * (unsigned)Tp;     // M < 2^31 (host-checked)
+  const unsigned xo = ((sx - s0) * (unsigned)p.c1T + 2u * tx) * 4u;
+  r.x[0] = __builtin_bit_cast(f32x4, (v4u)__builtin_amdgcn_raw_buffer_load_b128(rsX, xo, 0u, 0));
+  r.x[1] = __builtin_bit_cast(f32x4, (v4u)__builtin_amdgcn_raw_buffer_load_b128(rsX, xo + 16u, 0u, 0));
   return r;
 }
 __device__ __forceinline__ void v6_epilogue_c1w(const tl_nt_params& p, const f32x16 (&acc)[8], const v6_pre_c1w& pre, float* xw,
-                                                float* red, long long R0, int n0, int wm, int wn, int lr, int lh, long long tm) {
+                                                float* red, long long R0, int n0, int wm, int wn, int lr_in, int lh, long long tm) {
+  // (an opaque copy of the lane index: what the bit transposes derive from it is then computed here, per tile, instead of
+  // being hoisted out of the tile loop into registers that do not exist - they came back as scratch reloads)
+  int lr = lr_in;
+  asm volatile("" : "+v"(lr));
   const int colbase = n0 + wn * 32;
   const bool colok = colbase < p.N;
   const int col = colbase + lr;
@@ -377,38 +393,37 @@ __device__ __forceinline__ void v6_epilogue_c1w(const tl_nt_params& p, const f32
   // rows that count: time below Tvalid, inside the matrix
   const bits96 okA = v6_valid_bits96(rw.tA, Tp, p.Tvalid, Rw, p.M);
   const bits96 okB = v6_valid_bits96(rw.tB, Tp, p.Tvalid, Rw + 96, p.M);
-  float* xh = xw + lh * 192;                                 // this half's table: row r of the pass at xh + 4 r
+  float* xh = xw + lh * 256;                                 // this half's sample table: rows 3 l .. 3 l + 2 at xh + 8 l
+  *reinterpret_cast<f32x4*>(xh + 8 * lr) = pre.x[0];
+  *reinterpret_cast<f32x4*>(xh + 8 * lr + 4) = pre.x[1];
   c1w_acc ca;
   ca.clear();
+  uint32_t sT[3], cT[3];                                    // bit j: sign / conv1 arg-max of (row 32 k + j, this lane's column)
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 0) {
-      *reinterpret_cast<f32x4*>(xh + 4 * lr) = pre.x[0];                       // rows 0..31
-      if (lr < 16) *reinterpret_cast<f32x4*>(xh + 4 * (32 + lr)) = pre.x[1];   // rows 32..47
-    } else {
-      if (lr >= 16) *reinterpret_cast<f32x4*>(xh + 4 * (lr - 16)) = pre.x[1];  // rows 48..63
-      *reinterpret_cast<f32x4*>(xh + 4 * (16 + lr)) = pre.x[2];                // rows 64..95
+  for (int k = 0; k < 3; ++k) {
+    sT[k] = bit_transpose32(pre.s[k], lr);
+    cT[k] = bit_transpose32(pre.c[k], lr);
+  }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float y[6];
+    wino63_rows(acc, e, y);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      const int r = 6 * e + h;
+      // window of row r: samples 2 (r % 3) .. + 3 of the eight of its row triple (half-wave-uniform address: a broadcast)
+      const float2 xa = *reinterpret_cast<const float2*>(xh + 8 * (r / 3) + 2 * (r % 3));
+      const float2 xb = *reinterpret_cast<const float2*>(xh + 8 * (r / 3) + 2 * (r % 3) + 2);
+      const float dz = selm0(mask96(okA, okB, r), y[h] * selbit(sT[r >> 5], r & 31, 1.f, p.slope));
+      const uint32_t am = (uint32_t)__builtin_amdgcn_sbfe((int)cT[r >> 5], r & 31, 1);
+      auto pick = [am](float a, float b) { return __uint_as_float((__float_as_uint(a) & am) | (__float_as_uint(b) & ~am)); };
+      ca.s[0] = fmaf(dz, pick(xa.y, xa.x), ca.s[0]);
+      ca.s[1] = fmaf(dz, pick(xb.x, xa.y), ca.s[1]);
+      ca.s[2] = fmaf(dz, pick(xb.y, xb.x), ca.s[2]);
+      ca.b += dz;
     }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int e8 = 0; e8 < 8; ++e8) {
-      const int e = 8 * pass + e8;
-      float y[6];
-      wino63_rows(acc, e, y);
-#pragma unroll
-      for (int h = 0; h < 6; ++h) {
-        const int r = 6 * e + h;
-        const f32x4 xs = *reinterpret_cast<const f32x4*>(xh + 4 * (r - 48 * pass));
-        const unsigned long long mpos = words_as_mask(pre.s[r >> 5], r & 31);
-        const unsigned long long mam = words_as_mask(pre.c[r >> 5], r & 31);
-        const float dz = selm0(mask96(okA, okB, r), selm(mpos, y[h], y[h] * p.slope));
-        ca.s[0] = fmaf(dz, selm(mam, xs[1], xs[0]), ca.s[0]);
-        ca.s[1] = fmaf(dz, selm(mam, xs[2], xs[1]), ca.s[1]);
-        ca.s[2] = fmaf(dz, selm(mam, xs[3], xs[2]), ca.s[2]);
-        ca.b += dz;
-      }
-    }
-    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);                       // (keeps the loads of later hexes from being hoisted: they spill)
   }
   __syncthreads();                                          // `red` is a K-loop stage: every wave past its last fragment read
   c1w_reduce_store<4, 64>(p, red, ca, wm, wn * 32 + lr, lh, tm, col, colok);
