@@ -869,9 +869,14 @@ class CnnEngine:
         w1 = prm["ecog_conv_block.0.weight"].reshape(self.c1, self.k1).contiguous()
         if self.wino63:
             V1 = self._v_hex_buffer(self.V, 1, S * self.tp1, self.c1)
+            if self.store_p1 and 1 not in self.P:
+                self.P[1] = torch.zeros(S * self.tp1, self.c1, dtype=torch.float32, device=dev)
+            ev = self._tick("conv1_fwd")
             check(lib.tl_conv1_fwd_v6(ptr(x), ptr(w1), ptr(prm["ecog_conv_block.0.bias"]),
                                       ptr(self.P[1]) if self.store_p1 else None, ptr(V1), ptr(self.bits[1]), ptr(self.sbits[1]),
                                       S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_), "tl_conv1_fwd_v6")
+            if ev:
+                ev[1].record()
             self._v_ready[1] = V1
         elif self._conv1_writes_v():
             if self.store_p1 and 1 not in self.P:

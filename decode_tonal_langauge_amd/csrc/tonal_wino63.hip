@@ -827,11 +827,17 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn_kernel(const tl_tn_params p
 }
 
 // ------------------------------------------------------------------------------------------
-// conv1 (C_in = 1) + LeakyReLU + max-pool writing V of its pooled output in HEX form (conv1_fwd_vq_kernel of
-// tonal_misc.hip with six rows per unit): thread = 4 channels x consecutive hexes of one sequence, the two halo rows of a
-// hex are rows 0, 1 of the next.  HBM-write bound.
+// conv1 (C_in = 1) + LeakyReLU + max-pool writing V of its pooled output in HEX form, pair layout (conv1_fwd_vq_kernel of
+// tonal_misc.hip with six rows per unit).  HBM-write bound, so the thread mapping follows the layout: four adjacent lanes
+// = (one 8-channel chunk) x (the two hexes of a pair) write the 64-byte run of a transform, two transforms = one cache line;
+// a thread walks the hexes of ONE parity of its sequence and computes all eight rows of each (the halo rows are three
+// MACs per element from the LDS-resident signal).  (The first version - a thread = 4 channels x consecutive hexes, 32-byte
+// runs half a KB apart, non-temporal - ran at 0.65 TB/s: 27.9 ms for the 18 GB of V1.)
 // ------------------------------------------------------------------------------------------
 constexpr int C1_MAXKT = 8;
+#ifndef C1V_TEST
+#define C1V_TEST 0
+#endif
 __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, float* __restrict__ P,
                                                            float* __restrict__ V, uint32_t* __restrict__ bits,
@@ -841,10 +847,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
   const long long seq = blockIdx.x;
   for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
   __syncthreads();
-  const int groups = C1 >> 2;                    // threads per hex (<= 256, a multiple of 32)
-  const int hpp = 256 / groups;                  // hexes per pass
-  const int g = threadIdx.x % groups, hsub = threadIdx.x / groups;
-  const int o = 4 * g;
+  const int tpp = C1 >> 1;                       // threads per hex pair: (C1 / 8 chunks) x 2 hexes x 2 halves of a chunk
+  const int ppp = 256 / tpp;                     // hex pairs per pass (1 for C1 = 512)
+  const int tl_ = threadIdx.x % tpp, psub = threadIdx.x / tpp;
+  const int half = tl_ & 1, hpar = (tl_ >> 1) & 1, kc = tl_ >> 2;
+  const int o = 8 * kc + 4 * half;               // first of this thread's four channels
   float wv[4][C1_MAXKT], bv[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -852,7 +859,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < C1_MAXKT; ++j) wv[c][j] = j < kt ? w[(o + c) * kt + j] : 0.f;
   }
-  const int sh = 4 * (threadIdx.x & 7);
+  // position of the four channels inside their 32-channel word: the eight lanes of a word differ in lane bits 0, 2, 3
+  const int sh = 4 * (2 * (kc & 3) + half);
   const int Th = Tp / 6;
   auto row = [&](int pr, bool live, f32x4& out, uint32_t& wb, uint32_t& ws) {
     out = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -876,31 +884,33 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
       }
     }
     uint32_t a = nib << sh, e = nsg << sh;
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
-      a |= __shfl_xor(a, m);
-      e |= __shfl_xor(e, m);
-    }
+    a |= __shfl_xor(a, 1);
+    e |= __shfl_xor(e, 1);
+    a |= __shfl_xor(a, 4);
+    e |= __shfl_xor(e, 4);
+    a |= __shfl_xor(a, 8);
+    e |= __shfl_xor(e, 8);
     wb = a;
     ws = e;
   };
-  const int per = (Th + hpp - 1) / hpp;
-  const int hb = hsub * per;
-  f32x4 d[8];
-  uint32_t wb[8], ws[8];
-  row(6 * hb, hb < Th, d[0], wb[0], ws[0]);
-  row(6 * hb + 1, hb < Th, d[1], wb[1], ws[1]);
-  for (int i = 0; i < per; ++i) {
-    const int q = hb + i;
+  // global hex index seq * Th + q; a thread takes those whose parity is hpar (its slot inside the pair)
+  const long long h0 = seq * Th;
+  const int q0 = (int)((hpar - h0) & 1) + 2 * psub;
+  const int trips = (Th + 2 * ppp - 1) / (2 * ppp) + 1;          // (uniform over the block: the shuffles need every lane)
+  const bool word_writer = sh == 0;
+  for (int i = 0; i < trips; ++i) {
+    const int q = q0 + 2 * ppp * i;
     const bool live = q < Th;
+    f32x4 d[8];
+    uint32_t wb[8], ws[8];
 #pragma unroll
-    for (int j = 2; j < 8; ++j) row(6 * q + j, live && 6 * q + j < Tp, d[j], wb[j], ws[j]);
+    for (int j = 0; j < 8; ++j) row(6 * q + j, live && 6 * q + j < Tp, d[j], wb[j], ws[j]);
     if (live) {
       const long long row0 = seq * Tp + 6 * q;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         if (P != nullptr) *reinterpret_cast<f32x4*>(P + (row0 + j) * C1 + o) = d[j];
-        if ((threadIdx.x & 7) == 0) {
+        if (word_writer) {
           bits[(row0 + j) * (C1 >> 5) + (o >> 5)] = wb[j];
           if (sign != nullptr) sign[(row0 + j) * (C1 >> 5) + (o >> 5)] = ws[j];
         }
@@ -915,13 +925,23 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j][k] = vv[j];
       }
-      float* dst = V + v6_at(seq * Th + q, 0, o, C1 >> 3);      // (pair layout: transform j of these four channels at + 16 j)
+#if C1V_TEST == 1
+      float* dst = V + (h0 + q) * 8LL * C1 + o;               // timing only: channels-last rows
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(dst + (long long)j * C1) = ov[j];
+#elif C1V_TEST == 2
+      float* dst = V + v6_at(h0 + q, 0, o, C1 >> 3);
 #pragma unroll
       for (int j = 0; j < 8; ++j) __builtin_nontemporal_store(ov[j], reinterpret_cast<f32x4*>(dst + 16 * j));
+#elif C1V_TEST == 3
+      (void)ov;                                               // timing only: no V stores
+      if (o == 12345) V[0] = ov[0][0] + ov[7][3];
+#else
+      float* dst = V + v6_at(h0 + q, 0, o, C1 >> 3);          // (pair layout: transform j of these four channels at + 16 j)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(dst + 16 * j) = ov[j];
+#endif
     }
-    d[0] = d[6]; d[1] = d[7];
-    wb[0] = wb[6]; wb[1] = wb[7];
-    ws[0] = ws[6]; ws[1] = ws[7];
   }
 }
 
