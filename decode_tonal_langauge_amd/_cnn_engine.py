@@ -70,7 +70,7 @@ class CnnEngine:
         # 6 conv rows).  A sequence of stage 2 holds a multiple of 12 rows (hexes of 6 rows, pooled into hexes of stage 3);
         # the pooled output of stage 3 keeps the row stride of the default geometry (tl_nt_params.out_tp), so everything from
         # stage 4 on is unchanged.  Shapes the form does not cover fall back to TONAL_WINO=4 as a whole.
-        self.wino63 = os.environ.get("TONAL_WINO", "4") == "6" and self._f63_covers(stage_defs, n_timepoints)
+        self.wino63 = os.environ.get("TONAL_WINO", "6") == "6" and self._f63_covers(stage_defs, n_timepoints)
         tp1_default = self.tp1
         if self.wino63:
             self.tp1 = (self.tout1 + 11) // 12 * 12
@@ -104,14 +104,16 @@ class CnnEngine:
         self._sh = None
         self.timers = None
         # Winograd kernels for the pooled 3-tap stages.  TONAL_WINO selects the form:
+        #   6  default (round 4): F(6,3) on pre-transformed operands for all three passes of stages 2 and 3 where the stack
+        #      allows it (_f63_covers; 4/9 of the direct-form MFMA work), the F(4,3) forms below everywhere else
         #   0  direct-form MFMA kernels (the parity partner)
         #   1  F(2,3) for all three passes (2/3 of the direct-form MFMA work)
-        #   4  default: F(4,3) for the forward and input-gradient passes (1/2 of the MFMA work), F(2,3)
+        #   4  (default until round 3) F(4,3) for the forward and input-gradient passes (1/2 of the MFMA work), F(2,3)
         #      for the weight gradient: 3 % faster per step than F(2,3) (304.5 vs 314 ms at the
         #      north-star shape); rounding error against the direct kernels 1.4e-6 vs 8e-7.  Against the
         #      reference golden all three forms sit at the same noise floor (scripts/update_parity.py,
         #      DESIGN.md section 6)
-        mode = os.environ.get("TONAL_WINO", "4")
+        mode = os.environ.get("TONAL_WINO", "6")
         if mode == "6":
             mode = "4"                          # (the F(4,3) predicates describe the fallback; wino63 overrides stages 2, 3)
         self.wino = mode != "0"

@@ -59,6 +59,20 @@ def test_abi_argument_validation_without_gpu():
     t.Krows, t.Tp = 32, 6
     assert lib.tl_conv3_wino43_tn(C.byref(t), None) == -1 and b"Tp" in lib.tl_last_error()
     assert lib.tl_wino43_wgrad_finalize(None, None, 4, 4, 4, None) == -1
+    # round-4 entry points: Winograd F(6,3) on pre-transformed operands (argument checks only: no GPU call is reached)
+    assert lib.tl_conv3_wino63v_nt(None, None) == -1 and lib.tl_conv3_wino63v_tn(None, None) == -1
+    assert lib.tl_wino63_weights(16, 16, None, 8, 12, 12, 8, None) == -1 and b"multiples of 8" in lib.tl_last_error()
+    assert lib.tl_wino63_wgrad_finalize(None, None, 4, 4, 4, None) == -1
+    assert lib.tl_wino63_v_fixup(16, 16, 4, 1, 8, 8, 8, None) == -1 and b"Tq" in lib.tl_last_error()           # Tq % 6
+    assert lib.tl_conv1_fwd_v6(16, 16, 16, None, 16, 16, None, 4, 100, 3, 96, 48, 49, 0.01, None) == -1 and b"C1" in lib.tl_last_error()
+    assert lib.tl_conv1_fwd_v6(16, 16, 16, None, 16, 16, None, 4, 100, 3, 128, 50, 49, 0.01, None) == -1 and b"multiple of 6" in lib.tl_last_error()
+    t6 = _lib.TnParams()
+    t6.A = t6.B = t6.slab = t6.bbits = 16
+    t6.J, t6.loader, t6.Krows, t6.Mdim, t6.Ndim, t6.lda, t6.ldb, t6.ldc, t6.Tp, t6.Tvalid = 3, 1, 24, 128, 64, 128, 64, 64, 8, 4
+    t6.A_rows, t6.B_rows, t6.ld_bbits = 128, 12, 2
+    assert lib.tl_conv3_wino63v_tn(C.byref(t6), None) == -1 and b"Tp" in lib.tl_last_error()                   # Tp % 6
+    t6.Tp, t6.Mdim = 12, 64
+    assert lib.tl_conv3_wino63v_tn(C.byref(t6), None) == -1 and b"Mdim" in lib.tl_last_error()                 # C_in % 128
     assert lib.tl_lstm_cell_infer(None, 0, 0, None, 0, None, None, 4, 8, 1, None) == -1
     assert lib.tl_lstm_cell_infer(None, 0, 0, 16, 16, 16, 16, 4, 8, 0, None) == -1 and b"recurrent" in lib.tl_last_error()
     assert lib.tl_lstm_infer_seq(16, 10, 16, 16, 16, 16, 1, 4, 6, 3, None) == -1 and b"multiple of 4" in lib.tl_last_error()
@@ -118,15 +132,28 @@ def test_models_refuse_cpu_tensors_and_keep_reference_state_dict():
         LogisticRegressionClassifier(8, 2)(torch.randn(3, 9))
 
 
-def test_engine_geometry_north_star():
+def test_engine_geometry_north_star(monkeypatch):
     from decode_tonal_langauge_amd._cnn_engine import CnnEngine
     from oracle.synthesis_oracle import ECOG_STAGES
     stages = [(c if c else 64, k, p) for c, k, p in ECOG_STAGES]
+    monkeypatch.setenv("TONAL_WINO", "4")
     e = CnnEngine(80, 128, 400, 6, 64, 0.5, 0.01, stages, [128, 128, 128, 128, 64])
-    assert (e.tout1, e.tp1) == (199, 200)
+    assert (e.tout1, e.tp1) == (199, 200) and not e.wino63
     assert [(s.tin, s.tc, s.tout, s.tp_in, s.tp_out) for s in e.stages] == [
         (199, 197, 98, 200, 100), (98, 96, 48, 100, 50), (48, 48, 24, 50, 25), (24, 24, 24, 25, 25)]
     assert e.lat == 24 and e.H == 18432 and e.kflat == 128 * 25 * 64 and e.ldx == 72
+    # default since round 4: F(6,3) for stages 2 and 3 - sequences of whole hexes (204 = 34 x 6 rows, 102 = 17 x 6), the
+    # output of stage 3 back on the default row stride (50, not 51): nothing behind stage 3 changes
+    monkeypatch.delenv("TONAL_WINO")
+    e = CnnEngine(80, 128, 400, 6, 64, 0.5, 0.01, stages, [128, 128, 128, 128, 64])
+    assert e.wino63 and (e.tout1, e.tp1) == (199, 204)
+    assert [(s.tin, s.tc, s.tout, s.tp_in, s.tp_out) for s in e.stages] == [
+        (199, 197, 98, 204, 102), (98, 96, 48, 102, 50), (48, 48, 24, 50, 25), (24, 24, 24, 25, 25)]
+    assert e.lat == 24 and e.H == 18432 and e.kflat == 128 * 25 * 64 and e.ldx == 72
+    assert abs(e.f63_issue_factor(e.stages[0]) - 34 * 8 / (197 * 3)) < 1e-12
+    # a stack the F(6,3) kernels do not cover (C_out of stage 3 not a multiple of 64) keeps the F(4,3) geometry
+    e3 = CnnEngine(80, 8, 200, 4, 8, 0.0, 0.01, [(128, 3, True), (128, 3, True), (96, 3, True), (32, 1, True), (8, 1, False)], [16, 8])
+    assert not e3.wino63 and e3.tp1 % 8 == 0
     e2 = CnnEngine(80, 16, 200, 6, 64, 0.0, 0.01, stages, [128, 128, 128, 128, 64])
     assert e2.lat == 11 and e2.H == 1056
     with pytest.raises(ValueError):

@@ -524,16 +524,17 @@ def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
         lab = torch.randint(0, 4, (B, 2, 5), generator=g).float()
         tgt = torch.randn(B, 80, generator=g)
         outs, grads = [], []
-        for flag in ("0", "1", "4"):              # direct, F(2,3), default (F(4,3) forward / input gradient)
+        for flag in ("0", "1", "4", "6"):         # direct, F(2,3), F(4,3), default (F(6,3) on pre-transformed operands)
             monkeypatch.setenv("TONAL_WINO", flag)
             torch.manual_seed(1)
             model = SynthesisModelCNN(80, C, T, dropout=0.0).to(dev).train()
-            assert model._engine.wino == (flag != "0") and model._engine.wino43 == (flag == "4")
+            assert model._engine.wino == (flag != "0") and model._engine.wino43 == (flag in "46")
+            assert model._engine.wino63 == (flag == "6")
             out = model(x.to(dev), lab.to(dev))
             (out - tgt.to(dev)).abs().mean().backward()
             outs.append(out.detach().cpu().numpy())
             grads.append({k: p.grad.cpu().numpy() for k, p in model.named_parameters()})
-        for v in (1, 2):
+        for v in (1, 2, 3):
             assert rel(outs[v], outs[0]) < 1e-5
             for k in grads[0]:
                 assert rel_l2(grads[v][k], grads[0][k]) < 5e-3, k
@@ -621,6 +622,7 @@ def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
     res = {}
     for mode in ("0", "1", "4"):
         eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
+        assert not eng.wino63                      # (widths the F(6,3) kernels do not cover: the F(4,3) / F(2,3) / direct forms)
         eng.wino, eng.wino43, eng.fuse_c1 = mode != "0", mode == "4", False
         eng.wino_vout = False          # stage kernels one at a time on random inputs: every stage reads P
         eng._alloc(B, dev)
@@ -659,13 +661,14 @@ def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
 
 @pytest.mark.parametrize("shape", [(3, 5, 236, (128, 128, 64)), (2, 3, 400, (128, 256, 128)), (1, 1, 44, (128, 128, 128)),
                                    (7, 3, 100, (64, 192, 64))])
-def test_forward_epilogue_writes_the_next_stage_operand(dev, shape):
+def test_forward_epilogue_writes_the_next_stage_operand(dev, shape, monkeypatch):
     """Round 4: the forward kernel of a pooled 3-tap stage writes V = the F(4,3) input transform of its own pooled output
     (epilogue 5 + tl_wino43_v_fixup) instead of the raw rows.  With the raw rows stored as well (store_p1) the V it wrote
     must be the transform of exactly those rows - including the quads that take rows from the next half-wave, the next
     wave, the next tile (fix-up pass) and the quads that end a sequence - and rows / bits must equal the plain POOL launch."""
     from decode_tonal_langauge_amd._cnn_engine import CnnEngine
     from decode_tonal_langauge_amd._lib import check, ptr
+    monkeypatch.setenv("TONAL_WINO", "4")              # (the F(4,3) kernels; test_f63_* below hold the default form)
     B, C, T, (c1, c2, c3) = shape
     defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
     res = {}
@@ -701,12 +704,13 @@ def test_forward_epilogue_writes_the_next_stage_operand(dev, shape):
 
 
 @pytest.mark.parametrize("shape", [(3, 5, 236, (128, 128, 64)), (2, 3, 400, (128, 256, 128)), (1, 1, 44, (128, 128, 128))])
-def test_weight_gradient_tilings_agree_bit_for_bit(dev, shape):
+def test_weight_gradient_tilings_agree_bit_for_bit(dev, shape, monkeypatch):
     """The three V-form F(4,3) weight-gradient kernels (64-wide C_in tile; 128-wide with Y staged through registers; 128-wide
     with the Y side by LDS-DMA and the workgroups taking turns at Vd - the product path where C_in % 128 == 0 and C_out % 64
     == 0) keep the same k order per accumulator: weight gradient, bias gradient and the Vd they write must be identical,
     on shapes with ragged last K-steps, sequences shorter than a K-step and empty reduction splits."""
     from decode_tonal_langauge_amd._cnn_engine import CnnEngine
+    monkeypatch.setenv("TONAL_WINO", "4")
     B, C, T, (c1, c2, c3) = shape
     defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
     eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
@@ -830,7 +834,7 @@ def test_sparse_tone_mapping_keeps_the_label_lstm_finite(dev):
         assert torch.equal(v, finals[0][k]), k
 
 
-@pytest.mark.parametrize("wino", ["4", "1", "0"])
+@pytest.mark.parametrize("wino", ["6", "4", "1", "0"])
 def test_cnn_training_trajectory_matches_reference_golden(dev, monkeypatch, wino):
     """G14: 30 NAdam steps of the reference's SynthesisModelCNN(80, 16, 200, dropout=0) on 30 seeded batches - the HIP
     path's L1 loss, MCD and mel MSE mean((out - target)^2) stay within 1e-3 of the reference at EVERY step (the bound
@@ -844,7 +848,7 @@ def test_cnn_training_trajectory_matches_reference_golden(dev, monkeypatch, wino
     torch.manual_seed(int(g["seed"]))
     model = SynthesisModelCNN(D, C, T, dropout=0.0)
     tr = _trainer(model, dev, T)
-    assert model._engine.wino == (wino != "0") and model._engine.wino43 == (wino == "4")
+    assert model._engine.wino == (wino != "0") and model._engine.wino43 == (wino in "46") and model._engine.wino63 == (wino == "6")
     model.train()
     worst = 0.0
     for s in range(N):
@@ -1087,3 +1091,137 @@ def test_stage_step_and_slab_sums_small_entry_points(dev):
     assert float((ra - a.double().sum(0).float()).abs().max()) < 1e-5 and float((rb - b.double().sum(0).float()).abs().max()) < 1e-5
     check(lib.tl_sum_slabs2(ptr(a), ptr(ra), 300, None, None, 0, 17, st), "tl_sum_slabs2")      # second tensor optional
     assert float((ra - a.double().sum(0).float()).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 200, 128, 128, 64), (3, 5, 236, 128, 256, 128), (1, 1, 44, 128, 128, 128),
+                                   (7, 3, 100, 256, 128, 64), (6, 8, 400, 512, 512, 512)])
+def test_f63_stage_kernels_match_direct_kernels(dev, shape, monkeypatch):
+    """Round 4: the Winograd F(6,3) kernels (default where the stack allows them) against the direct MFMA kernels, stage by
+    stage through the C ABI: conv1 writing V1 in hex form (== B^T of the raw rows it stores on request), conv2 forward
+    writing V2 (epilogue 5 + fix-up: hexes that take rows from the next half-wave, wave, tile; hexes that end a sequence),
+    conv3 forward with the decoupled output row stride, both weight gradients incl. the Vd they write (== B^T of the
+    un-pooled gradient), both input gradients and the fused conv1 weight gradient.  Shapes: sequences shorter than a
+    half-wave's rows, ragged last tiles, a pooled row count that is odd (400 -> 51 rows per sequence behind conv3's hexes)."""
+    from decode_tonal_langauge_amd._cnn_engine import CnnEngine
+    from decode_tonal_langauge_amd._lib import check, ptr
+    from tests.wino63_ref import hex_transform, logical, unpool
+    B, C, T, c1, c2, c3 = shape
+    defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
+    engs = {}
+    for mode in ("0", "6"):
+        monkeypatch.setenv("TONAL_WINO", mode)
+        eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
+        eng.store_p1 = True
+        if mode == "0":
+            eng.fuse_c1 = False
+        eng._alloc(B, dev)
+        eng._alloc_bwd()
+        engs[mode] = eng
+    e0, e6 = engs["0"], engs["6"]
+    assert e6.wino63 and not e0.wino63 and e6.tp1 % 12 == 0
+    S = e6.S
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(B, C, T, device=dev, generator=g)
+    names = {1: "ecog_conv_block.0", 2: "ecog_conv_block.3", 3: "ecog_conv_block.6"}
+    prm = {names[1] + ".weight": torch.randn(c1, 1, 3, 1, device=dev, generator=g) * 0.5,
+           names[1] + ".bias": torch.randn(c1, device=dev, generator=g) * 0.1}
+    cin = c1
+    for i, co in ((2, c2), (3, c3)):
+        prm[names[i] + ".weight"] = torch.randn(co, cin, 3, 1, device=dev, generator=g) * (1.0 / (3 * cin) ** 0.5)
+        prm[names[i] + ".bias"] = torch.randn(co, device=dev, generator=g) * 0.1
+        cin = co
+    st_ = torch.cuda.current_stream().cuda_stream
+    w1 = prm[names[1] + ".weight"].reshape(c1, 3).contiguous()
+    for eng in (e0, e6):
+        eng._x = x.contiguous()
+        eng.generation += 1
+        eng._v_ready = {}
+        if eng.wino63:
+            V1 = eng._v_hex_buffer(eng.V, 1, S * eng.tp1, c1)
+            check(eng.lib.tl_conv1_fwd_v6(ptr(x), ptr(w1), ptr(prm[names[1] + ".bias"]), ptr(eng.P[1]), ptr(V1), ptr(eng.bits[1]),
+                                          ptr(eng.sbits[1]), S, T, 3, c1, eng.tp1, eng.tout1, eng.slope, st_), "tl_conv1_fwd_v6")
+            eng._v_ready[1] = V1
+        else:
+            check(eng.lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm[names[1] + ".bias"]), ptr(eng.P[1]), ptr(eng.bits[1]),
+                                       ptr(eng.sbits[1]), S, T, 3, c1, eng.tp1, eng.tout1, eng.slope, st_), "tl_conv1_fwd")
+
+    def rows(t, tp, n):          # the first n rows of every sequence of a (S * tp, C) tensor
+        return t.view(S, tp, -1)[:, :n]
+
+    tin2 = e6.stages[0].tin
+    assert torch.equal(rows(e6.P[1], e6.tp1, tin2), rows(e0.P[1], e0.tp1, tin2))
+    assert torch.equal(rows(e6.bits[1], e6.tp1, tin2), rows(e0.bits[1], e0.tp1, tin2))
+    Vref = hex_transform(e6.P[1], S, e6.tp1)
+    assert torch.allclose(logical(e6.V[1])[:Vref.shape[0]].double(), Vref, rtol=1e-6, atol=1e-6)
+    assert float(e6.V[1][Vref.shape[0]:].abs().max()) == 0.0
+    for si in (2, 3):
+        for eng in (e0, e6):
+            eng.stage_forward(eng.stages[si - 2], prm[names[si] + ".weight"], prm[names[si] + ".bias"])
+        s0, s6 = e0.stages[si - 2], e6.stages[si - 2]
+        nv = s6.tout
+        assert rel(rows(e6.P[si], s6.tp_out, nv).cpu().numpy(), rows(e0.P[si], s0.tp_out, nv).cpu().numpy()) < 2e-5, si
+        assert float(rows(e6.P[si], s6.tp_out, s6.tp_out)[:, nv:].abs().max()) == 0.0 if s6.tp_out > nv else True
+        for b6, b0 in ((e6.bits, e0.bits), (e6.sbits, e0.sbits)):
+            flips = rows(b6[si], s6.tp_out, nv) ^ rows(b0[si], s0.tp_out, nv)
+            assert int((flips != 0).sum()) <= 4, si                      # arg-max / sign ties only
+        if si == 2:
+            V2ref = hex_transform(e6.P[2], S, s6.tp_out)
+            V2 = e6._v_ready[2]
+            assert torch.allclose(logical(V2)[:V2ref.shape[0]].double(), V2ref, rtol=1e-6, atol=1e-6)
+            keep = V2.clone()
+            e6.stage_forward(s6, prm[names[2] + ".weight"], prm[names[2] + ".bias"])      # (raw hexes of the fix-up pass rewritten)
+            assert torch.equal(e6._v_ready[2], keep)
+    # ---- backward from a random G3; the direct engine un-pools with the F(6,3) engine's bits (ties may differ) ----
+    s0, s6 = e0.stages[1], e6.stages[1]
+    G3 = torch.randn(S, s6.tp_out, c3, device=dev, generator=g)
+    G3[:, s6.tout:] = 0
+    e6.G[3].copy_(G3.reshape(-1, c3))
+    e0.G[3].view(S, s0.tp_out, c3).zero_()
+    e0.G[3].view(S, s0.tp_out, c3)[:, :s6.tout] = G3[:, :s6.tout]
+    for idx in (2, 3):
+        a, b = e0.stages[idx - 2], e6.stages[idx - 2]
+        e0.bits[idx].view(S, a.tp_out, -1)[:, :b.tout] = e6.bits[idx].view(S, b.tp_out, -1)[:, :b.tout]
+        e0.sbits[idx].view(S, a.tp_out, -1)[:, :b.tout] = e6.sbits[idx].view(S, b.tp_out, -1)[:, :b.tout]
+    for si in (3, 2):
+        res = {}
+        for key, eng in (("0", e0), ("6", e6)):
+            st = eng.stages[si - 2]
+            w = prm[names[si] + ".weight"]
+            gw, gb = torch.zeros_like(w), torch.zeros(st.cout, device=dev)
+            eng.stage_wgrad(st, gw, gb)
+            res[key] = (gw, gb, eng.stage_dgrad(st, w))
+        s0, s6 = e0.stages[si - 2], e6.stages[si - 2]
+        assert rel_l2(res["6"][0].cpu().numpy(), res["0"][0].cpu().numpy()) < 1e-5, si
+        assert rel_l2(res["6"][1].cpu().numpy(), res["0"][1].cpu().numpy()) < 1e-5, si
+        dz = unpool(e6.G[si], e6.bits[si], S, s6.tp_out, 2 * s6.tout, s6.cout)
+        if 2 * s6.tp_out < s6.tp_in:
+            dz = torch.nn.functional.pad(dz, (0, 0, 0, s6.tp_in - 2 * s6.tp_out))
+        Vdref = hex_transform(dz[:, :s6.tp_in].reshape(-1, s6.cout), S, s6.tp_in, shift=-2)
+        assert torch.allclose(logical(e6.Vd[si])[:Vdref.shape[0]].double(), Vdref, rtol=1e-6, atol=1e-6), si
+        if si == 3:
+            nin = s6.tin
+            assert rel_l2(rows(e6.G[2], s6.tp_in, nin).cpu().numpy(), rows(e0.G[2], s0.tp_in, nin).cpu().numpy()) < 1e-5
+            e6.G[2].view(S, s6.tp_in, -1).zero_()
+            e6.G[2].view(S, s6.tp_in, -1)[:, :nin] = e0.G[2].view(S, s0.tp_in, -1)[:, :nin]
+        else:
+            nblk = int(min(2048, S))
+            p0 = torch.empty(nblk, 4 * c1, device=dev)
+            check(e0.lib.tl_conv1_wgrad(ptr(e0._x), ptr(e0.G[1]), ptr(e0.bits[1]), ptr(p0), nblk, S, T, 3, c1, e0.tp1, e0.tout1, st_),
+                  "tl_conv1_wgrad")
+            assert rel_l2(res["6"][2].sum(0).cpu().numpy(), p0.sum(0).cpu().numpy()) < 1e-5
+    # ---- the C ABI refuses what the kernels do not cover ----
+    lib = e6.lib
+    p = _lib_nt()
+    assert lib.tl_conv3_wino63v_nt(None, None) != 0 and lib.tl_conv3_wino63v_tn(None, None) != 0
+    dummy = torch.zeros(64, device=dev)
+    for k in ("A", "Bw", "out"):
+        setattr(p, k, dummy.data_ptr())
+    p.loader, p.J, p.M, p.N, p.K, p.lda, p.ldb, p.Tp, p.A_rows = 2, 3, 12, 32, 16, 16, 16, 12, 128      # K < 24
+    assert lib.tl_conv3_wino63v_nt(C_.byref(p), None) != 0 and b"wino63v_nt" in lib.tl_last_error()
+    p.K, p.lda, p.ldb, p.Tp = 32, 32, 32, 8                                                            # Tp % 6
+    assert lib.tl_conv3_wino63v_nt(C_.byref(p), None) != 0 and b"Tp" in lib.tl_last_error()
+
+
+def _lib_nt():
+    from decode_tonal_langauge_amd import _lib
+    return _lib.NtParams()
