@@ -18,6 +18,8 @@ from ._lib import EPI_LRELU, EPI_STORE, LOAD_DIRECT, check, ptr
 
 
 class CnnClassifierEngine(CnnEngine):
+    F63_CAPABLE = False        # this engine enqueues its stages itself on the F(4,3) / F(2,3) / direct kernels
+
     def __init__(self, n_electrodes: int, n_timepoints: int, stage_defs, hidden: int, n_classes: int,
                  negative_slope: float):
         # reuse the conv-stack geometry / buffers of the synthesis engine (no LSTM / concat part)

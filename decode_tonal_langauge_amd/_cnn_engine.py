@@ -42,6 +42,9 @@ class _Stage:
 
 
 class CnnEngine:
+    #: the forward-only classifier engine (a subclass that walks the stages itself) keeps the F(4,3) geometry
+    F63_CAPABLE = True
+
     def __init__(self, output_dim: int, n_channels: int, n_timepoints: int, lstm_channels: int,
                  conv_channels: int, dropout: float, negative_slope: float, stage_defs, concat_widths):
         if negative_slope < 0:
@@ -70,7 +73,8 @@ class CnnEngine:
         # 6 conv rows).  A sequence of stage 2 holds a multiple of 12 rows (hexes of 6 rows, pooled into hexes of stage 3);
         # the pooled output of stage 3 keeps the row stride of the default geometry (tl_nt_params.out_tp), so everything from
         # stage 4 on is unchanged.  Shapes the form does not cover fall back to TONAL_WINO=4 as a whole.
-        self.wino63 = os.environ.get("TONAL_WINO", "6") == "6" and self._f63_covers(stage_defs, n_timepoints)
+        self.wino63 = (self.F63_CAPABLE and os.environ.get("TONAL_WINO", "6") == "6"
+                       and self._f63_covers(stage_defs, n_timepoints))
         tp1_default = self.tp1
         if self.wino63:
             self.tp1 = (self.tout1 + 11) // 12 * 12
@@ -338,7 +342,9 @@ class CnnEngine:
         S = self.S
         wp = self._pack_wino63(w, True)
         V = self._v_ready[st.idx - 1]
-        Pout = self.P.get(st.idx)
+        if st.idx == 2 and self.store_p1 and 2 not in self.P:       # (tests: the raw pooled rows of stage 2 as well)
+            self.P[2] = torch.zeros(S * st.tp_out, st.cout, dtype=torch.float32, device=self._dev)
+        Pout = self.P.get(st.idx) if (st.idx != 2 or self.store_p1) else None
         kw = dict(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], loader=LOAD_V, Bw=ptr(wp), bias=ptr(bia), out=ptr(Pout),
                   M=S * st.tp_in, N=st.cout, K=st.cin, ldb=st.cin, ldo=Pout.shape[1] if Pout is not None else st.cout, J=3,
                   row_shift=0, Tp=st.tp_in, slope=self.slope, obits=ptr(self.bits[st.idx]), osign=ptr(self.sbits[st.idx]),

@@ -974,7 +974,7 @@ extern "C" int tl_wino63_v_fixup(float* V, const float* vhalo, int64_t hexes, in
   using namespace tl;
   TL_REQUIRE(V && vhalo, "wino63_v_fixup: null pointer");
   TL_REQUIRE(hexes > 0 && tiles > 0 && Tq > 0 && Tq % 6 == 0, "wino63_v_fixup: hexes, tiles > 0 and Tq %% 6 == 0 needed");
-  TL_REQUIRE(C > 0 && C % 4 == 0 && ldv >= C && ldv % 8 == 0 && hexes % 2 == 0, "wino63_v_fixup: C %% 4, ldv %% 8, whole hex pairs needed");
+  TL_REQUIRE(C > 0 && C % 4 == 0 && ldv >= C && ldv % 8 == 0, "wino63_v_fixup: C %% 4 and ldv %% 8 needed");
   const long long n = (long long)tiles * (C / 4);
   TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_v_fixup: grid too large");
   hipLaunchKernelGGL(wino63_v_fixup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, vhalo,

@@ -107,7 +107,7 @@ def test_c3_shape_train_step_matches_reference_golden(dev, c3):
     assert torch.equal(out2, out)
     from tests.wino63_ref import hex_transform, logical
     Vref = hex_transform(eng.P[1], S, eng.tp1)
-    assert torch.allclose(logical(V1)[:Vref.shape[0]].double(), Vref, rtol=1e-6, atol=1e-6)
+    assert float((logical(V1)[:Vref.shape[0]].double() - Vref).abs().max()) <= 1e-6 * float(Vref.abs().max())
     assert float(V1[Vref.shape[0]:].abs().max()) == 0.0
     for i in (1, 2, 3, 4):
         st_tp = eng.tp1 if i == 1 else eng.stages[i - 2].tp_out
