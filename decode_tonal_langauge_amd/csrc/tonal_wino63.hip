@@ -827,6 +827,421 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn_kernel(const tl_tn_params p
 }
 
 // ------------------------------------------------------------------------------------------
+// The same weight gradient with the eight transforms split over TWO workgroups: tile 256 (C_in) x 64 (C_out) x FOUR
+// transforms.  What bounds the kernel above is the Y side - every workgroup of a (split, C_out tile) rebuilds the whole
+// Y = A dy tile, and on gfx950 that vector work displaces matrix work one for one (measured: 9.8 of 46.0 ms at conv2).
+// Here a workgroup builds only the four Y planes of its transforms for the same 24 MFMAs per wave and K-step: the
+// un-pool selects are shared, the output arithmetic halves, the Y stores halve, the B fragments halve (12 reads per
+// slice instead of 16); V tile, rings and pieces keep their sizes ([4][6 hexes][256 channels] = the 24 KB of [8][6][128]).
+// Selected where C_in is a multiple of 256.  Same k order per accumulator as the kernel above: bit-identical results.
+// ------------------------------------------------------------------------------------------
+template <bool WVD>
+__global__ __launch_bounds__(512, 1) void wino63v_tn4_kernel(const tl_tn_params p, int mtn) {
+  constexpr int NA = T6_NA, NG = T6_NG, GW = T6_GW, GT = T6_GT;
+  constexpr int QT = 4 * T6_PLANE;               // floats per quarter-tile of V / per Y tile: [4 transforms][6 hexes][64]
+  __shared__ __attribute__((aligned(1024))) float lds[(NA * 4 + 2) * QT + NG * GT + 2 * QT];
+  float* As = lds;                               // [4][4][4][6][64]  V ring (four 64-channel quarter-tiles, four transforms)
+  float* Bs = lds + NA * 4 * QT;                 // [2][4][6][64]     Y
+  float* Gs = Bs + 2 * QT;                       // [6]{[6 hexes][4 rows][64], [6][4][2 words]}
+  float* Ydummy = Gs + NG * GT;                  // where waves 6, 7 (no hex of their own) put their Y: no branch in the K-step
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int ntn = p.Ndim / T6_BN;
+  const long long tiles = 2LL * mtn * ntn;        // (transform half, C_in tile, C_out tile)
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int z = __builtin_amdgcn_readfirstlane((int)(bid / tiles));
+  const int tt = __builtin_amdgcn_readfirstlane((int)(bid % tiles));
+  // (the workgroups of one (split, C_out tile) are neighbours: they share the gradient rows through the L2 and take turns at Vd)
+  const int mi = __builtin_amdgcn_readfirstlane(tt % (2 * mtn));                    // slot among them: 2 x C_in tile + transform half
+  const int th = mi & 1, i0 = 4 * th;                                               // this workgroup's transforms: i0 .. i0 + 3
+  const int m0 = (mi >> 1) * 256, n0 = __builtin_amdgcn_readfirstlane((tt / (2 * mtn)) * T6_BN);
+  const int nslots = 2 * mtn;
+
+  const long long hexes_all = p.Krows / 6;
+  const long long ksteps_all = (hexes_all + T6_H - 1) / T6_H;
+  const long long per = __builtin_amdgcn_readfirstlane((int)((ksteps_all + p.splitk - 1) / p.splitk));
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const int nsteps = ks_end > ks_begin ? (int)(ks_end - ks_begin) : 0;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // ---- V by LDS-DMA: piece 3 wave + t -> quarter-tile pc / 6, rows 4 (pc % 6) .. + 3 of its 24 ([transform][hex] order);
+  // lane -> (row offset lane >> 4, physical 16-byte chunk lane & 15); odd hexes: halves swapped = source chunk ^ 8
+  const long long v_h0 = ks_begin * T6_H;                           // first hex of this split
+  // (V in the pair layout: v_h0 is even, a K-step is three pairs; the channel tile enters through the chunk index)
+  const int kc8 = p.lda >> 3;
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + v_h0 * 8 * (long long)p.lda), 0, clip31((p.A_rows - v_h0) * 8 * (long long)p.lda * 4), 0x00020000);
+  unsigned vvoff[3], vdst[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int quarter = (wave * 3 + t) / 6, pc = (wave * 3 + t) % 6;
+    const int rho = 4 * pc + (lane >> 4), i = rho / 6, hx = rho % 6;
+    const int chunk = (lane & 15) ^ ((hx & 1) << 3);
+    vvoff[t] = (unsigned)(v6_at(hx, i0 + i, m0 + quarter * 64 + chunk * 4, kc8) * 4);
+    vdst[t] = (unsigned)((quarter * QT + pc * 256) * 4);
+  }
+  const unsigned v_step = (unsigned)(T6_H * 8 * p.lda * 4);         // bytes per K-step (host-checked to fit)
+  auto issue_v = [&](int step) {
+    char* base = reinterpret_cast<char*>(As) + (step & (NA - 1)) * (4 * QT * 4);
+    const unsigned soff = (unsigned)step * v_step;          // (in the per-lane offset: that one is range-checked)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dma16h(rsV, base + vdst[t], vvoff[t] + soff, 0u);
+  };
+  // ---- raw pooled gradient rows and arg-max words by LDS-DMA.  A lane follows ITS hex of the step (waves 0-5: hex `wave`;
+  // waves 6, 7: hex lane >> 3 for the word piece) through the G row layout: hs = hex index inside its sequence, goff = G
+  // row of the hex's first pooled row relative to the first hex of the split.
+  const int Tq = p.Tp >> 1, hps = p.Tp / 6;                        // pooled rows / hexes per sequence (hex layout)
+  const int g_tp = p.g_tp > 0 ? p.g_tp : Tq;
+  const bool wpiece = wave >= 6;
+  const int myhex = wpiece ? (lane >> 3) : wave;                    // (lanes >= 48 of a word piece: never fetched)
+  const long long seq0 = v_h0 / hps;
+  const int hs0 = (int)(v_h0 - seq0 * hps);
+  const long long g_r0 = seq0 * g_tp + 3LL * hs0;                   // G row of the split's first hex
+  int g_hs = hs0 + myhex, g_off = 3 * myhex;
+  while (g_hs >= hps) {
+    g_hs -= hps;
+    g_off += g_tp - Tq;
+  }
+  const int ldw4 = p.ld_bbits * 4;
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+      wpiece ? (void*)(p.bbits + g_r0 * (long long)p.ld_bbits + (n0 >> 5)) : (void*)(p.B + g_r0 * (long long)p.ldb + n0), 0,
+      wpiece ? clip31((p.B_rows - g_r0) * (long long)ldw4 - (long long)(n0 >> 5) * 4)
+             : clip31((p.B_rows - g_r0) * (long long)p.ldb * 4 - (long long)n0 * 4),
+      0x00020000);
+  const unsigned g_lane = wpiece ? (unsigned)(((lane >> 1) & 3) * ldw4 + (lane & 1) * 4)
+                                 : (unsigned)(((lane >> 4) * (long long)p.ldb + (lane & 15) * 4) * 4);
+  const unsigned g_row4 = wpiece ? (unsigned)ldw4 : (unsigned)(p.ldb * 4);
+  const unsigned gdst = wpiece ? (unsigned)(GW * 4) : (unsigned)(wave * 256 * 4);
+  const bool g_live = !wpiece || lane < 48;
+  auto issue_g = [&](int slot) {                                    // the piece of the NEXT step in line; advances the counters
+    const unsigned voff = g_live ? (unsigned)g_off * g_row4 + g_lane : 0xfffffff0u;
+    if (wpiece) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_void6_t*)(reinterpret_cast<char*>(Gs) + slot * (GT * 4) + gdst), 4, voff, 0u, 0, 0);
+    else dma16h(rsG, reinterpret_cast<char*>(Gs) + slot * (GT * 4) + gdst, voff, 0u);
+    g_hs += T6_H;
+    g_off += 3 * T6_H;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                           // (no loop: a branch would cut the K-step into basic blocks)
+      const bool wrap = g_hs >= hps;
+      g_hs -= wrap ? hps : 0;
+      g_off += wrap ? g_tp - Tq : 0;
+    }
+  };
+  auto next6 = [](int v) { return v == NG - 1 ? 0 : v + 1; };
+
+  // ---- Y side: wave w < 6 = hex w of the K-step, lane = channel ----
+  constexpr bool write_vd = WVD;
+  const bool ywave = wave < T6_H;
+  const int sw = lane ^ ((wave & 1) << 5);                  // swizzled channel position inside the 64-wide row
+  int tq = __builtin_amdgcn_readfirstlane((int)((6 * (v_h0 + (ywave ? wave : 0))) % p.Tp));   // first conv row of the NEXT hex to transform
+  const int dstep = __builtin_amdgcn_readfirstlane((6 * T6_H) % p.Tp);
+  float bsum = 0.f;
+  // Vd in the pair layout (ld_vd / 8 chunks): a lane stores four channels of transforms lane & 3 and 4 + (lane & 3)
+  const int kcd = write_vd ? (p.ld_vd >> 3) : 1;
+  const unsigned vd_pstride = (unsigned)(16 * p.ld_vd * 4);          // bytes per hex pair
+  const long long vd_hexes = ((hexes_all + 1) >> 1) << 1;
+  const __amdgpu_buffer_rsrc_t rsVd = __builtin_amdgcn_make_buffer_rsrc(
+      write_vd ? (void*)(p.vd + v_h0 * 8 * (long long)p.ld_vd) : (void*)p.slab, 0,
+      write_vd ? clip31((vd_hexes - v_h0) * 8 * (long long)p.ld_vd * 4) : 0, 0x00020000);
+  const unsigned vdA_lane = (unsigned)(v6_at(0, lane & 3, n0 + (lane & ~3), kcd) * 4);
+  const unsigned vdB_lane = vdA_lane + 4u * 64u;
+  const int nhex = (int)hexes_all, h_first = (int)v_h0;
+  const int h_end = h_first + nsteps * T6_H;
+  const int hs_lim = nhex < h_end ? nhex : h_end;           // hexes of this split that exist
+  struct y_in {
+    float g[3];
+    unsigned long long mo[3], me[3];
+    int tq;               // time index of the hex's first conv row
+  };
+  struct y_out {
+    float d[6];           // dZ rows 6 h .. 6 h + 5
+  };
+  auto uni = [](unsigned long long v) -> unsigned long long {   // a wave-uniform value out of vector registers
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v) |
+           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32);
+  };
+  const int wy = ywave ? wave : 0;                          // (waves 6, 7 run the same code on hex 0's data with all-zero masks)
+  struct y_raw {
+    float g[3];
+    unsigned long long w[3];
+  };
+  auto fetch_raw = [&](int slot, y_raw& r) {                 // the LDS reads of a hex: issued early in the K-step
+    const float* gs = Gs + slot * GT;
+    const unsigned long long* ws = reinterpret_cast<const unsigned long long*>(gs + GW) + wy * 4;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      r.g[q] = gs[wy * 256 + q * 64 + lane];
+      r.w[q] = ws[q];
+    }
+  };
+  auto masks_y = [&](int sd, const y_raw& r, y_in& y) {
+    const int h = h_first + sd * T6_H + wy;
+    const int live = ywave & (h < hs_lim);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      y.g[q] = r.g[q];
+#if T6_ABL & 64
+      (void)live;
+      y.mo[q] = 0x5555555555555555ull;                        // timing only: no word broadcast, no row validity
+      y.me[q] = 0xaaaaaaaaaaaaaaaaull;
+#else
+      const unsigned long long w = uni(r.w[q]);
+      const int v = live & (tq + 2 * q < p.Tvalid);
+      y.mo[q] = v ? w : 0ull;
+      y.me[q] = v ? ~w : 0ull;
+#endif
+    }
+    y.tq = tq;
+    tq += dstep;
+    tq -= tq >= p.Tp ? p.Tp : 0;
+  };
+  auto fetch_y = [&](int sd, int slot, y_in& y) {
+    y_raw r;
+    fetch_raw(slot, r);
+    masks_y(sd, r, y);
+  };
+  auto compute_y = [&](int sd, const y_in& y) -> y_out {
+    y_out u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      u.d[2 * r] = selm0(y.me[r], y.g[r]);
+      u.d[2 * r + 1] = selm0(y.mo[r], y.g[r]);
+    }
+    const float ev2 = fmaf(16.f, u.d[4], fmaf(4.f, u.d[2], u.d[0])), od2 = fmaf(32.f, u.d[5], fmaf(8.f, u.d[3], 2.f * u.d[1]));
+    float o[4];
+    if (th == 0) {                                          // (wave-uniform) transforms 0..3
+      const float ev1 = (u.d[0] + u.d[2]) + u.d[4], od1 = (u.d[1] + u.d[3]) + u.d[5];
+      o[0] = u.d[0];
+      o[1] = ev1 + od1;
+      o[2] = ev1 - od1;
+      o[3] = ev2 + od2;
+      bsum += o[1];
+    } else {                                                // transforms 4..7
+      const float ev3 = fmaf(0.0625f, u.d[4], fmaf(0.25f, u.d[2], u.d[0])), od3 = fmaf(0.03125f, u.d[5], fmaf(0.125f, u.d[3], 0.5f * u.d[1]));
+      o[0] = ev2 - od2;
+      o[1] = ev3 + od3;
+      o[2] = ev3 - od3;
+      o[3] = u.d[5];
+    }
+    {
+      float* dst = (ywave ? Bs + (sd & 1) * QT + wave * 64 : Ydummy + (wave - T6_H) * 64) + sw;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i * T6_PLANE] = o[i];
+    }
+    return u;
+  };
+  typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+  // Vd of the hexes of step sd.  gp / wp: the pooled row in front of the hex (conv rows 6 h - 2, 6 h - 1) and its word pair
+  auto vd_part = [&](int sd, int tqc, const y_out& u, float gp, unsigned long long wp) {
+    const int h = h_first + sd * T6_H + wy;
+    const int vp = ywave & (tqc >= 2) & (tqc - 2 < p.Tvalid) & (h < hs_lim);
+    float d[8], v[8];
+    d[1] = selm0(vp ? wp : 0ull, gp);
+    d[0] = selm0(vp ? ~wp : 0ull, gp);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[2 + k] = u.d[k];
+    wino63_bt(d, v);
+    // two 4 x 4 transposes over the lanes of a group (register n of lane r <- register r of lane n)
+    const bool odd = lane & 1, hi = lane & 2;
+    auto xch = [](float x, auto CTRL) -> float {
+      return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(CTRL)::value, 0xf, 0xf, true));
+    };
+    using X1 = std::integral_constant<int, 0xB1>;         // quad_perm [1,0,3,2]
+    using X2 = std::integral_constant<int, 0x4E>;         // quad_perm [2,3,0,1]
+    auto stage = [&](float& a, float& b, bool up, auto CTRL) {
+      const float r = xch(up ? a : b, CTRL);
+      a = up ? r : a;
+      b = up ? b : r;
+    };
+#pragma unroll
+    for (int g4 = 0; g4 < 8; g4 += 4) {
+      stage(v[g4 + 0], v[g4 + 1], odd, X1{});
+      stage(v[g4 + 2], v[g4 + 3], odd, X1{});
+      stage(v[g4 + 0], v[g4 + 2], hi, X2{});
+      stage(v[g4 + 1], v[g4 + 3], hi, X2{});
+    }
+    const f32x4 va4 = {v[0], v[1], v[2], v[3]};
+    const f32x4 vb4 = {v[4], v[5], v[6], v[7]};
+    const bool ok = ywave && h < hs_lim;
+    const unsigned hoff = (unsigned)((h - h_first) >> 1) * vd_pstride + (unsigned)((h - h_first) & 1) * 32u;
+    if (!(T6_ABL & 4)) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, va4), rsVd, ok ? hoff + vdA_lane : 0xfffffff0u, 0u, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, vb4), rsVd, ok ? hoff + vdB_lane : 0xfffffff0u, 0u, 2);
+    }
+  };
+  // the row in front of this wave's hex at step sd: row 2 of the piece in front (hex wave - 1; for wave 0 the last hex
+  // of the previous step, still in the ring)
+  auto front_row = [&](int slot, int pslot, float& gp, unsigned long long& wp) {
+    const int s_ = wy > 0 ? slot : pslot, hx = wy > 0 ? wy - 1 : T6_H - 1;
+    gp = Gs[s_ * GT + hx * 256 + 128 + lane];
+    wp = uni(reinterpret_cast<const unsigned long long*>(Gs + s_ * GT + GW)[hx * 4 + 2]);
+  };
+
+  // ---- MFMA side: k-slice sl of a K-step = hexes 2 sl (lanes 0-31) and 2 sl + 1 (lanes 32-63) ----
+  // wave (wm, wn): C_in rows m0 + 64 wm + {0..31, 32..63} (quarter-tile wm of V) x C_out columns n0 + 32 wn ..; accumulator
+  // 4 r + t = (row tile r, transform i0 + t)
+  const int a_off0 = wm * QT + lh * 64 + (lr ^ (lh << 5)), a_off1 = wm * QT + lh * 64 + ((32 + lr) ^ (lh << 5));
+  const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
+  float fa0[8], fb0[4], fa1[8], fb1[4], fac[8], fbc[4];     // slices 0, 1 of a step; slice 2, carried
+  auto load_frag = [&](float (&fa)[8], float (&fb)[4], int abuf, int bbuf, int sl) {
+    const float* a_s = As + abuf * (4 * QT) + sl * 128;
+    const float* b_s = Bs + bbuf * QT + sl * 128 + b_off;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fa[t] = a_s[a_off0 + t * T6_PLANE];
+      fa[4 + t] = a_s[a_off1 + t * T6_PLANE];
+      fb[t] = b_s[t * T6_PLANE];
+    }
+  };
+  auto mfma8 = [&](const float (&fa)[8], const float (&fb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i & 3], acc[i], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fac[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fbc[i] = 0.f;
+
+  {   // (also for an empty split: every access is clamped by its resource, the masks are all zero)
+    issue_v(0);
+    issue_v(1);
+    issue_v(2);
+    issue_g(0);
+    issue_g(1);
+    issue_g(2);
+    issue_g(3);
+    // the pooled row in front of the split's first hex (wave 0 only needs it, for Vd; everyone loads it - uniform code)
+    float gp0 = 0.f;
+    unsigned long long wp0 = 0ull;
+    if (write_vd && hs0 > 0) {
+      const long long pr = g_r0 - 1;                          // same sequence as the first hex (hs0 > 0)
+      if (pr < p.B_rows) {
+        gp0 = p.B[pr * (long long)p.ldb + n0 + lane];
+        const uint32_t* wsrc = p.bbits + pr * (long long)p.ld_bbits + (n0 >> 5);
+        wp0 = (unsigned long long)wsrc[0] | ((unsigned long long)wsrc[1] << 32);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      y_in y0;
+      fetch_y(0, 0, y0);
+      const y_out u0 = compute_y(0, y0);
+      if (write_vd && mi == 0) {
+        float gp;
+        unsigned long long wp;
+        front_row(0, NG - 1, gp, wp);                         // (wave 0 reads an unwritten slot here: replaced below)
+        if (wave == 0) {
+          gp = gp0;
+          wp = uni(wp0);
+        }
+        vd_part(0, y0.tq, u0, gp, wp);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  int slot1 = 1, slot4 = 4;                                 // ring slots of steps s + 1 and s + 4
+  int turn = 1;                                             // (s + 1) % nslots: whose turn it is to write Vd for step s + 1
+  for (int s = 0; s < nsteps; ++s) {
+    const int abuf = s & (NA - 1), bbuf = s & 1;
+    const int slot0 = slot1 == 0 ? NG - 1 : slot1 - 1;
+    __builtin_amdgcn_sched_barrier(0);
+    // first half: the pieces of steps s + 3 / s + 4 go out, the raw gradient rows and words of step s + 1 are read from
+    // the ring (they return under the 16 MFMAs), the carried slice and slice 0 run
+    if (!(T6_ABL & 1)) issue_v(s + 3);
+    if (!(T6_ABL & 2)) issue_g(slot4);
+    y_raw yr;
+    fetch_raw(slot1, yr);
+    load_frag(fa0, fb0, abuf, bbuf, 0);
+    mfma8(fac, fbc);                                        // slice 2 of the previous step
+    load_frag(fa1, fb1, abuf, bbuf, 1);
+    mfma8(fa0, fb0);
+    // (0x008 MFMA, 0x010 vector memory, 0x100 LDS read, 0x002 VALU, 0x200 LDS write)
+    __builtin_amdgcn_sched_group_barrier(0x100, 6 + 6, 0);   // raw rows / words, fragments of slice 0
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (t < 4) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      if (t >= 4 && t < 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // second half: the transform of step s + 1 between the MFMAs of slice 1 (no branch: waves 6, 7 run it on zero masks)
+    load_frag(fac, fbc, abuf, bbuf, 2);
+    y_in yn;
+    y_out un = {};
+    if (!(T6_ABL & 8)) {
+      masks_y(s + 1, yr, yn);
+      un = compute_y(s + 1, yn);
+    }
+    mfma8(fa1, fb1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      if (t >= 6) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (write_vd) {
+      if (ywave && turn == mi && s + 1 < nsteps && !(T6_ABL & (8 | 32))) {     // (wave-uniform; every nslots-th step)
+        float gp;
+        unsigned long long wp;
+        front_row(slot1, slot0, gp, wp);
+        vd_part(s + 1, yn.tq, un, gp, wp);
+      }
+      turn = turn + 1 == nslots ? 0 : turn + 1;
+    }
+    // everything issued up to step s - 2 has landed: V(s + 1), G(s + 2).  In flight: the 4 pieces of this step and of the
+    // one before (a Vd store among them only makes the wait reach further back)
+    __builtin_amdgcn_s_waitcnt(0x0078);                           // vmcnt(8) lgkmcnt(0)
+#if !(T6_ABL & 16)
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+    slot1 = next6(slot1);
+    slot4 = next6(slot4);
+  }
+  mfma8(fac, fbc);
+
+  if (p.colsum != nullptr && mi == 0) {
+    __syncthreads();
+    float* red = lds;
+    red[wave * 64 + lane] = ywave ? bsum : 0.f;
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < T6_H; ++q) t += red[q * 64 + tid];
+      p.colsum[(long long)z * p.Ndim + n0 + tid] = t;
+    }
+  }
+  float* out = p.slab + (long long)z * p.slab_stride;
+  const int col = n0 + wn * 32 + lr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 64 + (i >> 2) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      out[((long long)(i0 + (i & 3)) * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // conv1 (C_in = 1) + LeakyReLU + max-pool writing V of its pooled output in HEX form, pair layout (conv1_fwd_vq_kernel of
 // tonal_misc.hip with six rows per unit).  HBM-write bound, so the thread mapping follows the layout: four adjacent lanes
 // = (one 8-channel chunk) x (the two hexes of a pair) write the 64-byte run of a transform, two transforms = one cache line;
@@ -1065,8 +1480,19 @@ extern "C" int tl_conv3_wino63v_tn(const tl_tn_params* pp, void* stream) {
   TL_REQUIRE((per + 6) * 3LL * T6_H * p.ldb * 4 < (1LL << 31), "wino63v_tn: a reduction split spans more than 2 GB of G: raise splitk");
   TL_REQUIRE(p.vd == nullptr || (p.ld_vd >= p.Ndim && p.ld_vd % 8 == 0), "wino63v_tn: ld_vd must cover Ndim (multiple of 8)");
   TL_REQUIRE(p.vd == nullptr || (per + 4) * (long long)T6_H * 8 * p.ld_vd * 4 < (1LL << 31), "wino63v_tn: a reduction split spans more than 2 GB of Vd: raise splitk");
-  const int ntm = p.Mdim / 128, ntn = p.Ndim / T6_BN;
+  const int ntn = p.Ndim / T6_BN;
   hipStream_t st = (hipStream_t)stream;
+  // C_in a multiple of 256: the kernel that splits the eight transforms over two workgroups (bm = 128 asks for the other one)
+  TL_REQUIRE(p.bm == 0 || p.bm == 128 || (p.bm == 256 && p.Mdim % 256 == 0 && p.Tp >= 12),
+             "wino63v_tn: bm must be 0, 128, or 256 with Mdim %% 256 == 0 and Tp >= 12");
+  if (p.bm == 256 || (p.bm == 0 && p.Mdim % 256 == 0 && p.Tp >= 12)) {
+    const int ntm = p.Mdim / 256;
+    const dim3 grid((unsigned)(2 * ntm * ntn), (unsigned)p.splitk, 1);
+    if (p.vd != nullptr) hipLaunchKernelGGL((wino63v_tn4_kernel<true>), grid, dim3(512), 0, st, p, ntm);
+    else hipLaunchKernelGGL((wino63v_tn4_kernel<false>), grid, dim3(512), 0, st, p, ntm);
+    return check_launch("wino63v_tn (4 transforms per workgroup)");
+  }
+  const int ntm = p.Mdim / 128;
   const dim3 grid((unsigned)(ntm * ntn), (unsigned)p.splitk, 1);
   if (p.vd != nullptr) hipLaunchKernelGGL((wino63v_tn_kernel<true>), grid, dim3(512), 0, st, p, ntm);
   else hipLaunchKernelGGL((wino63v_tn_kernel<false>), grid, dim3(512), 0, st, p, ntm);
