@@ -22,8 +22,8 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_POOL, EPI_POOLV, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, LOAD_V, NtParams, TnParams,
-                   check, ptr)
+from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_MASKY, EPI_POOL, EPI_POOLV, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, LOAD_V,
+                   LOAD_Y, NtParams, TnParams, check, ptr)
 
 
 def _r4(n: int) -> int:
@@ -78,6 +78,12 @@ class CnnEngine:
         tp1_default = self.tp1
         if self.wino63:
             self.tp1 = (self.tout1 + 11) // 12 * 12
+        # the input gradient of stage 3 writes the operands of stage 2's backward - Y2 = A dz and Vd2 - instead of the gradient
+        # rows G2 (epilogue 6 of tl_conv3_wino63v_nt): the weight gradient of stage 2 then runs without a transform
+        # (tl_conv3_wino63v_tn, loader 3; needs C_in of stage 2 % 256 == 0).  TONAL_F63_YPROD=0: off (G2 is stored, the
+        # weight-gradient kernel un-pools and transforms it itself, as stage 3's does)
+        self.f63_yprod = (self.wino63 and os.environ.get("TONAL_F63_YPROD", "1") != "0" and stage_defs[0][0] % 256 == 0
+                          and self.tp1 >= 12)
         self.stages: List[_Stage] = []
         cin, tin, tp = self.c1, self.tout1, self.tp1
         for i, (cout, k, pool) in enumerate(stage_defs[1:], start=2):
@@ -181,6 +187,8 @@ class CnnEngine:
         self.Xc = z(rows5, self.ldx)
         self.Y = [z(rows5, d[3]) for d in self.concat_dims]
         self.out_slab = None
+        self.Yt = {}           # F(6,3): Y = A dz of stage idx, written by the input gradient of the stage above (f63_yprod)
+        self._y_ready = {}
         self.V = {}            # F(4,3) input transforms of P[idx] (quads, 6, channels) for the stages that read them
         self.Vd = {}           # ... and of the un-pooled dZ of stage idx (the operand of its input-gradient pass)
         self._vd_ready = {}
@@ -197,7 +205,8 @@ class CnnEngine:
         if not self.wino63 and not (self.fuse_c1 and self._c1_fusable() and self._use_wino(self.stages[0])):
             self.G[1] = z(S * self.tp1, self.c1)      # otherwise G1 never leaves the stage-2 epilogue
         for st in self.stages:
-            self.G[st.idx] = z(S * st.tp_out, st.cout if st.pool else self.ld5)
+            if not (self.f63_yprod and st.idx == 2):          # (with f63_yprod G2 is never stored)
+                self.G[st.idx] = z(S * st.tp_out, st.cout if st.pool else self.ld5)
         self.GY = [z(self.rows5, d[3]) for d in self.concat_dims]
         self.dXc = z(self.rows5, self.ldx)
 
@@ -370,21 +379,30 @@ class CnnEngine:
     def _stage_wgrad63(self, st, gw, gb) -> None:
         S = self.S
         f32 = dict(dtype=torch.float32, device=self._dev)
-        Gs = self.G[st.idx]
         rows_in = S * st.tp_in
-        ldg = Gs.shape[1]
         nd = st.cout
+        ldg = nd
         V = self._v_ready[st.idx - 1]
         tiles = (st.cin // 64) * (nd // 64)
         sk = self._splitk(tiles, (rows_in + 35) // 36, int(os.environ.get("TONAL_TN_TARGET", "4096")))
         slab = torch.empty(sk, 8 * st.cin, ldg, **f32)
         bias_part = torch.empty(sk, nd, **f32)
-        Vd = self._v_hex_buffer(self.Vd, st.idx, rows_in, nd)
-        self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino63v_tn", A=ptr(V), B=ptr(Gs), slab=ptr(slab), Krows=rows_in,
-                 A_rows=V.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=V.shape[2], ldb=ldg, ldc=ldg, J=3,
-                 Tp=st.tp_in, splitk=sk, slab_stride=8 * st.cin * ldg, loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]),
-                 ld_bbits=st.cout // 32, Tvalid=2 * st.tout, colsum=ptr(bias_part), vd=ptr(Vd), ld_vd=nd, g_tp=st.tp_out)
-        self._vd_ready[st.idx] = self.generation
+        if self._y_ready.get(st.idx) == self.generation:
+            # both operands pre-transformed: Y (and Vd) of this stage were written by the input gradient of the stage above
+            Y = self.Yt[st.idx]
+            self._y_ready[st.idx] = -1
+            self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino63v_tn", A=ptr(V), B=ptr(Y), slab=ptr(slab), Krows=rows_in,
+                     A_rows=V.shape[0], B_rows=Y.shape[0], Mdim=st.cin, Ndim=nd, lda=V.shape[2], ldb=Y.shape[2], ldc=ldg, J=3,
+                     Tp=st.tp_in, splitk=sk, slab_stride=8 * st.cin * ldg, loader=LOAD_Y, Tvalid=2 * st.tout,
+                     colsum=ptr(bias_part))
+        else:
+            Gs = self.G[st.idx]
+            Vd = self._v_hex_buffer(self.Vd, st.idx, rows_in, nd)
+            self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino63v_tn", A=ptr(V), B=ptr(Gs), slab=ptr(slab), Krows=rows_in,
+                     A_rows=V.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=V.shape[2], ldb=Gs.shape[1], ldc=ldg, J=3,
+                     Tp=st.tp_in, splitk=sk, slab_stride=8 * st.cin * ldg, loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]),
+                     ld_bbits=st.cout // 32, Tvalid=2 * st.tout, colsum=ptr(bias_part), vd=ptr(Vd), ld_vd=nd, g_tp=st.tp_out)
+            self._vd_ready[st.idx] = self.generation
         if sk > 1:
             red = torch.empty(8 * st.cin, ldg, **f32)
             n = 8 * st.cin * ldg
@@ -406,6 +424,25 @@ class CnnEngine:
         kw = dict(A=ptr(Vd), A_rows=Vd.shape[0], lda=Vd.shape[2], loader=LOAD_V, Bw=ptr(wd), M=rows_in, N=st.cin,
                   K=st.cout, ldb=st.cout, ldo=st.cin, J=3, row_shift=-2, Tp=st.tp_in, slope=self.slope,
                   auxbits=ptr(self.sbits[st.idx - 1]), ld_auxbits=self.sbits[st.idx - 1].shape[1])
+        if st.idx == 3 and self.f63_yprod:
+            below = self.stages[0]
+            rows2 = S * below.tp_in                              # conv rows of stage 2: six per hex = three of this GEMM's rows
+            Y2 = self._v_hex_buffer(self.Yt, 2, rows2, below.cout)
+            Vd2 = self._v_hex_buffer(self.Vd, 2, rows2, below.cout)
+            ntm = (rows_in + 767) // 768
+            if not hasattr(self, "_vhalo"):
+                self._vhalo = {}
+            halo = self._vhalo.get("d2")
+            if halo is None or halo.shape[0] != ntm or halo.shape[2] != below.cout:
+                halo = self._vhalo["d2"] = torch.zeros(ntm, 2, below.cout, dtype=torch.float32, device=self._dev)
+            self._nt(tag="conv3_dgrad", fn="tl_conv3_wino63v_nt", epilogue=EPI_MASKY, out=None, vout=ptr(Y2), vout2=ptr(Vd2),
+                     vhalo=ptr(halo), vout_quads=Y2.shape[0], ld_vout=Y2.shape[2], abits=ptr(self.bits[2]),
+                     ld_abits=below.cout // 32, Tvalid_in=2 * below.tout, **kw)
+            check(self.lib.tl_wino63_vd_fixup(ptr(Vd2), ptr(halo), rows_in // 3, ntm, below.tp_in // 6, below.cout, Vd2.shape[2],
+                                              self._stream()), "tl_wino63_vd_fixup")
+            self._y_ready[2] = self.generation
+            self._vd_ready[2] = self.generation
+            return None
         if st.idx == 3:
             self._nt(tag="conv3_dgrad", fn="tl_conv3_wino63v_nt", epilogue=EPI_MASK, out=ptr(self.G[2]), **kw)
             return None

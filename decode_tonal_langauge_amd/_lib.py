@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("TONAL_HIP_LIB", os.path.join(_HERE, "libtonal_hip.so"
 
 # epilogue / loader codes of tl_gemm_nt_window (include/tonal_hip.h)
 LOAD_DIRECT, LOAD_UNPOOL, LOAD_V = 0, 1, 2
-EPI_STORE, EPI_LRELU, EPI_POOL, EPI_MASK, EPI_C1WGRAD, EPI_POOLV = 0, 1, 2, 3, 4, 5
+EPI_STORE, EPI_LRELU, EPI_POOL, EPI_MASK, EPI_C1WGRAD, EPI_POOLV, EPI_MASKY = 0, 1, 2, 3, 4, 5, 6
+LOAD_Y = 3
 
 
 class NtParams(C.Structure):
@@ -35,7 +36,7 @@ class NtParams(C.Structure):
         ("osign", C.c_void_p), ("auxbits", C.c_void_p), ("ld_auxbits", C.c_int),
         ("c1x", C.c_void_p), ("c1bits", C.c_void_p), ("c1partial", C.c_void_p), ("c1T", C.c_int), ("c1kt", C.c_int),
         ("vout", C.c_void_p), ("vhalo", C.c_void_p), ("vout_quads", C.c_int64), ("ld_vout", C.c_int),
-        ("out_tp", C.c_int),
+        ("out_tp", C.c_int), ("vout2", C.c_void_p),
     ]
 
 
@@ -84,6 +85,7 @@ SIGNATURES = {
     "tl_wino63_v_fixup": (_I, [_P, _P, _L, _L, _I, _I, _I, _P]),
     "tl_conv3_wino63v_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino63_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
+    "tl_wino63_vd_fixup": (_I, [_P, _P, _L, _L, _I, _I, _I, _P]),
     "tl_conv1_fwd_v6": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
     "tl_sizeof_nt_params": (_I, []),
     "tl_sizeof_tn_params": (_I, []),

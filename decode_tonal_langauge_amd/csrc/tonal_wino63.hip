@@ -166,7 +166,7 @@ enum { KS_NORMAL = 0, KS_PRELAST = 1, KS_LAST = 2 };
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p) {
-  __shared__ __attribute__((aligned(1024))) char lds[3 * V6_STAGE + (EPI == W_EPI_POOLV ? 4096 : EPI == W_EPI_C1W ? 16384 : 0)];
+  __shared__ __attribute__((aligned(1024))) char lds[3 * V6_STAGE + ((EPI == W_EPI_POOLV || EPI == W_EPI_MASKY) ? 4096 : EPI == W_EPI_C1W ? 16384 : 0)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     auto prefetch = [&] {
       if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_POOLV) return v5_prefetch_pool(p, cur.n0, wn, lr);
       else if constexpr (EPI == W_EPI_MASK) return v6_prefetch_mask(p, cur.R0, cur.n0, wm, wn, lr, lh);
+      else if constexpr (EPI == W_EPI_MASKY) return v6_prefetch_masky(p, cur.R0, cur.n0, wm, wn, lr, lh);
       else return v6_prefetch_c1w(p, cur.R0, cur.n0, wm, wn, lr, lh);
     };
     decltype(prefetch()) pre;
@@ -437,6 +438,10 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     } else if constexpr (EPI == W_EPI_MASK) {
       if (full) v6_epilogue_mask<true>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
       else v6_epilogue_mask<false>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
+    } else if constexpr (EPI == W_EPI_MASKY) {
+      float* xch = reinterpret_cast<float*>(lds + 3 * V6_STAGE);
+      if (full) v6_epilogue_masky<true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      else v6_epilogue_masky<false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
     } else {
       v6_epilogue_c1w(p, acc, pre, reinterpret_cast<float*>(lds + 3 * V6_STAGE) + wave * 512, scratch, done.R0, done.n0, wm, wn,
                       lr, lh, done.tm);
@@ -1242,6 +1247,192 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn4_kernel(const tl_tn_params 
 }
 
 // ------------------------------------------------------------------------------------------
+// Second half of the Y / Vd-writing input-gradient epilogue (tonal_wino63_epi.h, MASKY): the first hex of every tile (256
+// hexes of the stage below) needs the pooled row in front of it, which the tile in front owns.  The tile left its six rows
+// raw in transform slots 2..7 and every tile stored its last pooled row (un-pooled: even, odd) to vhalo.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void wino63_vd_fixup_kernel(float* __restrict__ Vd, const float* __restrict__ halo, long long hexes,
+                                                               long long tiles, int hps, int C, int ldv) {
+  const int c4n = C >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= tiles * c4n) return;
+  const long long t = idx / c4n;
+  const int c = (int)(idx - t * c4n) * 4;
+  const long long q = t * 256;
+  if (q >= hexes) return;
+  float* v = Vd + v6_at(q, 0, c, ldv >> 3);
+  f32x4 d[8];
+#pragma unroll
+  for (int j = 2; j < 8; ++j) d[j] = *reinterpret_cast<const f32x4*>(v + 16 * j);
+  if (t > 0 && (q % hps) != 0) {
+    d[0] = *reinterpret_cast<const f32x4*>(halo + ((t - 1) * 2) * (long long)C + c);
+    d[1] = *reinterpret_cast<const f32x4*>(halo + ((t - 1) * 2 + 1) * (long long)C + c);
+  } else {
+    d[0] = d[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 o[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float dd[8], vv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dd[j] = d[j][k];
+    wino63_bt(dd, vv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j][k] = vv[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(v + 16 * j) = o[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient with BOTH operands pre-transformed (loader 3): slab_i[c_in][c_out] = sum_hexes V_i (x) Y_i, Y written by
+// the MASKY epilogue of the stage above.  wino63v_tn4_kernel (tile 256 x 64 x 4 transforms, 8 waves) without its Y side: V
+// and Y tiles of a K-step (six hexes) arrive by LDS-DMA into two 4-slot rings, three steps ahead (three V pieces per wave,
+// one Y piece for waves 0-5); the K-step is 18 ds_read2st64_b32 + 24 MFMAs per wave and nothing else.  colsum (the bias
+// gradient of the stage = the column sums of Y plane 1 = the sum of dz over a hex) is added up by wave 0 of slot 0.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void wino63v_tn4y_kernel(const tl_tn_params p, int mtn) {
+  constexpr int NA = 4;
+  constexpr int QT = 4 * T6_PLANE;               // floats per quarter-tile of V / per Y tile: [4 transforms][6 hexes][64]
+  __shared__ __attribute__((aligned(1024))) float lds[NA * 4 * QT + NA * QT + 256];
+  float* As = lds;                               // [4][4][4][6][64]  V ring
+  float* Ys = lds + NA * 4 * QT;                 // [4][4][6][64]     Y ring   (+ 1 KB: where waves 6, 7 aim their empty piece)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int ntn = p.Ndim / T6_BN;
+  const long long tiles = 2LL * mtn * ntn;
+  const long long nwg = tiles * p.splitk;
+  long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  {
+    const long long q = nwg / 8, r = nwg % 8, x = bid % 8, i = bid / 8;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int z = __builtin_amdgcn_readfirstlane((int)(bid / tiles));
+  const int tt = __builtin_amdgcn_readfirstlane((int)(bid % tiles));
+  const int mi = __builtin_amdgcn_readfirstlane(tt % (2 * mtn));
+  const int th = mi & 1, i0 = 4 * th;
+  const int m0 = (mi >> 1) * 256, n0 = __builtin_amdgcn_readfirstlane((tt / (2 * mtn)) * T6_BN);
+  const long long hexes_all = p.Krows / 6;
+  const long long ksteps_all = (hexes_all + T6_H - 1) / T6_H;
+  const long long per = __builtin_amdgcn_readfirstlane((int)((ksteps_all + p.splitk - 1) / p.splitk));
+  const long long ks_begin = z * per;
+  long long ks_end = ks_begin + per;
+  if (ks_end > ksteps_all) ks_end = ksteps_all;
+  const int nsteps = ks_end > ks_begin ? (int)(ks_end - ks_begin) : 0;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const long long v_h0 = ks_begin * T6_H;
+  const int kc8 = p.lda >> 3, kcy = p.ldb >> 3;
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + v_h0 * 8 * (long long)p.lda), 0, clip31((p.A_rows - v_h0) * 8 * (long long)p.lda * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.B + v_h0 * 8 * (long long)p.ldb), 0, clip31((p.B_rows - v_h0) * 8 * (long long)p.ldb * 4), 0x00020000);
+  unsigned vvoff[3], vdst[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int quarter = (wave * 3 + t) / 6, pc = (wave * 3 + t) % 6;
+    const int rho = 4 * pc + (lane >> 4), i = rho / 6, hx = rho % 6;
+    const int chunk = (lane & 15) ^ ((hx & 1) << 3);
+    vvoff[t] = (unsigned)(v6_at(hx, i0 + i, m0 + quarter * 64 + chunk * 4, kc8) * 4);
+    vdst[t] = (unsigned)((quarter * QT + pc * 256) * 4);
+  }
+  // the Y piece of wave w < 6: rows 4 w .. 4 w + 3 of the tile's 24 ([transform][hex] order), like a quarter-tile of V
+  const bool ypiece = wave < T6_H;
+  unsigned yvoff;
+  {
+    const int rho = 4 * (ypiece ? wave : 0) + (lane >> 4), i = rho / 6, hx = rho % 6;
+    const int chunk = (lane & 15) ^ ((hx & 1) << 3);
+    yvoff = (unsigned)(v6_at(hx, i0 + i, n0 + chunk * 4, kcy) * 4);
+  }
+  const unsigned v_step = (unsigned)(T6_H * 8 * p.lda * 4), y_step = (unsigned)(T6_H * 8 * p.ldb * 4);
+  auto issue = [&](int step) {
+    char* vb = reinterpret_cast<char*>(As) + (step & (NA - 1)) * (4 * QT * 4);
+    const unsigned soff = (unsigned)step * v_step;            // (in the per-lane offset: that one is range-checked)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dma16h(rsV, vb + vdst[t], vvoff[t] + soff, 0u);
+    // (waves 6, 7: an empty piece - offset past the resource - into the spare KB behind the ring: one operation per wave)
+    char* yb = reinterpret_cast<char*>(Ys) + (ypiece ? ((step & (NA - 1)) * QT + wave * 256) * 4 : NA * QT * 4);
+    dma16h(rsY, yb, ypiece ? yvoff + (unsigned)step * y_step : 0xfffffff0u, 0u);
+  };
+  const int a_off0 = wm * QT + lh * 64 + (lr ^ (lh << 5)), a_off1 = wm * QT + lh * 64 + ((32 + lr) ^ (lh << 5));
+  const int b_off = lh * 64 + ((wn * 32 + lr) ^ (lh << 5));
+  float fa0[8], fb0[4], fa1[8], fb1[4], fac[8], fbc[4];     // slices 0, 1 of a step; slice 2, carried
+  auto load_frag = [&](float (&fa)[8], float (&fb)[4], int buf, int sl) {
+    const float* a_s = As + buf * (4 * QT) + sl * 128;
+    const float* b_s = Ys + buf * QT + sl * 128 + b_off;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fa[t] = a_s[a_off0 + t * T6_PLANE];
+      fa[4 + t] = a_s[a_off1 + t * T6_PLANE];
+      fb[t] = b_s[t * T6_PLANE];
+    }
+  };
+  auto mfma8 = [&](const float (&fa)[8], const float (&fb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i & 3], acc[i], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fac[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fbc[i] = 0.f;
+  const bool summer = p.colsum != nullptr && mi == 0 && wave == 0;    // (slot 0 holds transform 1: Y plane 1 = the sum of a hex's dz)
+  float bsum = 0.f;
+  issue(0);
+  issue(1);
+  issue(2);
+  __builtin_amdgcn_s_waitcnt(0x0078);                         // vmcnt(8): step 0 has landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & (NA - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(s + 3);
+    load_frag(fa0, fb0, buf, 0);
+    mfma8(fac, fbc);                                        // slice 2 of the previous step
+    load_frag(fa1, fb1, buf, 1);
+    mfma8(fa0, fb0);
+    load_frag(fac, fbc, buf, 2);
+    mfma8(fa1, fb1);
+    // (0x008 MFMA, 0x010 vector memory, 0x100 LDS read): the reads of slice 0 first, one piece behind each of the first MFMAs,
+    // the reads of slices 1 and 2 between the others
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int t = 0; t < 24; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (t < 4) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      if (t >= 4 && t < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (summer) {
+      const float* y1 = Ys + buf * QT + T6_PLANE;
+#pragma unroll
+      for (int hx = 0; hx < T6_H; ++hx) bsum += y1[hx * 64 + (lane ^ ((hx & 1) << 5))];
+    }
+    // everything issued up to step s + 1 has landed; the 4 pieces of steps s + 2 and s + 3 may fly
+    __builtin_amdgcn_s_waitcnt(0x0078);                           // vmcnt(8) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  mfma8(fac, fbc);
+  if (summer) p.colsum[(long long)z * p.Ndim + n0 + lane] = bsum;
+  float* out = p.slab + (long long)z * p.slab_stride;
+  const int col = n0 + wn * 32 + lr;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * 64 + (i >> 2) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      out[((long long)(i0 + (i & 3)) * p.Mdim + m) * (long long)p.ldc + col] = acc[i][e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // conv1 (C_in = 1) + LeakyReLU + max-pool writing V of its pooled output in HEX form, pair layout (conv1_fwd_vq_kernel of
 // tonal_misc.hip with six rows per unit).  HBM-write bound, so the thread mapping follows the layout: four adjacent lanes
 // = (one 8-channel chunk) x (the two hexes of a pair) write the 64-byte run of a transform, two transforms = one cache line;
@@ -1397,6 +1588,19 @@ extern "C" int tl_wino63_v_fixup(float* V, const float* vhalo, int64_t hexes, in
   return check_launch("wino63_v_fixup");
 }
 
+extern "C" int tl_wino63_vd_fixup(float* Vd, const float* vhalo, int64_t hexes, int64_t tiles, int hexes_per_seq, int C, int ldv,
+                                  void* stream) {
+  using namespace tl;
+  TL_REQUIRE(Vd && vhalo, "wino63_vd_fixup: null pointer");
+  TL_REQUIRE(hexes > 0 && tiles > 0 && hexes_per_seq > 0, "wino63_vd_fixup: hexes, tiles, hexes per sequence > 0 needed");
+  TL_REQUIRE(C > 0 && C % 4 == 0 && ldv >= C && ldv % 8 == 0, "wino63_vd_fixup: C %% 4 and ldv %% 8 needed");
+  const long long n = (long long)tiles * (C / 4);
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_vd_fixup: grid too large");
+  hipLaunchKernelGGL(wino63_vd_fixup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Vd, vhalo,
+                     (long long)hexes, (long long)tiles, hexes_per_seq, C, ldv);
+  return check_launch("wino63_vd_fixup");
+}
+
 // NT passes on a pre-transformed operand: A = V[hex][8][lda], A_rows = hexes in V (whole 128-hex tiles), M = output rows
 // (6 per hex).  Forward: V of the stage input, POOL / POOLV epilogue.  Input gradient: Vd (written by tl_conv3_wino63v_tn),
 // taps = the flipped / transposed set, MASK or fused-conv1-weight-gradient epilogue.
@@ -1404,7 +1608,7 @@ extern "C" int tl_conv3_wino63v_nt(const tl_nt_params* pp, void* stream) {
   using namespace tl;
   TL_REQUIRE(pp != nullptr, "wino63v_nt: null params");
   const tl_nt_params& p = *pp;
-  TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W || p.epilogue == W_EPI_POOLV), "wino63v_nt: null V/Bw/out");
+  TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W || p.epilogue == W_EPI_POOLV || p.epilogue == W_EPI_MASKY), "wino63v_nt: null V/Bw/out");
   TL_REQUIRE(p.loader == W_LOAD_V, "wino63v_nt: loader 2 (pre-transformed operand) only");
   TL_REQUIRE(p.J == 3 && p.splitk <= 1, "wino63v_nt: 3 taps, no split-K");
   TL_REQUIRE(p.M > 0 && p.M % 6 == 0 && p.N > 0 && p.K >= 24 && p.K % 8 == 0, "wino63v_nt: M %% 6, K %% 8, K >= 24 needed");
@@ -1441,6 +1645,13 @@ extern "C" int tl_conv3_wino63v_nt(const tl_nt_params* pp, void* stream) {
     TL_REQUIRE(p.row_shift == -2 && p.ldo >= p.N, "wino63v_nt: input gradient needs row_shift -2");
     TL_REQUIRE(p.auxbits != nullptr, "wino63v_nt: MASK needs auxbits (the sign bits of the stage input)");
     hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_MASK>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
+  } else if (p.epilogue == W_EPI_MASKY) {
+    TL_REQUIRE(p.row_shift == -2 && p.auxbits != nullptr && p.abits != nullptr, "wino63v_nt: epilogue 6 needs row_shift -2, auxbits and abits");
+    TL_REQUIRE(p.ld_abits * 32 >= p.N && p.Tvalid_in % 2 == 0 && p.Tvalid_in <= 2 * p.Tp, "wino63v_nt: epilogue 6: bad abits / Tvalid_in");
+    TL_REQUIRE(p.vout && p.vout2 && p.vhalo && p.ld_vout >= p.N && p.ld_vout % 8 == 0 && p.vout_quads >= p.M / 3 && p.vout_quads % 2 == 0,
+               "wino63v_nt: epilogue 6 needs vout / vout2 (>= M / 3 hexes, whole pairs, ld_vout %% 8 == 0) and vhalo");
+    TL_REQUIRE(128LL * 8 * p.ld_vout * 4 < (1LL << 31), "wino63v_nt: ld_vout too large");
+    hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_MASKY>), dim3((unsigned)ngrid), dim3(512), 0, st, p);
   } else if (p.epilogue == W_EPI_C1W) {
     TL_REQUIRE(p.row_shift == -2, "wino63v_nt: input gradient needs row_shift -2");
     TL_REQUIRE(p.auxbits && p.c1x && p.c1bits && p.c1partial, "wino63v_nt: epilogue 4 needs auxbits, c1x, c1bits, c1partial");
@@ -1459,8 +1670,27 @@ extern "C" int tl_conv3_wino63v_tn(const tl_tn_params* pp, void* stream) {
   TL_REQUIRE(pp != nullptr, "wino63v_tn: null params");
   tl_tn_params p = *pp;
   if (p.splitk < 1) p.splitk = 1;
+  if (p.loader == 3) {
+    // both operands pre-transformed: B = Y[hex][8][ldb] (pair layout) from the MASKY epilogue of the stage above
+    TL_REQUIRE(p.A && p.B && p.slab, "wino63v_tn: null V/Y/slab");
+    TL_REQUIRE(p.J == 3 && p.Tp > 0 && p.Tp % 6 == 0 && p.Krows > 0 && p.Krows % p.Tp == 0, "wino63v_tn: loader 3: bad Tp / Krows");
+    TL_REQUIRE(p.Krows + 64 < (1LL << 31), "wino63v_tn: more than 2^31 reduction rows");
+    TL_REQUIRE(p.Mdim % 256 == 0 && p.Ndim % 64 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.lda >= p.Mdim && p.ldb >= p.Ndim &&
+               p.ldc >= p.Ndim, "wino63v_tn: loader 3 needs Mdim %% 256, Ndim %% 64, lda / ldb %% 8");
+    TL_REQUIRE(p.A_rows % 2 == 0 && p.B_rows % 2 == 0 && p.vd == nullptr, "wino63v_tn: loader 3: whole hex pairs in V and Y, no Vd");
+    TL_REQUIRE(p.splitk <= 65535 && (p.splitk == 1 || p.slab_stride >= 8LL * p.Mdim * p.ldc), "wino63v_tn: bad splitk / slab_stride");
+    const long long ks = (p.Krows / 6 + T6_H - 1) / T6_H;
+    TL_REQUIRE(p.A_rows >= ks * T6_H && p.B_rows >= ks * T6_H, "wino63v_tn: V and Y must hold whole 6-hex K-steps (pad with zero hexes)");
+    const long long per3 = (ks + p.splitk - 1) / p.splitk;
+    TL_REQUIRE((per3 + 4) * (long long)T6_H * 8 * p.lda * 4 < (1LL << 31) && (per3 + 4) * (long long)T6_H * 8 * p.ldb * 4 < (1LL << 31),
+               "wino63v_tn: a reduction split spans more than 2 GB of V or Y: raise splitk");
+    const int ntm3 = p.Mdim / 256;
+    hipLaunchKernelGGL(wino63v_tn4y_kernel, dim3((unsigned)(2 * ntm3 * (p.Ndim / T6_BN)), (unsigned)p.splitk, 1), dim3(512), 0,
+                       (hipStream_t)stream, p, ntm3);
+    return check_launch("wino63v_tn (both operands pre-transformed)");
+  }
   TL_REQUIRE(p.A && p.B && p.slab && p.bbits, "wino63v_tn: null V/B/bbits/slab");
-  TL_REQUIRE(p.J == 3 && p.loader == 1, "wino63v_tn: 3 taps, UNPOOL loader only");
+  TL_REQUIRE(p.J == 3 && p.loader == 1, "wino63v_tn: 3 taps, UNPOOL loader (1) or pre-transformed Y (3)");
   TL_REQUIRE(p.Tp > 0 && p.Tp % 6 == 0 && p.Tvalid % 2 == 0 && p.Tvalid <= p.Tp, "wino63v_tn: Tp %% 6 == 0 and an even Tvalid <= Tp needed");
   TL_REQUIRE(p.Krows > 0 && p.Krows % p.Tp == 0 && p.Mdim > 0 && p.Ndim > 0, "wino63v_tn: bad sizes (Krows must be whole sequences)");
   TL_REQUIRE(p.Krows + 64 < (1LL << 31), "wino63v_tn: more than 2^31 reduction rows");

@@ -288,7 +288,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
 // Vector-memory stores every wave issues per tile (lower bound where a branch adds some), see v5_stores
 template <int EPI>
 constexpr int v6_stores() {
-  return EPI == W_EPI_POOL ? 52 : EPI == W_EPI_POOLV ? 70 : EPI == W_EPI_MASK ? 96 : 0;
+  return EPI == W_EPI_POOL ? 52 : EPI == W_EPI_POOLV ? 70 : EPI == W_EPI_MASK ? 96 : EPI == 6 ? 63 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -337,6 +337,169 @@ __device__ __forceinline__ void v6_epilogue_mask(const tl_nt_params& p, const f3
       const unsigned vo = FULL ? ovoff : selmu(mask96(inA, inB, r), ovoff, V5_OOB);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsO, vo, (unsigned)r * ldo4, 0);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Input gradient that hands the stage BELOW its weight-gradient and input-gradient operands (epilogue 6, MASKY).  The rows
+// this GEMM produces are the pooled gradient rows G of the stage below (conv3's input gradient = conv2's pooled output
+// gradient); a lane owns 96 consecutive ones of a column = 32 hexes of that stage (three pooled rows = six conv rows each).
+// Instead of G it writes, per hex and in the pair layout,
+//   Y  = A dz   (eight planes: the second operand of the stage's weight gradient, tl_conv3_wino63v_tn with loader 3)
+//   Vd = B^T (dz rows 6 h - 2 .. 6 h + 5)  (the operand of its input gradient)
+// where dz is G un-pooled with the stage's arg-max bits (abits) and zeroed past the valid time (Tvalid_in conv rows).
+// The weight-gradient kernel of that stage then runs without a transform (the Y side costs it 8 of 45 ms at conv2 and
+// every C_in-tile workgroup repeats it) and G itself is never stored.  The first hex of a lane takes its front row from
+// the half-wave below (through xch, one raw barrier), the first hex of a tile from the tile in front: it is stored raw
+// (rows in slots 2..7) and finished by tl_wino63_vd_fixup from vhalo[tile - 1] = that tile's last pooled row, un-pooled.
+// ------------------------------------------------------------------------------------------
+struct v6_pre_masky {
+  uint32_t s[3], a[3];         // sign words (auxbits) and arg-max words (abits) of the half's rows lr, 32 + lr, 64 + lr
+};
+__device__ __forceinline__ v6_pre_masky v6_prefetch_masky(const tl_nt_params& p, long long R0, int n0, int wm, int wn, int lr, int lh) {
+  const int colbase = n0 + wn * 32;
+  const long long ra = R0 + wm * 192 + 96 * lh + lr;
+  v6_pre_masky r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    r.s[k] = r.a[k] = 0u;
+    if (colbase < p.N && ra + 32 * k < p.M) {
+      r.s[k] = p.auxbits[(ra + 32 * k) * (long long)p.ld_auxbits + (colbase >> 5)];
+      r.a[k] = p.abits[(ra + 32 * k) * (long long)p.ld_abits + (colbase >> 5)];
+    }
+  }
+  return r;
+}
+template <bool FULL>
+__device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f32x16 (&acc)[8], const v6_pre_masky& pre, float* xch,
+                                                  long long R0, int n0, int wm, int wn, int lr_in, int lh, long long tm) {
+  int lr = lr_in;                                           // (opaque copy: see v6_epilogue_c1w)
+  asm volatile("" : "+v"(lr));
+  const int colbase = n0 + wn * 32;
+  const bool colok = colbase < p.N;
+  const int col = colbase + lr;
+  const long long Rw = R0 + wm * 192;                       // first row of the wave; a half covers 96 rows = 32 hexes below
+  const int Tp = p.Tp, hps = Tp / 3;                        // rows / hexes of the stage below per sequence
+  const v6_rows rw = v6_rows_of(tm * 128 + wm * 32, Tp);   // (time index of row Rw / Rw + 96)
+  // rows whose gradient counts: pooled time below Tvalid_in / 2, inside the matrix
+  const bits96 okA = v6_valid_bits96(rw.tA, Tp, p.Tvalid_in >> 1, Rw, p.M);
+  const bits96 okB = v6_valid_bits96(rw.tB, Tp, p.Tvalid_in >> 1, Rw + 96, p.M);
+  uint32_t sT[3], aT[3];                                    // bit j: sign / arg-max of (row 32 k + j, this lane's column)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    sT[k] = bit_transpose32(pre.s[k], lr);
+    aT[k] = bit_transpose32(pre.a[k], lr);
+  }
+  const long long Hb = Rw / 3;                              // first hex (of the stage below) of the wave: 64 per wave
+  const long long nhex = p.M / 3;
+  // hexes that start their sequence (the rows in front belong to the sequence before: zero) / that exist
+  unsigned long long firstA = 0, firstB = 0;
+  {
+    int ha = rw.tA / 3, hb = rw.tB / 3;
+    for (int k = 0; k < 32; ++k) {
+      firstA |= (unsigned long long)(ha == 0) << k;
+      firstB |= (unsigned long long)(hb == 0) << k;
+      ha = ha + 1 == hps ? 0 : ha + 1;
+      hb = hb + 1 == hps ? 0 : hb + 1;
+    }
+  }
+  const unsigned pair4 = (unsigned)p.ld_vout * 64u;        // bytes per hex pair (pair layout, tonal_wino63.hip)
+  const __amdgpu_buffer_rsrc_t rsY = rsrc_of(p.vout + Hb * 8 * (long long)p.ld_vout, (p.vout_quads - Hb) * 8 * (long long)p.ld_vout * 4);
+  const __amdgpu_buffer_rsrc_t rsD = rsrc_of(p.vout2 + Hb * 8 * (long long)p.ld_vout, (p.vout_quads - Hb) * 8 * (long long)p.ld_vout * 4);
+  const unsigned vvoff = colok ? (unsigned)(16 * lh) * pair4 + ((unsigned)(col >> 3) * 128u + (unsigned)(col & 7)) * 4u : V5_OOB;
+  const unsigned long long mraw = (wm == 0) ? 0x00000000ffffffffull : 0ull;     // hex 0 of the tile's first half-wave: raw
+  // un-pooled rows of a pooled row r: (even, odd) conv row
+  float pe = 0.f, po = 0.f;                                 // the pooled row in front of the current hex, un-pooled
+  float last_e = 0.f, last_o = 0.f;
+  float first_d[6];                                         // hex 0 of the lane waits for the exchange
+#pragma unroll
+  for (int k = 0; k < 6; ++k) first_d[k] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float y[6];
+    wino63_rows(acc, e, y);
+    float dzr[12];                                          // the six pooled rows of accumulator element e, un-pooled
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      const int r = 6 * e + h;
+      const float o = selm0(mask96(okA, okB, r), y[h] * selbit(sT[r >> 5], r & 31, 1.f, p.slope));
+      const uint32_t am = (uint32_t)__builtin_amdgcn_sbfe((int)aT[r >> 5], r & 31, 1);
+      dzr[2 * h] = __uint_as_float(__float_as_uint(o) & ~am);
+      dzr[2 * h + 1] = __uint_as_float(__float_as_uint(o) & am);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {                        // two hexes of the stage below per accumulator element
+      const int j = 2 * e + hh;
+      const float* d6 = dzr + 6 * hh;
+      // Y = A dz
+      const float ev1 = (d6[0] + d6[2]) + d6[4], od1 = (d6[1] + d6[3]) + d6[5];
+      const float ev2 = fmaf(16.f, d6[4], fmaf(4.f, d6[2], d6[0])), od2 = fmaf(32.f, d6[5], fmaf(8.f, d6[3], 2.f * d6[1]));
+      const float ev3 = fmaf(0.0625f, d6[4], fmaf(0.25f, d6[2], d6[0])), od3 = fmaf(0.03125f, d6[5], fmaf(0.125f, d6[3], 0.5f * d6[1]));
+      const float Y[8] = {d6[0], ev1 + od1, ev1 - od1, ev2 + od2, ev2 - od2, ev3 + od3, ev3 - od3, d6[5]};
+      const unsigned long long mex = (j < 32) ? (((nhex - Hb > j) ? 0xffffffffull : 0ull) | ((nhex - Hb - 32 > j) ? 0xffffffff00000000ull : 0ull)) : 0ull;
+      const unsigned vo = FULL ? vvoff : selmu(mex, vvoff, V5_OOB);
+      const unsigned so = (unsigned)(j >> 1) * pair4 + (unsigned)((j & 1) * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, Y[i]), rsY, vo, so + (unsigned)(i * 64), 0);
+      if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) first_d[k] = d6[k];
+      } else {
+        const unsigned long long mfirst = mask2l(firstA, firstB, j);
+        float d[8], v[8];
+        d[0] = selm(mfirst, 0.f, pe);
+        d[1] = selm(mfirst, 0.f, po);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[2 + k] = d6[k];
+        wino63_bt(d, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsD, vo, so + (unsigned)(i * 64), 0);
+      }
+      pe = d6[4];
+      po = d6[5];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  last_e = pe;
+  last_o = po;
+  // ---- hex 0 of every lane: its front row is the last row of the half-wave below ----
+  const int slot = wm * 2 + lh;
+  {
+    float2 v2 = {last_e, last_o};
+    *reinterpret_cast<float2*>(xch + (slot * 64 + wn * 32 + lr) * 2) = v2;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0)  (not __syncthreads(): see v6_epilogue_pool)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    float fe = 0.f, fo = 0.f;
+    if (slot > 0) {
+      const float2 v2 = *reinterpret_cast<const float2*>(xch + ((slot - 1) * 64 + wn * 32 + lr) * 2);
+      fe = v2.x;
+      fo = v2.y;
+    }
+    const unsigned long long mfirst = mask2l(firstA, firstB, 0);
+    float d[8], v[8];
+    d[0] = selm(mfirst, 0.f, fe);
+    d[1] = selm(mfirst, 0.f, fo);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d[2 + k] = first_d[k];
+    wino63_bt(d, v);
+    // (the tile's very first hex: rows raw in slots 2..7 for tl_wino63_vd_fixup, which owns its front row)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = selm(mraw, k < 2 ? 0.f : d[k], v[k]);
+    const unsigned long long mex = ((nhex - Hb > 0) ? 0xffffffffull : 0ull) | ((nhex - Hb - 32 > 0) ? 0xffffffff00000000ull : 0ull);
+    const unsigned vo = FULL ? vvoff : selmu(mex, vvoff, V5_OOB);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsD, vo, (unsigned)(i * 64), 0);
+  }
+  // the tile's last pooled row, un-pooled: the front row of the next tile's first hex
+  {
+    const bool hw = wm == 3 && p.vhalo != nullptr;
+    const __amdgpu_buffer_rsrc_t rsH = rsrc_of(hw ? p.vhalo + tm * 2 * (long long)p.N : nullptr, hw ? 2LL * p.N * 4 : 0);
+    const unsigned ho = (colok && lh == 1) ? (unsigned)col * 4u : V5_OOB;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, last_e), rsH, ho, 0u, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, last_o), rsH, ho, (unsigned)p.N * 4u, 0);
   }
 }
 

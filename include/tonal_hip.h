@@ -87,6 +87,13 @@ typedef struct {
   /* tl_conv3_wino63v_nt, POOL epilogue: rows per sequence of out / obits / osign, [seq * out_tp + t'] (pooled rows t' >=
    * out_tp are dropped); 0: Tp / 2.  Decouples the row stride of a stage's output from the hex padding of its input.   */
   int out_tp;
+  /* tl_conv3_wino63v_nt, epilogue 6 (MASKY): the input gradient of a stage hands the stage BELOW its operands instead of the
+   * gradient rows G: vout = Y[hex][8][ld_vout] (Y = A dz: the second operand of that stage's weight gradient,
+   * tl_conv3_wino63v_tn with loader 3) and vout2 = Vd[hex][8][ld_vout] (the operand of its input gradient), both in the pair
+   * layout, hexes of the stage below (three output rows each; vout_quads of them); dz = G un-pooled with abits (ld_abits),
+   * zero from Tvalid_in conv rows on; `out` is not written.  The first hex of every 768-row tile is finished by
+   * tl_wino63_vd_fixup from vhalo[tile][2][N].                                                                        */
+  float* vout2;
 } tl_nt_params;
 int tl_gemm_nt_window(const tl_nt_params* p, void* stream);
 
@@ -198,7 +205,9 @@ int tl_conv3_wino43v_tn(const tl_tn_params* p, void* stream);
  *                            hex form, vout_quads = hexes, Tp % 12 == 0), MASK, conv1-weight-gradient (4)
  *   tl_wino63_v_fixup        second half of POOLV: the last hex of every 64 written by a tile (rows 6, 7 from vhalo)
  *   tl_conv3_wino63v_tn      tl_conv3_wino43v_tn with hexes (Mdim % 128 == 0, Ndim % 64 == 0; slab[z][8][Mdim][ldc],
- *                            slab_stride >= 8*Mdim*ldc; B / bbits rows [seq * g_tp + t']); vd optional: Vd[hex][8][ld_vd]
+ *                            slab_stride >= 8*Mdim*ldc; B / bbits rows [seq * g_tp + t']); vd optional: Vd[hex][8][ld_vd].
+ *                            loader 3: B = Y[hex][8][ldb] written by epilogue 6 of the stage above - no transform in the
+ *                            kernel (Mdim % 256 == 0; colsum from Y plane 1)
  *   tl_wino63_wgrad_finalize red [8][I][ld] -> dW (O, I, 3, 1)
  *   tl_conv1_fwd_v6          tl_conv1_fwd_v writing V[S * Tp / 6][8][C1] (Tp % 6 == 0)
  * ------------------------------------------------------------------------------------------ */
@@ -207,6 +216,9 @@ int tl_conv3_wino63v_nt(const tl_nt_params* p, void* stream);
 int tl_wino63_v_fixup(float* V, const float* vhalo, int64_t hexes, int64_t tiles, int Tq, int C, int ldv, void* stream);
 int tl_conv3_wino63v_tn(const tl_tn_params* p, void* stream);
 int tl_wino63_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
+/* second half of epilogue 6: the first hex of every tile (256 hexes) of a Vd written by it - its front row comes from
+ * vhalo[tile - 1] (zero where the hex starts its sequence: hexes_per_seq)                                              */
+int tl_wino63_vd_fixup(float* Vd, const float* vhalo, int64_t hexes, int64_t tiles, int hexes_per_seq, int C, int ldv, void* stream);
 int tl_conv1_fwd_v6(const float* x, const float* w, const float* b, float* P, float* V, uint32_t* bits, uint32_t* sign,
                     int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */

@@ -31,6 +31,9 @@ V1.normal_(generator=g)
 eng._v_ready = {1: V1}
 for k in eng.G:
     eng.G[k].normal_(generator=g)
+if eng.f63_yprod:         # stage 2's backward operands come out of stage 3's input gradient: give the isolated passes something to read
+    for store in (eng.Yt, eng.Vd):
+        eng._v_hex_buffer(store, 2, S * eng.tp1, 512).normal_(generator=g)
 for k in eng.bits:
     eng.bits[k].random_(-2**31, 2**31 - 1, generator=g)
     eng.sbits[k].random_(-2**31, 2**31 - 1, generator=g)
@@ -47,9 +50,14 @@ for si in [int(s) for s in args.stages.split(",")]:
     iss = eng.f63_issue_factor(st)
 
     def dgrad():
-        eng._vd_ready[st.idx] = eng.generation       # (Vd left by the last weight-gradient launch)
+        eng._vd_ready[st.idx] = eng.generation       # (Vd left by the last weight-gradient launch / by stage 3's input gradient)
         eng.stage_dgrad(st, w)
-    for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("wgrad", lambda: eng.stage_wgrad(st, gw, gb)), ("dgrad", dgrad)):
+
+    def wgrad():
+        if eng.f63_yprod and st.idx == 2:
+            eng._y_ready[2] = eng.generation
+        eng.stage_wgrad(st, gw, gb)
+    for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("wgrad", wgrad), ("dgrad", dgrad)):
         if name not in args.passes.split(","):
             continue
         if name == "dgrad" and st.idx not in eng.Vd:

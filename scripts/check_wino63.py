@@ -173,12 +173,26 @@ def run(shape, dev):
         s0, s6 = e0.stages[si - 2], e6.stages[si - 2]
         note(f"conv{si} weight gradient (rel L2)", rel_l2(res["6"][0], res["0"][0]), 1e-5)
         note(f"conv{si} bias gradient (rel L2)", rel_l2(res["6"][1], res["0"][1]), 1e-5)
-        dz = unpool(e6.G[si], e6.bits[si], S, s6.tp_out, 2 * s6.tout, s6.cout)
-        if 2 * s6.tp_out < s6.tp_in:
-            dz = torch.nn.functional.pad(dz, (0, 0, 0, s6.tp_in - 2 * s6.tp_out))
-        Vdref = hex_transform(dz[:, :s6.tp_in].reshape(-1, s6.cout), S, s6.tp_in, shift=-2)
-        note(f"Vd{si} == B^T dZ", rel(logical(e6.Vd[si])[:Vdref.shape[0]], Vdref), 1e-6)
-        if si == 3:
+        if si in e6.G:
+            dz = unpool(e6.G[si], e6.bits[si], S, s6.tp_out, 2 * s6.tout, s6.cout)
+            if 2 * s6.tp_out < s6.tp_in:
+                dz = torch.nn.functional.pad(dz, (0, 0, 0, s6.tp_in - 2 * s6.tp_out))
+            Vdref = hex_transform(dz[:, :s6.tp_in].reshape(-1, s6.cout), S, s6.tp_in, shift=-2)
+            note(f"Vd{si} == B^T dZ", rel(logical(e6.Vd[si])[:Vdref.shape[0]], Vdref), 1e-6)
+        if si == 3 and e6.f63_yprod:
+            # the input gradient of stage 3 wrote Y2 = A dz and Vd2 instead of G2: against the direct engine's G2
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from wino63_ref import y_transform
+            nin, b2 = s6.tin, e6.stages[0]
+            g2 = torch.zeros(S, s6.tp_in, s6.cin, device=dev)
+            g2[:, :nin] = e0.G[2].view(S, s0.tp_in, -1)[:, :nin]
+            dz2 = unpool(g2.reshape(-1, s6.cin), e6.bits[2], S, s6.tp_in, 2 * b2.tout, s6.cin).reshape(-1, s6.cin)
+            Yref = y_transform(dz2, S, b2.tp_in)
+            note("Y2 == A dz2 (from the direct G2)", rel(logical(e6.Yt[2])[:Yref.shape[0]], Yref), 1e-5)
+            Vd2ref = hex_transform(dz2, S, b2.tp_in, shift=-2)
+            note("Vd2 == B^T dz2 (from the direct G2)", rel(logical(e6.Vd[2])[:Vd2ref.shape[0]], Vd2ref), 1e-5)
+            assert float(e6.Yt[2][Yref.shape[0]:].abs().max()) == 0.0 and float(e6.Vd[2][Yref.shape[0]:].abs().max()) == 0.0
+        elif si == 3:
             nin = s6.tin
             note("conv3 input gradient (rel L2)", rel_l2(rows(e6, e6.G[2], s6.tp_in, nin), rows(e0, e0.G[2], s0.tp_in, nin)), 1e-5)
             pad = rows(e6, e6.G[2], s6.tp_in, s6.tp_in)[:, nin:]

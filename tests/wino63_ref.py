@@ -43,3 +43,19 @@ def unpool(G, bits, S, tp, tvalid, C):
     dz[:, 1::2] = torch.where(odd, g, torch.zeros_like(g))
     dz[:, tvalid:] = 0
     return dz
+
+
+AT = torch.tensor([[1, 1, 1, 1, 1, 1, 1, 0],
+                   [0, 1, -1, 2, -2, .5, -.5, 0],
+                   [0, 1, 1, 4, 4, .25, .25, 0],
+                   [0, 1, -1, 8, -8, .125, -.125, 0],
+                   [0, 1, 1, 16, 16, .0625, .0625, 0],
+                   [0, 1, -1, 32, -32, .03125, -.03125, 1]], dtype=torch.float64)
+
+
+def y_transform(dz, S, Tp):
+    """un-pooled gradient rows dz (S*Tp, C) -> Y (S*Tp/6, 8, C) = A dz per hex (A = the transpose of the output transform),
+    float64, channels last: the second operand of the F(6,3) weight gradient"""
+    C = dz.shape[1]
+    x = dz.double().view(S, Tp // 6, 6, C)
+    return torch.einsum("kj,shkc->shjc", AT.to(dz.device), x).reshape(S * (Tp // 6), 8, C)
