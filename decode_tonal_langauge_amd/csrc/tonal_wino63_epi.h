@@ -16,6 +16,17 @@ namespace tl {
 constexpr unsigned V6_DROP = 0x80000000u;     // added to any in-range byte offset (< 2^31) it stays past every resource
 constexpr unsigned long long V6_HI = 0xffffffff00000000ull;
 
+// A 4-byte buffer store at (per-lane offset vo) + (scalar offset so) + (compile-time constant k).  Interior tiles (IMM: no
+// lane carries a dropped-store offset) put k into the instruction's immediate - 512 distinct scalar offsets per tile would
+// spill; elsewhere k rides in the scalar offset: measured on gfx950, a store whose per-lane offset is the out-of-range
+// marker is NOT reliably dropped once an immediate is added to it (a lane of a partial tile lost its stores, differently
+// from run to run).
+template <bool IMM>
+__device__ __forceinline__ void v6_store_at(float x, __amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so, unsigned k) {
+  if constexpr (IMM) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs, vo + k, so, 0);
+  else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs, vo, so + k, 0);
+}
+
 // the six conv rows of a hex from its eight products: y = A^T m,
 //   A^T = [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 0; 0 1 1 4 4 1/4 1/4 0; 0 1 -1 8 -8 1/8 -1/8 0; 0 1 1 16 16 1/16 1/16 0;
 //          0 1 -1 32 -32 1/32 -1/32 1]
@@ -253,7 +264,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
     const __amdgpu_buffer_rsrc_t rsV = rsrc_of(p.vout + Hn * 8 * (long long)p.ld_vout,
                                               (p.vout_quads - Hn) * 8 * (long long)p.ld_vout * 4);
     const unsigned pair4 = (unsigned)p.ld_vout * 64u;        // bytes per hex pair
-    const unsigned vvoff = colok ? (unsigned)(4 * lh) * pair4 + ((unsigned)(col >> 3) * 128u + (unsigned)(col & 7)) * 4u : V5_OOB;
+    const unsigned vvoff = colok ? (unsigned)(4 * lh) * pair4 + ((unsigned)(col >> 3) * 128u + (unsigned)(col & 7)) * 4u : V6_DROP;
     const unsigned long long mraw = wm == 3 ? V6_HI : 0ull;   // H' = 7 of the tile's last half-wave
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -268,11 +279,10 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
 #pragma unroll
         for (int k = 0; k < 6; ++k) v[k] = selm(mraw, d[k], v[k]);
       }
-      const unsigned vo = selmu(mask2(nvA, nvB, q), vvoff, V5_OOB);
+      const unsigned vo = selmu(mask2(nvA, nvB, q), vvoff, V6_DROP);      // (V6_DROP: the immediate below must not wrap it)
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsV, vo,
-                                              (unsigned)(q >> 1) * pair4 + (unsigned)(i * 64 + (q & 1) * 32), 0);
+        v6_store_at<FULL>(v[i], rsV, vo, (unsigned)(q >> 1) * pair4, (unsigned)(i * 64 + (q & 1) * 32));
     }
     // the tile's first two pooled rows: rows 6, 7 of the last hex of the tile in front (tl_wino63_v_fixup)
     {
@@ -381,39 +391,46 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
   const long long Rw = R0 + wm * 192;                       // first row of the wave; a half covers 96 rows = 32 hexes below
   const int Tp = p.Tp, hps = Tp / 3;                        // rows / hexes of the stage below per sequence
   const v6_rows rw = v6_rows_of(tm * 128 + wm * 32, Tp);   // (time index of row Rw / Rw + 96)
-  // rows whose gradient counts: pooled time below Tvalid_in / 2, inside the matrix
-  const bits96 okA = v6_valid_bits96(rw.tA, Tp, p.Tvalid_in >> 1, Rw, p.M);
-  const bits96 okB = v6_valid_bits96(rw.tB, Tp, p.Tvalid_in >> 1, Rw + 96, p.M);
-  uint32_t sT[3], aT[3];                                    // bit j: sign / arg-max of (row 32 k + j, this lane's column)
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    sT[k] = bit_transpose32(pre.s[k], lr);
-    aT[k] = bit_transpose32(pre.a[k], lr);
-  }
-  const long long Hb = Rw / 3;                              // first hex (of the stage below) of the wave: 64 per wave
-  const long long nhex = p.M / 3;
-  // hexes that start their sequence (the rows in front belong to the sequence before: zero) / that exist
-  unsigned long long firstA = 0, firstB = 0;
+  // Everything per row / per hex is a bit of a word this LANE holds (its half's copy), tested with v_bfe_i32: no lane masks
+  // in scalar registers (this epilogue has 96 rows x 3 flags and 32 hexes x 2 flags per lane; they spilled).
+  //   okw: rows whose gradient counts (pooled time below Tvalid_in / 2, inside the matrix)
+  //   we / wo: ok and the arg-max bit clear / set - the masks of the un-pool select
+  //   firstw: hexes that start their sequence (the row in front belongs to the sequence before: zero)
+  uint32_t we[3], wo[3], sT[3], firstw = 0;
   {
+    const bits96 okA = v6_valid_bits96(rw.tA, Tp, p.Tvalid_in >> 1, Rw, p.M);
+    const bits96 okB = v6_valid_bits96(rw.tB, Tp, p.Tvalid_in >> 1, Rw + 96, p.M);
+    const uint32_t okw[3] = {lh ? (uint32_t)okB.lo : (uint32_t)okA.lo, lh ? (uint32_t)(okB.lo >> 32) : (uint32_t)(okA.lo >> 32),
+                             lh ? okB.hi : okA.hi};
+    uint32_t fA = 0, fB = 0;
     int ha = rw.tA / 3, hb = rw.tB / 3;
     for (int k = 0; k < 32; ++k) {
-      firstA |= (unsigned long long)(ha == 0) << k;
-      firstB |= (unsigned long long)(hb == 0) << k;
+      fA |= (uint32_t)(ha == 0) << k;
+      fB |= (uint32_t)(hb == 0) << k;
       ha = ha + 1 == hps ? 0 : ha + 1;
       hb = hb + 1 == hps ? 0 : hb + 1;
     }
+    firstw = lh ? fB : fA;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      sT[k] = bit_transpose32(pre.s[k], lr);
+      const uint32_t aT = bit_transpose32(pre.a[k], lr);
+      we[k] = okw[k] & ~aT;
+      wo[k] = okw[k] & aT;
+    }
   }
+  const long long Hb = Rw / 3;                              // first hex (of the stage below) of the wave: 64 per wave
+  const int nex = (int)((p.M / 3 - Hb - 32 * lh) < 32 ? (p.M / 3 - Hb - 32 * lh) : 32);      // hexes of this lane that exist
   const unsigned pair4 = (unsigned)p.ld_vout * 64u;        // bytes per hex pair (pair layout, tonal_wino63.hip)
   const __amdgpu_buffer_rsrc_t rsY = rsrc_of(p.vout + Hb * 8 * (long long)p.ld_vout, (p.vout_quads - Hb) * 8 * (long long)p.ld_vout * 4);
   const __amdgpu_buffer_rsrc_t rsD = rsrc_of(p.vout2 + Hb * 8 * (long long)p.ld_vout, (p.vout_quads - Hb) * 8 * (long long)p.ld_vout * 4);
-  const unsigned vvoff = colok ? (unsigned)(16 * lh) * pair4 + ((unsigned)(col >> 3) * 128u + (unsigned)(col & 7)) * 4u : V5_OOB;
-  const unsigned long long mraw = (wm == 0) ? 0x00000000ffffffffull : 0ull;     // hex 0 of the tile's first half-wave: raw
-  // un-pooled rows of a pooled row r: (even, odd) conv row
+  // (a dropped store carries V6_DROP: the immediates added below must not wrap it back into the resource)
+  const unsigned vvoff = colok ? (unsigned)(16 * lh) * pair4 + ((unsigned)(col >> 3) * 128u + (unsigned)(col & 7)) * 4u : V6_DROP;
   float pe = 0.f, po = 0.f;                                 // the pooled row in front of the current hex, un-pooled
-  float last_e = 0.f, last_o = 0.f;
   float first_d[6];                                         // hex 0 of the lane waits for the exchange
 #pragma unroll
   for (int k = 0; k < 6; ++k) first_d[k] = 0.f;
+  auto andf = [](float x, uint32_t m) { return __uint_as_float(__float_as_uint(x) & m); };
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     float y[6];
@@ -422,10 +439,9 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
       const int r = 6 * e + h;
-      const float o = selm0(mask96(okA, okB, r), y[h] * selbit(sT[r >> 5], r & 31, 1.f, p.slope));
-      const uint32_t am = (uint32_t)__builtin_amdgcn_sbfe((int)aT[r >> 5], r & 31, 1);
-      dzr[2 * h] = __uint_as_float(__float_as_uint(o) & ~am);
-      dzr[2 * h + 1] = __uint_as_float(__float_as_uint(o) & am);
+      const float t = y[h] * selbit(sT[r >> 5], r & 31, 1.f, p.slope);
+      dzr[2 * h] = andf(t, (uint32_t)__builtin_amdgcn_sbfe((int)we[r >> 5], r & 31, 1));
+      dzr[2 * h + 1] = andf(t, (uint32_t)__builtin_amdgcn_sbfe((int)wo[r >> 5], r & 31, 1));
     }
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {                        // two hexes of the stage below per accumulator element
@@ -436,36 +452,36 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
       const float ev2 = fmaf(16.f, d6[4], fmaf(4.f, d6[2], d6[0])), od2 = fmaf(32.f, d6[5], fmaf(8.f, d6[3], 2.f * d6[1]));
       const float ev3 = fmaf(0.0625f, d6[4], fmaf(0.25f, d6[2], d6[0])), od3 = fmaf(0.03125f, d6[5], fmaf(0.125f, d6[3], 0.5f * d6[1]));
       const float Y[8] = {d6[0], ev1 + od1, ev1 - od1, ev2 + od2, ev2 - od2, ev3 + od3, ev3 - od3, d6[5]};
-      const unsigned long long mex = (j < 32) ? (((nhex - Hb > j) ? 0xffffffffull : 0ull) | ((nhex - Hb - 32 > j) ? 0xffffffff00000000ull : 0ull)) : 0ull;
-      const unsigned vo = FULL ? vvoff : selmu(mex, vvoff, V5_OOB);
-      const unsigned so = (unsigned)(j >> 1) * pair4 + (unsigned)((j & 1) * 32);
+      const unsigned vo = FULL ? vvoff : (j < nex ? vvoff : V6_DROP);
+      // (scalar offset: the hex pair; the transform and the hex's slot in the pair ride in the instruction's immediate)
+      const unsigned so = (unsigned)(j >> 1) * pair4;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, Y[i]), rsY, vo, so + (unsigned)(i * 64), 0);
+      for (int i = 0; i < 8; ++i)
+        v6_store_at<FULL>(Y[i], rsY, vo, so, (unsigned)((j & 1) * 32 + i * 64));
       if (j == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) first_d[k] = d6[k];
       } else {
-        const unsigned long long mfirst = mask2l(firstA, firstB, j);
+        const uint32_t keep = ~(uint32_t)__builtin_amdgcn_sbfe((int)firstw, j, 1);      // all ones unless the hex starts its sequence
         float d[8], v[8];
-        d[0] = selm(mfirst, 0.f, pe);
-        d[1] = selm(mfirst, 0.f, po);
+        d[0] = andf(pe, keep);
+        d[1] = andf(po, keep);
 #pragma unroll
         for (int k = 0; k < 6; ++k) d[2 + k] = d6[k];
         wino63_bt(d, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsD, vo, so + (unsigned)(i * 64), 0);
+        for (int i = 0; i < 8; ++i)
+          v6_store_at<FULL>(v[i], rsD, vo, so, (unsigned)((j & 1) * 32 + i * 64));
       }
       pe = d6[4];
       po = d6[5];
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  last_e = pe;
-  last_o = po;
   // ---- hex 0 of every lane: its front row is the last row of the half-wave below ----
   const int slot = wm * 2 + lh;
   {
-    float2 v2 = {last_e, last_o};
+    float2 v2 = {pe, po};
     *reinterpret_cast<float2*>(xch + (slot * 64 + wn * 32 + lr) * 2) = v2;
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0)  (not __syncthreads(): see v6_epilogue_pool)
@@ -478,28 +494,28 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
       fe = v2.x;
       fo = v2.y;
     }
-    const unsigned long long mfirst = mask2l(firstA, firstB, 0);
+    const uint32_t keep = ~(uint32_t)__builtin_amdgcn_sbfe((int)firstw, 0, 1);
     float d[8], v[8];
-    d[0] = selm(mfirst, 0.f, fe);
-    d[1] = selm(mfirst, 0.f, fo);
+    d[0] = andf(fe, keep);
+    d[1] = andf(fo, keep);
 #pragma unroll
     for (int k = 0; k < 6; ++k) d[2 + k] = first_d[k];
     wino63_bt(d, v);
     // (the tile's very first hex: rows raw in slots 2..7 for tl_wino63_vd_fixup, which owns its front row)
+    const bool raw = slot == 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = selm(mraw, k < 2 ? 0.f : d[k], v[k]);
-    const unsigned long long mex = ((nhex - Hb > 0) ? 0xffffffffull : 0ull) | ((nhex - Hb - 32 > 0) ? 0xffffffff00000000ull : 0ull);
-    const unsigned vo = FULL ? vvoff : selmu(mex, vvoff, V5_OOB);
+    for (int k = 0; k < 8; ++k) v[k] = raw ? (k < 2 ? 0.f : d[k]) : v[k];
+    const unsigned vo = FULL ? vvoff : (0 < nex ? vvoff : V6_DROP);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rsD, vo, (unsigned)(i * 64), 0);
+    for (int i = 0; i < 8; ++i) v6_store_at<FULL>(v[i], rsD, vo, 0u, (unsigned)(i * 64));
   }
   // the tile's last pooled row, un-pooled: the front row of the next tile's first hex
   {
     const bool hw = wm == 3 && p.vhalo != nullptr;
     const __amdgpu_buffer_rsrc_t rsH = rsrc_of(hw ? p.vhalo + tm * 2 * (long long)p.N : nullptr, hw ? 2LL * p.N * 4 : 0);
     const unsigned ho = (colok && lh == 1) ? (unsigned)col * 4u : V5_OOB;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, last_e), rsH, ho, 0u, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, last_o), rsH, ho, (unsigned)p.N * 4u, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pe), rsH, ho, 0u, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, po), rsH, ho, (unsigned)p.N * 4u, 0);
   }
 }
 

@@ -1101,7 +1101,8 @@ def test_stage_step_and_slab_sums_small_entry_points(dev):
 
 @pytest.mark.parametrize("shape", [(2, 3, 200, 128, 128, 64), (3, 5, 236, 128, 256, 128), (1, 1, 44, 128, 128, 128),
                                    (7, 3, 100, 256, 128, 64), (6, 8, 400, 512, 512, 512)])
-def test_f63_stage_kernels_match_direct_kernels(dev, shape, monkeypatch):
+@pytest.mark.parametrize("yprod", ["1", "0"])
+def test_f63_stage_kernels_match_direct_kernels(dev, shape, yprod, monkeypatch):
     """Round 4: the Winograd F(6,3) kernels (default where the stack allows them) against the direct MFMA kernels, stage by
     stage through the C ABI: conv1 writing V1 in hex form (== B^T of the raw rows it stores on request), conv2 forward
     writing V2 (epilogue 5 + fix-up: hexes that take rows from the next half-wave, wave, tile; hexes that end a sequence),
@@ -1110,8 +1111,11 @@ def test_f63_stage_kernels_match_direct_kernels(dev, shape, monkeypatch):
     half-wave's rows, ragged last tiles, a pooled row count that is odd (400 -> 51 rows per sequence behind conv3's hexes)."""
     from decode_tonal_langauge_amd._cnn_engine import CnnEngine
     from decode_tonal_langauge_amd._lib import check, ptr
-    from tests.wino63_ref import hex_transform, logical, unpool
+    from tests.wino63_ref import hex_transform, logical, unpool, y_transform
     B, C, T, c1, c2, c3 = shape
+    if yprod == "0" and c1 % 256 != 0:
+        pytest.skip("the Y-producing epilogue needs C_in of stage 2 % 256 == 0: nothing to switch off")
+    monkeypatch.setenv("TONAL_F63_YPROD", yprod)
     defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
     engs = {}
     for mode in ("0", "6"):
@@ -1200,12 +1204,25 @@ def test_f63_stage_kernels_match_direct_kernels(dev, shape, monkeypatch):
         s0, s6 = e0.stages[si - 2], e6.stages[si - 2]
         assert rel_l2(res["6"][0].cpu().numpy(), res["0"][0].cpu().numpy()) < 1e-5, si
         assert rel_l2(res["6"][1].cpu().numpy(), res["0"][1].cpu().numpy()) < 1e-5, si
-        dz = unpool(e6.G[si], e6.bits[si], S, s6.tp_out, 2 * s6.tout, s6.cout)
-        if 2 * s6.tp_out < s6.tp_in:
-            dz = torch.nn.functional.pad(dz, (0, 0, 0, s6.tp_in - 2 * s6.tp_out))
-        Vdref = hex_transform(dz[:, :s6.tp_in].reshape(-1, s6.cout), S, s6.tp_in, shift=-2)
-        assert close(logical(e6.Vd[si])[:Vdref.shape[0]], Vdref), si
-        if si == 3:
+        if si in e6.G:
+            dz = unpool(e6.G[si], e6.bits[si], S, s6.tp_out, 2 * s6.tout, s6.cout)
+            if 2 * s6.tp_out < s6.tp_in:
+                dz = torch.nn.functional.pad(dz, (0, 0, 0, s6.tp_in - 2 * s6.tp_out))
+            Vdref = hex_transform(dz[:, :s6.tp_in].reshape(-1, s6.cout), S, s6.tp_in, shift=-2)
+            assert close(logical(e6.Vd[si])[:Vdref.shape[0]], Vdref), si
+        if si == 3 and e6.f63_yprod:
+            # the input gradient of stage 3 wrote the operands of stage 2's backward - Y2 = A dz2 and Vd2 = B^T dz2 - instead
+            # of G2 (epilogue 6 + tl_wino63_vd_fixup): against the direct engine's G2, un-pooled with the same bits
+            assert 2 not in e6.G and c1 % 256 == 0
+            nin, b2 = s6.tin, e6.stages[0]
+            g2 = torch.zeros(S, s6.tp_in, s6.cin, device=dev)
+            g2[:, :nin] = e0.G[2].view(S, s0.tp_in, -1)[:, :nin]
+            dz2 = unpool(g2.reshape(-1, s6.cin), e6.bits[2], S, s6.tp_in, 2 * b2.tout, s6.cin).reshape(-1, s6.cin)
+            Yref, Vd2ref = y_transform(dz2, S, b2.tp_in), hex_transform(dz2, S, b2.tp_in, shift=-2)
+            near = lambda a, b: float((a.double() - b).abs().max()) <= 1e-5 * float(b.abs().max())   # (two fp32 gradients apart)
+            assert near(logical(e6.Yt[2])[:Yref.shape[0]], Yref) and near(logical(e6.Vd[2])[:Yref.shape[0]], Vd2ref)
+            assert float(e6.Yt[2][Yref.shape[0]:].abs().max()) == 0.0 and float(e6.Vd[2][Yref.shape[0]:].abs().max()) == 0.0
+        elif si == 3:
             nin = s6.tin
             assert rel_l2(rows(e6.G[2], s6.tp_in, nin).cpu().numpy(), rows(e0.G[2], s0.tp_in, nin).cpu().numpy()) < 1e-5
             e6.G[2].view(S, s6.tp_in, -1).zero_()
