@@ -542,12 +542,18 @@ class CnnEngine:
             self._fam_share = {}
             st2, st3 = self.stages[0], self.stages[1]
             f6 = "Winograd F(6,3) on pre-transformed operands, LDS-DMA"
+            tn = "wino63v_tn4_kernel<true>" if st3.cin % 256 == 0 and st3.tp_in >= 12 else "wino63v_tn_kernel<true>"
+            tn2 = "wino63v_tn4_kernel<true>" if st2.cin % 256 == 0 else "wino63v_tn_kernel<true>"
             fams = {f"wino63v_nt_kernel<POOLV> (conv2 forward, {f6}; writes V of its pooled output for conv3)": ["conv2_fwd"],
                     f"wino63v_nt_kernel<POOL> (conv3 forward, {f6})": ["conv3_fwd"],
                     f"wino63v_nt_kernel<C1WGRAD> (conv2 input gradient + conv1 weight gradient, {f6})": ["conv2_dgrad"],
-                    f"wino63v_nt_kernel<MASK> (conv3 input gradient, {f6})": ["conv3_dgrad"],
-                    f"wino63v_tn_kernel<true> (conv2 weight gradient, {f6}; also writes Vd)": ["conv2_wgrad"],
-                    f"wino63v_tn_kernel<true> (conv3 weight gradient, {f6}; also writes Vd)": ["conv3_wgrad"]}
+                    f"{tn} (conv3 weight gradient, {f6}; also writes Vd)": ["conv3_wgrad"]}
+            if self.f63_yprod:
+                fams[f"wino63v_nt_kernel<MASKY> (conv3 input gradient, {f6}; writes Y and Vd of conv2 instead of the gradient rows)"] = ["conv3_dgrad"]
+                fams[f"wino63v_tn4y_kernel (conv2 weight gradient, {f6}: both operands by LDS-DMA, no transform in the kernel)"] = ["conv2_wgrad"]
+            else:
+                fams[f"wino63v_nt_kernel<MASK> (conv3 input gradient, {f6})"] = ["conv3_dgrad"]
+                fams[f"{tn2} (conv2 weight gradient, {f6}; also writes Vd)"] = ["conv2_wgrad"]
             issued = {k: self.f63_issue_factor(st2 if "conv2" in k else st3) for k in fams}
             return fams, issued
         if not self.wino:

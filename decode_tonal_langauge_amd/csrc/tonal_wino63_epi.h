@@ -27,6 +27,49 @@ __device__ __forceinline__ void v6_store_at(float x, __amdgpu_buffer_rsrc_t rs, 
   else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs, vo, so + k, 0);
 }
 
+// [aL | aH], [bL | bH] -> [aL | bL], [aH | bH]   (L / H: lanes 0-31 / 32-63; v_permlane32_swap)
+// The hexes a lane owns are consecutive, so the two hexes of a pair (the 2 x 32 B that are contiguous in the pair layout) sit
+// in ONE lane: stored as they are, a store instruction writes 32-byte runs - and partial-line writes are read-modify-write at
+// the memory side (PMC: the Y / Vd-writing epilogue fetched 30 GB it never reads).  After the swap, lanes 0-31 carry hex h of
+// lane-half 0's pair and lanes 32-63 hex h + 1 of the SAME pair and columns: one instruction writes 64-byte runs.
+__device__ __forceinline__ void v6_pair_swap(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+// The eight transforms of a hex PAIR of both lane-halves (ha / hb: the hexes h and h + 1 every lane owns) to memory in whole
+// 128-byte lines of the pair layout.  v6_pair_swap puts hex h of lane-half 0's pair into lanes 0-31 and hex h + 1 of the same
+// pair into lanes 32-63 (ha: half 0's pair, hb: half 1's); v_permlane16_swap then pairs transforms t, t + 1: lanes 0-15 / 16-31
+// of a 32-lane row = transform t / t + 1 of the wave's columns 0-15 (second register: columns 16-31).  A line of the layout is
+// [transform t: hex 0 (8 channels), hex 1][transform t + 1: hex 0, hex 1]: one store instruction now writes two whole lines
+// (stored lane by lane it wrote 32-byte runs: read-modify-write at the memory side - the PMC counters showed 30 GB of reads
+// the Y / Vd-writing epilogue never asks for).  voP / voQ: the per-lane offsets of the two registers (v6_pair_offsets).
+template <bool IMM>
+__device__ __forceinline__ void v6_store_hex_pair(float (&ha)[8], float (&hb)[8], __amdgpu_buffer_rsrc_t rs, unsigned voAP, unsigned voAQ,
+                                                  unsigned voBP, unsigned voBQ, unsigned so) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v6_pair_swap(ha[i], hb[i]);
+#pragma unroll
+  for (int t = 0; t < 8; t += 2) {
+    {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ha[t]), __float_as_uint(ha[t + 1]), false, false);
+      v6_store_at<IMM>(__uint_as_float(r[0]), rs, voAP, so, (unsigned)(t * 64));
+      v6_store_at<IMM>(__uint_as_float(r[1]), rs, voAQ, so, (unsigned)(t * 64));
+    }
+    {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(hb[t]), __float_as_uint(hb[t + 1]), false, false);
+      v6_store_at<IMM>(__uint_as_float(r[0]), rs, voBP, so, (unsigned)(t * 64));
+      v6_store_at<IMM>(__uint_as_float(r[1]), rs, voBQ, so, (unsigned)(t * 64));
+    }
+  }
+}
+// per-lane byte offset of the first register of v6_store_hex_pair inside its hex pair (the second: + 1024): 8-channel chunk
+// (colbase / 8 + bit 3 of lr), transform parity (bit 4 of lr), hex of the pair (lh), channel (lr & 7)
+__device__ __forceinline__ unsigned v6_pair_offset(int colbase, int lr, int lh) {
+  return (unsigned)((colbase >> 3) + ((lr >> 3) & 1)) * 512u + (unsigned)((lr >> 4) & 1) * 64u + (unsigned)lh * 32u + (unsigned)(lr & 7) * 4u;
+}
+
 // the six conv rows of a hex from its eight products: y = A^T m,
 //   A^T = [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 0; 0 1 1 4 4 1/4 1/4 0; 0 1 -1 8 -8 1/8 -1/8 0; 0 1 1 16 16 1/16 1/16 0;
 //          0 1 -1 32 -32 1/32 -1/32 1]
@@ -264,25 +307,31 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
     const __amdgpu_buffer_rsrc_t rsV = rsrc_of(p.vout + Hn * 8 * (long long)p.ld_vout,
                                               (p.vout_quads - Hn) * 8 * (long long)p.ld_vout * 4);
     const unsigned pair4 = (unsigned)p.ld_vout * 64u;        // bytes per hex pair
-    const unsigned vvoff = colok ? (unsigned)(4 * lh) * pair4 + ((unsigned)(col >> 3) * 128u + (unsigned)(col & 7)) * 4u : V6_DROP;
+    // after v6_pair_swap: lanes 0-31 / 32-63 = hex q / q + 1 of a pair; first the pairs of lane-half 0's eight hexes, then half 1's
+    const unsigned offP = v6_pair_offset(colbase, lr, lh);
+    const unsigned vvA = colok ? offP : V6_DROP, vvB = colok ? 4u * pair4 + offP : V6_DROP;
     const unsigned long long mraw = wm == 3 ? V6_HI : 0ull;   // H' = 7 of the tile's last half-wave
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const unsigned long long mend = mask2(seA, seB, q);
-      float d[8], v[8];
+    for (int qp = 0; qp < 4; ++qp) {
+      float vv[2][8];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) d[k] = pv[6 * q + k];
-      d[6] = selm(mend, 0.f, q < 7 ? pv[(6 * q + 6) % 48] : nb0);
-      d[7] = selm(mend, 0.f, q < 7 ? pv[(6 * q + 7) % 48] : nb1);
-      wino63_bt(d, v);
-      if (q == 7) {                                         // raw rows for tl_wino63_v_fixup (which owns rows 6, 7 of this hex)
+      for (int hq = 0; hq < 2; ++hq) {
+        const int q = 2 * qp + hq;
+        const unsigned long long mend = mask2(seA, seB, q);
+        float d[8];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) v[k] = selm(mraw, d[k], v[k]);
+        for (int k = 0; k < 6; ++k) d[k] = pv[6 * q + k];
+        d[6] = selm(mend, 0.f, q < 7 ? pv[(6 * q + 6) % 48] : nb0);
+        d[7] = selm(mend, 0.f, q < 7 ? pv[(6 * q + 7) % 48] : nb1);
+        wino63_bt(d, vv[hq]);
+        if (q == 7) {                                       // raw rows for tl_wino63_v_fixup (which owns rows 6, 7 of this hex)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vv[hq][k] = selm(mraw, d[k], vv[hq][k]);
+        }
       }
-      const unsigned vo = selmu(mask2(nvA, nvB, q), vvoff, V6_DROP);      // (V6_DROP: the immediate below must not wrap it)
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        v6_store_at<FULL>(v[i], rsV, vo, (unsigned)(q >> 1) * pair4, (unsigned)(i * 64 + (q & 1) * 32));
+      const int q = 2 * qp;
+      const unsigned voA = selmu(mask2(nvA, nvA >> 1, q), vvA, V6_DROP), voB = selmu(mask2(nvB, nvB >> 1, q), vvB, V6_DROP);
+      v6_store_hex_pair<FULL>(vv[0], vv[1], rsV, voA, voA + 1024u, voB, voB + 1024u, (unsigned)qp * pair4);
     }
     // the tile's first two pooled rows: rows 6, 7 of the last hex of the tile in front (tl_wino63_v_fixup)
     {
@@ -420,16 +469,20 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
     }
   }
   const long long Hb = Rw / 3;                              // first hex (of the stage below) of the wave: 64 per wave
-  const int nex = (int)((p.M / 3 - Hb - 32 * lh) < 32 ? (p.M / 3 - Hb - 32 * lh) : 32);      // hexes of this lane that exist
   const unsigned pair4 = (unsigned)p.ld_vout * 64u;        // bytes per hex pair (pair layout, tonal_wino63.hip)
   const __amdgpu_buffer_rsrc_t rsY = rsrc_of(p.vout + Hb * 8 * (long long)p.ld_vout, (p.vout_quads - Hb) * 8 * (long long)p.ld_vout * 4);
   const __amdgpu_buffer_rsrc_t rsD = rsrc_of(p.vout2 + Hb * 8 * (long long)p.ld_vout, (p.vout_quads - Hb) * 8 * (long long)p.ld_vout * 4);
   // (a dropped store carries V6_DROP: the immediates added below must not wrap it back into the resource)
-  const unsigned vvoff = colok ? (unsigned)(16 * lh) * pair4 + ((unsigned)(col >> 3) * 128u + (unsigned)(col & 7)) * 4u : V6_DROP;
+  // after v6_pair_swap: lanes 0-31 / 32-63 = hex j / j + 1 of a pair; first the pairs of lane-half 0's 32 hexes, then half 1's
+  const unsigned offP = v6_pair_offset(colbase, lr, lh);
+  const unsigned vvA = colok ? offP : V6_DROP, vvB = colok ? 16u * pair4 + offP : V6_DROP;
+  const int nexA = (int)(p.M / 3 - Hb < 64 ? p.M / 3 - Hb : 64) - lh, nexB = nexA - 32;      // (hex j + lh of the pair exists: j < nex)
   float pe = 0.f, po = 0.f;                                 // the pooled row in front of the current hex, un-pooled
-  float first_d[6];                                         // hex 0 of the lane waits for the exchange
+  float first_d[6], v1keep[8];                              // hex 0 of the lane waits for the exchange (and hex 1, its pair, with it)
 #pragma unroll
   for (int k = 0; k < 6; ++k) first_d[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v1keep[k] = 0.f;
   auto andf = [](float x, uint32_t m) { return __uint_as_float(__float_as_uint(x) & m); };
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
@@ -443,38 +496,50 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
       dzr[2 * h] = andf(t, (uint32_t)__builtin_amdgcn_sbfe((int)we[r >> 5], r & 31, 1));
       dzr[2 * h + 1] = andf(t, (uint32_t)__builtin_amdgcn_sbfe((int)wo[r >> 5], r & 31, 1));
     }
+    float Yp[2][8], Vp[2][8];                               // the pair of hexes (of the stage below) of accumulator element e
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {                        // two hexes of the stage below per accumulator element
+    for (int hh = 0; hh < 2; ++hh) {
       const int j = 2 * e + hh;
       const float* d6 = dzr + 6 * hh;
       // Y = A dz
       const float ev1 = (d6[0] + d6[2]) + d6[4], od1 = (d6[1] + d6[3]) + d6[5];
       const float ev2 = fmaf(16.f, d6[4], fmaf(4.f, d6[2], d6[0])), od2 = fmaf(32.f, d6[5], fmaf(8.f, d6[3], 2.f * d6[1]));
       const float ev3 = fmaf(0.0625f, d6[4], fmaf(0.25f, d6[2], d6[0])), od3 = fmaf(0.03125f, d6[5], fmaf(0.125f, d6[3], 0.5f * d6[1]));
-      const float Y[8] = {d6[0], ev1 + od1, ev1 - od1, ev2 + od2, ev2 - od2, ev3 + od3, ev3 - od3, d6[5]};
-      const unsigned vo = FULL ? vvoff : (j < nex ? vvoff : V6_DROP);
-      // (scalar offset: the hex pair; the transform and the hex's slot in the pair ride in the instruction's immediate)
-      const unsigned so = (unsigned)(j >> 1) * pair4;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        v6_store_at<FULL>(Y[i], rsY, vo, so, (unsigned)((j & 1) * 32 + i * 64));
+      Yp[hh][0] = d6[0];
+      Yp[hh][1] = ev1 + od1;
+      Yp[hh][2] = ev1 - od1;
+      Yp[hh][3] = ev2 + od2;
+      Yp[hh][4] = ev2 - od2;
+      Yp[hh][5] = ev3 + od3;
+      Yp[hh][6] = ev3 - od3;
+      Yp[hh][7] = d6[5];
       if (j == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) first_d[k] = d6[k];
       } else {
         const uint32_t keep = ~(uint32_t)__builtin_amdgcn_sbfe((int)firstw, j, 1);      // all ones unless the hex starts its sequence
-        float d[8], v[8];
+        float d[8];
         d[0] = andf(pe, keep);
         d[1] = andf(po, keep);
 #pragma unroll
         for (int k = 0; k < 6; ++k) d[2 + k] = d6[k];
-        wino63_bt(d, v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          v6_store_at<FULL>(v[i], rsD, vo, so, (unsigned)((j & 1) * 32 + i * 64));
+        wino63_bt(d, Vp[hh]);
       }
       pe = d6[4];
       po = d6[5];
+    }
+    {
+      const int j = 2 * e;
+      // (scalar offset: the hex pair; the transform rides in the instruction's immediate where no lane is dropped)
+      const unsigned so = (unsigned)e * pair4;
+      const unsigned voA = FULL ? vvA : (j < nexA ? vvA : V6_DROP), voB = FULL ? vvB : (j < nexB ? vvB : V6_DROP);
+      v6_store_hex_pair<FULL>(Yp[0], Yp[1], rsY, voA, voA + 1024u, voB, voB + 1024u, so);
+      if (e == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v1keep[i] = Vp[1][i];
+      } else {
+        v6_store_hex_pair<FULL>(Vp[0], Vp[1], rsD, voA, voA + 1024u, voB, voB + 1024u, so);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -505,9 +570,8 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
     const bool raw = slot == 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = raw ? (k < 2 ? 0.f : d[k]) : v[k];
-    const unsigned vo = FULL ? vvoff : (0 < nex ? vvoff : V6_DROP);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v6_store_at<FULL>(v[i], rsD, vo, 0u, (unsigned)(i * 64));
+    const unsigned voA = FULL ? vvA : (0 < nexA ? vvA : V6_DROP), voB = FULL ? vvB : (0 < nexB ? vvB : V6_DROP);
+    v6_store_hex_pair<FULL>(v, v1keep, rsD, voA, voA + 1024u, voB, voB + 1024u, 0u);
   }
   // the tile's last pooled row, un-pooled: the front row of the next tile's first hex
   {

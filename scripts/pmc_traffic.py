@@ -13,7 +13,16 @@ from collections import defaultdict
 
 # round 3: the V-form kernels (tonal_wino43v.hip); names as Engine.kernel_families() / rocprofv3 give them.  A weight-
 # gradient op is two launches (the Vd-writing first C_in tile, then the other tiles), listed apart.
+F6 = "Winograd F(6,3) on pre-transformed operands, LDS-DMA"
 FAMILIES = {
+    # round 4: the F(6,3) kernels (tonal_wino63.hip), the default
+    "wino63v_nt_kernel<5>": f"wino63v_nt_kernel<POOLV> (conv2 forward, {F6}; writes V of its pooled output for conv3)",
+    "wino63v_nt_kernel<2>": f"wino63v_nt_kernel<POOL> (conv3 forward, {F6})",
+    "wino63v_nt_kernel<4>": f"wino63v_nt_kernel<C1WGRAD> (conv2 input gradient + conv1 weight gradient, {F6})",
+    "wino63v_nt_kernel<6>": f"wino63v_nt_kernel<MASKY> (conv3 input gradient, {F6}; writes Y and Vd of conv2 instead of the gradient rows)",
+    "wino63v_nt_kernel<3>": f"wino63v_nt_kernel<MASK> (conv3 input gradient, {F6})",
+    "wino63v_tn4y_kernel": f"wino63v_tn4y_kernel (conv2 weight gradient, {F6}: both operands by LDS-DMA, no transform in the kernel)",
+    "wino63v_tn4_kernel<true>": f"wino63v_tn4_kernel<true> (conv3 weight gradient, {F6}; also writes Vd)",
     "wino43v_nt_kernel<5>": "wino43v_nt_kernel<POOLV> (conv2 forward, Winograd F(4,3) on V, LDS-DMA; writes V of its pooled output for conv3 instead of the raw rows)",
     "wino43v_nt_kernel<2>": "wino43v_nt_kernel<POOL> (conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)",
     "wino43v_nt_kernel<4>": "wino43v_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd F(4,3) on the pre-transformed dZ, LDS-DMA)",
