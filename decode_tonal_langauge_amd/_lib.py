@@ -151,6 +151,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  Loaded before it, this library would pull in
+    # the system one (/opt/rocm) instead and its kernels would register with a runtime that torch's streams and allocations
+    # do not belong to - every launch then fails with "no ROCm-capable device is detected" (seen with build() followed by
+    # smoke() in one process).  With torch's runtime already in the process the dependency resolves to it.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
