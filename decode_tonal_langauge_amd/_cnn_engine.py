@@ -84,6 +84,9 @@ class CnnEngine:
         # weight-gradient kernel un-pools and transforms it itself, as stage 3's does)
         self.f63_yprod = (self.wino63 and os.environ.get("TONAL_F63_YPROD", "1") != "0" and stage_defs[0][0] % 256 == 0
                           and self.tp1 >= 12)
+        # ... and stage 3's (whose gradient rows no Winograd epilogue produces) from a kernel of its own, tl_wino63_unpool_yvd
+        # (TONAL_F63_YPROD3=0: its weight-gradient kernel un-pools and transforms G3 itself and writes Vd3)
+        self.f63_yprod3 = (self.wino63 and os.environ.get("TONAL_F63_YPROD3", "1") != "0" and stage_defs[1][0] % 256 == 0)
         self.stages: List[_Stage] = []
         cin, tin, tp = self.c1, self.tout1, self.tp1
         for i, (cout, k, pool) in enumerate(stage_defs[1:], start=2):
@@ -387,6 +390,20 @@ class CnnEngine:
         sk = self._splitk(tiles, (rows_in + 35) // 36, int(os.environ.get("TONAL_TN_TARGET", "4096")))
         slab = torch.empty(sk, 8 * st.cin, ldg, **f32)
         bias_part = torch.empty(sk, nd, **f32)
+        if (st.idx == 3 and self.f63_yprod3 and self._y_ready.get(3) != self.generation):
+            # stage 3's gradient rows come out of stage 4's one-tap GEMM: a kernel of its own un-pools and transforms them
+            # (Y3, Vd3), and the weight gradient below runs without a transform like stage 2's
+            Gs = self.G[3]
+            Y3 = self._v_hex_buffer(self.Yt, 3, rows_in, nd)
+            Vd3 = self._v_hex_buffer(self.Vd, 3, rows_in, nd)
+            ev = self._tick("conv3_yvd")
+            check(self.lib.tl_wino63_unpool_yvd(ptr(Gs), ptr(self.bits[3]), ptr(Y3), ptr(Vd3), rows_in, Gs.shape[0], st.tp_in,
+                                                st.tp_out, 2 * st.tout, nd, Gs.shape[1], st.cout // 32, nd, self._stream()),
+                  "tl_wino63_unpool_yvd")
+            if ev:
+                ev[1].record()
+            self._y_ready[3] = self.generation
+            self._vd_ready[3] = self.generation
         if self._y_ready.get(st.idx) == self.generation:
             # both operands pre-transformed: Y (and Vd) of this stage were written by the input gradient of the stage above
             Y = self.Yt[st.idx]
@@ -547,7 +564,12 @@ class CnnEngine:
             fams = {f"wino63v_nt_kernel<POOLV> (conv2 forward, {f6}; writes V of its pooled output for conv3)": ["conv2_fwd"],
                     f"wino63v_nt_kernel<POOL> (conv3 forward, {f6})": ["conv3_fwd"],
                     f"wino63v_nt_kernel<C1WGRAD> (conv2 input gradient + conv1 weight gradient, {f6})": ["conv2_dgrad"],
-                    f"{tn} (conv3 weight gradient, {f6}; also writes Vd)": ["conv3_wgrad"]}
+                    }
+            if self.f63_yprod3:
+                fams[f"wino63v_tn4y_kernel (conv3 weight gradient, {f6}: both operands by LDS-DMA, no transform in the kernel; Y3 / Vd3 "
+                     "from wino63_unpool_yvd_kernel)"] = ["conv3_wgrad"]
+            else:
+                fams[f"{tn} (conv3 weight gradient, {f6}; also writes Vd)"] = ["conv3_wgrad"]
             if self.f63_yprod:
                 fams[f"wino63v_nt_kernel<MASKY> (conv3 input gradient, {f6}; writes Y and Vd of conv2 instead of the gradient rows)"] = ["conv3_dgrad"]
                 fams[f"wino63v_tn4y_kernel (conv2 weight gradient, {f6}: both operands by LDS-DMA, no transform in the kernel)"] = ["conv2_wgrad"]

@@ -86,6 +86,7 @@ SIGNATURES = {
     "tl_conv3_wino63v_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino63_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_wino63_vd_fixup": (_I, [_P, _P, _L, _L, _I, _I, _I, _P]),
+    "tl_wino63_unpool_yvd": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tl_conv1_fwd_v6": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
     "tl_sizeof_nt_params": (_I, []),
     "tl_sizeof_tn_params": (_I, []),

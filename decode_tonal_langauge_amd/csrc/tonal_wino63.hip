@@ -1433,6 +1433,72 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn4y_kernel(const tl_tn_params
 }
 
 // ------------------------------------------------------------------------------------------
+// (G, arg-max bits) -> Y = A dz and Vd = B^T (dz rows 6 h - 2 .. 6 h + 5) of a pooled 3-tap stage, as a kernel of its own:
+// the operands of the stage's transform-free weight gradient (tl_conv3_wino63v_tn, loader 3) and of its input gradient, for
+// a stage whose gradient rows come from a kernel that has no Y-producing epilogue (conv3 of the reference stack: G3 comes
+// out of the one-tap GEMM of stage 4).  Thread = 4 channels x one hex, lanes ordered (8-channel chunk, hex of the pair, half
+// chunk) as in conv1_fwd_vh_kernel: four adjacent lanes write the 64-byte run of a transform, two transforms one line.
+// HBM-write bound: 2 x 2.67 x the bytes of G.  G / bits rows in the layout [seq * g_tp + t'].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void wino63_unpool_yvd_kernel(const float* __restrict__ G, const uint32_t* __restrict__ bits,
+                                                                 float* __restrict__ Y, float* __restrict__ Vd, long long nhex,
+                                                                 long long g_rows, int hps, int g_tp, int Tvalid, int C, int ldg,
+                                                                 int ld_bits, int ldv) {
+  const int tpp = C >> 1;                                    // threads per hex pair
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long pair = idx / tpp;
+  const int tl_ = (int)(idx - pair * tpp);
+  const int half = tl_ & 1, hpar = (tl_ >> 1) & 1, kc = tl_ >> 2;
+  const int c = 8 * kc + 4 * half;
+  const long long hg = 2 * pair + hpar;
+  if (hg >= nhex) return;
+  const long long seq = hg / hps;
+  const int hs = (int)(hg - seq * hps);
+  const long long row0 = seq * g_tp + 3LL * hs;               // G row of the hex's first pooled row
+  float dz[8][4];                                             // un-pooled rows 6 h - 2 .. 6 h + 5, four channels
+#pragma unroll
+  for (int r = -1; r < 3; ++r) {
+    const long long row = row0 + r;
+    const bool ok = (r >= 0 || hs > 0) && 6 * hs + 2 * r < Tvalid && row >= 0 && row < g_rows;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    uint32_t w = 0;
+    if (ok) {
+      g = *reinterpret_cast<const f32x4*>(G + row * (long long)ldg + c);
+      w = bits[row * (long long)ld_bits + (c >> 5)] >> (c & 31);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool odd = (w >> k) & 1u;
+      dz[2 * (r + 1)][k] = odd ? 0.f : g[k];
+      dz[2 * (r + 1) + 1][k] = odd ? g[k] : 0.f;
+    }
+  }
+  f32x4 oy[8], ov[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float d[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = dz[j][k];
+    wino63_bt(d, v);
+    const float* d6 = d + 2;
+    const float ev1 = (d6[0] + d6[2]) + d6[4], od1 = (d6[1] + d6[3]) + d6[5];
+    const float ev2 = fmaf(16.f, d6[4], fmaf(4.f, d6[2], d6[0])), od2 = fmaf(32.f, d6[5], fmaf(8.f, d6[3], 2.f * d6[1]));
+    const float ev3 = fmaf(0.0625f, d6[4], fmaf(0.25f, d6[2], d6[0])), od3 = fmaf(0.03125f, d6[5], fmaf(0.125f, d6[3], 0.5f * d6[1]));
+    const float y[8] = {d6[0], ev1 + od1, ev1 - od1, ev2 + od2, ev2 - od2, ev3 + od3, ev3 - od3, d6[5]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      oy[j][k] = y[j];
+      ov[j][k] = v[j];
+    }
+  }
+  const long long at = v6_at(hg, 0, c, ldv >> 3);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(Y + at + 16 * j) = oy[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(Vd + at + 16 * j) = ov[j];
+}
+
+// ------------------------------------------------------------------------------------------
 // conv1 (C_in = 1) + LeakyReLU + max-pool writing V of its pooled output in HEX form, pair layout (conv1_fwd_vq_kernel of
 // tonal_misc.hip with six rows per unit).  HBM-write bound, so the thread mapping follows the layout: four adjacent lanes
 // = (one 8-channel chunk) x (the two hexes of a pair) write the 64-byte run of a transform, two transforms = one cache line;
@@ -1599,6 +1665,23 @@ extern "C" int tl_wino63_vd_fixup(float* Vd, const float* vhalo, int64_t hexes, 
   hipLaunchKernelGGL(wino63_vd_fixup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Vd, vhalo,
                      (long long)hexes, (long long)tiles, hexes_per_seq, C, ldv);
   return check_launch("wino63_vd_fixup");
+}
+
+extern "C" int tl_wino63_unpool_yvd(const float* G, const uint32_t* bits, float* Y, float* Vd, int64_t conv_rows, int64_t g_rows,
+                                    int Tp, int g_tp, int Tvalid, int C, int ldg, int ld_bits, int ldv, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(G && bits && Y && Vd, "wino63_unpool_yvd: null pointer");
+  TL_REQUIRE(Tp > 0 && Tp % 6 == 0 && conv_rows > 0 && conv_rows % Tp == 0 && Tvalid % 2 == 0 && Tvalid <= Tp,
+             "wino63_unpool_yvd: Tp %% 6 == 0, whole sequences, an even Tvalid <= Tp needed");
+  TL_REQUIRE(g_tp > 0 && 2 * g_tp >= Tvalid && g_rows >= (conv_rows / Tp) * (long long)g_tp, "wino63_unpool_yvd: G holds fewer rows than sequences x g_tp");
+  TL_REQUIRE(C > 0 && C % 8 == 0 && ldg >= C && ldg % 4 == 0 && ldv >= C && ldv % 8 == 0 && ld_bits * 32 >= C,
+             "wino63_unpool_yvd: C %% 8, ldg %% 4, ldv %% 8 needed, bits row must cover C");
+  const long long nhex = conv_rows / 6;
+  const long long n = ((nhex + 1) / 2) * (C / 2);
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_unpool_yvd: grid too large");
+  hipLaunchKernelGGL(wino63_unpool_yvd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, bits, Y, Vd,
+                     nhex, (long long)g_rows, Tp / 6, g_tp, Tvalid, C, ldg, ld_bits, ldv);
+  return check_launch("wino63_unpool_yvd");
 }
 
 // NT passes on a pre-transformed operand: A = V[hex][8][lda], A_rows = hexes in V (whole 128-hex tiles), M = output rows

@@ -219,6 +219,11 @@ int tl_wino63_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, 
 /* second half of epilogue 6: the first hex of every tile (256 hexes) of a Vd written by it - its front row comes from
  * vhalo[tile - 1] (zero where the hex starts its sequence: hexes_per_seq)                                              */
 int tl_wino63_vd_fixup(float* Vd, const float* vhalo, int64_t hexes, int64_t tiles, int hexes_per_seq, int C, int ldv, void* stream);
+/* Y[conv_rows / 6][8][ldv] = A dz and Vd = B^T (dz rows 6h-2 .. 6h+5) of a pooled 3-tap stage from its output gradient G (rows
+ * [seq * g_tp + t'], ldg) and arg-max bits, pair layout: the operands of tl_conv3_wino63v_tn (loader 3) and of the stage's input
+ * gradient for a stage whose G comes from a kernel without epilogue 6 (HBM-bound; conv3 of the reference stack)             */
+int tl_wino63_unpool_yvd(const float* G, const uint32_t* bits, float* Y, float* Vd, int64_t conv_rows, int64_t g_rows, int Tp,
+                         int g_tp, int Tvalid, int C, int ldg, int ld_bits, int ldv, void* stream);
 int tl_conv1_fwd_v6(const float* x, const float* w, const float* b, float* P, float* V, uint32_t* bits, uint32_t* sign,
                     int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */

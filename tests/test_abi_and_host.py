@@ -63,6 +63,9 @@ def test_abi_argument_validation_without_gpu():
     assert lib.tl_conv3_wino63v_nt(None, None) == -1 and lib.tl_conv3_wino63v_tn(None, None) == -1
     assert lib.tl_wino63_weights(16, 16, None, 8, 12, 12, 8, None) == -1 and b"multiples of 8" in lib.tl_last_error()
     assert lib.tl_wino63_wgrad_finalize(None, None, 4, 4, 4, None) == -1
+    assert lib.tl_wino63_vd_fixup(None, None, 4, 1, 2, 8, 8, None) == -1
+    assert lib.tl_wino63_unpool_yvd(16, 16, 16, 16, 24, 12, 12, 6, 8, 12, 12, 1, 16, None) == -1 and b"C %% 8" not in lib.tl_last_error()
+    assert b"unpool_yvd" in lib.tl_last_error()
     assert lib.tl_wino63_v_fixup(16, 16, 4, 1, 8, 8, 8, None) == -1 and b"Tq" in lib.tl_last_error()           # Tq % 6
     assert lib.tl_conv1_fwd_v6(16, 16, 16, None, 16, 16, None, 4, 100, 3, 96, 48, 49, 0.01, None) == -1 and b"C1" in lib.tl_last_error()
     assert lib.tl_conv1_fwd_v6(16, 16, 16, None, 16, 16, None, 4, 100, 3, 128, 50, 49, 0.01, None) == -1 and b"multiple of 6" in lib.tl_last_error()

@@ -1113,9 +1113,10 @@ def test_f63_stage_kernels_match_direct_kernels(dev, shape, yprod, monkeypatch):
     from decode_tonal_langauge_amd._lib import check, ptr
     from tests.wino63_ref import hex_transform, logical, unpool, y_transform
     B, C, T, c1, c2, c3 = shape
-    if yprod == "0" and c1 % 256 != 0:
-        pytest.skip("the Y-producing epilogue needs C_in of stage 2 % 256 == 0: nothing to switch off")
+    if yprod == "0" and c1 % 256 != 0 and c2 % 256 != 0:
+        pytest.skip("the producer paths need C_in of stage 2 / stage 3 % 256 == 0: nothing to switch off")
     monkeypatch.setenv("TONAL_F63_YPROD", yprod)
+    monkeypatch.setenv("TONAL_F63_YPROD3", yprod)
     defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
     engs = {}
     for mode in ("0", "6"):
@@ -1210,6 +1211,11 @@ def test_f63_stage_kernels_match_direct_kernels(dev, shape, yprod, monkeypatch):
                 dz = torch.nn.functional.pad(dz, (0, 0, 0, s6.tp_in - 2 * s6.tp_out))
             Vdref = hex_transform(dz[:, :s6.tp_in].reshape(-1, s6.cout), S, s6.tp_in, shift=-2)
             assert close(logical(e6.Vd[si])[:Vdref.shape[0]], Vdref), si
+        if si == 3 and e6.f63_yprod3:
+            # stage 3's own operands from the stand-alone producer: Y3 = A dz3 of the same un-pooled gradient
+            assert c2 % 256 == 0
+            Y3ref = y_transform(dz[:, :s6.tp_in].reshape(-1, s6.cout), S, s6.tp_in)
+            assert close(logical(e6.Yt[3])[:Y3ref.shape[0]], Y3ref) and float(e6.Yt[3][Y3ref.shape[0]:].abs().max()) == 0.0
         if si == 3 and e6.f63_yprod:
             # the input gradient of stage 3 wrote the operands of stage 2's backward - Y2 = A dz2 and Vd2 = B^T dz2 - instead
             # of G2 (epilogue 6 + tl_wino63_vd_fixup): against the direct engine's G2, un-pooled with the same bits
