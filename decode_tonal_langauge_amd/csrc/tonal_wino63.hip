@@ -158,6 +158,9 @@ constexpr int V6_A_BYTES = 8 * V6_BH * V6_ROWB;          // 32768
 constexpr int V6_B_BYTES = 8 * V6_BN * V6_ROWB;          // 16384
 constexpr int V6_STAGE = V6_A_BYTES + V6_B_BYTES;        // 49152
 constexpr int V6_ROWS = 6 * V6_BH;                       // conv rows per tile (768)
+#ifndef V6_RDSCHED
+#define V6_RDSCHED -1     // issue order of the second half-set's fragment reads: -1 per instantiation (see kstep), 0 / 1 force one
+#endif
 #ifndef V6_ABL
 #define V6_ABL 0          // timing-only build variants: 1 no steady-state DMA, 2 no epilogue, 4 no barrier
 #endif
@@ -331,10 +334,23 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     } else {
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     }
+    // The reads of H: one per MFMA in the first half of L's window, so that the last eight MFMAs cover their latency in front
+    // of the barrier - for the conv2 launches (POOLV, fused conv1 gradient: -0.5 / -0.4 ms, same-call A/B, twice); the
+    // instantiations of conv3 (POOL, MASKY) measure +0.2 ms with it and keep one read per two MFMAs (V6_RDSCHED: 0 / 1 force one)
+    constexpr bool early = V6_RDSCHED == 1 || (V6_RDSCHED < 0 && (EPI == W_EPI_POOLV || EPI == W_EPI_C1W));
+    if constexpr (early) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      for (int t = 0; t < 8; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
     }
     if constexpr (mode != KS_LAST) {
       // (the builtin, not inline asm: the compiler's own wait-count bookkeeping sees the drained counters)
