@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   // epilogue; between them and this step's pieces (step 2) sit that epilogue's stores: the closing wait leaves both in flight.
   auto kstep_first = [&](auto EPIN) {
     load_half(faL, fbL, stg, 0);
-    if (!(V6_ABL & 1) || true) issue(cur, 2, stg == 0 ? 2 : stg - 1);
+    issue(cur, 2, stg == 0 ? 2 : stg - 1);               // (stg + 2) % 3
     load_half(faH, fbH, stg, 4);
     mfma_half(Y{}, faL, fbL, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);

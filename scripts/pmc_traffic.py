@@ -21,7 +21,9 @@ FAMILIES = {
     "wino63v_nt_kernel<4>": f"wino63v_nt_kernel<C1WGRAD> (conv2 input gradient + conv1 weight gradient, {F6})",
     "wino63v_nt_kernel<6>": f"wino63v_nt_kernel<MASKY> (conv3 input gradient, {F6}; writes Y and Vd of conv2 instead of the gradient rows)",
     "wino63v_nt_kernel<3>": f"wino63v_nt_kernel<MASK> (conv3 input gradient, {F6})",
-    "wino63v_tn4y_kernel": f"wino63v_tn4y_kernel (conv2 weight gradient, {F6}: both operands by LDS-DMA, no transform in the kernel)",
+    "wino63v_tn4y_kernel": f"wino63v_tn4y_kernel (conv2 / conv3 weight gradient, {F6}: both operands by LDS-DMA, no transform in the kernel; average of the two launches)",
+    "wino63_unpool_yvd_kernel": "wino63_unpool_yvd_kernel (Y3 / Vd3 of conv3 from G3 and its arg-max bits)",
+    "conv1_fwd_vh_kernel": "conv1_fwd_vh_kernel (conv1 + LeakyReLU + pool writing V1 in hex form)",
     "wino63v_tn4_kernel<true>": f"wino63v_tn4_kernel<true> (conv3 weight gradient, {F6}; also writes Vd)",
     "wino43v_nt_kernel<5>": "wino43v_nt_kernel<POOLV> (conv2 forward, Winograd F(4,3) on V, LDS-DMA; writes V of its pooled output for conv3 instead of the raw rows)",
     "wino43v_nt_kernel<2>": "wino43v_nt_kernel<POOL> (conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)",

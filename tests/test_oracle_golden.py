@@ -283,3 +283,50 @@ def test_g15_hilbert_low_band_at_raw_rate():
     assert abs(float(np.abs(x).sum()) - float(g["x_checksum"])) < 1e-9
     for name, fr, env in (("low_env", [1.0, 4.0], True), ("low_real", [1.0, 4.0], False), ("hg_env", [70.0, 150.0], True)):
         assert rel(sg.hilbert_filter(x, fs, fr, envelope=env), g[name]) < 1e-12, name
+
+
+def test_f63_matrices_of_the_kernels_are_the_exact_cook_toom_construction():
+    """The constants the F(6,3) kernels and their GPU tests use (tests/wino63_ref.py: B^T, A^T; csrc/tonal_wino63.hip: the same
+    plus G) are the exact rational Cook-Toom matrices of the numerics gate (oracle/winograd_f63_gate.py) for the points
+    0, +-1, +-2, +-1/2, inf - and together they ARE the 3-tap correlation: sum_j A^T[i][j] G[j][k] B^T[j][s] = [s == i + k]."""
+    from fractions import Fraction
+    import numpy as np
+    import torch
+    from oracle.winograd_f63_gate import cook_toom
+    from tests.wino63_ref import AT, BT, hex_transform, logical, y_transform
+    At, G, Bt = cook_toom(6, 3, (0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2)))
+    assert torch.equal(At.double(), AT) and torch.equal(Bt.double(), BT)
+    Gk = torch.tensor([[-1, 0, 0], [-2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9], [1 / 90, 2 / 90, 4 / 90], [1 / 90, -2 / 90, 4 / 90],
+                       [32 / 45, 16 / 45, 8 / 45], [32 / 45, -16 / 45, 8 / 45], [0, 0, 1]], dtype=torch.float64)       # tl_wino63_weights
+    assert torch.allclose(G.double(), Gk, rtol=0, atol=1e-7)
+    ident = torch.einsum("ij,jk,js->iks", AT, Gk, BT)
+    want = torch.zeros(6, 3, 8, dtype=torch.float64)
+    for i in range(6):
+        for k in range(3):
+            want[i, k, i + k] = 1
+    assert torch.allclose(ident, want, atol=1e-12)
+    # the reference forms of the operand layouts: a random stage through hexes equals the direct correlation
+    g = torch.Generator().manual_seed(3)
+    S, Tp, C, O = 2, 12, 8, 5
+    x = torch.randn(S * Tp, C, generator=g, dtype=torch.float64)
+    w = torch.randn(O, C, 3, generator=g, dtype=torch.float64)
+    V = hex_transform(x, S, Tp)                                    # (S * Tp / 6, 8, C)
+    U = torch.einsum("jk,ock->joc", Gk, w)
+    M = torch.einsum("hjc,joc->hjo", V, U)
+    y = torch.einsum("ij,hjo->hio", AT, M).reshape(S, Tp, O)       # six conv rows per hex
+    xp = torch.nn.functional.pad(x.view(S, Tp, C), (0, 0, 0, 2))
+    ref = sum(torch.einsum("stc,oc->sto", xp[:, k:k + Tp], w[:, :, k]) for k in range(3))
+    assert torch.allclose(y, ref, atol=1e-10)
+    # weight gradient through Y = A dz: dW[o][c][k] = sum_rows dz[r][o] x[r + k][c]
+    dz = torch.randn(S * Tp, O, generator=g, dtype=torch.float64)
+    Y = y_transform(dz, S, Tp)
+    slab = torch.einsum("hjc,hjo->jco", V, Y)
+    dW = torch.einsum("jk,jco->ock", Gk, slab)
+    refW = torch.stack([torch.einsum("sto,stc->oc", dz.view(S, Tp, O), xp[:, k:k + Tp]) for k in range(3)], dim=2)
+    assert torch.allclose(dW, refW, atol=1e-9)
+    # the pair layout is a permutation: logical() undoes it
+    nh, Cc = 4, 16
+    lin = torch.arange(nh * 8 * Cc, dtype=torch.float32).reshape(nh, 8, Cc)
+    pair = lin.reshape(nh // 2, 2, 8, Cc // 8, 8).permute(0, 3, 2, 1, 4).reshape(nh, 8, Cc)       # store channels-last data pair-wise
+    assert torch.equal(logical(pair), lin)
+    assert np.isfinite(float(ident.sum()))
