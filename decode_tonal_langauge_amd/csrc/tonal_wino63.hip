@@ -158,6 +158,9 @@ constexpr int V6_A_BYTES = 8 * V6_BH * V6_ROWB;          // 32768
 constexpr int V6_B_BYTES = 8 * V6_BN * V6_ROWB;          // 16384
 constexpr int V6_STAGE = V6_A_BYTES + V6_B_BYTES;        // 49152
 constexpr int V6_ROWS = 6 * V6_BH;                       // conv rows per tile (768)
+#ifndef V6_PRIO
+#define V6_PRIO 0         // 1: s_setprio 1 for waves 4-7 (experiment)
+#endif
 #ifndef V6_RDSCHED
 #define V6_RDSCHED -1     // issue order of the second half-set's fragment reads: -1 per instantiation (see kstep), 0 / 1 force one
 #endif
@@ -176,6 +179,11 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
 
+#if V6_PRIO
+  // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4): waves
+  // 4-7 are the SIMD partners of waves 0-3 and lose the issue arbitration by age on every segment
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int ntn = (p.N + V6_BN - 1) / V6_BN;
   const long long ntm = (p.M + V6_ROWS - 1) / V6_ROWS;
   const long long nwg = ntm * ntn;
@@ -1316,6 +1324,9 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn4y_kernel(const tl_tn_params
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+#if V6_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);             // (static priority for the younger half: see wino63v_nt_kernel)
+#endif
   const int ntn = p.Ndim / T6_BN;
   const long long tiles = 2LL * mtn * ntn;
   const long long nwg = tiles * p.splitk;
@@ -1408,7 +1419,7 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn4y_kernel(const tl_tn_params
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & (NA - 1);
     __builtin_amdgcn_sched_barrier(0);
-    issue(s + 3);
+    if (!(T6_ABL & 1)) issue(s + 3);
     load_frag(fa0, fb0, buf, 0);
     mfma8(fac, fbc);                                        // slice 2 of the previous step
     load_frag(fa1, fb1, buf, 1);
@@ -1432,7 +1443,9 @@ __global__ __launch_bounds__(512, 1) void wino63v_tn4y_kernel(const tl_tn_params
     }
     // everything issued up to step s + 1 has landed; the 4 pieces of steps s + 2 and s + 3 may fly
     __builtin_amdgcn_s_waitcnt(0x0078);                           // vmcnt(8) lgkmcnt(0)
+#if !(T6_ABL & 16)
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
   }
   mfma8(fac, fbc);

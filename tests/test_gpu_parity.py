@@ -494,7 +494,8 @@ def test_cnn_rejects_bad_inputs(dev):
 
 
 def test_glds_variant_matches_default_kernel(dev, monkeypatch):
-    """The opt-in direct-to-LDS NT kernel (TONAL_GLDS=1) gives the same forward and gradients."""
+    """The direct-to-LDS NT kernel (default since round 4) and the register-staged one (TONAL_GLDS=0) give the same forward and
+    gradients."""
     from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
     xs, _t, _s, labs, tg = gi.train_batches(1, 6, 8, 200, seed=5)
     outs, grads = [], []
