@@ -1539,11 +1539,13 @@ constexpr int C1_MAXKT = 8;
 #ifndef C1V_TEST
 #define C1V_TEST 0
 #endif
+template <int KT>
 __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, float* __restrict__ P,
                                                            float* __restrict__ V, uint32_t* __restrict__ bits,
-                                                           uint32_t* __restrict__ sign, long long S, int T, int kt, int C1,
+                                                           uint32_t* __restrict__ sign, long long S, int T, int C1,
                                                            int Tp, int Tout, float slope) {
+  constexpr int kt = KT;                         // (a run-time tap count cost 547 scalar branches in the row loop)
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const long long seq = blockIdx.x;
   for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
@@ -1553,12 +1555,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
   const int tl_ = threadIdx.x % tpp, psub = threadIdx.x / tpp;
   const int half = tl_ & 1, hpar = (tl_ >> 1) & 1, kc = tl_ >> 2;
   const int o = 8 * kc + 4 * half;               // first of this thread's four channels
-  float wv[4][C1_MAXKT], bv[4];
+  float wv[4][KT], bv[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     bv[c] = b[o + c];
 #pragma unroll
-    for (int j = 0; j < C1_MAXKT; ++j) wv[c][j] = j < kt ? w[(o + c) * kt + j] : 0.f;
+    for (int j = 0; j < KT; ++j) wv[c][j] = w[(o + c) * kt + j];
   }
   // position of the four channels inside their 32-channel word: the eight lanes of a word differ in lane bits 0, 2, 3
   const int sh = 4 * (2 * (kc & 3) + half);
@@ -1571,11 +1573,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
       for (int c = 0; c < 4; ++c) {
         float z0 = 0.f, z1 = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < C1_MAXKT; ++jj)
-          if (jj < kt) {
-            z0 = fmaf(wv[c][jj], xs[2 * pr + jj], z0);
-            z1 = fmaf(wv[c][jj], xs[2 * pr + 1 + jj], z1);
-          }
+        for (int jj = 0; jj < KT; ++jj) {
+          z0 = fmaf(wv[c][jj], xs[2 * pr + jj], z0);
+          z1 = fmaf(wv[c][jj], xs[2 * pr + 1 + jj], z1);
+        }
         const float y0 = lrelu(z0 + bv[c], slope), y1 = lrelu(z1 + bv[c], slope);
         const bool sel = y1 > y0;
         const float v = sel ? y1 : y0;
@@ -1584,15 +1585,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
         nsg |= (v > 0.f ? 1u : 0u) << c;
       }
     }
-    uint32_t a = nib << sh, e = nsg << sh;
-    a |= __shfl_xor(a, 1);
-    e |= __shfl_xor(e, 1);
-    a |= __shfl_xor(a, 4);
-    e |= __shfl_xor(e, 4);
-    a |= __shfl_xor(a, 8);
-    e |= __shfl_xor(e, 8);
-    wb = a;
-    ws = e;
+    // OR over the eight lanes of the word (lane bits 0, 2, 3) with DPP operands: neighbour of the quad pair, then the row
+    // rotated by 4 and by 8
+    auto or8 = [](uint32_t v) {
+      v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
+      v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);     // row_ror 4
+      v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);     // row_ror 8
+      return v;
+    };
+    wb = or8(nib << sh);
+    ws = or8(nsg << sh);
   };
   // global hex index seq * Th + q; a thread takes those whose parity is hpar (its slot inside the pair)
   const long long h0 = seq * Th;
@@ -1637,6 +1639,26 @@ __global__ __launch_bounds__(256) void conv1_fwd_vh_kernel(const float* __restri
 #elif C1V_TEST == 3
       (void)ov;                                               // timing only: no V stores
       if (o == 12345) V[0] = ov[0][0] + ov[7][3];
+#elif C1V_TEST == 4
+      // timing experiment: whole 128-byte lines per store instruction.  The eight lanes of two neighbouring chunks trade
+      // transforms through a half-row mirror (lane i <-> 7 - i): the even chunk's lanes keep the even transform of a pair of
+      // transforms and write the odd chunk's even transform at the mirror lane's position, and the other way round
+      const int upper = (tl_ >> 2) & 1;
+      const int om = 8 * (kc ^ 1) + 4 * (half ^ 1);
+      float* dst = V + v6_at(h0 + q, 0, o, C1 >> 3) + 16 * upper;
+      float* mdst = V + v6_at((h0 + q) ^ 1, 0, om, C1 >> 3) + 16 * upper;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        f32x4 own, got;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float send = upper ? ov[2 * s2][k] : ov[2 * s2 + 1][k];
+          own[k] = upper ? ov[2 * s2 + 1][k] : ov[2 * s2][k];
+          got[k] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x141, 0xf, 0xf, false));
+        }
+        *reinterpret_cast<f32x4*>((upper ? mdst : dst) + 32 * s2) = upper ? got : own;      // the even chunk's line
+        *reinterpret_cast<f32x4*>((upper ? dst : mdst) + 32 * s2) = upper ? own : got;      // the odd chunk's line
+      }
 #else
       float* dst = V + v6_at(h0 + q, 0, o, C1 >> 3);          // (pair layout: transform j of these four channels at + 16 j)
 #pragma unroll
@@ -1851,7 +1873,15 @@ extern "C" int tl_conv1_fwd_v6(const float* x, const float* w, const float* b, f
   TL_REQUIRE(Tp > 0 && Tp % 6 == 0, "conv1_fwd_v6: Tp must be a multiple of 6");
   TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_fwd_v6: Tout/Tp/T inconsistent (%d,%d,%d)", Tout, Tp, T);
   TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_fwd_v6: T too large for the LDS window");
-  hipLaunchKernelGGL(conv1_fwd_vh_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P, V, bits,
-                     sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+#define TL_C1V_LAUNCH(KT_)                                                                                                   \
+  case KT_:                                                                                                                  \
+    hipLaunchKernelGGL(conv1_fwd_vh_kernel<KT_>, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P, V, \
+                       bits, sign, (long long)S, T, C1, Tp, Tout, slope);                                                    \
+    break;
+  switch (ktaps) {                               // the tap count is a template parameter: straight-line row arithmetic
+    TL_C1V_LAUNCH(1) TL_C1V_LAUNCH(2) TL_C1V_LAUNCH(3) TL_C1V_LAUNCH(4) TL_C1V_LAUNCH(5) TL_C1V_LAUNCH(6) TL_C1V_LAUNCH(7)
+    TL_C1V_LAUNCH(8)
+  }
+#undef TL_C1V_LAUNCH
   return check_launch("conv1_fwd_v6");
 }

@@ -23,6 +23,9 @@ e0.record()
 for _ in range(3): run()
 e1.record(); torch.cuda.synchronize()
 print(f"conv1_fwd_v6 {e0.elapsed_time(e1) / 3:.3f} ms  ({V.numel() * 4 / 1e9:.1f} GB of V)", flush=True)
+idx = torch.arange(0, V.numel(), 9973, device=dev)
+print(f"  checksum {V.view(-1)[idx].double().mul(torch.arange(idx.numel(), device=dev).double().remainder(17.0) + 1).sum().item():.9e}"
+      f" abs {V.view(-1)[idx].double().abs().sum().item():.9e}", flush=True)
 if len(sys.argv) > 1:
     # (b) with a large resident footprint, (c) with real model weights / data scale
     big = [torch.zeros(8 * 1024**3 // 4, device=dev) for _ in range(int(sys.argv[1]))]
