@@ -30,11 +30,13 @@ __device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
 // ------------------------------------------------------------------------------------------
 constexpr int MAXKT = 8;
 
+template <int KT>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ P,
                                                         uint32_t* __restrict__ bits, uint32_t* __restrict__ sign,
-                                                        long long S, int T, int kt, int C1, int Tp, int Tout,
+                                                        long long S, int T, int C1, int Tp, int Tout,
                                                         float slope) {
+  constexpr int kt = KT;                         // template parameter: the tap loops unroll without scalar branches
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const long long seq = blockIdx.x;
   for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
@@ -80,11 +82,13 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // rows per pass), so a pooled row leaves as 2 KB of contiguous dwordx4 stores instead of 4-byte ones, and the
 // arg-max / sign words are assembled from the 8 lanes x 4 bits that make up 32 channels with three xor-shuffles.
 // Used when C1 is a multiple of 128 (the 512- and 1024-wide stages of the models); HBM-write bound.
+template <int KT>
 __global__ __launch_bounds__(256) void conv1_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, float* __restrict__ P,
                                                            uint32_t* __restrict__ bits, uint32_t* __restrict__ sign,
-                                                           long long S, int T, int kt, int C1, int Tp, int Tout,
+                                                           long long S, int T, int C1, int Tp, int Tout,
                                                            float slope) {
+  constexpr int kt = KT;                         // template parameter: the tap loops unroll without scalar branches
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const long long seq = blockIdx.x;
   for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
@@ -148,11 +152,13 @@ __global__ __launch_bounds__(256) void conv1_fwd_v4_kernel(const float* __restri
 #ifndef CONV1_NT
 #define CONV1_NT 1      // same-box A/B under rocprofv3: 4.79 -> 4.65 ms per launch (20 GB written once, read by the next kernel)
 #endif
+template <int KT>
 __global__ __launch_bounds__(256) void conv1_fwd_vq_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b, float* __restrict__ P,
                                                            float* __restrict__ V, uint32_t* __restrict__ bits,
-                                                           uint32_t* __restrict__ sign, long long S, int T, int kt, int C1,
+                                                           uint32_t* __restrict__ sign, long long S, int T, int C1,
                                                            int Tp, int Tout, float slope) {
+  constexpr int kt = KT;                         // template parameter: the tap loops unroll without scalar branches
   extern __shared__ __attribute__((aligned(16))) float xs[];
   const long long seq = blockIdx.x;
   for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = x[seq * T + i];
@@ -1104,12 +1110,20 @@ extern "C" int tl_conv1_fwd(const float* x, const float* w, const float* b, floa
   TL_REQUIRE(C1 % 64 == 0, "conv1_fwd: C1 must be a multiple of 64");
   TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_fwd: Tout/Tp/T inconsistent (%d,%d,%d)", Tout, Tp, T);
   TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_fwd: T too large for the LDS window");
-  if (C1 % 128 == 0 && C1 <= 1024 && (C1 & (C1 - 1)) == 0)      // 256 % (C1 / 4) == 0: whole rows per pass
-    hipLaunchKernelGGL(conv1_fwd_v4_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,
-                       bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
-  else
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,
-                       bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+  const bool v4 = C1 % 128 == 0 && C1 <= 1024 && (C1 & (C1 - 1)) == 0;      // 256 % (C1 / 4) == 0: whole rows per pass
+#define TL_C1_LAUNCH(KT_)                                                                                                 \
+  case KT_:                                                                                                                \
+    if (v4)                                                                                                                \
+      hipLaunchKernelGGL(conv1_fwd_v4_kernel<KT_>, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P, \
+                         bits, sign, (long long)S, T, C1, Tp, Tout, slope);                                                \
+    else                                                                                                                   \
+      hipLaunchKernelGGL(conv1_fwd_kernel<KT_>, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P,    \
+                         bits, sign, (long long)S, T, C1, Tp, Tout, slope);                                                \
+    break;
+  switch (ktaps) {
+    TL_C1_LAUNCH(1) TL_C1_LAUNCH(2) TL_C1_LAUNCH(3) TL_C1_LAUNCH(4) TL_C1_LAUNCH(5) TL_C1_LAUNCH(6) TL_C1_LAUNCH(7) TL_C1_LAUNCH(8)
+  }
+#undef TL_C1_LAUNCH
   return check_launch("conv1_fwd");
 }
 
@@ -1123,8 +1137,15 @@ extern "C" int tl_conv1_fwd_v(const float* x, const float* w, const float* b, fl
   TL_REQUIRE(Tp > 0 && Tp % 4 == 0, "conv1_fwd_v: Tp must be a multiple of 4");
   TL_REQUIRE(Tout >= 0 && Tout <= Tp && 2 * Tout + ktaps - 1 <= T, "conv1_fwd_v: Tout/Tp/T inconsistent (%d,%d,%d)", Tout, Tp, T);
   TL_REQUIRE((size_t)T * 4 <= 64 * 1024, "conv1_fwd_v: T too large for the LDS window");
-  hipLaunchKernelGGL(conv1_fwd_vq_kernel, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P, V,
-                     bits, sign, (long long)S, T, ktaps, C1, Tp, Tout, slope);
+#define TL_C1_LAUNCH(KT_)                                                                                                 \
+  case KT_:                                                                                                                \
+    hipLaunchKernelGGL(conv1_fwd_vq_kernel<KT_>, dim3((unsigned)S), dim3(256), (size_t)T * 4, (hipStream_t)stream, x, w, b, P, V, \
+                       bits, sign, (long long)S, T, C1, Tp, Tout, slope);                                                  \
+    break;
+  switch (ktaps) {
+    TL_C1_LAUNCH(1) TL_C1_LAUNCH(2) TL_C1_LAUNCH(3) TL_C1_LAUNCH(4) TL_C1_LAUNCH(5) TL_C1_LAUNCH(6) TL_C1_LAUNCH(7) TL_C1_LAUNCH(8)
+  }
+#undef TL_C1_LAUNCH
   return check_launch("conv1_fwd_v");
 }
 
