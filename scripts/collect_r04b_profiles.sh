@@ -2,7 +2,7 @@
 # Round-4 evidence runs of the F(6,3) default on the GPU box (one gpurun call per section; outputs under gpurun_out/r04b/, summaries
 # copied into profiles/ afterwards).  Counter passes run on their own (one counter, no trace domain beside --kernel-trace).
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04b; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${R04TAG:-r04b}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-extras"
 case "$1" in

@@ -1256,3 +1256,71 @@ def test_f63_stage_kernels_match_direct_kernels(dev, shape, yprod, monkeypatch):
 def _lib_nt():
     from decode_tonal_langauge_amd import _lib
     return _lib.NtParams()
+
+
+@pytest.mark.parametrize("kt", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_conv1_kernels_for_every_tap_count(dev, kt):
+    """The first stage (reference models/synthesis_models.py:85-90, deep_classifiers.py:230-247: Conv2d(1, C1, (k, 1)) +
+    LeakyReLU + MaxPool (2, 1)) for every tap count the entry points take (the tap count is a template parameter of the
+    kernels): ``tl_conv1_fwd`` (rows, both thread mappings) against a float64 restatement, ``tl_conv1_fwd_v`` (quads) and
+    ``tl_conv1_fwd_v6`` (hexes, pair layout) against the transforms of those rows."""
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._lib import check, ptr
+    from tests import wino63_ref as w6
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(100 + kt)
+    S, T, slope = 5, 131, 0.01
+    tout = (T - kt + 1) // 2
+    tp = (tout + 11) // 12 * 12                                  # whole quads and whole hexes
+    bt43 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                         [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64, device=dev)
+    for c1 in (128, 192):                                       # 192: the one-channel-per-thread kernel
+        x = torch.randn(S, T, device=dev, generator=g)
+        w = torch.randn(c1, kt, device=dev, generator=g) * 0.5
+        b = torch.randn(c1, device=dev, generator=g) * 0.1
+        xd = x.double()
+        z = sum(w.double()[None, None, :, j] * xd[:, j:j + 2 * tout, None] for j in range(kt)) + b.double()
+        y = torch.where(z > 0, z, slope * z).view(S, tout, 2, c1)
+        odd = y[:, :, 1] > y[:, :, 0]
+        pooled = torch.where(odd, y[:, :, 1], y[:, :, 0])
+        ref = torch.zeros(S, tp, c1, dtype=torch.float64, device=dev)
+        ref[:, :tout] = pooled
+        P = torch.full((S * tp, c1), float("nan"), device=dev)
+        bits = torch.full((S * tp, c1 // 32), -1, dtype=torch.int32, device=dev)
+        sign = torch.full_like(bits, -1)
+        check(lib.tl_conv1_fwd(ptr(x), ptr(w), ptr(b), ptr(P), ptr(bits), ptr(sign), S, T, kt, c1, tp, tout, slope, st),
+              "tl_conv1_fwd")
+        torch.cuda.synchronize()
+        assert float((P.double().view(S, tp, c1) - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+        sh = torch.arange(32, device=dev, dtype=torch.int32)
+        got_odd = ((bits.view(S, tp, c1 // 32, 1) >> sh) & 1).reshape(S, tp, c1).bool()
+        got_pos = ((sign.view(S, tp, c1 // 32, 1) >> sh) & 1).reshape(S, tp, c1).bool()
+        # a bit may differ from the float64 restatement only where the two candidates (or the value and zero) tie in fp32
+        gap = (y[:, :, 1] - y[:, :, 0]).abs()
+        assert bool(((got_odd[:, :tout] == odd) | (gap < 1e-5)).all())
+        assert bool(((got_pos[:, :tout] == (pooled > 0)) | (pooled.abs() < 1e-5)).all())
+        assert not bool(got_odd[:, tout:].any()) and not bool(got_pos[:, tout:].any())
+        if c1 != 128:
+            continue
+        # quads: V[quad][6][C1] = B^T (rows 4q .. 4q+5), raw rows, bits and sign words identical to the row kernel's
+        P4, b4, s4 = torch.full_like(P, float("nan")), torch.full_like(bits, -1), torch.full_like(bits, -1)
+        V4 = torch.full((S * tp // 4, 6, c1), float("nan"), device=dev)
+        check(lib.tl_conv1_fwd_v(ptr(x), ptr(w), ptr(b), ptr(P4), ptr(V4), ptr(b4), ptr(s4), S, T, kt, c1, tp, tout, slope, st),
+              "tl_conv1_fwd_v")
+        rows = torch.nn.functional.pad(P.double().view(S, tp, c1), (0, 0, 0, 4))
+        idx = torch.arange(tp // 4, device=dev)[:, None] * 4 + torch.arange(6, device=dev)[None, :]
+        v4ref = torch.einsum("jk,sqkc->sqjc", bt43, rows[:, idx, :]).reshape(S * tp // 4, 6, c1)
+        torch.cuda.synchronize()
+        assert torch.equal(P4, P) and torch.equal(b4, bits) and torch.equal(s4, sign)
+        assert float((V4.double() - v4ref).abs().max()) < 2e-6 * max(1.0, float(v4ref.abs().max()))
+        # hexes, pair layout
+        P6, b6, s6 = torch.full_like(P, float("nan")), torch.full_like(bits, -1), torch.full_like(bits, -1)
+        nh = S * tp // 6
+        V6 = torch.zeros((nh + 1) // 2 * 2, 8, c1, device=dev)
+        check(lib.tl_conv1_fwd_v6(ptr(x), ptr(w), ptr(b), ptr(P6), ptr(V6), ptr(b6), ptr(s6), S, T, kt, c1, tp, tout, slope, st),
+              "tl_conv1_fwd_v6")
+        torch.cuda.synchronize()
+        assert torch.equal(P6, P) and torch.equal(b6, bits) and torch.equal(s6, sign)
+        v6ref = w6.hex_transform(P, S, tp)
+        assert float((w6.logical(V6)[:nh].double() - v6ref).abs().max()) < 2e-6 * max(1.0, float(v6ref.abs().max()))
