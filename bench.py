@@ -25,7 +25,9 @@ Objects on the JSON line beside the contract fields:
                dense fp32 MFMA peak (157.3 TFLOP/s), always <= 1.  ``algorithmic_tflops`` is the same
                time priced at the direct convolution's FLOPs.  ``step_mfma_issued_frac`` =
                all MFMA FLOPs issued in one step / step time / peak.  ``traffic`` = HBM bytes per
-               launch from the rocprofv3 PMC passes committed under profiles/ (static file, named).
+               launch from the rocprofv3 PMC passes committed under profiles/ (static file, named);
+               ``held_clock`` = the clock that kernel ran at in a committed GRBM_GUI_ACTIVE pass of this
+               command and ``frac`` re-priced at it (static file, named; ``peak`` stays the nominal figure).
   cpu_baseline the CPU oracle (oracle/synthesis_oracle.py, PyTorch-CPU fp32 restatement of the
                reference) timed on this box's host cores at two micro-batches inside --cpu-budget seconds.
                ``value`` is MEASURED (largest micro-batch / its median step time); the rate at the metric's
@@ -549,11 +551,24 @@ def main():
                     traffic = dict(tj[dom], source="profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / "
                                                    "WRITE_SIZE passes of this command, committed; not re-measured here)")
             issued_tf = d["tflops"] * issued
+            # the clock the chip held in this kernel under the same command (static, from a committed counter pass): the peak
+            # above is priced at the nominal 2.4 GHz, which an MFMA-dense launch does not get
+            held = None
+            cpath = os.path.join(ROOT, "profiles", "effective_clock.json")
+            if os.path.exists(cpath):
+                with open(cpath) as f:
+                    cj = json.load(f)
+                ghz = cj.get("effective_clock_ghz", {}).get(dom)
+                if ghz:
+                    held = {"effective_clock_ghz": ghz, "nominal_clock_ghz": cj.get("nominal_clock_ghz", 2.4),
+                            "frac_at_held_clock": round(issued_tf / PEAK_FP32_MFMA_TFLOPS / (ghz / cj.get("nominal_clock_ghz", 2.4)), 4),
+                            "source": "profiles/effective_clock.json (static: GRBM_GUI_ACTIVE pass of this command, committed; "
+                                      "not re-measured here)"}
             U = getattr(eng, "_U", 8)
             L = getattr(eng, "_L", 5)
             step_issued = step_issued_flops(eng, B, U, L)
             roof = {"bound": "mfma", "achieved": round(issued_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(issued_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
+                    "frac": round(issued_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "held_clock": held, "kernel": dom,
                     "flops_issued_per_launch": d["flops_per_launch"] * issued,
                     "avg_launch_ms": round(d["avg_launch_ms"], 3), "launches_per_step": d["launches_per_step"],
                     "achieved_is": "MFMA FLOPs issued per launch / HIP-event launch time (<= peak by construction)",
