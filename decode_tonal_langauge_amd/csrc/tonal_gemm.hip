@@ -80,6 +80,19 @@ __device__ __forceinline__ void nt_epilogue(const tl_nt_params& p, f32x16 (&acc)
             if (Rs < p.M && cb < p.N) sword = p.auxbits[Rs * (long long)p.ld_auxbits + (cb >> 5)];
           }
         }
+        // MASK from the stage input itself (no sign words: the 1x1 stack): all 16 values of the tile are requested before the
+        // first store - behind a store the compiler may not move a load that could alias it, and one dependent load per row
+        // (16 round trips per 32 x 32 tile) made this epilogue the longest part of a short-K launch
+        float ax[16];
+        if constexpr (EPI == EPI_MASK) {
+          if (p.auxbits == nullptr) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const long long R = rbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
+              ax[e] = (R < p.M && colok) ? p.aux[R * (long long)p.ldaux + col] : 1.f;
+            }
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const long long R = rbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -93,7 +106,7 @@ __device__ __forceinline__ void nt_epilogue(const tl_nt_params& p, f32x16 (&acc)
               if (p.auxbits != nullptr)
                 pos = (word >> lr) & 1u;
               else
-                pos = p.aux[R * (long long)p.ldaux + col] > 0.f;
+                pos = ax[e] > 0.f;
               v = pos ? v : v * p.slope;
             }
             outp[R * (long long)p.ldo + col] = v;
