@@ -512,6 +512,45 @@ def test_glds_variant_matches_default_kernel(dev, monkeypatch):
         assert rel_l2(grads[1][k], grads[0][k]) < 5e-3, k
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 16), (130, 72, 48), (1000, 200, 128), (517, 128, 272), (256, 64, 64)])
+def test_one_tap_nt_gemm_forms_match_matmul(dev, shape, monkeypatch):
+    """``tl_gemm_nt_window`` with one tap (conv4 / conv5 / the 1x1 stack / Linear: reference models/synthesis_models.py:99-131)
+    on ragged shapes - partial row and column tiles, 1 .. 17 K-stages, split-K - for the register-staged kernel and the
+    direct-to-LDS kernel (default): STORE (+ split-K slabs), bias + LeakyReLU, and the input-gradient MASK from the stage input
+    (whose values a tile requests before its first store), against float64 matmul."""
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._classifier_engine import _launch_nt
+    from decode_tonal_langauge_amd._lib import LOAD_DIRECT, EPI_STORE, EPI_LRELU, EPI_MASK, ptr
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn(M + 3, K + 4, device=dev, generator=g)           # lda > K, rows behind M never read as outputs
+    W = torch.randn(N, K + 8, device=dev, generator=g)
+    bias = torch.randn(N, device=dev, generator=g)
+    aux = torch.randn(M, N + 4, device=dev, generator=g)
+    ref = A[:M, :K].double() @ W[:, :K].double().t()
+    scale = float(ref.abs().max())
+    for glds in ("0", "1"):
+        monkeypatch.setenv("TONAL_GLDS", glds)
+        kw = dict(A=ptr(A), Bw=ptr(W), M=M, A_rows=M + 3, N=N, K=K, lda=K + 4, ldb=K + 8, loader=LOAD_DIRECT)
+        out = torch.full((M, N + 4), float("nan"), device=dev)
+        _launch_nt(lib, out=ptr(out), ldo=N + 4, epilogue=EPI_STORE, **kw)
+        assert float((out[:, :N].double() - ref).abs().max()) < 2e-6 * scale and bool(torch.isnan(out[:, N:]).all())
+        out.fill_(float("nan"))
+        _launch_nt(lib, out=ptr(out), ldo=N + 4, epilogue=EPI_LRELU, bias=ptr(bias), slope=0.1, **kw)
+        y = ref + bias.double()
+        assert float((out[:, :N].double() - torch.where(y > 0, y, 0.1 * y)).abs().max()) < 2e-6 * scale
+        out.fill_(float("nan"))
+        _launch_nt(lib, out=ptr(out), ldo=N + 4, epilogue=EPI_MASK, aux=ptr(aux), ldaux=N + 4, slope=0.1, **kw)
+        assert float((out[:, :N].double() - torch.where(aux[:, :N] > 0, ref, 0.1 * ref)).abs().max()) < 2e-6 * scale
+        assert bool(torch.isnan(out[:, N:]).all())
+        nk = K // 16
+        for sk in sorted({1, min(2, nk), min(3, nk), nk}):
+            slab = torch.full((sk, M, N), float("nan"), device=dev)
+            _launch_nt(lib, out=ptr(slab), ldo=N, epilogue=EPI_STORE, splitk=sk, slab_stride=M * N, **kw)
+            assert float((slab.double().sum(0) - ref).abs().max()) < 2e-6 * scale, (glds, sk)
+
+
 def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
     """The Winograd conv kernels (F(2,3); default F(4,3) + F(2,3)) against the direct MFMA kernels (TONAL_WINO=0):
     same forward, same gradients, on a ragged shape (row tiles, time padding and the last
