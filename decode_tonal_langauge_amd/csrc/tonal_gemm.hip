@@ -374,6 +374,9 @@ __global__ __launch_bounds__(nt_cfg<BM>::NTHR, 2) void nt_window_kernel(const tl
 // fragment read, which makes the ds_read_b128 of 16 consecutive rows conflict-free.
 // Preconditions (host-checked): DIRECT loader, row_shift == 0, K % 16 == 0.
 // ------------------------------------------------------------------------------------------
+#ifndef G_ABL
+#define G_ABL 0                        // timing-only ablations of nt_glds_kernel (scripts/bench_nt1.py): 1 no epilogue stores, 2 no A pieces
+#endif                                 // after the first, 4 no B pieces after the first three, 8 no wait / barrier in the loop
 constexpr int GK = 16;                 // K depth of a stage
 constexpr int G_AROWS = 144;           // 130 staged rows, 9 DMA pieces of 16 rows
 constexpr int G_NB = 4;                // B ring slots
@@ -536,8 +539,8 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
     const bool has_next = chunk + 1 < nchunks;
     const bool lda_ = (j == 0) && has_next;
     const bool ldb = s + 3 < nsteps;
-    if (lda_) issue_a(chunk + 1);
-    if (ldb) issue_b(s + 3, c_ld, j_ld);
+    if (lda_ && !(G_ABL & 2)) issue_a(chunk + 1);
+    if (ldb && !(G_ABL & 4)) issue_b(s + 3, c_ld, j_ld);
     if (s > 0) mfma_group(fa1, fb1);             // k-group 1 of the previous step (registers)
     load_frag(fa1, fb1, abuf, bslot, j, 1);
     mfma_group(fa0, fb0);
@@ -555,14 +558,29 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
         n += (lda_ ? 3 : 0) + ((s + 2 < nsteps) ? 2 : 0);
         if (j == 1 && j != J - 1 && has_next) n += 3;
       }
-      wait_all_but(n);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(G_ABL & 8)) {
+        wait_all_but((G_ABL & 6) ? 0 : n);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       asm volatile("" ::: "memory");
     }
   }
   if (nsteps > 0) mfma_group(fa1, fb1);
+#if G_ABL & 1
+  {                                                      // timing only: one store per lane instead of the epilogue
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+    if (t == 12345.678f) p.out[0] = t;
+  }
+#else
   nt_epilogue<EPI, MI, NI>(p, acc, R0, n0, wm, wn, lr, lh, z);
+#endif
 }
 
 template <int EPI>
