@@ -86,31 +86,41 @@ __device__ __forceinline__ void nt_epilogue(const tl_nt_params& p, f32x16 (&acc)
         float ax[16];
         if constexpr (EPI == EPI_MASK) {
           if (p.auxbits == nullptr) {
+            // (through a buffer resource like the stores below: rows from M on and columns from N on read 0)
+            const long long ab = (p.M - rbase) * (long long)p.ldaux * 4;
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(p.aux + rbase * (long long)p.ldaux), 0, (int)(ab <= 0 ? 0 : (ab < 0x7fffffffLL ? ab : 0x7fffffffLL)), 0x00020000);
+            const unsigned lda4 = (unsigned)p.ldaux * 4u;
+            const unsigned xo0 = colok ? (unsigned)(4 * lh) * lda4 + (unsigned)col * 4u : 0x80000000u;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const long long R = rbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
-              ax[e] = (R < p.M && colok) ? p.aux[R * (long long)p.ldaux + col] : 1.f;
-            }
+            for (int e = 0; e < 16; ++e)
+              ax[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, xo0 + (unsigned)((e & 3) + 8 * (e >> 2)) * lda4, 0u, 0));
           }
         }
+        // stores through a buffer resource over the rows of this 32-row tile that exist (rows from M on are past its end and
+        // dropped by the range check; a lane whose column is past N carries an offset no resource reaches): one 32-bit add per
+        // store instead of a 64-bit address and a branch
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(outp + rbase * (long long)p.ldo), 0,
+            (int)((p.M - rbase) <= 0 ? 0 : ((p.M - rbase) * (long long)p.ldo * 4 < 0x7fffffffLL ? (p.M - rbase) * (long long)p.ldo * 4 : 0x7fffffffLL)),
+            0x00020000);
+        const unsigned ldo4 = (unsigned)p.ldo * 4u;
+        const unsigned vo0 = colok ? (unsigned)(4 * lh) * ldo4 + (unsigned)col * 4u : 0x80000000u;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const long long R = rbase + (e & 3) + 8 * (e >> 2) + 4 * lh;
           uint32_t word = 0;
           if constexpr (EPI == EPI_MASK) word = __shfl(sword, e + 32 * lh);
-          if (R < p.M && colok) {
-            float v = acc[mi][ni][e] + bv;
-            if constexpr (EPI == EPI_LRELU) v = lrelu(v, p.slope);
-            if constexpr (EPI == EPI_MASK) {
-              bool pos;
-              if (p.auxbits != nullptr)
-                pos = (word >> lr) & 1u;
-              else
-                pos = ax[e] > 0.f;
-              v = pos ? v : v * p.slope;
-            }
-            outp[R * (long long)p.ldo + col] = v;
+          float v = acc[mi][ni][e] + bv;
+          if constexpr (EPI == EPI_LRELU) v = lrelu(v, p.slope);
+          if constexpr (EPI == EPI_MASK) {
+            bool pos;
+            if (p.auxbits != nullptr)
+              pos = (word >> lr) & 1u;
+            else
+              pos = ax[e] > 0.f;
+            v = pos ? v : v * p.slope;
           }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, vo0 + (unsigned)((e & 3) + 8 * (e >> 2)) * ldo4, 0u, 0);
         }
       }
     }
