@@ -391,9 +391,11 @@ constexpr int GK = 16;                 // K depth of a stage
 constexpr int G_AROWS = 144;           // 130 staged rows, 9 DMA pieces of 16 rows
 constexpr int G_NB = 4;                // B ring slots
 
-template <int EPI>
+// NI = 32 x 32 tiles per wave along N: 2 = the 128-column tile, 1 = a 64-column tile for N <= 64 (the last layer of the 1x1 stack,
+// conv5: with the 128-column tile half of their MFMAs were masked columns)
+template <int EPI, int NI>
 __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
-  constexpr int BM = 128, MI = 2, NI = 2, WN = 2;
+  constexpr int BM = 128, MI = 2, WN = 2, BN = 64 * NI;          // (shadows the file's 128-column constant)
   __shared__ __attribute__((aligned(16))) float lds[2 * G_AROWS * GK + G_NB * BN * GK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -446,10 +448,10 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
     asrc[i] = p.A + row * (long long)p.lda + src_chunk * 4;
     adst[i] = (unsigned)(piece * 16 * GK * 4);
   }
-  const float* bsrc[2];
-  unsigned bdst[2];
+  const float* bsrc[NI];
+  unsigned bdst[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int piece = wave + 4 * i;
     int n = n0 + piece * 16 + prow;
     if (n > p.N - 1) n = p.N - 1;                         // clamped columns are masked by the epilogue
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
     const long long off = (long long)j * tap_stride + (long long)(kc_begin + chunk) * GK;
     char* base = lds_b + (step & (G_NB - 1)) * (BN * GK * 4);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma(bsrc[i] + off, base + bdst[i]);
+    for (int i = 0; i < NI; ++i) dma(bsrc[i] + off, base + bdst[i]);
   };
 
   // fragment read offsets (bytes): row r, logical chunk c -> r*64 + ((c ^ ((r >> 2) & 3)) * 16)
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int r = wn * 64 + i * 32 + lr;
+      const int r = wn * (NI * 32) + i * 32 + lr;
       fb[i] = *reinterpret_cast<const f32x4*>(lds_b + bslot * (BN * GK * 4) + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
     }
   };
@@ -519,9 +521,15 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
     if (nsteps > 2) issue_b(2, c_ld, j_ld);
     advance(c_ld, j_ld);
     // everything but the last two B pieces-pairs must have landed (A(0), B(0))
-    if (nsteps > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nsteps > 2) {
+      if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else if (nsteps > 1) {
+      if constexpr (NI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
   auto wait_all_but = [&](int n) {
     switch (n) {
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
       case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
       case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
       case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -561,11 +570,11 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
       // wave's pieces in issue order, so allow exactly the pieces issued AFTER the youngest needed
       // one to stay in flight: this step's own, B(s+2) (issued one step ago) and - when the next
       // step stays in this chunk - an A(chunk+1) issued one step ago.
-      int n = (ldb ? 2 : 0);
+      int n = (ldb ? NI : 0);                              // (NI B pieces per wave and step)
       if (J == 1) {
         // A(chunk+1) was issued this step (before B(s+3)) and is needed next step
       } else {
-        n += (lda_ ? 3 : 0) + ((s + 2 < nsteps) ? 2 : 0);
+        n += (lda_ ? 3 : 0) + ((s + 2 < nsteps) ? NI : 0);
         if (j == 1 && j != J - 1 && has_next) n += 3;
       }
       if (!(G_ABL & 8)) {
@@ -595,11 +604,16 @@ __global__ __launch_bounds__(256, 2) void nt_glds_kernel(const tl_nt_params p) {
 
 template <int EPI>
 static int launch_glds(const tl_nt_params& p, hipStream_t st) {
-  const long long nwg = ((p.M + 127) / 128) * ((p.N + BN - 1) / BN);
+  const bool narrow = p.N <= 64 && p.J == 1;              // one 64-column tile (the wait counts of the narrow form cover J == 1)
+  const int bn = narrow ? 64 : BN;
+  const long long nwg = ((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
   if (nwg <= 0) return TL_OK;
   TL_REQUIRE(nwg < (1LL << 31), "nt_glds: grid too large");
   dim3 grid((unsigned)nwg, (unsigned)p.splitk, 1);
-  hipLaunchKernelGGL((nt_glds_kernel<EPI>), grid, dim3(256), 0, st, p);
+  if (narrow)
+    hipLaunchKernelGGL((nt_glds_kernel<EPI, 1>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((nt_glds_kernel<EPI, 2>), grid, dim3(256), 0, st, p);
   return check_launch("nt_glds");
 }
 
