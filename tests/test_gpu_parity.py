@@ -512,7 +512,7 @@ def test_glds_variant_matches_default_kernel(dev, monkeypatch):
         assert rel_l2(grads[1][k], grads[0][k]) < 5e-3, k
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 16), (130, 72, 48), (1000, 200, 128), (517, 128, 272), (256, 64, 64)])
+@pytest.mark.parametrize("shape", [(1, 64, 16), (130, 72, 48), (1000, 200, 128), (517, 128, 272), (256, 64, 64), (70, 20, 32), (300, 36, 80)])
 def test_one_tap_nt_gemm_forms_match_matmul(dev, shape, monkeypatch):
     """``tl_gemm_nt_window`` with one tap (conv4 / conv5 / the 1x1 stack / Linear: reference models/synthesis_models.py:99-131)
     on ragged shapes - partial row and column tiles, 1 .. 17 K-stages, split-K - for the register-staged kernel and the
