@@ -6,6 +6,6 @@ set -e
 cd "$(dirname "$0")/../decode_tonal_langauge_amd/csrc"
 mkdir -p ../../build/variants
 for v in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -D${ABL_MACRO:-V6_ABL}=$v ${V_EXTRA} -c tonal_wino63.hip -o ../../build/variants/w63_${TAG}$v.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops -D${ABL_MACRO:-V6_ABL}=$v ${V_EXTRA} -c tonal_wino63.hip -o ../../build/variants/w63_${TAG}$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/variants/lib63_${TAG}$v.so tonal_gemm.o tonal_misc.o tonal_signal.o tonal_lite.o tonal_steps.o tonal_wino.o tonal_wino43_tn.o tonal_wino43v.o ../../build/variants/w63_${TAG}$v.o
 done
