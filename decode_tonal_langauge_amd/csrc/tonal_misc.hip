@@ -1203,6 +1203,49 @@ extern "C" int tl_conv1_wgrad(const float* x, const float* G, const uint32_t* bi
   return check_launch("conv1_wgrad");
 }
 
+namespace tl {
+// Permutation whose innermost destination dimension is strided in the source while another dimension K is contiguous there
+// (the per-step packs of the Linear layer's 63 MB weight): 32 x 32 tiles through LDS, reads run along K, writes along the
+// innermost dimension.  The element-per-thread kernel above reads such a source one cache line per element (0.6 TB/s).
+template <int K>
+__global__ __launch_bounds__(256) void permute_tiled_kernel(const float* __restrict__ src, float* __restrict__ dst, perm_args a) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long tk_n = (a.d[K] + 31) / 32, t3_n = (a.d[3] + 31) / 32;
+  long long b = blockIdx.x;
+  const long long t3 = b % t3_n; b /= t3_n;
+  const long long tk = b % tk_n; b /= tk_n;
+  // the two dimensions that are neither K nor 3, in order
+  constexpr int P = (K == 0) ? 1 : 0, Q = (K == 2) ? 1 : 2;
+  const long long iq = b % a.d[Q], ip = b / a.d[Q];
+  long long idx[4];
+  idx[P] = ip;
+  idx[Q] = iq;
+  const bool pq_ok = ip < a.lim[P] && iq < a.lim[Q];
+  const long long base = ip * a.s[P] + iq * a.s[Q];
+  {
+    const long long ik = tk * 32 + tx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long i3 = t3 * 32 + ty + 8 * r;
+      float v = 0.f;
+      if (pq_ok && ik < a.d[K] && ik < a.lim[K] && i3 < a.d[3] && i3 < a.lim[3]) v = src[base + ik * a.s[K] + i3 * a.s[3]];
+      tile[ty + 8 * r][tx] = v;
+    }
+  }
+  __syncthreads();
+  const long long i3 = t3 * 32 + tx;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long ik = tk * 32 + ty + 8 * r;
+    if (ik < a.d[K] && i3 < a.d[3]) {
+      idx[K] = ik;
+      dst[((idx[0] * a.d[1] + idx[1]) * a.d[2] + idx[2]) * a.d[3] + i3] = tile[tx][ty + 8 * r];
+    }
+  }
+}
+}  // namespace tl
+
 extern "C" int tl_permute_reduce(const float* src, float* dst, const int64_t dims[4], const int64_t strides[4],
                                  const int64_t lims[4], int nz, int64_t zs, const float* bias_last, void* stream) {
   TL_REQUIRE(src && dst && dims && strides && lims, "permute_reduce: null pointer");
@@ -1218,6 +1261,25 @@ extern "C" int tl_permute_reduce(const float* src, float* dst, const int64_t dim
   }
   a.zs = zs;
   a.nz = nz;
+  if (nz == 1 && bias_last == nullptr && a.s[3] != 1 && a.d[3] >= 16) {
+    // a dimension that is contiguous in the source and long enough for whole read lines: the tiled transpose
+    int k = -1;
+    for (int i = 0; i < 3; ++i)
+      if (a.s[i] == 1 && a.d[i] >= 32) k = i;
+    if (k >= 0) {
+      const long long blocks = (total / a.d[k] / a.d[3]) * ((a.d[k] + 31) / 32) * ((a.d[3] + 31) / 32);
+      if (blocks > 0 && blocks < (1LL << 31)) {
+        const dim3 grid((unsigned)blocks);
+        if (k == 0)
+          hipLaunchKernelGGL(permute_tiled_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, a);
+        else if (k == 1)
+          hipLaunchKernelGGL(permute_tiled_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, a);
+        else
+          hipLaunchKernelGGL(permute_tiled_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, a);
+        return check_launch("permute_tiled");
+      }
+    }
+  }
   if (nz >= 64 && total <= 16384)
     hipLaunchKernelGGL(permute_reduce_zpar_kernel, dim3(grid_for(total * 64)), dim3(256), 0, (hipStream_t)stream, src,
                        dst, bias_last, a, total);

@@ -1363,3 +1363,60 @@ def test_conv1_kernels_for_every_tap_count(dev, kt):
         assert torch.equal(P6, P) and torch.equal(b6, bits) and torch.equal(s6, sign)
         v6ref = w6.hex_transform(P, S, tp)
         assert float((w6.logical(V6)[:nh].double() - v6ref).abs().max()) < 2e-6 * max(1.0, float(v6ref.abs().max()))
+
+
+def test_permute_reduce_forms(dev):
+    """``tl_permute_reduce`` (the per-step weight packs and split-K slab reductions of the engine; reference side: the layouts
+    torch keeps its Conv2d / Linear weights in, models/synthesis_models.py:86-135): the element-per-thread kernel, the slab-parallel
+    one and the tiled transpose (innermost destination dimension strided in the source, another one contiguous) against torch
+    indexing, with limits that cut every dimension."""
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._lib import check, ptr
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(77)
+
+    def run(src, dims, strides, lims=None, nz=1, zs=0, bias=None):
+        d = (C_.c_int64 * 4)(*dims)
+        s = (C_.c_int64 * 4)(*strides)
+        l = (C_.c_int64 * 4)(*(lims if lims is not None else dims))
+        out = torch.full(tuple(dims), float("nan"), device=dev)
+        check(lib.tl_permute_reduce(ptr(src), ptr(out), d, s, l, nz, zs, ptr(bias) if bias is not None else None, st),
+              "tl_permute_reduce")
+        torch.cuda.synchronize()
+        return out
+
+    def ref(src, dims, strides, lims=None, nz=1, zs=0, bias=None):
+        lims = lims if lims is not None else dims
+        idx = [torch.arange(n, device=dev) for n in dims]
+        off = sum(i.view([-1 if k == j else 1 for k in range(4)]) * strides[j] for j, i in enumerate(idx))
+        ok = torch.ones(tuple(dims), dtype=torch.bool, device=dev)
+        for j, i in enumerate(idx):
+            ok = ok & (i.view([-1 if k == j else 1 for k in range(4)]) < lims[j])
+        flat = src.reshape(-1).double()
+        acc = sum(flat[(off + z * zs).clamp(max=flat.numel() - 1)] for z in range(nz))
+        if bias is not None:
+            acc = acc + bias.double().view(1, 1, 1, -1)
+        return torch.where(ok, acc, torch.zeros_like(acc)).float()
+
+    # the Linear layer's packs at a reduced size: (C, tp, ld, out) from torch's (out, Cc, lat, C) and back
+    Cn, tp, lat, Cc, ld, nout, ldd = 40, 7, 6, 12, 16, 10, 12
+    w = torch.randn(nout, Cc * lat * Cn, device=dev, generator=g)
+    cases = [
+        (w, (Cn, tp, ld, ldd), (1, Cn, lat * Cn, Cc * lat * Cn), (Cn, lat, Cc, nout)),            # dgrad pack: K = 0 contiguous
+        (torch.randn(ldd, Cn * tp * ld, device=dev, generator=g), (nout, Cc, lat, Cn), (Cn * tp * ld, 1, ld, tp * ld), None),   # K = 1... short
+        (torch.randn(5, 3, 70, 50, device=dev, generator=g), (5, 3, 50, 70), (3 * 70 * 50, 70 * 50, 1, 50), (5, 2, 45, 70)),     # K = 2, ragged tiles
+        (torch.randn(64, 3, 2, 33, device=dev, generator=g), (33, 3, 2, 64), (1, 2 * 33, 33, 3 * 2 * 33), None),                  # K = 0, 33 x 64
+        (torch.randn(9, 11, 13, 17, device=dev, generator=g), (9, 13, 11, 17), (11 * 13 * 17, 17, 13 * 17, 1), None),             # contiguous innermost: element kernel
+    ]
+    for src, dims, strides, lims in cases:
+        got, exp = run(src, dims, strides, lims), ref(src, dims, strides, lims)
+        assert torch.equal(got, exp), (dims, strides)
+    # slab reductions (nz > 1) and the bias of the last dimension
+    slabs = torch.randn(70, 6, 8, 4, 5, device=dev, generator=g)
+    b = torch.randn(5, device=dev, generator=g)
+    got = run(slabs, (6, 8, 4, 5), (8 * 4 * 5, 4 * 5, 5, 1), nz=70, zs=6 * 8 * 4 * 5, bias=b)
+    assert float((got - ref(slabs, (6, 8, 4, 5), (8 * 4 * 5, 4 * 5, 5, 1), nz=70, zs=6 * 8 * 4 * 5, bias=b)).abs().max()) < 1e-4
+    big = torch.randn(3, 40, 30, 20, 16, device=dev, generator=g)
+    got = run(big, (40, 20, 30, 16), (30 * 20 * 16, 16, 20 * 16, 1), nz=3, zs=40 * 30 * 20 * 16)
+    assert float((got - ref(big, (40, 20, 30, 16), (30 * 20 * 16, 16, 20 * 16, 1), nz=3, zs=40 * 30 * 20 * 16)).abs().max()) < 1e-5
