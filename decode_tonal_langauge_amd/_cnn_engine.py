@@ -803,6 +803,11 @@ class CnnEngine:
             kw.update(loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
         else:
             kw.update(loader=LOAD_DIRECT, Tvalid=st.tout)
+        # one-tap direct kernel: the bias gradient rides in the launch (see the 1x1 stack in backward())
+        fold = (not st.pool) and st.k == 1 and rows_in > 512 and st.cin > 32
+        bpart = torch.empty(sk, nd, **f32) if fold else None
+        if fold:
+            kw.update(colsum=ptr(bpart))
         self._tn(tag=f"conv{st.idx}_wgrad", **kw)
         # sum the split-K slabs with coalesced reads first ([j][i][o], o contiguous), then permute the
         # small result to torch's (O, I, J, 1)
@@ -813,7 +818,10 @@ class CnnEngine:
         else:
             red = slab
         self._permute(red, gw, (1, st.cout, st.cin, st.k), (0, 1, ldg, st.cin * ldg))
-        self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
+        if fold:
+            self._permute(bpart, gb, (1, 1, 1, st.cout), (0, 0, 0, 1), nz=sk, zs=nd)
+        else:
+            self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
 
     def stage_dgrad(self, st: _Stage, w: torch.Tensor):
         """G[idx-1] = (dZ[idx] (*) flipped W) * LeakyReLU'(P[idx-1]).
@@ -1180,12 +1188,20 @@ class CnnEngine:
             tiles = ((cin_ld + 127) // 128) * ((cout_ld + 127) // 128)
             sk = self._splitk(tiles, (rows5 + 31) // 32)
             slab = torch.empty(sk, cin_ld, cout_ld, **f32)
+            # the bias gradient (column sums of Gi over the valid rows) rides in the weight-gradient launch where that is the
+            # one-tap direct kernel (not its short-reduction / skinny forms, whose colsum means something else): Gi is not read
+            # a third time
+            fold = rows5 > 512 and cin_ld > 32
+            bpart = torch.empty(sk, cout_ld, **f32) if fold else None
             self._tn(A=ptr(src), B=ptr(Gi), slab=ptr(slab), Krows=rows5, A_rows=rows5, B_rows=rows5, Mdim=cin_ld,
                      Ndim=cout_ld, lda=cin_ld, ldb=cout_ld, ldc=cout_ld, loader=LOAD_DIRECT, Tp=self.tp5,
-                     Tvalid=self.lat, splitk=sk, slab_stride=cin_ld * cout_ld)
+                     Tvalid=self.lat, splitk=sk, slab_stride=cin_ld * cout_ld, colsum=ptr(bpart))
             self._permute(slab, grads[name + ".weight"], (1, 1, cout_t, cin_t), (0, 0, 1, cout_ld), nz=sk,
                           zs=cin_ld * cout_ld)
-            colsum(Gi, rows5, cout_t, cout_ld, self.tp5, self.lat, grads[name + ".bias"])
+            if fold:
+                self._permute(bpart, grads[name + ".bias"], (1, 1, 1, cout_t), (0, 0, 0, 1), nz=sk, zs=cout_ld)
+            else:
+                colsum(Gi, rows5, cout_t, cout_ld, self.tp5, self.lat, grads[name + ".bias"])
             wd = self._pack_conv(prm[name + ".weight"], cin_ld, True)          # [1][cin_ld][cout_ld]
             if i > 0:
                 self._nt(A=ptr(Gi), Bw=ptr(wd), aux=ptr(src), out=ptr(self.GY[i - 1]), M=rows5, A_rows=rows5,

@@ -706,6 +706,11 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+  // column sums of B over this split (the bias gradient of a one-tap layer: B = the layer's output gradient): the first row
+  // tile's workgroup of a (split, column tile) adds up the rows it stages anyway - no pass of its own over B
+  const bool do_cs = LOADER == LOAD_DIRECT && p.colsum != nullptr && tm == 0 && j == 0;
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+
   // two staging sets (P/Q): tiles are prefetched two K-steps ahead
   f32x4 raP[4], rbP[4], raQ[4], rbQ[4];
   uint32_t rnP[2], rnQ[2];
@@ -771,6 +776,9 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
         if constexpr (LOADER == LOAD_UNPOOL) nib = *bbptr[i];
       }
       rb[i] = v;
+      if constexpr (LOADER == LOAD_DIRECT) {
+        if (do_cs) cs += v;
+      }
       if constexpr (LOADER == LOAD_UNPOOL) {
         rnib[i] = nib;
         bbptr[i] += bb_step;
@@ -869,6 +877,18 @@ __global__ __launch_bounds__(256, 2) void tn_window_kernel(const tl_tn_params p)
   }
   if (s < nsteps) kstep(s, raP, rbP, rnP, raQ, rbQ, rnQ);
   if (nsteps > 0) mfma_group(ta1, tb1);
+
+  if (do_cs) {                                            // (workgroup-uniform; every LDS read of the loop is behind its last barrier)
+    float* red = lds;                                     // [8 row groups][128 columns]
+    *reinterpret_cast<f32x4*>(red + (tid >> 5) * 128 + (tid & 31) * 4) = cs;
+    __syncthreads();
+    if (tid < 128 && n0 + tid < p.Ndim) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += red[g * 128 + tid];
+      p.colsum[(long long)z * p.Ndim + n0 + tid] = t;
+    }
+  }
 
   float* out = p.slab + (long long)z * p.slab_stride;
 #pragma unroll
@@ -1360,7 +1380,8 @@ extern "C" int tl_gemm_tn_window(const tl_tn_params* pp, void* stream) {
     hipLaunchKernelGGL(tn_short_kernel, dim3((unsigned)nwg, (unsigned)p.splitk), dim3(256), 0, st, p);
     return check_launch("tn_short");
   }
-  TL_REQUIRE(p.colsum == nullptr, "tn_window: colsum is produced by the short-reduction kernel only (Krows <= 512, splitk <= 8, Mdim * Ndim <= 2^20)");
+  TL_REQUIRE(p.colsum == nullptr || (p.J == 1 && p.loader == LOAD_DIRECT && p.Mdim > 32),
+             "tn_window: colsum comes from the short-reduction kernel (Krows <= 512, splitk <= 8, Mdim * Ndim <= 2^20) or the one-tap direct kernel (Mdim > 32)");
   if (p.Mdim <= 32 && p.J == 1 && p.loader == LOAD_DIRECT) {       // skinny-M streaming variant
     dim3 grid((unsigned)((p.Ndim + SK_BN - 1) / SK_BN), (unsigned)p.splitk, 1);
     hipLaunchKernelGGL(tn_skinny_kernel, grid, dim3(256), 0, st, p);

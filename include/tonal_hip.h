@@ -115,7 +115,10 @@ typedef struct {
   int loader;
   int splitk; int64_t slab_stride;
   float* colsum;      /* optional.  tl_gemm_tn_window on its short-reduction kernel (Krows <= 512, splitk 1): colsum[m] = sum
-                         over the rows of A[.][m], Mdim floats (the bias gradient of a Linear layer); tl_conv3_wino43_tn:
+                         over the rows of A[.][m], Mdim floats (the bias gradient of a Linear layer); tl_gemm_tn_window on its
+                         one-tap direct kernel (J == 1, loader 0, Mdim > 32, Krows > 512): colsum[z][n] = sum over the valid
+                         rows of split z of B[.][n], Ndim floats per split (the bias gradient of a 1x1 convolution, from the
+                         launch that reads its output gradient anyway); tl_conv3_wino43_tn:
                          colsum[z][n] = sum over split z of the un-pooled
                          dZ column n (the bias gradient partial sums; Ndim floats per split), or null */
   float* vd; int ld_vd; /* optional (tl_conv3_wino43v_tn): also write Vd[quad][6][ld_vd] = the F(4,3) input transform of

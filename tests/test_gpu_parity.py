@@ -1420,3 +1420,32 @@ def test_permute_reduce_forms(dev):
     big = torch.randn(3, 40, 30, 20, 16, device=dev, generator=g)
     got = run(big, (40, 20, 30, 16), (30 * 20 * 16, 16, 20 * 16, 1), nz=3, zs=40 * 30 * 20 * 16)
     assert float((got - ref(big, (40, 20, 30, 16), (30 * 20 * 16, 16, 20 * 16, 1), nz=3, zs=40 * 30 * 20 * 16)).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(3000, 128, 128, 25, 24), (1037, 72, 64, 12, 11), (5000, 256, 200, 1, 1)])
+def test_one_tap_weight_gradient_carries_the_bias_gradient(dev, shape):
+    """``tl_gemm_tn_window`` on its one-tap direct kernel: slab[z] = A^T B over split z and, with ``colsum``, the column sums of
+    B over the same rows - rows whose time index (row % Tp) is past Tvalid excluded from both (the weight and bias gradients of
+    a 1x1 convolution, reference models/synthesis_models.py:103-131, from one pass over the output gradient)."""
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._lib import TnParams, LOAD_DIRECT, check, ptr
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    K, M, N, Tp, Tv = shape
+    g = torch.Generator(device=dev).manual_seed(K + M)
+    A = torch.randn(K, M + 4, device=dev, generator=g)
+    B = torch.randn(K, N + 8, device=dev, generator=g)
+    valid = (torch.arange(K, device=dev) % Tp) < Tv
+    Bd = torch.where(valid[:, None], B[:, :N].double(), torch.zeros((), dtype=torch.float64, device=dev))
+    ref_w, ref_b = A[:, :M].double().t() @ Bd, Bd.sum(0)
+    for sk in (1, 3, 16):
+        slab = torch.full((sk, M, N), float("nan"), device=dev)
+        cs = torch.full((sk, N), float("nan"), device=dev)
+        p = TnParams()
+        p.J, p.Tp, p.Tvalid, p.splitk, p.slab_stride = 1, Tp, Tv, sk, M * N
+        p.A, p.B, p.slab, p.colsum = ptr(A), ptr(B), ptr(slab), ptr(cs)
+        p.Krows, p.A_rows, p.B_rows, p.Mdim, p.Ndim, p.lda, p.ldb, p.ldc, p.loader = K, K, K, M, N, M + 4, N + 8, N, LOAD_DIRECT
+        check(lib.tl_gemm_tn_window(C_.byref(p), st), "tl_gemm_tn_window")
+        torch.cuda.synchronize()
+        assert float((slab.double().sum(0) - ref_w).abs().max()) < 2e-6 * float(ref_w.abs().max()) * max(1.0, K / 1000)
+        assert float((cs.double().sum(0) - ref_b).abs().max()) < 2e-6 * float(ref_b.abs().max() + K ** 0.5), sk
