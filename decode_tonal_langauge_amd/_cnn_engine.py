@@ -698,6 +698,27 @@ class CnnEngine:
         check(self.lib.tl_colsum(ptr(Gm), ptr(part), nblk, rows, nc4, ld, Tp, Tvalid, self._stream()), "tl_colsum")
         self._permute(part, dst, (1, 1, 1, ncols), (0, 0, 0, 1), nz=nblk, zs=nc4)
 
+    def _reduce_c1_partials(self, part: torch.Tensor, gw: torch.Tensor, gb: torch.Tensor) -> None:
+        """Partial sums of the first stage's weight / bias gradient, ``part[tile][(k1 + 1) * c1]`` in the layout of
+        ``tl_conv1_wgrad`` (tap-major weight sums, then the bias sums), -> torch's (c1, 1, k1, 1) weight and (c1,) bias."""
+        f32 = dict(dtype=torch.float32, device=part.device)
+        nblk = part.shape[0]
+        zs = (self.k1 + 1) * self.c1
+        if nblk >= 256 and zs % 4 == 0:
+            # many partial rows (one per row tile of the fused epilogue: 8 704 x 2 048 floats at the north-star shape): sum them
+            # with the column-sum kernel (reads run along the row) and permute the 2 048 results - the slab-parallel permute
+            # reads such a matrix one element per cache line (94 + 78 us for 71 MB)
+            red = torch.empty(zs, **f32)
+            flat = part.view(-1)
+            for c0 in range(0, zs, 1024):
+                nc = min(1024, zs - c0)
+                self._colsum(flat[c0:], nblk, nc, zs, 1, 1, red[c0:c0 + nc])
+            self._permute(red, gw, (1, 1, self.c1, self.k1), (0, 0, 1, self.c1))
+            self._permute(red, gb, (1, 1, 1, self.c1), (0, 0, 0, 1), src_off=self.k1 * self.c1)
+        else:
+            self._permute(part, gw, (1, 1, self.c1, self.k1), (0, 0, 1, self.c1), nz=nblk, zs=zs)
+            self._permute(part, gb, (1, 1, 1, self.c1), (0, 0, 0, 1), nz=nblk, zs=zs, src_off=self.k1 * self.c1)
+
     def stage_wgrad(self, st: _Stage, gw: torch.Tensor, gb: torch.Tensor) -> None:
         """dW, db of one stage from its input P[idx-1] and G[idx] (pooled gradient + arg-max bits)."""
         if self._f63(st):
@@ -1186,7 +1207,9 @@ class CnnEngine:
             Gi = self.GY[i]
             name = f"concat_conv_block.{2 * i}"
             tiles = ((cin_ld + 127) // 128) * ((cout_ld + 127) // 128)
-            sk = self._splitk(tiles, (rows5 + 31) // 32)
+            # (512 splits: the launch itself is flat between 256 and 1 024 - scripts/bench_tn1.py -, the slab reduction behind
+            # it reads half of what 1 024 leave)
+            sk = self._splitk(tiles, (rows5 + 31) // 32, 512)
             slab = torch.empty(sk, cin_ld, cout_ld, **f32)
             # the bias gradient (column sums of Gi over the valid rows) rides in the weight-gradient launch where that is the
             # one-tap direct kernel (not its short-reduction / skinny forms, whose colsum means something else): Gi is not read
@@ -1239,11 +1262,6 @@ class CnnEngine:
             part = torch.empty(nblk, (self.k1 + 1) * self.c1, **f32)
             check(lib.tl_conv1_wgrad(ptr(self._x), ptr(self.G[1]), ptr(self.bits[1]), ptr(part), nblk, S, self.T, self.k1,
                                      self.c1, self.tp1, self.tout1, st_), "tl_conv1_wgrad")
-        nblk = part.shape[0]
-        zs = (self.k1 + 1) * self.c1
-        self._permute(part, grads["ecog_conv_block.0.weight"], (1, 1, self.c1, self.k1), (0, 0, 1, self.c1), nz=nblk,
-                      zs=zs)
-        self._permute(part, grads["ecog_conv_block.0.bias"], (1, 1, 1, self.c1), (0, 0, 0, 1), nz=nblk, zs=zs,
-                      src_off=self.k1 * self.c1)
+        self._reduce_c1_partials(part, grads["ecog_conv_block.0.weight"], grads["ecog_conv_block.0.bias"])
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)

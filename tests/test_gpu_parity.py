@@ -1449,3 +1449,23 @@ def test_one_tap_weight_gradient_carries_the_bias_gradient(dev, shape):
         torch.cuda.synchronize()
         assert float((slab.double().sum(0) - ref_w).abs().max()) < 2e-6 * float(ref_w.abs().max()) * max(1.0, K / 1000)
         assert float((cs.double().sum(0) - ref_b).abs().max()) < 2e-6 * float(ref_b.abs().max() + K ** 0.5), sk
+
+
+@pytest.mark.parametrize("nblk", [40, 300, 1111])
+def test_first_stage_gradient_partials_reduce_to_torch_layout(dev, nblk):
+    """The per-tile partial sums of conv1's weight / bias gradient (``tl_conv1_wgrad`` / the fused epilogue of conv2's input
+    gradient; reference: the gradient of ``ecog_conv_block[0]``, models/synthesis_models.py:87) summed and permuted into
+    torch's layouts - the slab-parallel permute (few tiles) and the column-sum form (many tiles) against torch."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    model = SynthesisModelCNN(80, 8, 200, dropout=0.0).to(dev)
+    eng = model._engine
+    g = torch.Generator(device=dev).manual_seed(nblk)
+    part = torch.randn(nblk, (eng.k1 + 1) * eng.c1, device=dev, generator=g)
+    gw = torch.full((eng.c1, 1, eng.k1, 1), float("nan"), device=dev)
+    gb = torch.full((eng.c1,), float("nan"), device=dev)
+    eng._reduce_c1_partials(part, gw, gb)
+    torch.cuda.synchronize()
+    tot = part.double().sum(0)
+    ref_w = tot[:eng.k1 * eng.c1].view(eng.k1, eng.c1).t()
+    assert float((gw.view(eng.c1, eng.k1).double() - ref_w).abs().max()) < 1e-5 * float(ref_w.abs().max())
+    assert float((gb.double() - tot[eng.k1 * eng.c1:]).abs().max()) < 1e-5 * float(tot.abs().max())
