@@ -720,25 +720,27 @@ __global__ __launch_bounds__(512, 2) void lstm_step_fused_kernel(const float* __
 // ------------------------------------------------------------------------------------------
 // concat + dropout glue
 // ------------------------------------------------------------------------------------------
+// (IDX = unsigned where the element count allows it: the index arithmetic - three divisions per element - is what this
+// kernel spends its time on, and the 64-bit forms cost several times the 32-bit ones)
+template <typename IDX>
 __global__ __launch_bounds__(256) void concat_pack_kernel(const float* __restrict__ O5, const float* __restrict__ h,
                                                           const int32_t* __restrict__ uid, float* __restrict__ Xc, int B,
                                                           int C, int Tp, int lat, int Cc, int Lc, int ld5, int ldh, int ldx,
                                                           float p_drop, uint64_t seed, long long drop_row0) {
-  const long long total = (long long)B * C * Tp * ldx;
+  const IDX total = (IDX)((long long)B * C * Tp * ldx);
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int col = (int)(i % ldx);
-    const long long row = i / ldx;
-    const int t = (int)(row % Tp);
-    const long long seq = row / Tp;
-    const int cch = (int)(seq % C);
-    const int b = (int)(seq / C);
+  for (IDX i = (IDX)blockIdx.x * (IDX)blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * (IDX)blockDim.x) {
+    const IDX row = i / (IDX)ldx;
+    const int col = (int)(i - row * (IDX)ldx);
+    const IDX seq = row / (IDX)Tp;
+    const int t = (int)(row - seq * (IDX)Tp);
+    const int b = (int)(seq / (IDX)C);
+    const int cch = (int)(seq - (IDX)b * (IDX)C);
     float v = 0.f;
     if (t < lat) {
       if (col < Cc) {
-        v = O5[row * ld5 + col];
-        if (p_drop > 0.f) v = u01(seed, (uint64_t)((drop_row0 + row) * Cc + col)) >= p_drop ? v * keep_scale : 0.f;
+        v = O5[(long long)row * ld5 + col];
+        if (p_drop > 0.f) v = u01(seed, (uint64_t)((drop_row0 + (long long)row) * Cc + col)) >= p_drop ? v * keep_scale : 0.f;
       } else if (col < Cc + Lc) {
         v = h[(long long)uid[b] * ldh + ((long long)(col - Cc) * lat + t) * C + cch];
       }
@@ -747,15 +749,16 @@ __global__ __launch_bounds__(256) void concat_pack_kernel(const float* __restric
   }
 }
 
+template <typename IDX>
 __global__ __launch_bounds__(256) void concat_g5_kernel(const float* __restrict__ dXc, const float* __restrict__ O5,
                                                         float* __restrict__ G5, long long rows, int Cc, int ld5, int ldx,
                                                         float slope, float p_drop, uint64_t seed, long long drop_row0) {
-  const long long total = rows * Cc;
+  const IDX total = (IDX)(rows * Cc);
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int col = (int)(i % Cc);
-    const long long row = i / Cc;
+  for (IDX i = (IDX)blockIdx.x * (IDX)blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * (IDX)blockDim.x) {
+    const IDX rowi = i / (IDX)Cc;
+    const int col = (int)(i - rowi * (IDX)Cc);
+    const long long row = (long long)rowi;
     float g = dXc[row * ldx + col];
     if (p_drop > 0.f) g = u01(seed, (uint64_t)((drop_row0 + row) * Cc + col)) >= p_drop ? g * keep_scale : 0.f;
     const float a = O5[row * ld5 + col];
@@ -1408,8 +1411,13 @@ extern "C" int tl_concat_pack(const float* O5, const float* h, const int32_t* ui
   TL_REQUIRE(O5 && h && uid && Xc, "concat_pack: null pointer");
   TL_REQUIRE(ldx >= Cc + Lc && ld5 >= Cc && lat <= Tp && p_drop >= 0.f && p_drop < 1.f, "concat_pack: bad arguments");
   const long long total = (long long)B * C * Tp * ldx;
-  hipLaunchKernelGGL(concat_pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, O5, h, uid, Xc, B,
-                     C, Tp, lat, Cc, Lc, ld5, ldh, ldx, p_drop, seed, (long long)drop_row0);
+  // (the grid-stride loop adds up to 2^31 to the index before it tests it: 32-bit indices below 2^31 elements only)
+  if (total < (1LL << 31))
+    hipLaunchKernelGGL(concat_pack_kernel<unsigned>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, O5, h, uid, Xc, B,
+                       C, Tp, lat, Cc, Lc, ld5, ldh, ldx, p_drop, seed, (long long)drop_row0);
+  else
+    hipLaunchKernelGGL(concat_pack_kernel<long long>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, O5, h, uid, Xc, B,
+                       C, Tp, lat, Cc, Lc, ld5, ldh, ldx, p_drop, seed, (long long)drop_row0);
   return check_launch("concat_pack");
 }
 
@@ -1420,8 +1428,12 @@ extern "C" int tl_concat_unpack_bwd(const float* dXc, const float* O5, const int
   TL_REQUIRE(dXc && O5 && offsets && G5 && dh, "concat_unpack_bwd: null pointer");
   TL_REQUIRE(ldx >= Cc + Lc && ld5 >= Cc && lat <= Tp && p_drop >= 0.f && p_drop < 1.f, "concat_unpack_bwd: bad arguments");
   const long long rows = (long long)B * C * Tp;
-  hipLaunchKernelGGL(concat_g5_kernel, dim3(grid_for(rows * Cc)), dim3(256), 0, (hipStream_t)stream, dXc, O5, G5, rows,
-                     Cc, ld5, ldx, slope, p_drop, seed, (long long)drop_row0);
+  if (rows * Cc < (1LL << 31))
+    hipLaunchKernelGGL(concat_g5_kernel<unsigned>, dim3(grid_for(rows * Cc)), dim3(256), 0, (hipStream_t)stream, dXc, O5, G5, rows,
+                       Cc, ld5, ldx, slope, p_drop, seed, (long long)drop_row0);
+  else
+    hipLaunchKernelGGL(concat_g5_kernel<long long>, dim3(grid_for(rows * Cc)), dim3(256), 0, (hipStream_t)stream, dXc, O5, G5, rows,
+                       Cc, ld5, ldx, slope, p_drop, seed, (long long)drop_row0);
   int rc = check_launch("concat_g5");
   if (rc) return rc;
   const long long total = (long long)U * Lc * lat * C;
