@@ -73,15 +73,19 @@ def parse_args(argv=None):
     ap.add_argument("--timepoints", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4, help="micro-batch of the CPU-oracle leg")
-    ap.add_argument("--cpu-budget", type=float, default=100.0,
-                    help="seconds of host time the CPU-oracle leg may spend (default 100: two micro-batches of 4 and 12, "
-                         "2-3 timed steps each); >= 400 times micro-batches 32 and 64 directly with >= 5 steps each")
+    ap.add_argument("--cpu-budget", type=float, default=130.0,
+                    help="seconds of host time the CPU-oracle leg aims at (default 130: five timed steps at micro-batch 12 - "
+                         "always - then 2-5 at micro-batch 4 for the extrapolation); >= 400 times micro-batches 32 and 64")
     ap.add_argument("--no-kernel-timers", action="store_true",
                     help="skip the untimed second pass that collects the per-kernel HIP-event timers")
     ap.add_argument("--timer-steps", type=int, default=3, help="steps of that second pass")
     ap.add_argument("--init", choices=["auto", "each", "broadcast"], default="auto",
                     help="initial weights under data parallelism: every rank draws all 1.38 G of them (each), or rank 0 "
                          "draws and broadcasts (broadcast; auto = broadcast when more than one rank) - same bits either way")
+    ap.add_argument("--lstm-shard", choices=["auto", "on", "off"], default="auto",
+                    help="data parallel: the label LSTM sharded by gate rows (ten small dependent collectives per step replace "
+                         "(N-1)/N of the W_hh streams and of its NAdam pass) or whole on every rank (one 9.4 MB all-reduce of the "
+                         "factor rows); auto times both for two steps during warm-up and keeps the faster (max over ranks)")
     ap.add_argument("--no-extras", action="store_true", help="skip the c2_lite / signal_c5 sub-results")
     ap.add_argument("--dropout", type=float, default=None, help="default: the model's own default (0.5 / 0.3)")
     ap.add_argument("--model", choices=["full", "lite"], default="full",
@@ -207,14 +211,14 @@ def host_ram_gb() -> float:
     return float("nan")
 
 
-def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0, budget_s: float = 100.0):
+def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0, budget_s: float = 130.0):
     """The oracle's train step on the host cores, timed at two micro-batches so that the batch-independent part of
     a step (5.5 GB of LSTM weights streamed per LSTM step + NAdam over 1.38 G parameters, ~9 s) is separated from the
     per-window part: s/step = a + b * B.  ``value`` is the rate that fit gives at the metric's batch of 256 (batch 256
     itself needs ~190 GB of eager activations and minutes per step); the raw micro-batch rates are reported beside it.
     Bounded by ``budget_s`` seconds of CPU time (the default bench run must finish within minutes): one warm-up step,
-    then alternating steps at the two sizes until the budget is spent - at ~10-25 s per step that is 2-3 timed steps
-    per size, not BASELINE.md's >= 5."""
+    FIVE timed steps at the larger micro-batch (the measured ``value``: BASELINE.md's >= 5), then 2-5 at the smaller one
+    (the second point of the extrapolation) as the budget allows - ~11 + 5 x 15 + 2 x 11 s on 16 host threads."""
     import torch
     from oracle import synthesis_oracle as so
     threads = host_threads()
@@ -241,13 +245,16 @@ def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0
     t_begin = time.perf_counter()
     warm = one(B_cpu)
     times = {B_cpu: [], B_big: []}
-    while True:
-        for Bc in (B_cpu, B_big):
-            times[Bc].append(one(Bc))
+    # the measured value first: FIVE timed steps at the larger micro-batch whatever the budget (>= 5), then the
+    # smaller one - which only feeds the extrapolation - with what is left of it (at least min_steps)
+    while len(times[B_big]) < 5:
+        times[B_big].append(one(B_big))
+    while len(times[B_cpu]) < 5:
         spent = time.perf_counter() - t_begin
-        per_round = (times[B_cpu][-1] + times[B_big][-1])
-        if (spent + per_round > budget_s and len(times[B_cpu]) >= min_steps) or len(times[B_cpu]) >= max(5, min_steps):
+        nxt = times[B_cpu][-1] if times[B_cpu] else warm
+        if len(times[B_cpu]) >= min_steps and spent + nxt > budget_s:
             break
+        times[B_cpu].append(one(B_cpu))
     m_small, m_big = statistics.median(times[B_cpu]), statistics.median(times[B_big])
     b = max((m_big - m_small) / (B_big - B_cpu), 1e-9)
     a = max(m_small - b * B_cpu, 0.0)
@@ -265,7 +272,7 @@ def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0
             "warmup_steps": 1, "warmup_s": round(warm, 3), "budget_s": budget_s,
             "host_ram_gb": round(host_ram_gb(), 1), "torch": torch.__version__,
             "sample": f"CPU oracle (same model, C={C}, T={T}, dropout mask 0.5, NAdam on all 1.38 G parameters): 1 warm-up "
-                      f"step, then {len(times[B_cpu])} timed steps each at micro-batch {B_cpu} and {B_big}, bounded by a "
+                      f"step, then {len(times[B_big])} timed steps at micro-batch {B_big} and {len(times[B_cpu])} at {B_cpu}, bounded by a "
                       f"{budget_s:.0f} s budget (a full batch of 256 needs ~190 GB of eager activations and minutes per "
                       f"step; the default bench run has to finish within minutes).  A step costs a = {a:.1f} s that does not "
                       f"depend on the batch (LSTM weight + NAdam traffic) plus b = {b:.2f} s per window, so the measured "
@@ -336,7 +343,15 @@ def signal_subresult(dev, with_cpu: bool):
         finally:
             os.environ.pop("TONAL_HILBERT", None)
 
+    def hilbert_f32():
+        os.environ["TONAL_HILBERT_F32"] = "1"
+        try:
+            return ff.hilbert_filter(x, FS, [70., 150.])
+        finally:
+            os.environ.pop("TONAL_HILBERT_F32", None)
+
     cases = [("hilbert", lambda: ff.hilbert_filter(x, FS, [70., 150.]), 8),
+             ("hilbert_f32_math", hilbert_f32, 8),               # opt-in: fp32 transforms end to end (ols_bank_bl_kernel<float,8,float>)
              ("hilbert_dft_domain_path", hilbert_dft, 8),       # the path long (low-band / raw-rate) kernels take
              ("butter_filtfilt", lambda: ff.butter_filter(x, [0.3, 100], FS), 8),
              ("fir390", lambda: ff.fir_bandpass_filter(x, FS, 390, [100.]), 4)]
@@ -346,7 +361,8 @@ def signal_subresult(dev, with_cpu: bool):
         rec = {"ms": round(ms, 4), "algorithmic_GBps": round(gb / ms * 1e3, 1),
                "frac_of_hbm_peak": round(gb / ms * 1e3 / PEAK_HBM_GBPS, 4),
                "channel_samples_per_s": round(C * T / ms * 1e3)}
-        if name == "hilbert":
+        if name in ("hilbert", "hilbert_f32_math"):
+            f32m = name == "hilbert_f32_math"
             taps = 209                                 # analytic_taps() at fs = 400 Hz, 70-150 Hz, tol 1e-13
             try:
                 cfs, sds = ff.gaussian_bank([70., 150.], FS)[:2]
@@ -361,13 +377,15 @@ def signal_subresult(dev, with_cpu: bool):
             segs = C * -(-T // (nfft - (taps - 1)))
             fl = segs * ((5 + 8 * 4) * (nfft // 4) * 40.0 + 8 * nfft * (8 + 5))
             fl_plain = 2.0 * 2 * 8 * taps * C * T      # 8 bands x taps complex FMAs (2 real FMA = 4 FLOP) per sample
-            rec.update({"bound": "fp64 VALU issue + LDS round trips of the in-LDS FFTs (band-limited overlap-save: 1024-point forward, "
-                                 "four wave-private 256-point inverses per band, last exchange by lane swaps; 4 workgroups per CU); "
-                                 "the time-domain form of the same convolution is fp64-VALU bound at 0.47 ms",
-                        "taps": taps, "fp64_tflops_issued": round(fl / (ms * 1e-3) / 1e12, 2),
-                        "fp64_tflops_plain_bank_equivalent": round(fl_plain / (ms * 1e-3) / 1e12, 2),
-                        "fp64_peak_tflops": PEAK_FP64_VALU_TFLOPS,
-                        "frac_of_fp64_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 4)})
+            prec, peak = ("fp32", PEAK_FP32_MFMA_TFLOPS) if f32m else ("fp64", PEAK_FP64_VALU_TFLOPS)   # (fp32 vector peak = 157.3 too)
+            rec.update({"kernel": f"ols_bank_bl_kernel<float, 8, {'float' if f32m else 'double'}>", "math": prec,
+                        "bound": f"{prec} VALU issue + LDS round trips of the in-LDS FFTs (band-limited overlap-save: 1024-point forward, "
+                                 "four wave-private 256-point inverses per band, last exchange by lane swaps; 4 workgroups per CU)"
+                                 + ("" if f32m else "; the time-domain form of the same convolution is fp64-VALU bound at 0.47 ms"),
+                        "taps": taps, f"{prec}_tflops_issued": round(fl / (ms * 1e-3) / 1e12, 2),
+                        f"{prec}_tflops_plain_bank_equivalent": round(fl_plain / (ms * 1e-3) / 1e12, 2),
+                        f"{prec}_vector_peak_tflops": peak,
+                        f"frac_of_{prec}_peak": round(fl / (ms * 1e-3) / 1e12 / peak, 4)})
         elif name == "hilbert_dft_domain_path":
             rec["bound"] = ("HBM / L2 (Bluestein chirp-z over radix-2 Stockham passes in fp64: 18 FFTs of 65 536 points per "
                             "channel, one pass over a 1 MB buffer per radix-2 stage); not the default for this band")
@@ -415,6 +433,77 @@ def step_issued_flops(eng, B: int, U: int, L: int) -> float:
     return tot
 
 
+def replica_spread(modules, parallel, dist) -> float:
+    """max over every parameter (and buffer) of (MAX over ranks - MIN over ranks) of two checksums of it - the fp64 sum
+    and the fp64 2-norm.  0.0 exactly when all ranks hold the same values (up to the astronomically unlikely collision of
+    both checksums); NaN anywhere gives NaN (reported, and != 0)."""
+    import torch
+    sums = []
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            t = t.detach()
+            if not t.is_floating_point():
+                t = t.double()
+            sums.append(torch.sum(t, dtype=torch.float64))
+            sums.append(torch.linalg.vector_norm(t.reshape(-1), dtype=torch.float64))
+    v = torch.stack(sums)
+    # (a NaN / inf checksum on ANY rank must read as NaN on EVERY rank - MIN / MAX reductions need not propagate NaN - or the
+    # ranks would take different branches behind this call: the flag travels as a number of its own)
+    bad = (~torch.isfinite(v)).any().to(torch.float64).reshape(1)
+    v = torch.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0)
+    lo, hi = v.clone(), torch.cat([v, bad])
+    parallel.all_reduce_(lo, op=dist.ReduceOp.MIN)
+    parallel.all_reduce_(hi, op=dist.ReduceOp.MAX)
+    if float(hi[-1].item()) != 0.0:
+        return float("nan")
+    return float((hi[:-1] - lo).abs().max().item())
+
+
+def choose_lstm_mode(trainer, data, want: str, sync, parallel, dist, dev) -> dict:
+    """--lstm-shard: run the label LSTM sharded by gate rows or whole on every rank.  ``auto`` times both for two steps
+    each (after one step that allocates), max over ranks, and keeps the faster - DESIGN.md section 7's falsifier (i): the
+    sharded form's ten dependent small collectives per step must cost less than the (N-1)/N of 14.6 ms it saves."""
+    import torch
+    rec = {"requested": want}
+    if want in ("on", "off"):
+        rec["sharded"] = trainer.set_lstm_shard(want == "on")
+        return rec
+    ms = {}
+    for mode in (True, False):
+        if trainer.set_lstm_shard(mode) != mode:
+            continue                                   # (the model / label table does not allow the sharded form)
+        trainer.train_step(*data[1 % len(data)])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(2):
+            trainer.train_step(*data[(2 + i) % len(data)])
+        sync()
+        tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        parallel.all_reduce_(tt, op=dist.ReduceOp.MAX)
+        ms["sharded" if mode else "whole"] = float(tt.item()) / 2 * 1e3
+    pick = min(ms, key=ms.get) if ms else "whole"
+    rec["sharded"] = trainer.set_lstm_shard(pick == "sharded")
+    rec["probe_ms_per_step"] = {k: round(v, 3) for k, v in ms.items()}
+    return rec
+
+
+def step0_record(step0, args, C, T, GB, drop):
+    """The first step's loss / MCD beside the committed single-GPU value for the same seeded global batch."""
+    if step0 is None:
+        return None
+    key = f"{args.model}:{C}x{T}:batch{GB}:dropout{drop}"
+    rec = {"loss": step0[0], "mcd": step0[1], "key": key, "golden": None}
+    path = os.path.join(ROOT, "profiles", "bench_step0_golden.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            g = json.load(f).get(key)
+        if g:
+            rel = max(abs(step0[0] - g["loss"]) / abs(g["loss"]), abs(step0[1] - g["mcd"]) / abs(g["mcd"]))
+            rec.update(golden=g, rel_diff=rel, ok=bool(rel < 1e-4),
+                       source="profiles/bench_step0_golden.json (1-GPU run of this command, committed)")
+    return rec
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -459,12 +548,25 @@ def main():
         else:
             model = SynthesisModelCNN(D, C, T, **({} if args.dropout is None else {"dropout": args.dropout}))
     drop = args.dropout if args.dropout is not None else (0.3 if args.model == "lite" else 0.5)
+    # The classifiers are drawn from a seed of their own: under --init broadcast the ranks other than 0 skip the model's
+    # draws, so their global RNG stands elsewhere than rank 0's behind the model - and classifiers drawn from THAT state
+    # would differ from rank to rank (different predicted labels per shard: no longer the single-process computation).
+    torch.manual_seed(1234 + 7)
     tone_m = LogisticRegressionClassifier(8 * T, 4)
     syl_m = LogisticRegressionClassifier(8 * T, 2)
     trainer = SynthesisTrainer(model, tone_m, syl_m, TONE_MAP, device=dev, verbose=False)
     if bcast_init:
         parallel.broadcast_parameters_(model, src=0)
+        parallel.broadcast_parameters_(trainer.tone_model, src=0)
+        parallel.broadcast_parameters_(trainer.syllable_model, src=0)
     eng = model._engine
+    dp_check = None
+    if world > 1:
+        # every rank must start from the same bits (model AND classifiers), whichever way they were initialised
+        spread0 = replica_spread([model, trainer.tone_model, trainer.syllable_model], parallel, dist)
+        dp_check = {"init_checksum_spread": spread0}
+        if spread0 != 0.0:
+            raise SystemExit(f"bench.py: rank {rank}: initial parameters differ between the ranks (checksum spread {spread0})")
 
     # synthetic data, resident in HBM: every rank builds the same global batches and takes its shard
     gen = torch.Generator(device=dev).manual_seed(1234)
@@ -482,8 +584,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step0 = None
+    lstm_mode = None
     for i in range(args.warmup):
         trainer.train_step(*data[i % nb])
+        if i == 0:
+            # loss / MCD of the first step on the seeded first global batch: under strong scaling the same number whatever
+            # the rank count (rows sharded, masks hashed by the global element) - checked against the committed 1-GPU value
+            s0 = trainer._stats[2:4].detach().clone().double()
+            if dist.is_initialized():
+                parallel.all_reduce_(s0)               # per-rank statistics carry their weight in the global mean
+            step0 = [float(v) for v in s0.tolist()]
+            if world > 1 and args.model == "full":
+                lstm_mode = choose_lstm_mode(trainer, data, args.lstm_shard, sync, parallel, dist, dev)
     if world > 1:
         trainer.exchange_events = []
         trainer.exchange_wait_events = []
@@ -512,6 +625,15 @@ def main():
             trainer.train_step(*data[(args.warmup + args.steps + i) % nb])
         tsum = eng.timer_summary()
         eng.enable_timers(False)
+    if world > 1:
+        # Self-check of the data-parallel run: after re-assembling the shard-wise updated W_hh every rank must hold the same
+        # bits (the replicas see identical reduced gradients and run deterministic kernels) - a spread means the ranks did
+        # not stay in lockstep and the throughput above is not that of the single-process computation.
+        trainer.sync_parameters()
+        dp_check["param_checksum_spread"] = replica_spread([model], parallel, dist)
+        dp_check["ranks_seen"] = dist.get_world_size()
+        dp_check["backend"] = dist.get_backend()
+        dp_check["lstm"] = lstm_mode
     if dist.is_initialized():
         tt = torch.tensor([dt, exch_ms or 0.0, exposed_ms or 0.0], device=dev, dtype=torch.float64)
         parallel.all_reduce_(tt, op=dist.ReduceOp.MAX)
@@ -634,11 +756,21 @@ def main():
         }
         if roof is not None:
             roof["timers_from"] = f"a second, untimed pass of {max(1, args.timer_steps)} steps (the timed region carries no instrumentation)"
+        line["step0"] = step0_record(step0, args, C, T, GB, drop)
+        if dp_check is not None:
+            dp_check["loss_step0_vs_dp1_golden"] = line["step0"]
+            dp_check["ok"] = dp_check["param_checksum_spread"] == 0.0 and dp_check["init_checksum_spread"] == 0.0
+            line["dp_check"] = dp_check
         line.update(extras)
         print(json.dumps(line), flush=True)
+    bad = dp_check is not None and not (dp_check.get("param_checksum_spread") == 0.0)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        print(f"bench.py: rank {rank}: replicas diverged (parameter checksum spread {dp_check.get('param_checksum_spread')})",
+              file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

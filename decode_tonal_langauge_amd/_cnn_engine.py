@@ -180,7 +180,10 @@ class CnnEngine:
         for st in self.stages:
             rows = S * st.tp_out
             ld = st.cout if st.pool else self.ld5
-            if not (self._writes_v(st) or (self.wino63 and st.idx == 2)) or self.store_p1:
+            # raw rows are not stored where the forward epilogue hands the next stage V instead: F(6,3) stage 2 (POOLV), or
+            # an F(4,3) stage whose successor reads V - but never F(6,3) stage 3, whose POOL epilogue always writes rows
+            no_rows = (self.wino63 and st.idx == 2) or (self._writes_v(st) and not self._f63(st))
+            if not no_rows or self.store_p1:
                 self.P[st.idx] = z(rows, ld)
             if st.pool:
                 self.bits[st.idx] = zi(rows, st.cout // 32)
@@ -376,6 +379,8 @@ class CnnEngine:
                                              self._stream()), "tl_wino63_v_fixup")
             self._v_ready[2] = Vn
         else:
+            if Pout is None:
+                raise RuntimeError("F(6,3) stage 3 writes pooled rows: its output buffer was not allocated")
             kw.update(epilogue=EPI_POOL, out_tp=st.tp_out)
             self._nt(tag="conv3_fwd", fn="tl_conv3_wino63v_nt", **kw)
 

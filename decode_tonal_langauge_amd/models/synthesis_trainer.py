@@ -122,6 +122,7 @@ class SynthesisTrainer:
             # first runs the collective, on every rank (a collective: all ranks must call state_dict together).  The
             # NAdam moments of that parameter stay per-rank shards: optimizer state under data parallelism is per rank.
             self.model.register_state_dict_pre_hook(self._state_dict_guard)
+            self._guard_hooked = True
 
     def _state_dict_guard(self, module, prefix, keep_vars) -> None:
         """``state_dict()`` of the model while its label LSTM is row-sharded and out of date.  Re-assembling the weight is a
@@ -303,8 +304,17 @@ class SynthesisTrainer:
                 for h in pending:
                     h.wait(wait_events)
             else:
+                # The row-sharded LSTM fell back for this step (its shard decision is per forward: (L - 1) U > 64, a gate-row
+                # count the world size does not divide, no label table) or started to shard after the flat layout was fixed:
+                # the flat span no longer matches what must be reduced.  The early bucket (output layer) is already in
+                # flight: wait for it and reduce every OTHER gradient exactly once.
+                wait_events = getattr(self, "exchange_wait_events", None)
+                reduced = set()
+                for h in pending:
+                    h.wait(wait_events)
+                    reduced.update(("output_layer.weight", "output_layer.bias"))
                 self._timed(parallel.allreduce_bucketed)([g for k, g in self._grads.items()
-                                                          if k != skip and k not in local_only])
+                                                          if k != skip and k not in local_only and k not in reduced])
             self._whh_dirty = self._whh_dirty or sharded
         factors = getattr(eng, "whh_factors", None)
         if graph:            # scalars of the step from device memory (advanced by the caller per replay)
@@ -345,6 +355,27 @@ class SynthesisTrainer:
         rows = p.shape[0] // self.world
         parallel.all_gather_param_rows_(p.data, self.rank * rows, rows)
         self._whh_dirty = False
+
+    def set_lstm_shard(self, on: bool) -> bool:
+        """Switch the gate-row sharding of the label LSTM on or off BETWEEN steps (data parallel only; a collective: every
+        rank must call it with the same value).  The weight is re-assembled first; the NAdam moments of ``weight_hh_l0``
+        change shape with the mode (row shard <-> whole matrix), so they - and the flat gradient layout - start afresh:
+        this is for choosing the faster mode during warm-up (bench.py ``--lstm-shard auto``), not for mid-training use.
+        Returns whether the LSTM will run sharded (False where the model / label table does not allow it)."""
+        eng = getattr(self.model, "_engine", None)
+        if not self.dp or eng is None or not hasattr(eng, "lstm_shard"):
+            return False
+        self.sync_parameters()
+        want = (self.rank, self.world) if (on and self._pair_table is not None and self.world > 1) else None
+        if want != eng.lstm_shard:
+            eng.lstm_shard = want
+            p = dict(self.model.named_parameters())[eng.lowrank_param]
+            self.optimizer.state.pop(p, None)
+            self._grads, self._flat = None, None
+            if want is not None and not getattr(self, "_guard_hooked", False):
+                self.model.register_state_dict_pre_hook(self._state_dict_guard)
+                self._guard_hooked = True
+        return eng.lstm_shard is not None
 
     def model_state_dict(self):
         """``model.state_dict()`` with the shard-wise updated parameters re-assembled first.  Collective under data
@@ -396,11 +427,12 @@ class SynthesisTrainer:
         re-loaded classifier or a re-assigned ``.data`` would otherwise leave the graph reading freed or stale buffers."""
         opt = self.optimizer
         fp = []
+        name_of = {id(p): k for k, p in self.model.named_parameters()}       # gradient storage is keyed by parameter NAME
         for group in opt.param_groups:
             fp.append((tuple(group["betas"]), group["eps"], group["weight_decay"], group["momentum_decay"]))
             for p in group["params"]:
                 st = opt.state.get(p) or {}
-                g = (self._grads or {}).get(p)
+                g = (self._grads or {}).get(name_of.get(id(p)))
                 fp.append((p.data_ptr(), None if g is None else g.data_ptr(),
                            None if "exp_avg" not in st else st["exp_avg"].data_ptr(),
                            None if "exp_avg_sq" not in st else st["exp_avg_sq"].data_ptr()))

@@ -263,9 +263,12 @@ def hilbert_filter(data, sampling_rate: int, freq_ranges: Union[List[Tuple[float
         return _ret(_hilbert_dft(x, sampling_rate, cfs, sds, bool(envelope)), was_np)
     y = torch.empty(C, T, dtype=torch.float64, device=x.device)
     if ols is not None and ols[3] is not None and mode in ("auto", "ols") and os.environ.get("TONAL_HILBERT_BL", "1") != "0":
-        # float32 recordings: fp32 transforms, the reference's own precision for that dtype (scipy.fft keeps complex64:
-        # reference frequency_filter.py:167-181; golden G6 hilbert_f32_odd is held at 1e-5); TONAL_HILBERT_F32=0: fp64 math
-        mode_x = 1 if x.dtype == torch.float64 else (0 if os.environ.get("TONAL_HILBERT_F32", "1") != "0" else 2)
+        # float32 recordings: fp64 math on the fp32 samples by default.  In the reference only the forward transform stays
+        # single precision (scipy.fft(float32) -> complex64, frequency_filter.py:167); the product with the float64 kernel
+        # promotes to complex128 and the inverse transform, |.| and the band mean run in fp64 (:170-184).  fp64 throughout
+        # is at least that precise.  TONAL_HILBERT_F32=1 opts into fp32 transforms end to end (0.135 instead of ~0.16 ms
+        # at 256 x 24 000; ~1e-6 relative, golden G6 hilbert_f32_odd holds it to 1e-5)
+        mode_x = 1 if x.dtype == torch.float64 else (0 if os.environ.get("TONAL_HILBERT_F32", "0") == "1" else 2)
         check(_lib.load().tl_hilbert_ols_bl(ptr(x), mode_x, ptr(ols[3][0]), ptr(ols[3][1]), ptr(ols[1]), ptr(y),
                                             C, T, len(cfs), half, ols[2], int(bool(envelope)), _stream()), "tl_hilbert_ols_bl")
         return _ret(y, was_np)

@@ -90,6 +90,27 @@ def _worker(rank, world, port, q):
     parallel.broadcast_parameters_(net, src=0)
     ok = ok and all(torch.equal(a, b) for a, b in zip(net.parameters(), everywhere.parameters()))
     ok = ok and torch.nn.init.uniform_ is not None and torch.nn.init.uniform_(torch.zeros(4)).abs().sum() > 0   # patch undone
+    # round 5: the self-check bench.py prints under data parallelism (dp_check): spread of two checksums of every parameter
+    # over the ranks - exactly 0 for identical replicas, non-zero as soon as ONE element of one rank differs, NaN for NaN
+    import bench
+    # (collectives are never placed behind a short-circuiting `ok and`: a rank that skipped one would strand its peer)
+    sp_same = bench.replica_spread([net], parallel, dist)
+    with torch.no_grad():
+        list(net.parameters())[1].view(-1)[3] += 1e-6 * rank            # rank 1 drifts by one element
+    sp_drift = bench.replica_spread([net], parallel, dist)
+    with torch.no_grad():
+        list(net.parameters())[0].view(-1)[0] = float("nan") if rank == 1 else 0.0
+    sp = bench.replica_spread([net], parallel, dist)                    # NaN on rank 1 only: NaN on BOTH ranks
+    ok = ok and sp_same == 0.0 and sp_drift > 0.0 and sp != sp
+    # classifiers drawn behind a model whose draws rank != 0 skipped: only a seed of their own makes them rank-identical
+    torch.manual_seed(1234)
+    with (parallel.skip_param_init() if rank != 0 else contextlib.nullcontext()):
+        torch.nn.Linear(64, 64)
+    drifted = torch.nn.Linear(16, 4)
+    torch.manual_seed(1234 + 7)
+    seeded = torch.nn.Linear(16, 4)
+    sp_d, sp_s = bench.replica_spread([drifted], parallel, dist), bench.replica_spread([seeded], parallel, dist)
+    ok = ok and sp_d > 0.0 and sp_s == 0.0
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

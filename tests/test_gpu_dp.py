@@ -13,30 +13,35 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _build(dev, sizes=(8, 8), dropout=0.0):
+LONG_TONE_MAP = {"0": [3] * 10, "1": list(range(1, 11)), "2": [3, 2, 1, 2, 4, 3, 2, 1, 2, 4], "3": list(range(10, 0, -1))}
+
+
+def _build(dev, sizes=(8, 8), dropout=0.0, tone_map=None):
     from decode_tonal_langauge_amd.models import LogisticRegressionClassifier, SynthesisModelCNN, SynthesisTrainer
     from tests import golden_inputs as gi
     torch.manual_seed(0)
     model = SynthesisModelCNN(80, 8, 100, dropout=dropout)
     tone = LogisticRegressionClassifier(4 * 100, 4)
     syl = LogisticRegressionClassifier(4 * 100, 2)
-    tr = SynthesisTrainer(model, tone, syl, gi.TONE_MAP, device=dev, verbose=False)
+    tr = SynthesisTrainer(model, tone, syl, tone_map or gi.TONE_MAP, device=dev, verbose=False)
     g = torch.Generator().manual_seed(11)
     batches = [(torch.randn(n, 8, 100, generator=g), torch.randn(n, 4, 100, generator=g),
                 torch.randn(n, 4, 100, generator=g), 10 * torch.randn(n, 80, generator=g)) for n in sizes]
     return model, tr, batches
 
 
-def _worker(rank, world, port, q, sizes=(8, 8), dropout=0.0, shard="1"):
+def _worker(rank, world, port, q, sizes=(8, 8), dropout=0.0, shard="1", tone_map=None, switch=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", TONAL_LSTM_SHARD=shard)
     from decode_tonal_langauge_amd import parallel
     parallel.init_from_env(backend="gloo")
     dev = torch.device("cuda:0")
-    model, tr, batches = _build(dev, sizes, dropout)
+    model, tr, batches = _build(dev, sizes, dropout, tone_map)
     assert tr.world == world
     model.train()
-    for b in batches:
+    for i, b in enumerate(batches):
+        if switch is not None and i in switch:       # trainer.set_lstm_shard between steps (bench.py --lstm-shard auto)
+            assert tr.set_lstm_shard(switch[i]) == switch[i]
         tr.train_step(*b)
     sharded = model._engine._sh is not None          # the label LSTM ran row-sharded over the two ranks
     tr.sync_parameters()                             # re-assemble the shard-wise updated W_hh on every rank
@@ -199,6 +204,58 @@ def test_two_rank_training_unsharded_lstm_reduces_the_factor_rows():
         assert (res[0][1][k] == res[1][1][k]).all(), k
 
 
+def _two_rank_run(port, **kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q), kwargs=kw) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_training_when_the_sharded_lstm_falls_back_reduces_every_gradient_once():
+    """A ten-entry tone dynamic: (L - 1) U = 72 factor rows exceed what the row-sharded LSTM (and the fused low-rank
+    NAdam kernel) takes, so the engine runs the whole LSTM on every rank for the step although the trainer asked for the
+    sharded form.  The flat gradient layout was fixed for the sharded form and the output layer's all-reduce is already
+    in flight when that is known: every gradient must still be reduced exactly ONCE (round 4 reduced the output layer
+    twice on this path: 63 MB of gradients N times too large, silently)."""
+    dev = torch.device("cuda:0")
+    model, tr, batches = _build(dev, tone_map=LONG_TONE_MAP)
+    model.train()
+    for b in batches:
+        tr.train_step(*b)
+    ref = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    res = _two_rank_run(33500 + (os.getpid() % 1000), tone_map=LONG_TONE_MAP)
+    torch.manual_seed(0)
+    from decode_tonal_langauge_amd.models import SynthesisModelCNN
+    init = {k: v.detach().clone() for k, v in SynthesisModelCNN(80, 8, 100, dropout=0.0).named_parameters()}
+    for rank, params, stats, sharded in res:
+        assert not sharded, "72 factor rows: the engine must have fallen back to the whole LSTM per rank"
+        for k in ref:
+            upd = (ref[k] - init[k]).double()
+            err = float((torch.from_numpy(params[k]).double() - ref[k].double()).norm() / max(float(upd.norm()), 1e-30))
+            assert err < 2e-2, (rank, k, err)
+    for k in ref:
+        assert (res[0][1][k] == res[1][1][k]).all(), k
+
+
+def test_lstm_shard_can_be_switched_between_steps():
+    """trainer.set_lstm_shard (bench.py --lstm-shard auto probes both forms during warm-up): sharded step, whole-LSTM step,
+    sharded step.  The NAdam moments of W_hh start afresh at each switch (documented), so the comparison is between the two
+    ranks - bit-identical parameters after the re-assembly - and against finiteness, not against a single process."""
+    res = _two_rank_run(34500 + (os.getpid() % 1000), sizes=(8, 8, 8), switch={1: False, 2: True})
+    import numpy as np
+    for rank, params, stats, sharded in res:
+        assert sharded
+        assert all(np.isfinite(v).all() for v in params.values())
+    for k in res[0][1]:
+        assert (res[0][1][k] == res[1][1][k]).all(), k
+
+
 def _bench(extra_env, *flags, timeout=900):
     import json
     import subprocess
@@ -226,6 +283,14 @@ def test_bench_two_rank_launch_at_the_headline_shape():
     assert cfg["parallelism"] == "dp2" and line["scaling"] == "strong"
     assert math.isfinite(cfg["exchange_ms_per_step"]) and cfg["exchange_ms_per_step"] > 0
     assert line["value"] > 0 and abs(line["value"] - 256 / (line["ms_per_step"] * 1e-3)) < 1e-2 * line["value"]
+    # the run verifies itself: identical replicas before and after, both LSTM forms probed, the first step's loss reported
+    chk = line["dp_check"]
+    assert chk["ok"] and chk["init_checksum_spread"] == 0.0 and chk["param_checksum_spread"] == 0.0
+    assert chk["ranks_seen"] == 2 and chk["backend"] == "gloo"
+    assert set(chk["lstm"]["probe_ms_per_step"]) == {"sharded", "whole"} and chk["lstm"]["requested"] == "auto"
+    assert math.isfinite(line["step0"]["loss"]) and line["step0"]["loss"] > 0
+    if line["step0"].get("golden"):           # the committed 1-GPU value of the same seeded global batch
+        assert line["step0"]["ok"], line["step0"]
 
 
 def test_bench_ends_non_zero_when_a_rank_dies():

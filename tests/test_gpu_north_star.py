@@ -20,7 +20,12 @@ import pytest
 import torch
 
 from tests import golden_inputs as gi
+from tests.parity_record import record
 from tests.test_gpu_parity import rel, rel_l2, _trainer
+
+# one-step NAdam update-vector deviation from the reference golden G11 observed on the MI355X with the default kernels
+# (profiles/parity_observed.json, round 5); the test allows twice that
+UPD_OBSERVED, UPD_OBSERVED_BIAS = 1e-2, 2.5e-2
 
 pytestmark = pytest.mark.gpu
 
@@ -117,11 +122,13 @@ def test_c3_shape_train_step_matches_reference_golden(dev, c3):
     acts["ecog5"] = eng.P[5].view(B, Cn, eng.tp5, eng.ld5)[:, :, :eng.lat, :eng.Cc].permute(0, 3, 2, 1)
     acts["lstm_h"] = eng._h[-1][eng._uid.long()]
     acts["concat5"] = eng.Y[-1].view(B, Cn, eng.tp5, eng.ldy5)[:, :, :eng.lat, :eng.Cc].permute(0, 3, 2, 1)
+    act_obs = {}
     for k, t in acts.items():
         ref, stride, sums = _sampled(g, "act.", k)
         got = _take(t, stride)
         assert got.shape == ref.reshape(-1).shape, k
         assert rel(got, ref.reshape(-1)) < 1e-4, k
+        act_obs[k] = rel(got, ref.reshape(-1))
         if sums is not None:
             assert abs(float(t.double().abs().sum()) - sums[1]) < 1e-4 * sums[1], k
     # ---- one fused train step: loss, MCD, gradients, NAdam update ----
@@ -130,6 +137,8 @@ def test_c3_shape_train_step_matches_reference_golden(dev, c3):
     st = tr._stats.cpu().numpy()
     assert abs(st[2] - float(g["loss"])) < 1e-4 * float(g["loss"])
     assert abs(st[3] - float(g["mcd"])) < 1e-4 * float(g["mcd"])
+    observed = {**{"act." + k: v for k, v in act_obs.items()}, "out": rel(out.cpu().numpy(), g["out"]), "loss": abs(st[2] - float(g["loss"])) / float(g["loss"]),
+                "mcd": abs(st[3] - float(g["mcd"])) / float(g["mcd"])}
     grads = dict(tr._grads)
     assert eng.whh_factors is not None, "the W_hh gradient must stay in factored form at this shape"
     fa, fb = eng.whh_factors
@@ -148,15 +157,23 @@ def test_c3_shape_train_step_matches_reference_golden(dev, c3):
             got = _take(grads[k], stride)
             absum = float(grads[k].double().abs().sum())
         assert got.shape == ref.reshape(-1).shape, k
-        assert rel_l2(got, ref.reshape(-1)) < 5e-3, k
+        observed["grad." + k] = rel_l2(got, ref.reshape(-1))
+        assert observed["grad." + k] < 5e-3, k
         if sums is not None:
             assert abs(absum - sums[1]) < 5e-3 * sums[1], k
     # parameters after the step (NAdam, low-rank path for W_hh): the update vector against the reference's
+    upd = {}
     for k, p in model.named_parameters():
         ref, stride, _ = _sampled(g, "final.", k)
         fin = _take(p.detach(), stride)
-        tol = 5e-2 if k in ("ecog_conv_block.9.bias", "concat_conv_block.4.bias") else 2e-2
-        assert gi.update_rel_l2(fin, ref.reshape(-1), init[k]) < tol, k
+        upd[k] = gi.update_rel_l2(fin, ref.reshape(-1), init[k])
+    record("G11 one step at 128x400 (TONAL_WINO=6)", dict(observed, **{"upd." + k: v for k, v in upd.items()}))
+    for k, v in upd.items():
+        # round 5: 2 x what this test observes on the MI355X with the F(6,3) default (profiles/parity_observed.json: the
+        # two bias vectors whose tiny gradients NAdam divides by their own magnitude sit at UPD_OBSERVED_BIAS, every other
+        # tensor below UPD_OBSERVED) - round 2's bounds were 5e-2 / 2e-2
+        tol = 2 * UPD_OBSERVED_BIAS if k in ("ecog_conv_block.9.bias", "concat_conv_block.4.bias") else 2 * UPD_OBSERVED
+        assert v < tol, (k, v)
 
 
 def test_c3_shape_three_steps_follow_reference_golden(dev, c3):
@@ -203,6 +220,7 @@ def test_c3_shape_three_steps_follow_reference_golden(dev, c3):
         # other tensor below 6e-4 - the bound is ~2.5 x that, not the 2e-2 / 5e-2 the one-step test had to allow in round 2
         assert err < 2.5e-3, (k, err)
     print("G11b observed deviations (largest):", {k: f"{v:.2e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:10]})
+    record("G11b three steps at 128x400 (TONAL_WINO=6)", worst)
     _pristine(model, dev)
 
 
@@ -245,6 +263,134 @@ def test_c3_batch256_gradient_is_mean_of_half_batches(dev, c3):
         mean = 0.5 * (g_a[k].double() + g_b[k].double())
         err = float((g_all[k].double() - mean).norm() / max(float(mean.norm()), 1e-30))
         assert err < 2e-4, (k, err)
+
+
+def test_f63_kernels_at_the_timed_batch_match_direct_kernels(dev, monkeypatch):
+    """Round 5: the F(6,3) default against the direct MFMA kernels (TONAL_WINO=0) at the TIMED row count - batch 256,
+    128 ch x 400 samples, 512 channels: 6.68 M conv rows per stage-2 pass, 8 704 row tiles, the 4 096-way split-K of the
+    weight gradients - the one place the 6.5 M-row reductions meet the F(6,3) constants (32/45, 1/90 ...).  Same inputs
+    for both engines, stage by stage through the C ABI: pooled rows 2e-5 (max norm), weight / bias gradients of conv2 and
+    conv3 and the fused conv1 gradient 1e-4 relative L2, the input gradient of conv3 (which the default path only ever
+    holds as Y2 = A dz: its planes 0 and 7 ARE un-pooled gradient rows) against the direct engine's G2 on the sequences
+    at both ends of the batch."""
+    from decode_tonal_langauge_amd._cnn_engine import CnnEngine
+    from decode_tonal_langauge_amd._lib import check, ptr
+    from tests.wino63_ref import logical
+    B, C, T, c1, c2, c3 = 256, 128, 400, 512, 512, 512
+    defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
+    engs = {}
+    for mode in ("0", "6"):
+        monkeypatch.setenv("TONAL_WINO", mode)
+        eng = CnnEngine(80, C, T, 1, 8, 0.0, 0.01, defs, [16, 8])
+        if mode == "0":
+            eng.fuse_c1 = False
+        eng._alloc(B, dev)
+        eng._alloc_bwd()
+        engs[mode] = eng
+    e0, e6 = engs["0"], engs["6"]
+    assert e6.wino63 and e6.f63_yprod and e6.f63_yprod3 and not e0.wino63 and not e0.wino
+    S = e6.S
+    g = torch.Generator(device=dev).manual_seed(17)
+    x = torch.randn(B, C, T, device=dev, generator=g)
+    names = {1: "ecog_conv_block.0", 2: "ecog_conv_block.3", 3: "ecog_conv_block.6"}
+    prm = {names[1] + ".weight": torch.randn(c1, 1, 3, 1, device=dev, generator=g) * 0.5,
+           names[1] + ".bias": torch.randn(c1, device=dev, generator=g) * 0.1}
+    cin = c1
+    for i, co in ((2, c2), (3, c3)):
+        prm[names[i] + ".weight"] = torch.randn(co, cin, 3, 1, device=dev, generator=g) * (1.0 / (3 * cin) ** 0.5)
+        prm[names[i] + ".bias"] = torch.randn(co, device=dev, generator=g) * 0.1
+        cin = co
+    st_ = torch.cuda.current_stream().cuda_stream
+    w1 = prm[names[1] + ".weight"].reshape(c1, 3).contiguous()
+    for eng in (e0, e6):
+        eng._x = x.contiguous()
+        eng.generation += 1
+        eng._v_ready = {}
+        if eng.wino63:
+            V1 = eng._v_hex_buffer(eng.V, 1, S * eng.tp1, c1)
+            check(eng.lib.tl_conv1_fwd_v6(ptr(x), ptr(w1), ptr(prm[names[1] + ".bias"]), None, ptr(V1), ptr(eng.bits[1]),
+                                          ptr(eng.sbits[1]), S, T, 3, c1, eng.tp1, eng.tout1, eng.slope, st_), "tl_conv1_fwd_v6")
+            eng._v_ready[1] = V1
+        else:
+            check(eng.lib.tl_conv1_fwd(ptr(x), ptr(w1), ptr(prm[names[1] + ".bias"]), ptr(eng.P[1]), ptr(eng.bits[1]),
+                                       ptr(eng.sbits[1]), S, T, 3, c1, eng.tp1, eng.tout1, eng.slope, st_), "tl_conv1_fwd")
+        for si in (2, 3):
+            eng.stage_forward(eng.stages[si - 2], prm[names[si] + ".weight"], prm[names[si] + ".bias"])
+    obs = {}
+    rows = lambda t, tp, n: t.view(S, tp, -1)[:, :n]
+    s0, s6 = e0.stages[1], e6.stages[1]
+    a, b = rows(e6.P[3], s6.tp_out, s6.tout), rows(e0.P[3], s0.tp_out, s6.tout)
+    obs["pooled_rows_conv3.max_norm"] = float((a - b).abs().max() / b.abs().max())
+    assert obs["pooled_rows_conv3.max_norm"] < 2e-5
+    for si, name in ((1, "conv1"), (2, "conv2"), (3, "conv3")):
+        t6 = e6.tout1 if si == 1 else e6.stages[si - 2].tout
+        tp6 = e6.tp1 if si == 1 else e6.stages[si - 2].tp_out
+        tp0 = e0.tp1 if si == 1 else e0.stages[si - 2].tp_out
+        for kind, b6, b0 in (("argmax", e6.bits, e0.bits), ("sign", e6.sbits, e0.sbits)):
+            flips = rows(b6[si], tp6, t6) ^ rows(b0[si], tp0, t6)
+            nz = flips[flips != 0]
+            cnt = int(sum(bin(int(v) & 0xffffffff).count("1") for v in nz.cpu().tolist())) if nz.numel() < 100000 else -1
+            obs[f"{name}.{kind}_bits_that_differ"] = cnt
+            assert 0 <= cnt <= (0 if si == 1 else 4096), (name, kind, cnt)       # ties / near-ties only (of 1.7 G / 0.8 G / 0.4 G bits)
+    # ---- backward from one random G3; the direct engine un-pools with the F(6,3) engine's bits (ties may differ) ----
+    G3 = torch.randn(S, s6.tp_out, c3, device=dev, generator=g)
+    G3[:, s6.tout:] = 0
+    e6.G[3].copy_(G3.reshape(-1, c3))
+    e0.G[3].copy_(G3.reshape(-1, c3))                              # (tp_out of stage 3 is the default geometry's in both)
+    del G3
+    for idx in (1, 2, 3):
+        tpa = e0.tp1 if idx == 1 else e0.stages[idx - 2].tp_out
+        tpb = e6.tp1 if idx == 1 else e6.stages[idx - 2].tp_out
+        tb = e6.tout1 if idx == 1 else e6.stages[idx - 2].tout
+        e0.bits[idx].view(S, tpa, -1)[:, :tb] = e6.bits[idx].view(S, tpb, -1)[:, :tb]
+        e0.sbits[idx].view(S, tpa, -1)[:, :tb] = e6.sbits[idx].view(S, tpb, -1)[:, :tb]
+    for si in (3, 2):
+        res = {}
+        for key, eng in (("0", e0), ("6", e6)):
+            st = eng.stages[si - 2]
+            w = prm[names[si] + ".weight"]
+            gw, gb = torch.zeros_like(w), torch.zeros(st.cout, device=dev)
+            eng.stage_wgrad(st, gw, gb)
+            res[key] = (gw, gb, eng.stage_dgrad(st, w))
+        obs[f"conv{si}.weight_grad.rel_l2"] = rel_l2(res["6"][0].cpu().numpy(), res["0"][0].cpu().numpy())
+        obs[f"conv{si}.bias_grad.rel_l2"] = rel_l2(res["6"][1].cpu().numpy(), res["0"][1].cpu().numpy())
+        assert obs[f"conv{si}.weight_grad.rel_l2"] < 1e-4 and obs[f"conv{si}.bias_grad.rel_l2"] < 1e-4, (si, obs)
+        if si == 3:
+            # conv3's input gradient: Y2 plane 0 / 7 of hex h (of stage 2) = un-pooled gradient row 6 h / 6 h + 5, i.e. pooled
+            # row 3 h where its arg-max bit is clear / pooled row 3 h + 2 where it is set
+            b2 = e6.stages[0]
+            nh = b2.tp_in // 6
+            Y2 = e6.Yt[2]
+            worst = 0.0
+            for q0 in (0, S // 2 - 64, S - 128):                  # 128 sequences at the front, the middle and the back
+                sl = slice(q0, q0 + 128)
+                y = logical(Y2[q0 * nh:(q0 + 128) * nh]).view(128, nh, 8, s6.cin)
+                g2 = e0.G[2].view(S, s0.tp_in, -1)[sl]
+                wbits = e6.bits[2].view(S, b2.tp_out, -1)[sl]
+                sh = torch.arange(32, device=dev, dtype=torch.int32)
+                odd = ((wbits[..., None] >> sh) & 1).reshape(128, b2.tp_out, -1).bool()
+                nrow = min(3 * nh, g2.shape[1], b2.tout)
+                hv = (nrow + 2) // 3                               # hexes with pooled row 3 h inside the valid time
+                ref0 = torch.where(odd[:, 0:3 * hv:3], torch.zeros_like(g2[:, 0:3 * hv:3]), g2[:, 0:3 * hv:3])
+                worst = max(worst, float((y[:, :hv, 0] - ref0).abs().max() / g2.abs().max()))
+                hv7 = max(0, (min(nrow, g2.shape[1]) - 2 + 2) // 3)
+                r7 = slice(2, 3 * hv7, 3)
+                ref7 = torch.where(odd[:, r7], g2[:, r7], torch.zeros_like(g2[:, r7]))
+                worst = max(worst, float((y[:, :ref7.shape[1], 7] - ref7).abs().max() / g2.abs().max()))
+            obs["conv3.input_grad_rows_via_Y2.max_norm"] = worst
+            assert worst < 2e-5, worst
+        else:
+            nblk = int(min(2048, S))
+            p0 = torch.empty(nblk, 4 * c1, device=dev)
+            check(e0.lib.tl_conv1_wgrad(ptr(e0._x), ptr(e0.G[1]), ptr(e0.bits[1]), ptr(p0), nblk, S, T, 3, c1, e0.tp1, e0.tout1, st_),
+                  "tl_conv1_wgrad")
+            obs["conv1.weight_and_bias_grad_through_conv2_input_grad.rel_l2"] = rel_l2(res["6"][2].double().sum(0).cpu().numpy(),
+                                                                                        p0.double().sum(0).cpu().numpy())
+            assert obs["conv1.weight_and_bias_grad_through_conv2_input_grad.rel_l2"] < 1e-4, obs
+    print("F(6,3) vs direct kernels at batch 256:", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in obs.items()})
+    record("F(6,3) vs direct MFMA kernels at batch 256, 128x400, 512 channels", obs)
+    del engs, e0, e6, res
+    torch.cuda.empty_cache()
 
 
 def test_train_mode_dropout_mask_forward_and_gradients_against_oracle(dev):
