@@ -167,6 +167,21 @@ constexpr int V6_ROWS = 6 * V6_BH;                       // conv rows per tile (
 #ifndef V6_ABL
 #define V6_ABL 0          // timing-only build variants: 1 no steady-state DMA, 2 no epilogue, 4 no barrier
 #endif
+#ifndef V6_STAMP
+#define V6_STAMP 0        // diagnostic build only (scripts/build_w63_variants.sh): wave 0 of every workgroup stamps s_memtime at the
+#endif                    // phase boundaries of its first V6_STAMP_TILES tiles into a buffer of its own (tl_debug_v6_stamps reads it)
+#if V6_STAMP
+constexpr int V6_STAMP_TILES = 96, V6_STAMP_SLOTS = 8;
+__device__ unsigned long long v6_stamp_buf[256 * V6_STAMP_TILES * V6_STAMP_SLOTS];
+#define V6_STAMP_AT(k)                                                                                                         \
+  do {                                                                                                                         \
+    if (tid == 0 && stamp_tile < V6_STAMP_TILES && blockIdx.x < 256)                                                           \
+      v6_stamp_buf[((long long)blockIdx.x * V6_STAMP_TILES + stamp_tile) * V6_STAMP_SLOTS + (k)] =                             \
+          ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();                           \
+  } while (0)
+#else
+#define V6_STAMP_AT(k) do { } while (0)
+#endif
 
 enum { KS_NORMAL = 0, KS_PRELAST = 1, KS_LAST = 2 };
 
@@ -398,10 +413,15 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   issue(cur, 0, 0);
   issue(cur, 1, 1);
   __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0)
+#if V6_STAMP
+  int stamp_tile = 0;
+#endif
   for (long long vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
     // stage stg of this tile has landed (waited for at the end of the tile in front), every wave is past that epilogue
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    V6_STAMP_AT(0);
+    V6_STAMP_AT(1);
     // What the epilogue reads from global memory is requested in front of the LAST K-step (tonal_wino43v.hip)
     auto prefetch = [&] {
       if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_POOLV) return v5_prefetch_pool(p, cur.n0, wn, lr);
@@ -414,7 +434,9 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     kstep_first(std::integral_constant<int, NST>{});
     if (nsteps > 3) {
       kstep(std::integral_constant<int, KS_NORMAL>{}, Y{}, 1);
+      V6_STAMP_AT(2);
       for (int s = 2; s + 2 < nsteps; ++s) kstep(std::integral_constant<int, KS_NORMAL>{}, N{}, s);
+      V6_STAMP_AT(3);
       kstep(std::integral_constant<int, KS_PRELAST>{}, N{}, nsteps - 2);
     } else {
       kstep(std::integral_constant<int, KS_PRELAST>{}, Y{}, 1);
@@ -423,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     __builtin_amdgcn_sched_barrier(0);
     kstep(std::integral_constant<int, KS_LAST>{}, N{}, nsteps - 1);
     mfma_half(N{}, faH, fbH, 4);
+    V6_STAMP_AT(4);
 
 #if V6_ABL & 2
     {
@@ -471,14 +494,37 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
                       lr, lh, done.tm);
     }
 #endif
+    V6_STAMP_AT(5);
     {
       // The next tile's first stage (issued in front of the epilogue) has landed; its second stage and the epilogue's own
       // stores need not: vmcnt counts in issue order (6 bits)
       constexpr int n = NST + 6 > 63 ? 63 : NST + 6;
       __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14));
     }
+    V6_STAMP_AT(6);
+    V6_STAMP_AT(7);
+#if V6_STAMP
+    ++stamp_tile;
+#endif
   }
 }
+
+#if V6_STAMP
+}  // namespace tl
+// diagnostic build only: the stamps of the last wino63v_nt launch (256 workgroups x 96 tiles x 8 slots: realtime (100 MHz) at the
+// tile's first barrier, s_memtime there / after K-step 1 / after the steady-state loop / at the end of the K loop / at the
+// end of the epilogue's instruction stream / behind its closing wait, realtime there)
+extern "C" int tl_debug_v6_stamps(unsigned long long* dst, int clear) {
+  if (dst && hipMemcpyFromSymbol(dst, HIP_SYMBOL(tl::v6_stamp_buf), sizeof(tl::v6_stamp_buf)) != hipSuccess) return -1;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(tl::v6_stamp_buf)) != hipSuccess) return -1;
+    if (hipMemset(p, 0, sizeof(tl::v6_stamp_buf)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+namespace tl {
+#endif
 
 
 // ------------------------------------------------------------------------------------------

@@ -14,7 +14,50 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--passes", default="fwd,wgrad,dgrad")
 ap.add_argument("--stages", default="2,3")
+ap.add_argument("--stamps", action="store_true",
+                help="diagnostic build (TONAL_HIP_LIB=build/variants/lib63_stamp1.so): print the in-kernel phase timeline of the NT launches")
 args = ap.parse_args()
+
+
+def stamp_report(eng, tag):
+    """Phase timeline of the last wino63v_nt launch from the stamps of a -DV6_STAMP=1 build (wave 0 of every workgroup)."""
+    import ctypes as C
+    import numpy as np
+    fn = getattr(eng.lib, "tl_debug_v6_stamps", None)
+    if fn is None:
+        print("   (no tl_debug_v6_stamps in this library: not a stamp build)")
+        return
+    fn.argtypes, fn.restype = [C.c_void_p, C.c_int], C.c_int
+    torch.cuda.synchronize()
+    buf = np.zeros((256, 96, 8), dtype=np.uint64)
+    assert fn(buf.ctypes.data, 1) == 0
+    s = buf.astype(np.int64)
+    live = (s[:, :, 7] != 0) & (s[:, :, 0] != 0)
+    nt = live.sum(1)
+    full = min(int(nt.min()), 96)
+    if full < 4:
+        print(f"   ({tag}: fewer than 4 stamped tiles per workgroup)")
+        return
+    t = s[:, 1:full - 1]                                   # drop the first and the last stamped tile of every workgroup
+    cyc = (t[:, :, 6] - t[:, :, 1]).astype(np.float64)
+    rt = (t[:, :, 7] - t[:, :, 0]).astype(np.float64) * 10e-9      # 100 MHz
+    ghz = cyc.sum() / rt.sum() / 1e9
+    seg = {"first two K-steps": t[:, :, 2] - t[:, :, 1], "steady-state loop": t[:, :, 3] - t[:, :, 2],
+           "last two K-steps + carried MFMAs": t[:, :, 4] - t[:, :, 3], "epilogue instruction stream": t[:, :, 5] - t[:, :, 4],
+           "closing wait": t[:, :, 6] - t[:, :, 5], "whole tile": t[:, :, 6] - t[:, :, 1]}
+    gap = s[:, 2:full - 1, 1] - s[:, 1:full - 2, 6]
+    print(f"   {tag}: {full} stamped tiles per workgroup, in-kernel clock {ghz:.3f} GHz")
+    tot = float(seg["whole tile"].mean())
+    for k, v in seg.items():
+        v = v.astype(np.float64)
+        print(f"     {k:36s} {v.mean():10.0f} cycles ({100 * v.mean() / tot:5.1f} %)  p5 {np.percentile(v, 5):9.0f}  p95 {np.percentile(v, 95):9.0f}"
+              f"  = {v.mean() / ghz / 1e3:7.2f} us")
+    print(f"     {'between tiles (barrier)':36s} {gap.mean():10.0f} cycles")
+    # how much in step the workgroups are: spread over the workgroups of the time (100 MHz) their j-th epilogue begins
+    e = s[:, 1:full - 1, 0].astype(np.float64) * 0.01      # tile start in us
+    ph = e - e.mean(0, keepdims=True)
+    print(f"     tile start across workgroups: std {ph.std(0).mean():.1f} us, range {np.ptp(ph, axis=0).mean():.1f} us "
+          f"(tile {tot / ghz / 1e3:.1f} us)")
 dev = torch.device("cuda:0")
 stages_def = [(512, 3, True), (512, 3, True), (512, 3, True), (256, 1, True), (64, 1, False)]
 eng = CnnEngine(80, 128, 400, 6, 64, 0.0, 0.01, stages_def, [128, 128, 128, 128, 64])
@@ -70,3 +113,5 @@ for si in [int(s) for s in args.stages.split(",")]:
         ms = ts[f"conv{si}_{name}"][1]
         print(f"F63 conv{si}_{name:6s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TFLOP/s algorithmic  {fl * iss / ms / 1e9:7.2f} issued "
               f"({100 * fl * iss / ms / 1e9 / 157.3:.1f}% of fp32 MFMA peak)", flush=True)
+        if args.stamps and name in ("fwd", "dgrad"):
+            stamp_report(eng, f"conv{si}_{name}")

@@ -24,8 +24,9 @@ from tests.parity_record import record
 from tests.test_gpu_parity import rel, rel_l2, _trainer
 
 # one-step NAdam update-vector deviation from the reference golden G11 observed on the MI355X with the default kernels
-# (profiles/parity_observed.json, round 5); the test allows twice that
-UPD_OBSERVED, UPD_OBSERVED_BIAS = 1e-2, 2.5e-2
+# (profiles/parity_observed.json, round 5: worst 5.84e-4, ecog_conv_block.3.weight; the two bias vectors whose tiny gradients
+# NAdam divides by their own magnitude - 5e-2 allowed in round 2 - sit below 5e-5 at this shape); the test allows twice that
+UPD_OBSERVED, UPD_OBSERVED_BIAS = 6e-4, 6e-4
 
 pytestmark = pytest.mark.gpu
 
