@@ -28,6 +28,7 @@
 #include "tonal_wino43_epi.h"
 #include "tonal_wino43v_epi.h"
 #include "tonal_wino63_epi.h"
+#include "tonal_wino63_kloop.h"
 #include <type_traits>
 
 namespace tl {
@@ -35,6 +36,15 @@ namespace tl {
 typedef __attribute__((address_space(3))) void lds_void6_t;
 __device__ __forceinline__ void dma16h(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void6_t*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+// A raw buffer resource as four scalar words (what __builtin_amdgcn_make_buffer_rsrc builds: base, stride 0, num_records =
+// bytes, flags) - as a plain vector it can be an "s" operand of the K-loop asm statements (tonal_wino63_kloop.h)
+typedef int v6_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v6_i32x4 v6_rsrc_words(const void* base, long long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  const long long n = bytes < 0 ? 0 : (bytes < 0x7fffffffLL ? bytes : 0x7fffffffLL);
+  return v6_i32x4{(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xffffu), (int)n, 0x00020000};
 }
 
 // float offset of (hex, transform i, channel c) in the pair layout; kc8 = ldv / 8
@@ -171,7 +181,7 @@ constexpr int V6_ROWS = 6 * V6_BH;                       // conv rows per tile (
 #define V6_STAMP 0        // diagnostic build only (scripts/build_w63_variants.sh): wave 0 of every workgroup stamps s_memtime at the
 #endif                    // phase boundaries of its first V6_STAMP_TILES tiles into a buffer of its own (tl_debug_v6_stamps reads it)
 #if V6_STAMP
-constexpr int V6_STAMP_TILES = 96, V6_STAMP_SLOTS = 8;
+constexpr int V6_STAMP_TILES = 96, V6_STAMP_SLOTS = 16;
 __device__ unsigned long long v6_stamp_buf[256 * V6_STAMP_TILES * V6_STAMP_SLOTS];
 #define V6_STAMP_AT(k)                                                                                                         \
   do {                                                                                                                         \
@@ -182,8 +192,6 @@ __device__ unsigned long long v6_stamp_buf[256 * V6_STAMP_TILES * V6_STAMP_SLOTS
 #else
 #define V6_STAMP_AT(k) do { } while (0)
 #endif
-
-enum { KS_NORMAL = 0, KS_PRELAST = 1, KS_LAST = 2 };
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p) {
@@ -202,20 +210,22 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   const int ntn = (p.N + V6_BN - 1) / V6_BN;
   const long long ntm = (p.M + V6_ROWS - 1) / V6_ROWS;
   const long long nwg = ntm * ntn;
-  const int nsteps = p.K / V6_BK;                          // host-checked: K % 8 == 0, K >= 24
+  const int nsteps = p.K / V6_BK;                          // host-checked: K % 8 == 0, K >= 40
+  // Accumulators and fragments live in FIXED registers (tonal_wino63_kloop.h: v0 - v127, v128 - v191): every K-step is one asm
+  // statement tied to them, the epilogues read `acc` where the last statement left it.
   f32x16 acc[8];
+  f32x4 faL[4], fbL[4], faH[4], fbH[4];
 
   // ---- LDS-DMA plan.  Piece = 32 rows x 32 B; lane -> (row = lane >> 1, physical chunk = lane & 1); the source chunk
   // is the swizzled one, chunk ^ ((row >> 3) & 1).  Wave w fetches transform w: its four 32-hex blocks of A and its two
-  // 32-column blocks of B.
+  // 32-column blocks of B: LDS destinations (wave w, piece t) = stage + (w 128 + 32 t) 32 B for A, + 32 KB + (w 64 + 32 t) 32 B
+  // for B - M0 of the first piece of each kind, + 1 KB per further piece.
   const int prow = lane >> 1;
   const int src_chunk = (lane & 1) ^ ((lane >> 4) & 1);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bw, 0, (int)(8LL * p.N * p.ldb * 4), 0x00020000);
-  unsigned adst[4], bdst[2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) adst[t] = (unsigned)((wave * V6_BH + t * 32) * V6_ROWB);
-#pragma unroll
-  for (int t = 0; t < 2; ++t) bdst[t] = (unsigned)(V6_A_BYTES + (wave * V6_BN + t * 32) * V6_ROWB);
+  const v6_i32x4 rsB = v6_rsrc_words(p.Bw, 8LL * p.N * p.ldb * 4);
+  const unsigned lds0 = (unsigned)(unsigned long long)(lds_void6_t*)lds;        // LDS byte address of the first stage
+  const unsigned dst_a0 = lds0 + (unsigned)(wave * V6_BH * V6_ROWB);
+  const unsigned dst_b0 = lds0 + (unsigned)(V6_A_BYTES + wave * V6_BN * V6_ROWB);
   // LDS row rho = 8 g + 4 lh' + j' of a wave's 32 (the MFMA row whose results lane half lh' holds in accumulator elements
   // 4 g + j') takes hex 16 lh' + 4 g + j': a lane owns 16 consecutive hexes (tonal_wino63_epi.h)
   const int hex_of_row = (prow & 3) | ((prow >> 3) << 2) | (((prow >> 2) & 1) << 4);
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   struct tile_t {
     long long tm, R0;
     int n0;
-    __amdgpu_buffer_rsrc_t rsA;
+    v6_i32x4 rsA;
     unsigned bvoff[2];
   };
   const long long a_tile_bytes = (long long)V6_BH * 8 * p.lda * 4, a_total_bytes = p.A_rows * 8LL * p.lda * 4;
@@ -241,9 +251,8 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     t.tm = tm;
     t.R0 = tm * V6_ROWS;
     t.n0 = tn * V6_BN;
-    const long long ab = tm * a_tile_bytes, left = a_total_bytes - ab;
-    t.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(p.A) + ab), 0,
-                                              (int)(left < 0x7fffffffLL ? left : 0x7fffffffLL), 0x00020000);
+    const long long ab = tm * a_tile_bytes;
+    t.rsA = v6_rsrc_words(reinterpret_cast<const char*>(p.A) + ab, a_total_bytes - ab);
     if (t.n0 + V6_BN <= p.N) {
       const unsigned nb4 = (unsigned)t.n0 * 32u;
 #pragma unroll
@@ -278,136 +287,39 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     place(t, tm, tn);
     return t;
   };
-  auto issue = [&](const tile_t& tl_, int step, int stage) {
-    char* base = lds + stage * V6_STAGE;
-    const unsigned soff = (unsigned)step * 512u, soff_b = (unsigned)step * b_step;
-#if V6_ABL & 8
-    // timing only: the A pieces of a step as 1 KB contiguous blocks of the tile's span (same bytes per tile, full lines)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dma16h(tl_.rsA, base + adst[t], (unsigned)(lane * 16 + (wave * 4 + t) * 1024), (unsigned)step * 32768u);
-#else
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dma16h(tl_.rsA, base + adst[t], avoff[t], soff);
-#endif
-#if V6_ABL & 16
-#pragma unroll
-    for (int t = 0; t < 2; ++t) dma16h(rsB, base + bdst[t], (unsigned)(lane * 16 + (wave * 2 + t) * 1024 + (tl_.n0 / 64) * 1048576), (unsigned)step * 16384u);
-#else
-#pragma unroll
-    for (int t = 0; t < 2; ++t) dma16h(rsB, base + bdst[t], tl_.bvoff[t], soff_b);
-#endif
-  };
   auto next3 = [](int s) { return s == 2 ? 0 : s + 1; };
 
   // ---- fragment reads: row r of a plane, logical chunk lh -> r * 32 + ((lh ^ ((r >> 3) & 1)) << 4)
   const int cphys = (lh ^ ((lr >> 3) & 1)) << 4;
-  const int a_row = (wm * 32 + lr) * V6_ROWB + cphys, b_row = V6_A_BYTES + (wn * 32 + lr) * V6_ROWB + cphys;
-  f32x4 faL[4], fbL[4], faH[4], fbH[4];
-  auto load_half = [&](f32x4 (&fa)[4], f32x4 (&fb)[4], int stage, int i0) {
-    const char* a_s = lds + stage * V6_STAGE + a_row + i0 * (V6_BH * V6_ROWB);
-    const char* b_s = lds + stage * V6_STAGE + b_row + i0 * (V6_BN * V6_ROWB);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i] = *reinterpret_cast<const f32x4*>(a_s + i * (V6_BH * V6_ROWB));
-      fb[i] = *reinterpret_cast<const f32x4*>(b_s + i * (V6_BN * V6_ROWB));
-    }
-  };
-  // 16 MFMAs of one half-set (ZERO: the accumulators start from the zero constant of the first MFMA of each)
-  auto mfma_half = [&](auto ZERO, const f32x4 (&fa)[4], const f32x4 (&fb)[4], int i0) {
-    if constexpr (decltype(ZERO)::value) {
-      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][0], fb[i][0], zero, 0, 0, 0);
-#pragma unroll
-      for (int q = 1; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[i][q], acc[i0 + i], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i0 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[i][q], acc[i0 + i], 0, 0, 0);
-    }
-  };
-  using Y = std::true_type;
-  using N = std::false_type;
+  const unsigned a_row = lds0 + (unsigned)((wm * 32 + lr) * V6_ROWB + cphys);
+  const unsigned b_row = lds0 + (unsigned)((wn * 32 + lr) * V6_ROWB + cphys);     // (+ 32 KB: in the instructions' offsets)
   int stg = 0;                                             // stage of the K-step about to run (rolls on across tiles)
-  // One K-step s >= 1 of the current tile: the first half-set of stage stg is read behind the barrier that opened the step,
-  // the carried half-set H(s - 1) runs, the pieces of step s + 2 go out (one per two MFMAs), the second half-set is read
-  // between the MFMAs of the first.  Closing wait: the pieces of step s + 1 have landed, those of step s + 2 may fly.
-  auto kstep = [&](auto MODE, auto ZH, int s) {
-    constexpr int mode = decltype(MODE)::value;
-    load_half(faL, fbL, stg, 0);
-    if constexpr (mode == KS_NORMAL) {
-      if (!(V6_ABL & 1)) issue(cur, s + 2, stg == 0 ? 2 : stg - 1);       // (stg + 2) % 3: released at the last barrier
-    }
-    mfma_half(ZH, faH, fbH, 4);                             // half-set H of the previous step (registers)
-    load_half(faH, fbH, stg, 4);
-    mfma_half(N{}, faL, fbL, 0);
-    // issue order (sched_group_barrier: 0x008 MFMA, 0x010 vector memory, 0x100 LDS read): the 8 reads of L first, then
-    // the carried MFMAs with one LDS-DMA piece per two of them, then the MFMAs of L with one read of H per two
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-    if constexpr (mode == KS_NORMAL) {
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    } else {
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-    }
-    // The reads of H: one per MFMA in the first half of L's window, so that the last eight MFMAs cover their latency in front
-    // of the barrier - for the conv2 launches (POOLV, fused conv1 gradient: -0.5 / -0.4 ms, same-call A/B, twice); the
-    // instantiations of conv3 (POOL, MASKY) measure +0.2 ms with it and keep one read per two MFMAs (V6_RDSCHED: 0 / 1 force one)
-    constexpr bool early = V6_RDSCHED == 1 || (V6_RDSCHED < 0 && (EPI == W_EPI_POOLV || EPI == W_EPI_C1W));
-    if constexpr (early) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    } else {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-    }
-    if constexpr (mode != KS_LAST) {
-      // (the builtin, not inline asm: the compiler's own wait-count bookkeeping sees the drained counters)
-      if constexpr (mode == KS_NORMAL) __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
-      else __builtin_amdgcn_s_waitcnt(0x0070);                                // vmcnt(0) lgkmcnt(0)
-#if !(V6_ABL & 4)
-      __builtin_amdgcn_s_barrier();
-#endif
-      asm volatile("" ::: "memory");
-    }
-    stg = next3(stg);
+
+  // The operands every K-step statement shares.  `step`: the K-step whose six pieces it issues (into stage `dst`); `wimm`: the
+  // closing wait of the first step as an immediate.
+#define V6K_INPUTS(tl_, step, dst, wimm)                                                                                       \
+  [a] "v"(a_row + (unsigned)stg * (unsigned)V6_STAGE), [b] "v"(b_row + (unsigned)stg * (unsigned)V6_STAGE),                    \
+      [va0] "v"(avoff[0]), [va1] "v"(avoff[1]), [va2] "v"(avoff[2]), [va3] "v"(avoff[3]), [vb0] "v"((tl_).bvoff[0]),          \
+      [vb1] "v"((tl_).bvoff[1]), [ra] "s"((tl_).rsA), [rb] "s"(rsB), [m0a] "s"(dst_a0 + (unsigned)(dst) * (unsigned)V6_STAGE), \
+      [m0b] "s"(dst_b0 + (unsigned)(dst) * (unsigned)V6_STAGE), [sa] "s"((unsigned)(step) * 512u),                            \
+      [sb] "s"((unsigned)(step) * b_step), [w] "n"(wimm)
+  // (clobbers: the statements advance M0 with s_add_u32, which writes SCC - a compare the compiler placed in front of a
+  // statement must not be consumed behind it; M0 itself is only ever written inside these statements)
+#define V6K_STMT_R(REGS, TEXT, tl_, step, dst, wimm) \
+  asm volatile(TEXT : REGS(acc, faL, fbL, faH, fbH) : V6K_INPUTS(tl_, step, dst, wimm) : "memory", "scc")
+#define V6K_STMT(TEXT, tl_, step, dst, wimm) V6K_STMT_R(V6K_REGS, TEXT, tl_, step, dst, wimm)
+  // the six LDS-DMA pieces of K-step `step` of tile tl_ into stage `dst` (no MFMAs, no vector operands: the first two stages
+  // of a tile, issued in front of the epilogue of the tile before - which must not see fragments or accumulators as live)
+  auto issue = [&](const tile_t& tl_, int step, int dst) {
+    asm volatile(V6K_ISSUE : : V6K_INPUTS(tl_, step, dst, 0) : "memory", "scc");
   };
-  // First K-step of a tile: no carried half-set.  The pieces of step 1 were issued in front of the previous tile's
-  // epilogue; between them and this step's pieces (step 2) sit that epilogue's stores: the closing wait leaves both in flight.
-  auto kstep_first = [&](auto EPIN) {
-    load_half(faL, fbL, stg, 0);
-    issue(cur, 2, stg == 0 ? 2 : stg - 1);               // (stg + 2) % 3
-    load_half(faH, fbH, stg, 4);
-    mfma_half(Y{}, faL, fbL, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if (t < 6) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    }
-    {
-      constexpr int n = decltype(EPIN)::value + 6 > 63 ? 63 : decltype(EPIN)::value + 6;
-      __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (0 << 8) | ((n >> 4) << 14));     // vmcnt(n) lgkmcnt(0)
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    stg = next3(stg);
-  };
+  // The reads of H between L's MFMAs: one per MFMA in the first half of L's window, so that the last eight MFMAs cover their
+  // latency behind the barrier - for the conv2 launches (POOLV, fused conv1 gradient: -0.5 / -0.4 ms, same-call A/B, twice);
+  // the instantiations of conv3 (POOL, MASKY) measured +0.2 ms with it and keep one read per two MFMAs (V6_RDSCHED forces one)
+  constexpr bool early = V6_RDSCHED == 1 || (V6_RDSCHED < 0 && (EPI == W_EPI_POOLV || EPI == W_EPI_C1W));
+  constexpr int NST = v6_stores<EPI>();
+  constexpr int first_n = NST + 6 > 63 ? 63 : NST + 6;
+  constexpr int first_wait = (first_n & 15) | (7 << 4) | (0 << 8) | ((first_n >> 4) << 14);       // vmcnt(n) lgkmcnt(0)
 
   // the first tile's first two stages
   issue(cur, 0, 0);
@@ -430,21 +342,34 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
       else return v6_prefetch_c1w(p, cur.R0, cur.n0, wm, wn, lr, lh);
     };
     decltype(prefetch()) pre;
-    constexpr int NST = v6_stores<EPI>();
-    kstep_first(std::integral_constant<int, NST>{});
-    if (nsteps > 3) {
-      kstep(std::integral_constant<int, KS_NORMAL>{}, Y{}, 1);
-      V6_STAMP_AT(2);
-      for (int s = 2; s + 2 < nsteps; ++s) kstep(std::integral_constant<int, KS_NORMAL>{}, N{}, s);
-      V6_STAMP_AT(3);
-      kstep(std::integral_constant<int, KS_PRELAST>{}, N{}, nsteps - 2);
-    } else {
-      kstep(std::integral_constant<int, KS_PRELAST>{}, Y{}, 1);
+    // ---- K loop.  Step 0 has no carried half-set (its L starts accumulators 0-3 from zero, its H is read and runs in step
+    // 1, which starts 4-7 from zero); a step issues the pieces of the step two ahead into the stage released by the barrier in
+    // front of it; the pieces of step 1 went out in front of the previous tile's epilogue: between them and step 0's pieces
+    // sit that epilogue's stores, which the closing wait of step 0 leaves in flight (first_wait).
+    V6K_STMT_R(V6K_REGS_FIRST, V6K_FIRST, cur, 2, stg == 0 ? 2 : stg - 1, first_wait);
+    stg = next3(stg);
+    // (straight-line control flow between the statements - nsteps >= 5 is host-checked, the steady-state loop runs at least
+    // once: across a branch with two successors the allocator moves the pinned values out of their registers and back)
+    if constexpr (early) V6K_STMT_R(V6K_REGS_STEP1, V6K_STEP1_E, cur, 3, stg == 0 ? 2 : stg - 1, 0);
+    else V6K_STMT_R(V6K_REGS_STEP1, V6K_STEP1_L, cur, 3, stg == 0 ? 2 : stg - 1, 0);
+    stg = next3(stg);
+    V6_STAMP_AT(2);
+    {
+      int s = 2;
+      do {
+        if constexpr (early) V6K_STMT(V6K_NORM_E, cur, s + 2, stg == 0 ? 2 : stg - 1, 0);
+        else V6K_STMT(V6K_NORM_L, cur, s + 2, stg == 0 ? 2 : stg - 1, 0);
+        stg = next3(stg);
+      } while (++s + 2 < nsteps);
     }
+    V6_STAMP_AT(3);
+    if constexpr (early) V6K_STMT(V6K_PRELAST_E, cur, 0, 0, 0);
+    else V6K_STMT(V6K_PRELAST_L, cur, 0, 0, 0);
+    stg = next3(stg);
     pre = prefetch();
-    __builtin_amdgcn_sched_barrier(0);
-    kstep(std::integral_constant<int, KS_LAST>{}, N{}, nsteps - 1);
-    mfma_half(N{}, faH, fbH, 4);
+    if constexpr (early) V6K_STMT(V6K_LAST_E, cur, 0, 0, 0);
+    else V6K_STMT(V6K_LAST_L, cur, 0, 0, 0);
+    stg = next3(stg);
     V6_STAMP_AT(4);
 
 #if V6_ABL & 2
@@ -471,24 +396,30 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
       issue(cur, 1, next3(stg));
     }
     __builtin_amdgcn_sched_barrier(0);
+#if V6_STAMP
+    unsigned long long* est = (tid == 0 && stamp_tile < V6_STAMP_TILES && blockIdx.x < 256)
+                                  ? v6_stamp_buf + ((long long)blockIdx.x * V6_STAMP_TILES + stamp_tile) * V6_STAMP_SLOTS : nullptr;
+#else
+    constexpr unsigned long long* est = nullptr;
+#endif
 #if !(V6_ABL & 2)
     float* scratch = reinterpret_cast<float*>(lds + last_stage * V6_STAGE);
     (void)scratch;
     const bool full = done.R0 + V6_ROWS <= p.M && done.n0 + V6_BN <= p.N;
     if constexpr (EPI == W_EPI_POOL) {
-      if (full) v6_epilogue_pool<false, true>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm);
-      else v6_epilogue_pool<false, false>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      if (full) v6_epilogue_pool<false, true>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
+      else v6_epilogue_pool<false, false>(p, acc, pre, nullptr, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
     } else if constexpr (EPI == W_EPI_POOLV) {
       float* xch = reinterpret_cast<float*>(lds + 3 * V6_STAGE);
-      if (full) v6_epilogue_pool<true, true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
-      else v6_epilogue_pool<true, false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      if (full) v6_epilogue_pool<true, true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
+      else v6_epilogue_pool<true, false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
     } else if constexpr (EPI == W_EPI_MASK) {
       if (full) v6_epilogue_mask<true>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
       else v6_epilogue_mask<false>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
     } else if constexpr (EPI == W_EPI_MASKY) {
       float* xch = reinterpret_cast<float*>(lds + 3 * V6_STAGE);
-      if (full) v6_epilogue_masky<true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
-      else v6_epilogue_masky<false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm);
+      if (full) v6_epilogue_masky<true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
+      else v6_epilogue_masky<false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
     } else {
       v6_epilogue_c1w(p, acc, pre, reinterpret_cast<float*>(lds + 3 * V6_STAGE) + wave * 512, scratch, done.R0, done.n0, wm, wn,
                       lr, lh, done.tm);
@@ -511,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
 
 #if V6_STAMP
 }  // namespace tl
-// diagnostic build only: the stamps of the last wino63v_nt launch (256 workgroups x 96 tiles x 8 slots: realtime (100 MHz) at the
+// diagnostic build only: the stamps of the last wino63v_nt launch (256 workgroups x 96 tiles x 16 slots; 8.. inside the epilogue: realtime (100 MHz) at the
 // tile's first barrier, s_memtime there / after K-step 1 / after the steady-state loop / at the end of the K loop / at the
 // end of the epilogue's instruction stream / behind its closing wait, realtime there)
 extern "C" int tl_debug_v6_stamps(unsigned long long* dst, int clear) {
@@ -1791,7 +1722,7 @@ extern "C" int tl_conv3_wino63v_nt(const tl_nt_params* pp, void* stream) {
   TL_REQUIRE(p.A && p.Bw && (p.out || p.epilogue == W_EPI_C1W || p.epilogue == W_EPI_POOLV || p.epilogue == W_EPI_MASKY), "wino63v_nt: null V/Bw/out");
   TL_REQUIRE(p.loader == W_LOAD_V, "wino63v_nt: loader 2 (pre-transformed operand) only");
   TL_REQUIRE(p.J == 3 && p.splitk <= 1, "wino63v_nt: 3 taps, no split-K");
-  TL_REQUIRE(p.M > 0 && p.M % 6 == 0 && p.N > 0 && p.K >= 24 && p.K % 8 == 0, "wino63v_nt: M %% 6, K %% 8, K >= 24 needed");
+  TL_REQUIRE(p.M > 0 && p.M % 6 == 0 && p.N > 0 && p.K >= 40 && p.K % 8 == 0, "wino63v_nt: M %% 6, K %% 8, K >= 40 needed");
   TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K && p.lda % 8 == 0 && p.ldb % 8 == 0, "wino63v_nt: bad leading dimensions (multiples of 8)");
   TL_REQUIRE(p.A_rows % 2 == 0, "wino63v_nt: V holds hex pairs");
   TL_REQUIRE(p.Tp > 0 && p.Tp % 6 == 0 && p.M % p.Tp == 0, "wino63v_nt: Tp must be a positive multiple of 6, M whole sequences");

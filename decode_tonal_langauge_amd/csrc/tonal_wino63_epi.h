@@ -13,6 +13,11 @@
 
 namespace tl {
 
+// diagnostic builds (-DV6_STAMP=1, tonal_wino63.hip): lane 0 of wave 0 writes s_memtime into its workgroup's slot; nullptr otherwise
+__device__ __forceinline__ void v6_stamp(unsigned long long* st, int k) {
+  if (st != nullptr) st[k] = __builtin_amdgcn_s_memtime();
+}
+
 constexpr unsigned V6_DROP = 0x80000000u;     // added to any in-range byte offset (< 2^31) it stays past every resource
 constexpr unsigned long long V6_HI = 0xffffffff00000000ull;
 
@@ -164,7 +169,8 @@ __device__ __forceinline__ bits96 v6_valid_bits96(int t0, int Tp, int tlim, long
 // ------------------------------------------------------------------------------------------
 template <bool VOUT, bool FULL>
 __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f32x16 (&acc)[8], const v5_pre_pool& pre, float* xch,
-                                                 long long R0, int n0, int wm, int wn, int lr_in, int lh, long long tm) {
+                                                 long long R0, int n0, int wm, int wn, int lr_in, int lh, long long tm,
+                                                 unsigned long long* st = nullptr) {
   int lr = lr_in;                                           // (opaque copy: see v6_epilogue_c1w)
   asm volatile("" : "+v"(lr));
   const int colbase = n0 + wn * 32;
@@ -195,6 +201,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
   const unsigned seq_step = (unsigned)(out_tp - Tq) * ldo4;  // (wraps: added when a half enters its next sequence)
   float pv[48];
   uint32_t wb0 = 0, wb1 = 0, ws0 = 0, ws1 = 0;
+  v6_stamp(st, 8);
   static_for<0, 16>([&](auto E) {
     constexpr int e = decltype(E)::value;
     float y[6];
@@ -235,6 +242,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
       rb += wbb ? seq_step : 0u;
     }
   });
+  v6_stamp(st, 9);
   {
     // bit words: after the transposes lane lr of a half holds those of its pooled rows lr (block 0) and 32 + lr (block 1,
     // lr < 16).  Buffer stores with a constant count per wave and tile (v6_stores below).
@@ -260,6 +268,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
       __builtin_amdgcn_raw_buffer_store_b32(b ? ws1 : ws0, rsS, wo, 0u, 0);
     }
   }
+  v6_stamp(st, 10);
   if constexpr (VOUT) {
     if (p.out != nullptr) {                                 // (tests, TONAL_STORE_P1: the raw pooled rows as well, [seq * Tp / 2 + t'])
       const __amdgpu_buffer_rsrc_t rsP = rsrc_of(p.out + P0 * (long long)p.ldo, (prows - P0) * (long long)p.ldo * 4);
@@ -280,6 +289,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
     __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    v6_stamp(st, 11);
     float nb0 = 0.f, nb1 = 0.f;
     if (slot < 7) {                                         // (the last half-wave of a tile: finished by the fix-up pass)
       const float2 v2 = *reinterpret_cast<const float2*>(xch + ((slot + 1) * 64 + wn * 32 + lr) * 2);
@@ -333,6 +343,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
       const unsigned voA = selmu(mask2(nvA, nvA >> 1, q), vvA, V6_DROP), voB = selmu(mask2(nvB, nvB >> 1, q), vvB, V6_DROP);
       v6_store_hex_pair<FULL>(vv[0], vv[1], rsV, voA, voA + 1024u, voB, voB + 1024u, (unsigned)qp * pair4);
     }
+    v6_stamp(st, 12);
     // the tile's first two pooled rows: rows 6, 7 of the last hex of the tile in front (tl_wino63_v_fixup)
     {
       const bool hw = wm == 0 && p.vhalo != nullptr;
@@ -431,7 +442,8 @@ __device__ __forceinline__ v6_pre_masky v6_prefetch_masky(const tl_nt_params& p,
 }
 template <bool FULL>
 __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f32x16 (&acc)[8], const v6_pre_masky& pre, float* xch,
-                                                  long long R0, int n0, int wm, int wn, int lr_in, int lh, long long tm) {
+                                                  long long R0, int n0, int wm, int wn, int lr_in, int lh, long long tm,
+                                                  unsigned long long* st = nullptr) {
   int lr = lr_in;                                           // (opaque copy: see v6_epilogue_c1w)
   asm volatile("" : "+v"(lr));
   const int colbase = n0 + wn * 32;
@@ -484,8 +496,13 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
 #pragma unroll
   for (int k = 0; k < 8; ++k) v1keep[k] = 0.f;
   auto andf = [](float x, uint32_t m) { return __uint_as_float(__float_as_uint(x) & m); };
+  v6_stamp(st, 8);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
+    if (e == 1) v6_stamp(st, 9);
+    if (e == 4) v6_stamp(st, 10);
+    if (e == 8) v6_stamp(st, 11);
+    if (e == 12) v6_stamp(st, 12);
     float y[6];
     wino63_rows(acc, e, y);
     float dzr[12];                                          // the six pooled rows of accumulator element e, un-pooled
@@ -543,6 +560,7 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  v6_stamp(st, 13);
   // ---- hex 0 of every lane: its front row is the last row of the half-wave below ----
   const int slot = wm * 2 + lh;
   {

@@ -204,7 +204,7 @@ int tl_conv3_wino43v_tn(const tl_tn_params* p, void* stream);
  * taken as zero), zero hexes appended to whole 128-hex tiles; Vd the same of the un-pooled dZ rows 6H-2 .. 6H+5.
  *   tl_wino63_weights        w (O, I, 3, 1) -> forward taps [8][O][ld_f], input-gradient taps [8][I][ld_d] (flipped)
  *   tl_conv3_wino63v_nt      tl_conv3_wino43v_nt with A = V in hex form (loader 2, A_rows = hexes, whole 128-hex tiles;
- *                            M % 6 == 0, K % 8 == 0, K >= 24, N % 32 == 0); epilogues POOL (+ out_tp), POOLV (vout in
+ *                            M % 6 == 0, K % 8 == 0, K >= 40, N % 32 == 0); epilogues POOL (+ out_tp), POOLV (vout in
  *                            hex form, vout_quads = hexes, Tp % 12 == 0), MASK, conv1-weight-gradient (4)
  *   tl_wino63_v_fixup        second half of POOLV: the last hex of every 64 written by a tile (rows 6, 7 from vhalo)
  *   tl_conv3_wino63v_tn      tl_conv3_wino43v_tn with hexes (Mdim % 128 == 0, Ndim % 64 == 0; slab[z][8][Mdim][ldc],

@@ -29,7 +29,7 @@ def stamp_report(eng, tag):
         return
     fn.argtypes, fn.restype = [C.c_void_p, C.c_int], C.c_int
     torch.cuda.synchronize()
-    buf = np.zeros((256, 96, 8), dtype=np.uint64)
+    buf = np.zeros((256, 96, 16), dtype=np.uint64)
     assert fn(buf.ctypes.data, 1) == 0
     s = buf.astype(np.int64)
     live = (s[:, :, 7] != 0) & (s[:, :, 0] != 0)
@@ -53,6 +53,11 @@ def stamp_report(eng, tag):
         print(f"     {k:36s} {v.mean():10.0f} cycles ({100 * v.mean() / tot:5.1f} %)  p5 {np.percentile(v, 5):9.0f}  p95 {np.percentile(v, 95):9.0f}"
               f"  = {v.mean() / ghz / 1e3:7.2f} us")
     print(f"     {'between tiles (barrier)':36s} {gap.mean():10.0f} cycles")
+    # inside the epilogue (slots 8..13, where the epilogue has them): cycles from the end of the K loop
+    inner = [(k, (t[:, :, k] - t[:, :, 4]).astype(np.float64)) for k in range(8, 14) if (t[:, :, k] != 0).all()]
+    if inner:
+        print("     inside the epilogue, cycles after the K loop: " + "  ".join(f"[{k}] {v.mean():.0f}" for k, v in inner)
+              + f"  [end] {(t[:, :, 5] - t[:, :, 4]).mean():.0f}")
     # how much in step the workgroups are: spread over the workgroups of the time (100 MHz) their j-th epilogue begins
     e = s[:, 1:full - 1, 0].astype(np.float64) * 0.01      # tile start in us
     ph = e - e.mean(0, keepdims=True)
