@@ -330,6 +330,11 @@ class CnnEngine:
     def _f63(self, st) -> bool:
         return self.wino63 and st.idx in (2, 3)
 
+    def _nt63_rows(self) -> int:
+        """conv rows of a row tile of tl_conv3_wino63v_nt: its halo arrays and the fused conv1 gradient's partial sums hold one
+        entry per row tile"""
+        return int(self.lib.tl_wino63_nt_tile_rows())
+
     def _v_hex_buffer(self, store, idx, rows, cin):
         """V / Vd of a stage input in hex form: rows / 6 hexes, padded with zero hexes to whole 128-hex tiles (and by at
         least 24: the weight-gradient kernel prefetches three 6-hex K-steps past the last one it uses)."""
@@ -367,7 +372,7 @@ class CnnEngine:
         if st.idx == 2:
             rows_out = S * st.tp_out
             Vn = self._v_hex_buffer(self.V, 2, rows_out, st.cout)
-            ntm = (S * st.tp_in + 767) // 768
+            ntm = -(-(S * st.tp_in) // self._nt63_rows())
             if not hasattr(self, "_vhalo"):
                 self._vhalo = {}
             halo = self._vhalo.get(2)
@@ -451,7 +456,7 @@ class CnnEngine:
             rows2 = S * below.tp_in                              # conv rows of stage 2: six per hex = three of this GEMM's rows
             Y2 = self._v_hex_buffer(self.Yt, 2, rows2, below.cout)
             Vd2 = self._v_hex_buffer(self.Vd, 2, rows2, below.cout)
-            ntm = (rows_in + 767) // 768
+            ntm = -(-rows_in // self._nt63_rows())
             if not hasattr(self, "_vhalo"):
                 self._vhalo = {}
             halo = self._vhalo.get("d2")
@@ -468,7 +473,7 @@ class CnnEngine:
         if st.idx == 3:
             self._nt(tag="conv3_dgrad", fn="tl_conv3_wino63v_nt", epilogue=EPI_MASK, out=ptr(self.G[2]), **kw)
             return None
-        ntm = (rows_in + 767) // 768
+        ntm = -(-rows_in // self._nt63_rows())
         part = torch.empty(ntm, (self.k1 + 1) * self.c1, dtype=torch.float32, device=self._dev)
         self._nt(tag="conv2_dgrad", fn="tl_conv3_wino63v_nt", epilogue=EPI_C1WGRAD, out=None, c1x=ptr(self._x),
                  c1bits=ptr(self.bits[1]), c1partial=ptr(part), c1T=self.T, c1kt=self.k1, Tvalid=self.tout1, **kw)

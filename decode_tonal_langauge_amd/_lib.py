@@ -82,6 +82,7 @@ SIGNATURES = {
     "tl_conv3_wino43v_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino63_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_conv3_wino63v_nt": (_I, [C.POINTER(NtParams), _P]),
+    "tl_wino63_nt_tile_rows": (_I, []),
     "tl_wino63_v_fixup": (_I, [_P, _P, _L, _L, _I, _I, _I, _P]),
     "tl_conv3_wino63v_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino63_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -1715,6 +1715,8 @@ extern "C" int tl_wino63_unpool_yvd(const float* G, const uint32_t* bits, float*
 // NT passes on a pre-transformed operand: A = V[hex][8][lda], A_rows = hexes in V (whole 128-hex tiles), M = output rows
 // (6 per hex).  Forward: V of the stage input, POOL / POOLV epilogue.  Input gradient: Vd (written by tl_conv3_wino63v_tn),
 // taps = the flipped / transposed set, MASK or fused-conv1-weight-gradient epilogue.
+extern "C" int tl_wino63_nt_tile_rows(void) { return tl::V6_ROWS; }
+
 extern "C" int tl_conv3_wino63v_nt(const tl_nt_params* pp, void* stream) {
   using namespace tl;
   TL_REQUIRE(pp != nullptr, "wino63v_nt: null params");

@@ -201,12 +201,15 @@ int tl_conv3_wino43v_tn(const tl_tn_params* p, void* stream);
  * 8 channel contractions per 6 conv rows (0.444 of the direct form's multiplies; F(4,3): 0.5).  Points 0, +-1, +-2,
  * +-1/2, inf (numerics: oracle/winograd_f63_gate.py).  A sequence holds Tp rows, Tp % 6 == 0 (% 12 where the pooled
  * output feeds another F(6,3) stage); V[hex][8][ldv], hex H of a sequence = its rows 6H .. 6H+7 (rows past the sequence
- * taken as zero), zero hexes appended to whole 128-hex tiles; Vd the same of the un-pooled dZ rows 6H-2 .. 6H+5.
+ * taken as zero), zero hexes appended to whole tiles (tl_wino63_nt_tile_rows() / 6 hexes; the callers of this package pad to
+ * 128, a multiple of it); Vd the same of the un-pooled dZ rows 6H-2 .. 6H+5.
  *   tl_wino63_weights        w (O, I, 3, 1) -> forward taps [8][O][ld_f], input-gradient taps [8][I][ld_d] (flipped)
- *   tl_conv3_wino63v_nt      tl_conv3_wino43v_nt with A = V in hex form (loader 2, A_rows = hexes, whole 128-hex tiles;
+ *   tl_conv3_wino63v_nt      tl_conv3_wino43v_nt with A = V in hex form (loader 2, A_rows = hexes, whole tiles;
  *                            M % 6 == 0, K % 8 == 0, K >= 40, N % 32 == 0); epilogues POOL (+ out_tp), POOLV (vout in
  *                            hex form, vout_quads = hexes, Tp % 12 == 0), MASK, conv1-weight-gradient (4)
- *   tl_wino63_v_fixup        second half of POOLV: the last hex of every 64 written by a tile (rows 6, 7 from vhalo)
+ *   tl_wino63_nt_tile_rows   conv rows of a row tile of tl_conv3_wino63v_nt (768: 128 hexes): vhalo holds 2 x C floats per row tile, c1partial one row per row tile, the fix-up passes
+ *                            take tiles = ceil(M / that)
+ *   tl_wino63_v_fixup        second half of POOLV: the last output hex of every row tile (rows 6, 7 from vhalo)
  *   tl_conv3_wino63v_tn      tl_conv3_wino43v_tn with hexes (Mdim % 128 == 0, Ndim % 64 == 0; slab[z][8][Mdim][ldc],
  *                            slab_stride >= 8*Mdim*ldc; B / bbits rows [seq * g_tp + t']); vd optional: Vd[hex][8][ld_vd].
  *                            loader 3: B = Y[hex][8][ldb] written by epilogue 6 of the stage above - no transform in the
@@ -216,10 +219,11 @@ int tl_conv3_wino43v_tn(const tl_tn_params* p, void* stream);
  * ------------------------------------------------------------------------------------------ */
 int tl_wino63_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
 int tl_conv3_wino63v_nt(const tl_nt_params* p, void* stream);
+int tl_wino63_nt_tile_rows(void);
 int tl_wino63_v_fixup(float* V, const float* vhalo, int64_t hexes, int64_t tiles, int Tq, int C, int ldv, void* stream);
 int tl_conv3_wino63v_tn(const tl_tn_params* p, void* stream);
 int tl_wino63_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
-/* second half of epilogue 6: the first hex of every tile (256 hexes) of a Vd written by it - its front row comes from
+/* second half of epilogue 6: the first hex of every row tile (tile rows / 3 hexes of the stage below) of a Vd written by it - its front row comes from
  * vhalo[tile - 1] (zero where the hex starts its sequence: hexes_per_seq)                                              */
 int tl_wino63_vd_fixup(float* Vd, const float* vhalo, int64_t hexes, int64_t tiles, int hexes_per_seq, int C, int ldv, void* stream);
 /* Y[conv_rows / 6][8][ldv] = A dz and Vd = B^T (dz rows 6h-2 .. 6h+5) of a pooled 3-tap stage from its output gradient G (rows
