@@ -251,13 +251,16 @@ class CnnRnnConvEngine:
         self.tq = self.tb // 3                                # after pool (3,1)
         if self.tq < 1:
             raise ValueError("input_length too small for the CNN-RNN convolution stack")
-        self.Tp = (self.t1 + 3) // 4 * 4
-        # 7-tap stack: "wino43+1" (default) two F(4,3) segments (taps 0..5) plus tap 6 as a one-tap GEMM
-        # added in the epilogue; "wino43" three segments; "direct" the 7-tap window GEMM.  CNN-RNN forward at
-        # C5 (batch 64): 57.0 / 60.3 / 72.8 ms
-        self.conv7_form = os.environ.get("TONAL_CONV7", "wino43+1")
-        if self.conv7_form not in ("wino43", "wino43+1", "direct"):
-            raise ValueError("TONAL_CONV7 must be wino43, wino43+1 or direct")
+        # 7-tap stack: "wino63" (default since round 5) three F(6,3) segments summed in the transform domain by ONE launch of
+        # the V-form NT kernel of the synthesis stack (tl_conv7_wino63v_nt: segment 2 re-reads V0 one hex on, so only two
+        # transformed arrays exist); "wino43+1" two F(4,3) segments (taps 0..5) plus tap 6 as a one-tap GEMM added in the
+        # epilogue; "wino43" three F(4,3) segments; "direct" the 7-tap window GEMM.  CNN-RNN forward at C5 (batch 64), rounds
+        # 2-4: 57.0 (wino43+1) / 60.3 / 72.8 ms
+        self.conv7_form = os.environ.get("TONAL_CONV7", "wino63")
+        if self.conv7_form not in ("wino63", "wino43", "wino43+1", "direct"):
+            raise ValueError("TONAL_CONV7 must be wino63, wino43, wino43+1 or direct")
+        # rows per sequence: whole hexes for the F(6,3) form, whole quads for the others
+        self.Tp = (self.t1 + 5) // 6 * 6 if self.conv7_form == "wino63" else (self.t1 + 3) // 4 * 4
         self._packed: Dict[str, Tuple[tuple, torch.Tensor]] = {}
         self._B = None
 
@@ -284,13 +287,40 @@ class CnnRnnConvEngine:
         self.Pb, self.Pa = self.P[:nb], self.P[nb:rows]
         self.bits_a, self.bits_b = zi(B * self.C * self.Tp, 32), zi(B * self.w1 * self.Tp, 32)
         self.Tap = z(rows, 512) if self.conv7_form == "wino43+1" else None
+        self.V7 = None
+        if self.conv7_form == "wino63":
+            # V0 / V1 of a 7-tap layer's input (hex transforms of the rows and of the rows shifted by 3, pair layout, whole
+            # 128-hex tiles + one pair: the third segment reads one hex past a tile); shared by the two layers (1024, then 512
+            # channels: the second fits into the first's storage)
+            nh_pad = (rows // 6 + 2 + 127) // 128 * 128
+            self.V7 = (z(nh_pad, 8, 1024), z(nh_pad, 8, 1024))
 
     def _conv7(self, src, w, b, dst, cin, cout, key, rows):
         """dst[r] = lrelu(sum_j w[:, :, j] src[r + j] + b) for r < rows; src holds rows + 8 rows."""
         from ._lib import NtParams
         import ctypes as C
         st_ = torch.cuda.current_stream().cuda_stream
-        wino = self.conv7_form != "direct" and cin % 32 == 0
+        if self.conv7_form == "wino63" and cin % 8 == 0 and cout % 32 == 0:
+            nhex = rows // 6
+            V0 = self.V7[0].view(-1)[: self.V7[0].shape[0] * 8 * cin].view(-1, 8, cin)
+            V1 = self.V7[1].view(-1)[: self.V7[1].shape[0] * 8 * cin].view(-1, 8, cin)
+            # rows from the valid length of THIS layer's input on enter as zeros (they only feed rows nobody reads)
+            tvalid = self.t1 if cin == 1024 else self.ta
+            check(self.lib.tl_wino63_xform2(ptr(src), ptr(V0), ptr(V1), rows, self.Tp, tvalid, cin, src.shape[1], cin, st_),
+                  "tl_wino63_xform2")
+
+            def pack63():
+                wp = torch.empty(3 * cin // 8, 8, cout, 8, dtype=torch.float32, device=w.device)
+                check(self.lib.tl_wino63_weights7(ptr(w.detach().reshape(cout, cin, self.K).contiguous()), ptr(wp), cout, cin,
+                                                  self.K, st_), "tl_wino63_weights7")
+                return wp
+            wp = self._cached(key + "wino63", w, pack63)
+            from ._lib import LOAD_V
+            _launch_nt(self.lib, fn="tl_conv7_wino63v_nt", A=ptr(V0), aux=ptr(V1), A_rows=V0.shape[0], lda=cin, Bw=ptr(wp),
+                       bias=ptr(b.detach()), out=ptr(dst), M=rows, N=cout, K=cin, ldb=3 * cin, ldo=dst.shape[1], J=self.K,
+                       row_shift=0, Tp=self.Tp, Tvalid=self.Tp, slope=self.slope, loader=LOAD_V, epilogue=EPI_LRELU)
+            return
+        wino = self.conv7_form not in ("direct", "wino63") and cin % 32 == 0
         nseg = 2 if self.conv7_form == "wino43+1" else 3
         # the segmented kernel reads A rows up to A_rows + 3 (nseg - 1) = rows + 2 + 3 (nseg - 1); the direct form rows + 8
         if src.shape[0] < rows + max(8, 2 + 3 * (nseg - 1)):

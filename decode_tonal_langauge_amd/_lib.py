@@ -71,6 +71,9 @@ SIGNATURES = {
     "tl_conv3_wino43_nt": (_I, [C.POINTER(NtParams), _P]),
     "tl_wino43_weights7": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "tl_conv7_wino43_nt": (_I, [C.POINTER(NtParams), _P]),
+    "tl_wino63_xform2": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "tl_wino63_weights7": (_I, [_P, _P, _I, _I, _I, _P]),
+    "tl_conv7_wino63v_nt": (_I, [C.POINTER(NtParams), _P]),
     "tl_conv3_wino_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_conv3_wino43_tn": (_I, [C.POINTER(TnParams), _P]),

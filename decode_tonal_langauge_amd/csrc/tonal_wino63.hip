@@ -113,6 +113,76 @@ __global__ void wino63_wgrad_finalize_kernel(const float* __restrict__ red, floa
   d[2] = -(2.f / 9.f) * a12 + (2.f / 45.f) * a34 + (8.f / 45.f) * a56 + m[7];
 }
 
+// Taps of a 7-tap (k,1) convolution as three F(6,3) segments (taps 3 s .. 3 s + 2 of segment s, missing ones zero), chunk-major
+// over the concatenated reduction index k = s I + i: fwd[3 I / 8][8 transforms][O][8]
+__global__ void wino63_weights7_kernel(const float* __restrict__ w, float* __restrict__ fwd, int O, int I, int taps) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 3LL * O * I) return;
+  const int k = (int)(idx % (3LL * I)), o = (int)(idx / (3LL * I));
+  const int seg = k / I, i = k - seg * I;
+  const float* s = w + ((long long)o * I + i) * taps + 3 * seg;
+  const float g0 = 3 * seg < taps ? s[0] : 0.f, g1 = 3 * seg + 1 < taps ? s[1] : 0.f, g2 = 3 * seg + 2 < taps ? s[2] : 0.f;
+  float* d0 = fwd + (((long long)(k >> 3) * 8) * O + o) * 8 + (k & 7);
+  const long long n = (long long)O * 8;
+  const float sm = g0 + g2;
+  d0[0] = -g0;
+  d0[n] = (-2.f / 9.f) * (sm + g1);
+  d0[2 * n] = (-2.f / 9.f) * (sm - g1);
+  const float a = fmaf(4.f, g2, g0), b = 2.f * g1;
+  d0[3 * n] = (1.f / 90.f) * (a + b);
+  d0[4 * n] = (1.f / 90.f) * (a - b);
+  const float c = fmaf(4.f, g0, g2), d = 2.f * g1;
+  d0[5 * n] = (8.f / 45.f) * (c + d);
+  d0[6 * n] = (8.f / 45.f) * (c - d);
+  d0[7 * n] = g2;
+}
+
+// Rows P[seq * Tp + t][C] -> V0 = B^T (rows 6 h .. 6 h + 7) and V1 = B^T (rows 6 h + 3 .. 6 h + 10) of every hex, pair layout:
+// the operands of tl_conv7_wino63v_nt.  Rows from Tvalid on (and past the sequence) enter as zeros.  Thread = 4 channels x one
+// hex, lanes ordered (8-channel chunk, hex of the pair, half chunk) like wino63_unpool_yvd_kernel: whole 64-byte runs.
+__global__ __launch_bounds__(256, 4) void wino63_xform2_kernel(const float* __restrict__ P, float* __restrict__ V0, float* __restrict__ V1,
+                                                             long long nhex, int hps, int Tp, int Tvalid, int C, int ldp, int ldv) {
+  const int tpp = C >> 1;                                    // threads per hex pair
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long pair = idx / tpp;
+  const int tl_ = (int)(idx - pair * tpp);
+  const int half = tl_ & 1, hpar = (tl_ >> 1) & 1, kc = tl_ >> 2;
+  const int c = 8 * kc + 4 * half;
+  const long long hg = 2 * pair + hpar;
+  if (hg >= nhex) return;
+  const long long seq = hg / hps;
+  const int hs = (int)(hg - seq * hps);
+  const float* src = P + (seq * Tp + 6LL * hs) * (long long)ldp + c;
+  f32x4 d[11];
+#pragma unroll
+  for (int j = 0; j < 11; ++j) {
+    d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (6 * hs + j < Tvalid) d[j] = *reinterpret_cast<const f32x4*>(src + (long long)j * ldp);
+  }
+  f32x4 o0[8], o1[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a[8], b[8], va[8], vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = d[j][k];
+      b[j] = d[j + 3][k];
+    }
+    wino63_bt(a, va);
+    wino63_bt(b, vb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o0[j][k] = va[j];
+      o1[j][k] = vb[j];
+    }
+  }
+  const long long at = v6_at(hg, 0, c, ldv >> 3);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(V0 + at + 16 * j) = o0[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(V1 + at + 16 * j) = o1[j];
+}
+
 // ------------------------------------------------------------------------------------------
 // Second half of the V-writing forward epilogue (tonal_wino63_epi.h, POOLV): the last output hex of every 128-hex tile
 // (64 next-stage hexes) needs pooled rows 6, 7 from the next tile.  The tile left rows 0..5 raw in the hex's transform
@@ -210,7 +280,12 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   const int ntn = (p.N + V6_BN - 1) / V6_BN;
   const long long ntm = (p.M + V6_ROWS - 1) / V6_ROWS;
   const long long nwg = ntm * ntn;
-  const int nsteps = p.K / V6_BK;                          // host-checked: K % 8 == 0, K >= 40
+  // EPI == LRELU: a SEVEN-tap convolution as three 3-tap segments summed in the transform domain (tl_conv7_wino63v_nt): the K
+  // loop runs over 3 K channels - segment 0 = V0 (A), hex H; segment 1 = V1 (aux: the transform of the rows shifted by 3);
+  // segment 2 = V0 again, hex H + 1 (rows shifted by 6 ARE the next hex) - against taps [3 K / 8][8][N][8]
+  constexpr bool SEG3 = EPI == W_EPI_LRELU;
+  const int kseg = p.K / V6_BK;                            // K-steps per segment (host-checked: K % 8 == 0)
+  const int nsteps = SEG3 ? 3 * kseg : kseg;               // host-checked: >= 5
   // Accumulators and fragments live in FIXED registers (tonal_wino63_kloop.h: v0 - v127, v128 - v191): every K-step is one asm
   // statement tied to them, the epilogues read `acc` where the last statement left it.
   f32x16 acc[8];
@@ -234,6 +309,9 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   unsigned avoff[4], bv_lane[2];
 #pragma unroll
   for (int t = 0; t < 4; ++t) avoff[t] = (unsigned)(v6_at(t * 32 + hex_of_row, wave, src_chunk * 4, kc8) * 4);
+  unsigned avoff1[4];                                      // the same pieces one hex on (SEG3, third segment)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) avoff1[t] = SEG3 ? (unsigned)(v6_at(t * 32 + hex_of_row + 1, wave, src_chunk * 4, kc8) * 4) : avoff[t];
 #pragma unroll
   for (int t = 0; t < 2; ++t) bv_lane[t] = (unsigned)((((long long)wave * p.N + t * 32 + prow) * 8 + src_chunk * 4) * 4);
   const unsigned b_step = (unsigned)p.N * 256u;
@@ -243,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   struct tile_t {
     long long tm, R0;
     int n0;
-    v6_i32x4 rsA;
+    v6_i32x4 rsA, rsA1;
     unsigned bvoff[2];
   };
   const long long a_tile_bytes = (long long)V6_BH * 8 * p.lda * 4, a_total_bytes = p.A_rows * 8LL * p.lda * 4;
@@ -253,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     t.n0 = tn * V6_BN;
     const long long ab = tm * a_tile_bytes;
     t.rsA = v6_rsrc_words(reinterpret_cast<const char*>(p.A) + ab, a_total_bytes - ab);
+    t.rsA1 = SEG3 ? v6_rsrc_words(reinterpret_cast<const char*>(p.aux) + ab, a_total_bytes - ab) : t.rsA;
     if (t.n0 + V6_BN <= p.N) {
       const unsigned nb4 = (unsigned)t.n0 * 32u;
 #pragma unroll
@@ -297,21 +376,54 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
 
   // The operands every K-step statement shares.  `step`: the K-step whose six pieces it issues (into stage `dst`); `wimm`: the
   // closing wait of the first step as an immediate.
-#define V6K_INPUTS(tl_, step, dst, wimm)                                                                                       \
+  // where the six pieces of a K-step come from: resource and per-lane offsets of the A pieces, scalar offsets of both kinds
+  struct dma_src {
+    v6_i32x4 ra;
+    unsigned va[4], vb[2], sa, sb;
+  };
+  auto src_of = [&](const tile_t& t, int step) {
+    dma_src d;
+    int ks = step;
+    if constexpr (SEG3) {                                  // (selects, no branches: see the K loop below)
+      const int seg = (step >= kseg ? 1 : 0) + (step >= 2 * kseg ? 1 : 0);
+      ks = step - seg * kseg;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        d.ra[k] = seg == 1 ? t.rsA1[k] : t.rsA[k];
+        d.va[k] = seg == 2 ? avoff1[k] : avoff[k];
+      }
+    } else {
+      d.ra = t.rsA;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d.va[k] = avoff[k];
+    }
+    d.vb[0] = t.bvoff[0];
+    d.vb[1] = t.bvoff[1];
+    // (wave-uniform by construction; said explicitly: an "s" operand the compiler believes divergent is handed over in a VGPR)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d.ra[k] = __builtin_amdgcn_readfirstlane(d.ra[k]);
+    d.sa = (unsigned)__builtin_amdgcn_readfirstlane(ks * 512);
+    d.sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)step * b_step));
+    return d;
+  };
+#define V6K_INPUTS(src, dst, wimm)                                                                                             \
   [a] "v"(a_row + (unsigned)stg * (unsigned)V6_STAGE), [b] "v"(b_row + (unsigned)stg * (unsigned)V6_STAGE),                    \
-      [va0] "v"(avoff[0]), [va1] "v"(avoff[1]), [va2] "v"(avoff[2]), [va3] "v"(avoff[3]), [vb0] "v"((tl_).bvoff[0]),          \
-      [vb1] "v"((tl_).bvoff[1]), [ra] "s"((tl_).rsA), [rb] "s"(rsB), [m0a] "s"(dst_a0 + (unsigned)(dst) * (unsigned)V6_STAGE), \
-      [m0b] "s"(dst_b0 + (unsigned)(dst) * (unsigned)V6_STAGE), [sa] "s"((unsigned)(step) * 512u),                            \
-      [sb] "s"((unsigned)(step) * b_step), [w] "n"(wimm)
+      [va0] "v"((src).va[0]), [va1] "v"((src).va[1]), [va2] "v"((src).va[2]), [va3] "v"((src).va[3]), [vb0] "v"((src).vb[0]), \
+      [vb1] "v"((src).vb[1]), [ra] "s"((src).ra), [rb] "s"(rsB), [m0a] "s"(dst_a0 + (unsigned)(dst) * (unsigned)V6_STAGE),     \
+      [m0b] "s"(dst_b0 + (unsigned)(dst) * (unsigned)V6_STAGE), [sa] "s"((src).sa), [sb] "s"((src).sb), [w] "n"(wimm)
   // (clobbers: the statements advance M0 with s_add_u32, which writes SCC - a compare the compiler placed in front of a
   // statement must not be consumed behind it; M0 itself is only ever written inside these statements)
-#define V6K_STMT_R(REGS, TEXT, tl_, step, dst, wimm) \
-  asm volatile(TEXT : REGS(acc, faL, fbL, faH, fbH) : V6K_INPUTS(tl_, step, dst, wimm) : "memory", "scc")
+#define V6K_STMT_R(REGS, TEXT, tl_, step, dst, wimm)                                                                     \
+  do {                                                                                                                   \
+    const dma_src src_ = src_of(tl_, step);                                                                              \
+    asm volatile(TEXT : REGS(acc, faL, fbL, faH, fbH) : V6K_INPUTS(src_, dst, wimm) : "memory", "scc");                  \
+  } while (0)
 #define V6K_STMT(TEXT, tl_, step, dst, wimm) V6K_STMT_R(V6K_REGS, TEXT, tl_, step, dst, wimm)
   // the six LDS-DMA pieces of K-step `step` of tile tl_ into stage `dst` (no MFMAs, no vector operands: the first two stages
   // of a tile, issued in front of the epilogue of the tile before - which must not see fragments or accumulators as live)
   auto issue = [&](const tile_t& tl_, int step, int dst) {
-    asm volatile(V6K_ISSUE : : V6K_INPUTS(tl_, step, dst, 0) : "memory", "scc");
+    const dma_src src_ = src_of(tl_, step);
+    asm volatile(V6K_ISSUE : : V6K_INPUTS(src_, dst, 0) : "memory", "scc");
   };
   // The reads of H between L's MFMAs: one per MFMA in the first half of L's window, so that the last eight MFMAs cover their
   // latency behind the barrier - for the conv2 launches (POOLV, fused conv1 gradient: -0.5 / -0.4 ms, same-call A/B, twice);
@@ -336,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     V6_STAMP_AT(1);
     // What the epilogue reads from global memory is requested in front of the LAST K-step (tonal_wino43v.hip)
     auto prefetch = [&] {
-      if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_POOLV) return v5_prefetch_pool(p, cur.n0, wn, lr);
+      if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_POOLV || EPI == W_EPI_LRELU) return v5_prefetch_pool(p, cur.n0, wn, lr);
       else if constexpr (EPI == W_EPI_MASK) return v6_prefetch_mask(p, cur.R0, cur.n0, wm, wn, lr, lh);
       else if constexpr (EPI == W_EPI_MASKY) return v6_prefetch_masky(p, cur.R0, cur.n0, wm, wn, lr, lh);
       else return v6_prefetch_c1w(p, cur.R0, cur.n0, wm, wn, lr, lh);
@@ -413,6 +525,9 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
       float* xch = reinterpret_cast<float*>(lds + 3 * V6_STAGE);
       if (full) v6_epilogue_pool<true, true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
       else v6_epilogue_pool<true, false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
+    } else if constexpr (EPI == W_EPI_LRELU) {
+      if (full) v6_epilogue_lrelu<true>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
+      else v6_epilogue_lrelu<false>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
     } else if constexpr (EPI == W_EPI_MASK) {
       if (full) v6_epilogue_mask<true>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
       else v6_epilogue_mask<false>(p, acc, pre, done.R0, done.n0, wm, wn, lr, lh);
@@ -1710,6 +1825,55 @@ extern "C" int tl_wino63_unpool_yvd(const float* G, const uint32_t* bits, float*
   hipLaunchKernelGGL(wino63_unpool_yvd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, bits, Y, Vd,
                      nhex, (long long)g_rows, Tp / 6, g_tp, Tvalid, C, ldg, ld_bits, ldv);
   return check_launch("wino63_unpool_yvd");
+}
+
+// ---- the CNN-RNN classifier's 7-tap convolutions on the F(6,3) NT kernel (reference models/deep_classifiers.py:250-256) ----
+extern "C" int tl_wino63_weights7(const float* w, float* fwd, int O, int I, int taps, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(w && fwd && O > 0 && I > 0 && I % 8 == 0 && taps >= 7 && taps <= 9, "wino63_weights7: I %% 8 == 0 and 7..9 taps needed");
+  const long long n = 3LL * O * I;
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_weights7: grid too large");
+  hipLaunchKernelGGL(wino63_weights7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, fwd, O, I, taps);
+  return check_launch("wino63_weights7");
+}
+
+extern "C" int tl_wino63_xform2(const float* P, float* V0, float* V1, int64_t rows, int Tp, int Tvalid, int C, int ldp, int ldv,
+                                void* stream) {
+  using namespace tl;
+  TL_REQUIRE(P && V0 && V1, "wino63_xform2: null pointer");
+  TL_REQUIRE(Tp > 0 && Tp % 6 == 0 && rows > 0 && rows % Tp == 0 && Tvalid >= 0 && Tvalid <= Tp, "wino63_xform2: Tp %% 6 == 0, whole sequences, Tvalid <= Tp needed");
+  TL_REQUIRE(C > 0 && C % 8 == 0 && ldp >= C && ldp % 4 == 0 && ldv >= C && ldv % 8 == 0, "wino63_xform2: C %% 8, ldp %% 4, ldv %% 8 needed");
+  const long long nhex = rows / 6;
+  const long long n = ((nhex + 1) / 2) * (C / 2);
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_xform2: grid too large");
+  hipLaunchKernelGGL(wino63_xform2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, V0, V1, nhex,
+                     Tp / 6, Tp, Tvalid, C, ldp, ldv);
+  return check_launch("wino63_xform2");
+}
+
+// out[R][n] = LeakyReLU(sum_{j < 7..9} sum_k w[n][k][j] x[R + j][k] + bias[n]) from A = V0, aux = V1 (tl_wino63_xform2 of x) and
+// Bw = tl_wino63_weights7: K = input channels (per segment), ldb >= 3 K
+extern "C" int tl_conv7_wino63v_nt(const tl_nt_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "conv7_wino63: null params");
+  const tl_nt_params& p = *pp;
+  TL_REQUIRE(p.A && p.aux && p.Bw && p.out, "conv7_wino63: null V0 (A) / V1 (aux) / Bw / out");
+  TL_REQUIRE(p.loader == W_LOAD_V && p.epilogue == W_EPI_LRELU && p.row_shift == 0 && p.splitk <= 1,
+             "conv7_wino63: loader 2 (pre-transformed operands), LRELU epilogue, row_shift 0, no split-K");
+  TL_REQUIRE(p.J >= 7 && p.J <= 9, "conv7_wino63: 7..9 taps (three segments)");
+  TL_REQUIRE(p.M > 0 && p.M % 6 == 0 && p.N > 0 && p.N % 32 == 0 && p.K >= 16 && p.K % 8 == 0, "conv7_wino63: M %% 6, N %% 32, K %% 8, K >= 16 needed");
+  TL_REQUIRE(p.lda >= p.K && p.lda % 8 == 0 && p.ldb >= 3 * p.K && p.ldb % 8 == 0 && p.ldo >= p.N, "conv7_wino63: bad leading dimensions");
+  TL_REQUIRE(p.A_rows % 2 == 0 && p.Tp > 0 && p.Tp % 6 == 0 && p.M % p.Tp == 0, "conv7_wino63: V holds hex pairs; Tp %% 6, whole sequences");
+  TL_REQUIRE(8LL * p.N * p.ldb * 4 < (1LL << 31), "conv7_wino63: tap set larger than a buffer resource");
+  TL_REQUIRE(128LL * 8 * p.lda * 4 + 4LL * p.K < (1LL << 31) && p.M + V6_ROWS < (1LL << 31), "conv7_wino63: tile span / M too large");
+  TL_REQUIRE(p.slope >= 0.f && p.slope <= 1.f, "conv7_wino63: LeakyReLU slope must lie in [0, 1]");
+  const long long ntm = (p.M + V6_ROWS - 1) / V6_ROWS;
+  const long long nwg = ntm * ((p.N + V6_BN - 1) / V6_BN);
+  TL_REQUIRE(nwg < (1LL << 31), "conv7_wino63: grid too large");
+  TL_REQUIRE(p.A_rows >= ntm * V6_BH, "conv7_wino63: V0 / V1 must hold whole 128-hex tiles (pad them with zero hexes)");
+  const long long ngrid = nwg < 256 ? nwg : 256;
+  hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_LRELU>), dim3((unsigned)ngrid), dim3(512), 0, (hipStream_t)stream, p);
+  return check_launch("conv7_wino63");
 }
 
 // NT passes on a pre-transformed operand: A = V[hex][8][lda], A_rows = hexes in V (whole 128-hex tiles), M = output rows

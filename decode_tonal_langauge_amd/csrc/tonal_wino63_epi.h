@@ -358,7 +358,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
 // Vector-memory stores every wave issues per tile (lower bound where a branch adds some), see v5_stores
 template <int EPI>
 constexpr int v6_stores() {
-  return EPI == W_EPI_POOL ? 52 : EPI == W_EPI_POOLV ? 70 : EPI == W_EPI_MASK ? 96 : EPI == 6 ? 63 : 0;
+  return EPI == W_EPI_POOL ? 52 : EPI == W_EPI_POOLV ? 70 : (EPI == W_EPI_MASK || EPI == W_EPI_LRELU) ? 96 : EPI == 6 ? 63 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -404,6 +404,42 @@ __device__ __forceinline__ void v6_epilogue_mask(const tl_nt_params& p, const f3
     for (int h = 0; h < 6; ++h) {
       const int r = 6 * e + h;
       const float o = y[h] * selbit(sT[r >> 5], r & 31, 1.f, p.slope);
+      const unsigned vo = FULL ? ovoff : selmu(mask96(inA, inB, r), ovoff, V5_OOB);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsO, vo, (unsigned)r * ldo4, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Plain rows: out[R][col] = LeakyReLU(y + bias) - the 7-tap convolutions of the CNN-RNN classifier (tl_conv7_wino63v_nt,
+// reference models/deep_classifiers.py:250-256), whose three 3-tap segments the K loop has summed in the transform domain.
+// ------------------------------------------------------------------------------------------
+template <bool FULL>
+__device__ __forceinline__ void v6_epilogue_lrelu(const tl_nt_params& p, const f32x16 (&acc)[8], const v5_pre_pool& pre, long long R0,
+                                                  int n0, int wm, int wn, int lr_in, int lh) {
+  int lr = lr_in;                                           // (opaque copy: see v6_epilogue_c1w)
+  asm volatile("" : "+v"(lr));
+  const int colbase = n0 + wn * 32;
+  const bool colok = colbase < p.N;
+  const int col = colbase + lr;
+  const long long Rw = R0 + wm * 192;                       // first row of the wave; a half covers 96 rows
+  const __amdgpu_buffer_rsrc_t rsO = rsrc_of(p.out + Rw * (long long)p.ldo, (p.M - Rw) * (long long)p.ldo * 4);
+  const unsigned ovoff = colok ? ((unsigned)(96 * lh) * (unsigned)p.ldo + (unsigned)col) * 4u : V5_OOB;
+  const unsigned ldo4 = (unsigned)p.ldo * 4u;
+  bits96 inA = {~0ull, ~0u}, inB = inA;
+  if (!FULL) {
+    inA = v6_in_bits96(Rw, p.M);
+    inB = v6_in_bits96(Rw + 96, p.M);
+  }
+  const float bv = pre.bv;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float y[6];
+    wino63_rows(acc, e, y);
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      const int r = 6 * e + h;
+      const float o = lrelu01(y[h] + bv, p.slope);
       const unsigned vo = FULL ? ovoff : selmu(mask96(inA, inB, r), ovoff, V5_OOB);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsO, vo, (unsigned)r * ldo4, 0);
     }

@@ -233,6 +233,18 @@ int tl_wino63_unpool_yvd(const float* G, const uint32_t* bits, float* Y, float* 
                          int g_tp, int Tvalid, int C, int ldg, int ld_bits, int ldv, void* stream);
 int tl_conv1_fwd_v6(const float* x, const float* w, const float* b, float* P, float* V, uint32_t* bits, uint32_t* sign,
                     int64_t S, int T, int ktaps, int C1, int Tp, int Tout, float slope, void* stream);
+/* Round 5 - the CNN-RNN classifier's 7-tap (7,1) convolutions + LeakyReLU (models/deep_classifiers.py:250-256) on the F(6,3) NT
+ * kernel: three 3-tap segments summed in the transform domain by ONE launch whose K loop runs over 3 K channels.
+ *   tl_wino63_xform2     x rows [seq * Tp + t][C] -> V0 = B^T (rows 6h .. 6h+7), V1 = B^T (rows 6h+3 .. 6h+10), pair layout, rows
+ *                        from Tvalid on taken as zero (segment 2 - rows 6h+6 .. 6h+13 - is V0 of hex h + 1: no third array)
+ *   tl_wino63_weights7   w (O, I, taps = 7..9) -> taps [3 I / 8][8][O][8] (segment s = taps 3s .. 3s+2, missing ones zero)
+ *   tl_conv7_wino63v_nt  A = V0, aux = V1 (A_rows hexes each, whole 128-hex tiles), Bw = the taps, K = I, ldb >= 3 K, J = 7..9,
+ *                        loader 2, epilogue LRELU: out[R][n] = lrelu(conv + bias), R < M (M % 6 == 0).  Windows stop at the end
+ *                        of their sequence EXCEPT in the last hex of a sequence (rows t >= Tp - 6), whose third segment is
+ *                        the first hex of the next sequence: those rows are never valid outputs of a 7-tap convolution     */
+int tl_wino63_xform2(const float* P, float* V0, float* V1, int64_t rows, int Tp, int Tvalid, int C, int ldp, int ldv, void* stream);
+int tl_wino63_weights7(const float* w, float* fwd, int O, int I, int taps, void* stream);
+int tl_conv7_wino63v_nt(const tl_nt_params* p, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
 int tl_sizeof_nt_params(void);
 int tl_sizeof_tn_params(void);

@@ -153,6 +153,67 @@ def test_segmented_winograd_conv7_against_float64(dev, nseq, Tp, cin, cout, taps
     assert lib.tl_conv7_wino43_nt(C.byref(p), st) != 0
 
 
+@pytest.mark.parametrize("nseq,Tp,tvalid,cin,cout,taps", [(3, 24, 21, 64, 96, 7), (2, 516, 516, 32, 64, 7), (700, 198, 197, 64, 64, 7),
+                                                          (5, 12, 12, 16, 32, 9), (4, 18, 13, 48, 160, 8)])
+def test_conv7_on_the_f63_nt_kernel_against_float64(dev, nseq, Tp, tvalid, cin, cout, taps):
+    """Round 5: tl_wino63_xform2 + tl_wino63_weights7 + tl_conv7_wino63v_nt (a 7..9-tap convolution + LeakyReLU as three
+    F(6,3) segments summed in the transform domain by ONE launch of the synthesis stack's V-form NT kernel; the third segment
+    re-reads V0 one hex on) against a float64 sliding-window convolution.  Rows of a sequence from ``tvalid`` on enter as
+    zeros and a window stops at its sequence's end (the operand's hexes are per sequence): that is what the reference
+    computes for every row the classifier reads.  Ragged column tile, partial row tiles, a shape with several tiles per
+    persistent workgroup, 7 / 8 / 9 taps; a second launch is bit-identical."""
+    import ctypes as C
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._lib import NtParams, LOAD_V, EPI_LRELU, check, ptr
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(100 * nseq + taps)
+    rows = nseq * Tp
+    x = torch.randn(rows, cin, generator=gen)
+    w = torch.randn(cout, cin, taps, generator=gen) / np.sqrt(cin * taps)
+    b = torch.randn(cout, generator=gen)
+    xd, wd, bd = x.to(dev), w.to(dev).contiguous(), b.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nh = rows // 6
+    nh_pad = (nh + 2 + 127) // 128 * 128
+    V0 = torch.zeros(nh_pad, 8, cin, device=dev)
+    V1 = torch.zeros(nh_pad, 8, cin, device=dev)
+    check(lib.tl_wino63_xform2(ptr(xd), ptr(V0), ptr(V1), rows, Tp, tvalid, cin, cin, cin, st), "tl_wino63_xform2")
+    wp = torch.empty(3 * cin // 8, 8, cout, 8, device=dev)
+    check(lib.tl_wino63_weights7(ptr(wd), ptr(wp), cout, cin, taps, st), "tl_wino63_weights7")
+    outs = []
+    for _ in range(2):
+        out = torch.full((rows, cout + 4), float("nan"), device=dev)
+        p = NtParams()
+        p.A, p.aux, p.Bw, p.bias, p.out = ptr(V0), ptr(V1), ptr(wp), ptr(bd), ptr(out)
+        p.M, p.A_rows, p.N, p.K, p.lda, p.ldb, p.ldo = rows, nh_pad, cout, cin, cin, 3 * cin, cout + 4
+        p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = taps, 0, Tp, Tp, 0.3
+        p.loader, p.epilogue, p.splitk, p.bm = LOAD_V, EPI_LRELU, 1, 128
+        check(lib.tl_conv7_wino63v_nt(C.byref(p), st), "tl_conv7_wino63v_nt")
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][:, :cout], outs[1][:, :cout]) and bool(torch.isnan(outs[0][:, cout:]).all())
+    xs = x.double().view(nseq, Tp, cin).clone()
+    xs[:, tvalid:] = 0
+    xpad = torch.nn.functional.pad(xs, (0, 0, 0, taps))               # a window does not cross into the next sequence
+    ref = torch.zeros(nseq, Tp, cout, dtype=torch.float64)
+    for j in range(taps):
+        ref += xpad[:, j:j + Tp] @ w[:, :, j].double().T
+    ref = torch.nn.functional.leaky_relu(ref + b.double(), 0.3).view(rows, cout)
+    got = outs[0][:, :cout].cpu().double()
+    assert torch.isfinite(got).all()
+    # (the LAST hex of a sequence is outside the contract: its third segment is the first hex of the next sequence - no row of
+    # it can be a valid output of a 7-tap convolution, whose valid rows end at tvalid - taps + 1 <= Tp - 6)
+    keep = (torch.arange(rows) % Tp) < Tp - 6
+    assert float((got - ref)[keep].abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    # bad arguments are refused
+    p.ldb = 2 * cin
+    assert lib.tl_conv7_wino63v_nt(C.byref(p), st) != 0 and b"leading" in lib.tl_last_error()
+    p.ldb, p.J = 3 * cin, 3
+    assert lib.tl_conv7_wino63v_nt(C.byref(p), st) != 0
+    p.J, p.aux = taps, None
+    assert lib.tl_conv7_wino63v_nt(C.byref(p), st) != 0
+
+
 def _chain_steps():
     return deepcopy(gi.CHAIN_STEPS)
 
