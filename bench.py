@@ -327,6 +327,19 @@ def lite_subresult(dev, steps: int = 200, warm: int = 20):
             "cpu_reference_ms_per_step": 19.0, "cpu_reference_note": "SURVEY section 6: reference trainer on 8 host cores"}
 
 
+def with_kernels(setting: str, fn):
+    """Run ``fn`` under TONAL_KERNELS=<setting> (appended to what is set), restoring the variable afterwards."""
+    old = os.environ.get("TONAL_KERNELS")
+    os.environ["TONAL_KERNELS"] = setting if not old else old + "," + setting
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop("TONAL_KERNELS", None)
+        else:
+            os.environ["TONAL_KERNELS"] = old
+
+
 def signal_subresult(dev, with_cpu: bool):
     """C5 signal stage: frequency_filter methods on 256 ch x 24 000 float32 samples @ 400 Hz, in HBM."""
     import numpy as np
@@ -337,18 +350,10 @@ def signal_subresult(dev, with_cpu: bool):
     x = torch.from_numpy(x_np).to(dev)
     out = {"shape": [C, T], "fs": FS, "dtype_in": "f32", "dtype_out": "f64"}
     def hilbert_dft():
-        os.environ["TONAL_HILBERT"] = "fft"
-        try:
-            return ff.hilbert_filter(x, FS, [70., 150.])
-        finally:
-            os.environ.pop("TONAL_HILBERT", None)
+        return with_kernels("hilbert=fft", lambda: ff.hilbert_filter(x, FS, [70., 150.]))
 
     def hilbert_f32():
-        os.environ["TONAL_HILBERT_F32"] = "1"
-        try:
-            return ff.hilbert_filter(x, FS, [70., 150.])
-        finally:
-            os.environ.pop("TONAL_HILBERT_F32", None)
+        return with_kernels("hilbert_f32=1", lambda: ff.hilbert_filter(x, FS, [70., 150.]))
 
     cases = [("hilbert", lambda: ff.hilbert_filter(x, FS, [70., 150.]), 8),
              ("hilbert_f32_math", hilbert_f32, 8),               # opt-in: fp32 transforms end to end (ols_bank_bl_kernel<float,8,float>)

@@ -13,6 +13,7 @@ from typing import Dict, List, Tuple
 
 import torch
 
+from . import _kernels
 from ._cnn_engine import CnnEngine, _r4
 from ._lib import EPI_LRELU, EPI_STORE, LOAD_DIRECT, check, ptr
 
@@ -166,7 +167,7 @@ class LstmInferEngine:
         self.Kp, self.Hp = _r4(in_dim), (hidden + 7) // 8 * 8
         self._packed = None
         # "1": one fused launch per step (tl_lstm_infer_seq_fused); "0": split-K GEMM + cell launch per step
-        self.fused = os.environ.get("TONAL_LSTM_FUSED", "1") != "0"
+        self.fused = _kernels.get("lstm_fused") != "0"
 
     def _weights(self, w_ih, w_hh, b_ih, b_hh):
         ver = tuple((t._version, t.data_ptr()) for t in (w_ih, w_hh, b_ih, b_hh))
@@ -217,7 +218,7 @@ class LstmInferEngine:
         tiles = ((B + 31) // 32) * ((4 * Hp + 127) // 128)
         # split factor: about one workgroup per CU.  Measured on the C5 shapes (hidden 800, batch 64, 400 steps):
         # 2 -> 9.2 ms, 4 -> 8.0, 6 -> 8.4, 10 -> 10.4, 20 (whole rounds of 512) -> 16.3; MIOpen 9.0 ms
-        sk = int(os.environ.get("TONAL_LSTM_SK", "0")) or max(1, 224 // tiles)
+        sk = int(_kernels.get("lstm_sk")) or max(1, 224 // tiles)
         sk = max(1, min(sk, (Hp + 31) // 32))
         slab = torch.empty(sk, B, 4 * Hp, **f32)
         # phase 2: the T dependent steps, enqueued from C in one call (tl_lstm_infer_seq)
@@ -256,9 +257,8 @@ class CnnRnnConvEngine:
         # transformed arrays exist); "wino43+1" two F(4,3) segments (taps 0..5) plus tap 6 as a one-tap GEMM added in the
         # epilogue; "wino43" three F(4,3) segments; "direct" the 7-tap window GEMM.  CNN-RNN forward at C5 (batch 64), rounds
         # 2-4: 57.0 (wino43+1) / 60.3 / 72.8 ms
-        self.conv7_form = os.environ.get("TONAL_CONV7", "wino63")
-        if self.conv7_form not in ("wino63", "wino43", "wino43+1", "direct"):
-            raise ValueError("TONAL_CONV7 must be wino63, wino43, wino43+1 or direct")
+        _kernels.validate()
+        self.conv7_form = _kernels.get("conv7")
         # rows per sequence: whole hexes for the F(6,3) form, whole quads for the others
         self.Tp = (self.t1 + 5) // 6 * 6 if self.conv7_form == "wino63" else (self.t1 + 3) // 4 * 4
         self._packed: Dict[str, Tuple[tuple, torch.Tensor]] = {}

@@ -21,7 +21,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import _lib
+from . import _kernels, _lib
 from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_MASKY, EPI_POOL, EPI_POOLV, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, LOAD_V,
                    LOAD_Y, NtParams, TnParams, check, ptr)
 
@@ -73,7 +73,8 @@ class CnnEngine:
         # 6 conv rows).  A sequence of stage 2 holds a multiple of 12 rows (hexes of 6 rows, pooled into hexes of stage 3);
         # the pooled output of stage 3 keeps the row stride of the default geometry (tl_nt_params.out_tp), so everything from
         # stage 4 on is unchanged.  Shapes the form does not cover fall back to TONAL_WINO=4 as a whole.
-        self.wino63 = (self.F63_CAPABLE and os.environ.get("TONAL_WINO", "6") == "6"
+        _kernels.validate()                    # TONAL_KERNELS: unknown keys / values raise here, not on the hot path
+        self.wino63 = (self.F63_CAPABLE and _kernels.get("wino") == "6"
                        and self._f63_covers(stage_defs, n_timepoints))
         tp1_default = self.tp1
         if self.wino63:
@@ -82,11 +83,11 @@ class CnnEngine:
         # rows G2 (epilogue 6 of tl_conv3_wino63v_nt): the weight gradient of stage 2 then runs without a transform
         # (tl_conv3_wino63v_tn, loader 3; needs C_in of stage 2 % 256 == 0).  TONAL_F63_YPROD=0: off (G2 is stored, the
         # weight-gradient kernel un-pools and transforms it itself, as stage 3's does)
-        self.f63_yprod = (self.wino63 and os.environ.get("TONAL_F63_YPROD", "1") != "0" and stage_defs[0][0] % 256 == 0
+        self.f63_yprod = (self.wino63 and _kernels.get("f63_yprod") != "0" and stage_defs[0][0] % 256 == 0
                           and self.tp1 >= 12)
         # ... and stage 3's (whose gradient rows no Winograd epilogue produces) from a kernel of its own, tl_wino63_unpool_yvd
         # (TONAL_F63_YPROD3=0: its weight-gradient kernel un-pools and transforms G3 itself and writes Vd3)
-        self.f63_yprod3 = (self.wino63 and os.environ.get("TONAL_F63_YPROD3", "1") != "0" and stage_defs[1][0] % 256 == 0)
+        self.f63_yprod3 = (self.wino63 and _kernels.get("f63_yprod3") != "0" and stage_defs[1][0] % 256 == 0)
         self.stages: List[_Stage] = []
         cin, tin, tp = self.c1, self.tout1, self.tp1
         for i, (cout, k, pool) in enumerate(stage_defs[1:], start=2):
@@ -126,36 +127,36 @@ class CnnEngine:
         #      north-star shape); rounding error against the direct kernels 1.4e-6 vs 8e-7.  Against the
         #      reference golden all three forms sit at the same noise floor (scripts/update_parity.py,
         #      DESIGN.md section 6)
-        mode = os.environ.get("TONAL_WINO", "6")
+        mode = _kernels.get("wino")
         if mode == "6":
             mode = "4"                          # (the F(4,3) predicates describe the fallback; wino63 overrides stages 2, 3)
         self.wino = mode != "0"
         self.wino43 = mode == "4"
         # weight gradient: F(4,3) with the transforms applied at LDS-staging time (tonal_wino43_tn.hip; half
         # the direct-form MFMA work) under TONAL_WINO=4 unless TONAL_WINO_TN=2 asks for the F(2,3) kernel
-        self.wino43_tn = self.wino43 and os.environ.get("TONAL_WINO_TN", "4") == "4"
+        self.wino43_tn = self.wino43 and _kernels.get("wino_tn") == "4"
         # round 3: the F(4,3) input transform V = B^T d is written once by the producer of an activation and the
         # forward / weight-gradient GEMMs read it by LDS-DMA (tonal_wino43v.hip).  TONAL_WINO_V: 0 off, 1 on
-        self.wino_v = self.wino43 and os.environ.get("TONAL_WINO_V", "1") != "0"
+        self.wino_v = self.wino43 and _kernels.get("wino_v") != "0"
         # with V written by the first stage the raw pooled rows P1 (13.4 GB at the north-star shape) have no reader
         # left (the LeakyReLU' mask of the backward pass comes from the 1-bit sign array); store_p1 keeps them anyway
-        self.store_p1 = os.environ.get("TONAL_STORE_P1", "0") == "1"
+        self.store_p1 = _kernels.get("store_p1") == "1"
         # round 4: the forward epilogue of a pooled 3-tap stage whose successor reads V writes that V itself (epilogue 5 of
         # tl_conv3_wino43v_nt + tl_wino43_v_fixup): the stand-alone transform kernel and the raw pooled rows of stage 2
         # (6.6 GB written, 6.6 GB re-read at the north-star shape) go; store_p1 keeps the raw rows as well (tests).  0: off
-        self.wino_vout = os.environ.get("TONAL_WINO_VOUT", "1") != "0"
+        self.wino_vout = _kernels.get("wino_vout") != "0"
         # fold the first stage's weight gradient into the stage-2 input-gradient epilogue (Winograd kernels)
-        self.fuse_c1 = os.environ.get("TONAL_FUSE_C1", "1") != "0"
+        self.fuse_c1 = _kernels.get("fuse_c1") != "0"
         # TONAL_OVERLAP=1: run the label LSTM (forward and BPTT: HBM-bound streams of the 5.4 GB W_hh) and the W_hh update
         # on a side stream beside the MFMA-bound convolution stack they do not depend on.  Measured equal to one stream
         # (251.1 vs 250.7 ms): a conv workgroup holds 144 KB of LDS and both waves' worth of registers of every SIMD, so
         # the streaming kernels (which stage through LDS too) find no free CU and the two streams serialise.  Off.
-        self.overlap = os.environ.get("TONAL_OVERLAP", "0") == "1"
-        self.vd_mode = os.environ.get("TONAL_WINO_VD", "tn")
+        self.overlap = _kernels.get("overlap") == "1"
+        self.vd_mode = _kernels.get("wino_vd")
         # C_in tile of the V-form weight-gradient kernel: 0 = 128 (8 waves, wino43v_tn8_kernel) where the shape allows, else
         # 64; 64 / 127 force the 4-wave kernel / the 8-wave kernel that stages Y through registers (the A/B partners: same
         # results bit for bit)
-        self.tn_bm = int(os.environ.get("TONAL_TN_BM", "0"))
+        self.tn_bm = int(_kernels.get("tn_bm"))
         self._side = None
         self._B = None
         self.generation = 0
@@ -318,7 +319,7 @@ class CnnEngine:
         """The F(6,3) kernels cover the stack: stages 2 and 3 are pooled 3-tap convolutions with C_in % 128 == 0 and
         C_out % 64 == 0, the first stage has 1..3 taps, one input channel and a width tl_conv1_fwd_v6 takes, and the fused
         first-stage weight gradient can read its sample windows."""
-        if len(stage_defs) < 4 or os.environ.get("TONAL_FUSE_C1", "1") == "0":
+        if len(stage_defs) < 4 or _kernels.get("fuse_c1") == "0":
             return False
         (c1, k1, p1), (c2, k2, p2), (c3, k3, p3) = stage_defs[0], stage_defs[1], stage_defs[2]
         tout1 = (T - k1 + 1) // 2
@@ -397,7 +398,7 @@ class CnnEngine:
         ldg = nd
         V = self._v_ready[st.idx - 1]
         tiles = (st.cin // 64) * (nd // 64)
-        sk = self._splitk(tiles, (rows_in + 35) // 36, int(os.environ.get("TONAL_TN_TARGET", "4096")))
+        sk = self._splitk(tiles, (rows_in + 35) // 36, int(_kernels.get("tn_target") or "4096"))
         slab = torch.empty(sk, 8 * st.cin, ldg, **f32)
         bias_part = torch.empty(sk, nd, **f32)
         if (st.idx == 3 and self.f63_yprod3 and self._y_ready.get(3) != self.generation):
@@ -749,7 +750,7 @@ class CnnEngine:
             tiles = ((st.cin + 63) // 64) * ((nd + 63) // 64)
             # (the 8-wave kernel, one workgroup per CU: 8 rounds of 256 measure 0.3 ms better at conv2 than 16 - 42.2 / 42.55 ms)
             tn8 = self._use_wino_v(st) and self._tn_bm(st) == 128
-            sk = self._splitk(tiles, (rows_in + 31) // 32, int(os.environ.get("TONAL_TN_TARGET", "4096" if tn8 else "8192")))
+            sk = self._splitk(tiles, (rows_in + 31) // 32, int(_kernels.get("tn_target") or ("4096" if tn8 else "8192")))
             slab = torch.empty(sk, 6 * st.cin, ldg, **f32)
             bias_part = torch.empty(sk, nd, **f32)     # the kernel's Y1 = sum of the quad's dZ rows doubles as the bias gradient
             kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=rows_in, B_rows=Gs.shape[0],

@@ -1,0 +1,117 @@
+"""ONE validated setting for every kernel-selection switch of the package: ``TONAL_KERNELS``.
+
+    TONAL_KERNELS="wino=4,fuse_c1=0"  python train_synthesizer.py ...
+
+A comma-separated list of ``key=value`` pairs.  Unknown keys and values that a key does not take raise ``ValueError`` where
+the setting is read - engine construction - instead of silently selecting something (round 4's review: 26 independent
+``TONAL_*`` variables read in product code, any of which could quietly put a round-1 kernel on the hot path).  Nothing set =
+the defaults = the kernels ``bench.py`` times.
+
+The per-switch variables of rounds 1-4 (``TONAL_WINO``, ``TONAL_WINO_V``, ...) still exist for the A/B tests and the timing
+scripts, which flip one switch at a time - but ONLY under ``TONAL_AB=1`` (tests/conftest.py sets it): a legacy variable found
+in the environment without it raises, naming the ``TONAL_KERNELS`` key that replaces it.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Dict, Tuple, Union
+
+_Allowed = Union[frozenset, Callable[[str], bool]]
+
+
+def _int(lo: int, hi: int) -> Callable[[str], bool]:
+    def ok(v: str) -> bool:
+        try:
+            return lo <= int(v) <= hi
+        except ValueError:
+            return False
+    return ok
+
+
+_B = frozenset({"0", "1"})
+#: key -> (legacy variable, allowed values, default, what it selects)
+KEYS: Dict[str, Tuple[str, _Allowed, str, str]] = {
+    # ---- SynthesisModelCNN conv stack (_cnn_engine.py)
+    "wino": ("TONAL_WINO", frozenset({"6", "4", "1", "0"}), "6",
+             "conv2 / conv3: 6 Winograd F(6,3) on pre-transformed operands (F(4,3) where the stack does not allow it), 4 F(4,3), "
+             "1 F(2,3), 0 direct MFMA kernels"),
+    "wino_tn": ("TONAL_WINO_TN", frozenset({"4", "2"}), "4", "weight gradient under wino=4: 4 F(4,3), 2 the F(2,3) kernel"),
+    "wino_v": ("TONAL_WINO_V", _B, "1", "F(4,3): operands pre-transformed by their producer (0: transforms inside the GEMM loops)"),
+    "wino_vout": ("TONAL_WINO_VOUT", _B, "1", "F(4,3): the forward epilogue writes the next stage's V"),
+    "wino_vd": ("TONAL_WINO_VD", frozenset({"tn", "side", "0"}), "tn", "F(4,3): who writes the input-gradient operand Vd"),
+    "tn_bm": ("TONAL_TN_BM", frozenset({"0", "64", "127", "128"}), "0", "F(4,3) weight-gradient tiling (0 = auto)"),
+    "tn_target": ("TONAL_TN_TARGET", _int(64, 1 << 20), "", "split-K target of the Winograd weight-gradient kernels"),
+    "f63_yprod": ("TONAL_F63_YPROD", _B, "1", "F(6,3): stage 3's input gradient writes Y2 / Vd2 instead of G2"),
+    "f63_yprod3": ("TONAL_F63_YPROD3", _B, "1", "F(6,3): Y3 / Vd3 from tl_wino63_unpool_yvd"),
+    "fuse_c1": ("TONAL_FUSE_C1", _B, "1", "conv1 weight gradient fused into the conv2 input-gradient epilogue"),
+    "store_p1": ("TONAL_STORE_P1", _B, "0", "keep the raw pooled rows of stages 1 / 2 beside V (tests)"),
+    "overlap": ("TONAL_OVERLAP", _B, "0", "label LSTM / W_hh update on a side stream (measured: does not pay)"),
+    # ---- deep classifiers (_classifier_engine.py)
+    "conv7": ("TONAL_CONV7", frozenset({"wino63", "wino43", "wino43+1", "direct"}), "wino63", "the CNN-RNN classifier's 7-tap convolutions"),
+    "lstm_fused": ("TONAL_LSTM_FUSED", _B, "1", "classifier LSTMs: one fused launch per step"),
+    "lstm_sk": ("TONAL_LSTM_SK", _int(0, 1024), "0", "classifier LSTMs (unfused form): split-K of the W_hh product (0 = auto)"),
+    # ---- optimiser / trainer
+    "nadam_multi": ("TONAL_NADAM_MULTI", _B, "1", "one NAdam launch for all dense tensors"),
+    "graph": ("TONAL_GRAPH", _B, "1", "SynthesisLite step replayed as a HIP graph"),
+    "lstm_shard": ("TONAL_LSTM_SHARD", _B, "1", "data parallel: label LSTM sharded by gate rows"),
+    # ---- preprocess/signal
+    "hilbert": ("TONAL_HILBERT", frozenset({"auto", "ols", "sym", "taps", "fft"}), "auto", "Hilbert bank: force a path"),
+    "hilbert_bl": ("TONAL_HILBERT_BL", _B, "1", "band-limited overlap-save (0: all 1024 bins per band)"),
+    "hilbert_f32": ("TONAL_HILBERT_F32", _B, "0", "float32 recordings: fp32 transforms end to end (default: fp64 math)"),
+    "hilbert_sym": ("TONAL_HILBERT_SYM", _B, "1", "Hermitian-symmetric time-domain kernel"),
+    "fir": ("TONAL_FIR", frozenset({"ols", "taps"}), "ols", "FIR bank by overlap-save (taps: time domain)"),
+}
+_LEGACY = {v[0]: k for k, v in KEYS.items()}
+_cache: Tuple[str, Dict[str, str]] = ("", {})
+
+
+def _check(key: str, value: str) -> str:
+    allowed = KEYS[key][1]
+    ok = allowed(value) if callable(allowed) else value in allowed
+    if not ok:
+        what = "an integer in range" if callable(allowed) else "one of " + ", ".join(sorted(allowed))
+        raise ValueError(f"TONAL_KERNELS: {key}={value!r} is not a value this switch takes ({what})")
+    return value
+
+
+def _parsed() -> Dict[str, str]:
+    global _cache
+    raw = os.environ.get("TONAL_KERNELS", "")
+    if raw == _cache[0]:
+        return _cache[1]
+    out: Dict[str, str] = {}
+    for item in raw.split(","):
+        item = item.strip()
+        if not item:
+            continue
+        key, sep, value = item.partition("=")
+        key, value = key.strip(), value.strip()
+        if not sep or key not in KEYS:
+            raise ValueError(f"TONAL_KERNELS: unknown setting {item!r}; keys: " + ", ".join(sorted(KEYS)))
+        out[key] = _check(key, value)
+    _cache = (raw, out)
+    return out
+
+
+def get(key: str, default: str = None) -> str:
+    """The value of switch ``key``: from ``TONAL_KERNELS``, else (under ``TONAL_AB=1`` only) from its legacy variable, else
+    ``default`` (or the table's default)."""
+    legacy, _allowed, table_default, _doc = KEYS[key]
+    spec = _parsed()
+    if key in spec:
+        return spec[key]
+    if legacy in os.environ:
+        if os.environ.get("TONAL_AB") != "1":
+            raise RuntimeError(f"{legacy} is an A/B switch of the test suite and is ignored by the product: use "
+                               f"TONAL_KERNELS={key}={os.environ[legacy]} (or set TONAL_AB=1 to run an A/B comparison)")
+        return _check(key, os.environ[legacy])
+    return table_default if default is None else default
+
+
+def validate() -> None:
+    """Raise for an unknown key / value in ``TONAL_KERNELS`` or a legacy switch without ``TONAL_AB=1`` (engine construction)."""
+    _parsed()
+    if os.environ.get("TONAL_AB") != "1":
+        for legacy, key in _LEGACY.items():
+            if legacy in os.environ:
+                get(key)

@@ -1253,7 +1253,9 @@ extern "C" int tl_gemm_nt_window(const tl_nt_params* pp, void* stream) {
   // stages - conv4 / conv5 forward, the 1x1 stack, the Linear layer - it is the faster one (train step 209.7 -> 208.9 ms,
   // same-call A/B, round 4): default on; TONAL_GLDS=0 selects the register-staged kernel (the A/B partner,
   // tests/test_gpu_parity.py holds the two against each other).
-  const char* genv = getenv("TONAL_GLDS");
+  // (an A/B switch of the test suite: honoured only under TONAL_AB=1, like the per-switch variables of _kernels.py)
+  const char* ab = getenv("TONAL_AB");
+  const char* genv = (ab != nullptr && ab[0] == '1') ? getenv("TONAL_GLDS") : nullptr;
   const bool glds_on = genv == nullptr || genv[0] != '0';
   if (glds_on && p.J <= 3 && p.bm == 128 && p.loader == LOAD_DIRECT && p.row_shift == 0 && (p.K % GK) == 0 && p.A_rows > 0) {
     switch (p.epilogue) {

@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 from torch.utils.data import DataLoader
 
-from .. import _lib, parallel
+from .. import _kernels, _lib, parallel
 from .._lib import check, ptr
 from ..optim import FusedNAdam
 from .classifier import ClassifierModel
@@ -111,11 +111,11 @@ class SynthesisTrainer:
         self.rank, self.world = parallel.world()
         self.dp = parallel.active()
         self._whh_dirty = False
-        self._graph_enabled = os.environ.get("TONAL_GRAPH", "1") != "0"
+        self._graph_enabled = _kernels.get("graph") != "0"
         self._graphs, self._g_scal = {}, None
         eng = getattr(self.model, "_engine", None)
         if (self.dp and eng is not None and hasattr(eng, "lstm_shard") and self._pair_table is not None
-                and os.environ.get("TONAL_LSTM_SHARD", "1") != "0"):
+                and _kernels.get("lstm_shard") != "0"):
             eng.lstm_shard = (self.rank, self.world)        # row-sharded label LSTM (parallel.py docstring)
             # Between steps each rank holds current values only for its own rows of weight_hh_l0.  `train` / `evaluate`
             # re-assemble it, but `train_step` is public: anything that reads the whole model (state_dict -> checkpoints)

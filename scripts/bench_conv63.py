@@ -4,6 +4,7 @@
 Prints ms, algorithmic TFLOP/s (direct-convolution FLOPs of the valid rows) and the MFMA TFLOP/s issued.
 """
 import argparse, os, sys
+os.environ.setdefault("TONAL_AB", "1")      # timing / A/B script: the per-switch variables are honoured (_kernels.py)
 os.environ["TONAL_WINO"] = "6"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

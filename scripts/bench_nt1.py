@@ -1,6 +1,7 @@
 """Timing of the one-tap NT GEMM launches of the train step in isolation (1x1 stack layer, its input gradient, conv4 / conv5
 forward) - for build variants selected with TONAL_HIP_LIB (scripts/build_variant.sh tonal_gemm.hip 'name|-DG_ABL=..|')."""
 import os, sys
+os.environ.setdefault("TONAL_AB", "1")      # timing / A/B script: the per-switch variables are honoured (_kernels.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from decode_tonal_langauge_amd import _lib

@@ -5,6 +5,7 @@ tl_hilbert_ols (1024-point inverse per band, workgroup-wide) and tl_hilbert_ols_
     python scripts/check_hilbert_bl.py [--iters 20]
 """
 import argparse, os, sys
+os.environ.setdefault("TONAL_AB", "1")      # timing / A/B script: the per-switch variables are honoured (_kernels.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

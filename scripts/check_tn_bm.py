@@ -6,6 +6,7 @@ turns at Vd).  They must agree bit for bit (same k order per accumulator): weigh
     python scripts/check_tn_bm.py [--batch 4] [--channels 16] [--iters 5]
 """
 import argparse, os, sys
+os.environ.setdefault("TONAL_AB", "1")      # timing / A/B script: the per-switch variables are honoured (_kernels.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("TONAL_TN_TARGET", "4096")     # the same reduction splits for every tiling (bit-identity needs that)
 import torch

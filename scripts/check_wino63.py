@@ -7,6 +7,7 @@ gradient and the fused conv1 weight gradient.  Prints relative errors; exit code
     python scripts/check_wino63.py [--shape B,C,T,c1,c2,c3]
 """
 import os
+os.environ.setdefault("TONAL_AB", "1")      # timing / A/B script: the per-switch variables are honoured (_kernels.py)
 import sys
 
 import torch

@@ -1,5 +1,6 @@
 """3-step NAdam update of golden G4 under the three conv forms: relative L2 of the update vs the reference golden."""
 import os, sys
+os.environ.setdefault("TONAL_AB", "1")      # timing / A/B script: the per-switch variables are honoured (_kernels.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests import golden_inputs as gi

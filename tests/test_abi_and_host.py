@@ -349,3 +349,34 @@ def test_state_dict_of_a_row_sharded_model_raises_instead_of_hiding_a_collective
         SynthesisTrainer._state_dict_guard(fake, None, "", False)
     fake._whh_dirty = False
     SynthesisTrainer._state_dict_guard(fake, None, "", False)      # in sync: nothing to do
+
+
+def test_kernel_setting_is_one_validated_variable(monkeypatch):
+    """TONAL_KERNELS: unknown keys / values raise where the setting is read; the per-switch variables of rounds 1-4 are
+    honoured only under TONAL_AB=1 (the A/B tests) and raise otherwise, naming their replacement."""
+    from decode_tonal_langauge_amd import _kernels
+    monkeypatch.delenv("TONAL_KERNELS", raising=False)
+    monkeypatch.delenv("TONAL_WINO", raising=False)
+    assert _kernels.get("wino") == "6" and _kernels.get("conv7") == "wino63" and _kernels.get("hilbert_f32") == "0"
+    monkeypatch.setenv("TONAL_KERNELS", "wino=4, fuse_c1=0,tn_target=2048")
+    assert _kernels.get("wino") == "4" and _kernels.get("fuse_c1") == "0" and _kernels.get("tn_target") == "2048"
+    assert _kernels.get("wino_v") == "1"                               # not mentioned: the default
+    for bad in ("wino=5", "winograd=4", "wino", "tn_target=abc", "hilbert=fast"):
+        monkeypatch.setenv("TONAL_KERNELS", bad)
+        with pytest.raises(ValueError):
+            _kernels.validate()
+    monkeypatch.setenv("TONAL_KERNELS", "wino=0")
+    monkeypatch.setenv("TONAL_WINO", "1")                              # TONAL_KERNELS wins over a legacy variable
+    assert _kernels.get("wino") == "0"
+    monkeypatch.delenv("TONAL_KERNELS")
+    monkeypatch.setenv("TONAL_AB", "1")
+    assert _kernels.get("wino") == "1"
+    monkeypatch.setenv("TONAL_WINO", "7")
+    with pytest.raises(ValueError):
+        _kernels.get("wino")
+    monkeypatch.setenv("TONAL_WINO", "1")
+    monkeypatch.delenv("TONAL_AB")
+    with pytest.raises(RuntimeError, match="TONAL_KERNELS=wino=1"):
+        _kernels.get("wino")
+    with pytest.raises(RuntimeError):
+        _kernels.validate()
