@@ -18,6 +18,9 @@ __device__ __forceinline__ void v6_stamp(unsigned long long* st, int k) {
   if (st != nullptr) st[k] = __builtin_amdgcn_s_memtime();
 }
 
+#ifndef V6_ST_AUX
+#define V6_ST_AUX 0
+#endif
 constexpr unsigned V6_DROP = 0x80000000u;     // added to any in-range byte offset (< 2^31) it stays past every resource
 constexpr unsigned long long V6_HI = 0xffffffff00000000ull;
 
@@ -28,8 +31,10 @@ constexpr unsigned long long V6_HI = 0xffffffff00000000ull;
 // from run to run).
 template <bool IMM>
 __device__ __forceinline__ void v6_store_at(float x, __amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned so, unsigned k) {
-  if constexpr (IMM) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs, vo + k, so, 0);
-  else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs, vo, so + k, 0);
+  // V6_ST_AUX: cache policy of the bulk V / Y / Vd stores (0 default; 2 nt; 16 sc1 = write through and drop the line from the
+  // XCD's L2 - the consumers are later launches: measured in round 5, see profiles/r05_kernel_notes.md)
+  if constexpr (IMM) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs, vo + k, so, V6_ST_AUX);
+  else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rs, vo, so + k, V6_ST_AUX);
 }
 
 // [aL | aH], [bL | bH] -> [aL | bL], [aH | bH]   (L / H: lanes 0-31 / 32-63; v_permlane32_swap)

@@ -1,0 +1,51 @@
+"""profiles/r05_c3_step_summary.md from the committed rocprofv3 kernel stats, PMC traffic, clock pass and bench line of round 5.
+
+    python scripts/make_profile_summary_r05.py
+"""
+import csv, json, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = lambda *a: os.path.join(ROOT, "profiles", *a)
+rows = list(csv.DictReader(open(P("r05_c3_step_kernel_stats.csv"))))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+tr = json.load(open(P("pmc_traffic.json")))
+ck = json.load(open(P("effective_clock.json")))["effective_clock_ghz"]
+line = json.loads([l for l in open(P("r05_c3_bench_line.log")) if l.startswith("{")][-1])
+roof = line["roofline"]
+pl = roof["per_launch"]
+out = ["# Round 5 - C3 train step, 1x MI355X, rocprofv3 --kernel-trace --stats (asm K loop build, `gpurun_out/r05f`)\n",
+       "Command (GPU box, `R05TAG=r05f scripts/collect_r05_profiles.sh bench c3stats c3fetch c3write c3clock sq c5`, one call, one box): "
+       "`rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -o r3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+       "--no-kernel-timers --no-extras`\n",
+       f"4 train steps (1 warm-up incl. the one-time zero-fills + 3 timed) of SynthesisModelCNN 128ch x 400t, batch 256, fp32.  Total kernel time "
+       f"{tot/1e6:.1f} ms = {tot/1e6/4:.1f} ms/step under the profiler; the un-profiled default run of the same call (`python bench.py --steps 20 --warmup 5`, "
+       f"`r05_c3_bench_line.log`) **{line['ms_per_step']:.1f} ms/step = {line['value']:.0f} mel-frames/s**, `roofline.frac` {roof['frac']:.4f} "
+       f"({roof['kernel'][:40]}..., {roof['avg_launch_ms']} ms per launch by HIP events), `step_mfma_issued_frac` {roof['step_mfma_issued_frac']:.4f}; "
+       f"`cpu_baseline` {line['cpu_baseline']['value']} mel-frames/s measured at micro-batch 12 over 5 timed steps on {line['cpu_baseline']['cores']} threads.\n",
+       "| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|"]
+for r in rows[:28]:
+    out.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e6:.3f} | {float(r['Percentage']):.1f} |")
+out.append("")
+out.append("Kernel names: `wino63v_nt_kernel<5>` = <POOLV> conv2 forward (writes V2), `<4>` = <C1WGRAD> conv2 input gradient + fused conv1 weight "
+           "gradient, `<2>` = <POOL> conv3 forward, `<6>` = <MASKY> conv3 input gradient writing Y2 / Vd2; `wino63v_tn4y_kernel`: both weight "
+           "gradients; `wino63_unpool_yvd_kernel`: Y3 / Vd3 from G3; `conv1_fwd_vh_kernel`: conv1 writing V1.  Since this round the K loop of "
+           "`wino63v_nt_kernel` is asm with pinned registers: `Scratch_Size` of all its launches in the trace is 0 (`r05_kernel_resources.md`).\n")
+out.append("HIP-event timers of the bench line (second, untimed pass) against the rocprof averages above: "
+           + ", ".join(f"{k} {v['ms']:.2f}" for k, v in sorted(pl.items()) if k.startswith(("conv2", "conv3"))) + " ms.\n")
+out.append("| family | ms (HIP events) | issued TFLOP/s | of 157.3 nominal | held clock GHz (GRBM pass) | at the held clock | HBM-side read GB | write GB |\n|---|---|---|---|---|---|---|---|")
+for fam, v in roof["families"].items():
+    t = tr.get(fam, {})
+    g = ck.get(fam)
+    out.append(f"| {fam[:70]} | {v['ms_per_step']:.2f} | {v['issued_tflops']:.1f} | {v['frac']:.3f} | {g if g else '-'} | "
+               f"{(v['frac'] / (g / 2.4)):.3f} |" .replace("| - | nan |", "| - | - |") if g else
+               f"| {fam[:70]} | {v['ms_per_step']:.2f} | {v['issued_tflops']:.1f} | {v['frac']:.3f} | - | - |"
+               )
+    out[-1] += f" {t.get('read_bytes', 0)/1e9:.1f} | {t.get('write_bytes', 0)/1e9:.1f} |"
+out.append("")
+out.append("Traffic: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of the same bench command, FETCH_SIZE x 2 (gfx950 tallies the 128-B "
+           "requests of 16-B/lane streaming reads at 64 B), per launch.  Against the algorithmic bytes: conv2 forward writes 9.6 GB for 9.1 GB of V2 + 0.4 GB "
+           "of bit words (round 4: 14.2 GB - the difference was spill traffic), reads 39.8 GB for 18.3 GB of V1 (V once + the 8.4 MB tap set per round of "
+           "tiles against a 4 MB L2: Infinity-Cache traffic, `r04_kernel_notes.md` 4); `<MASKY>` writes 36.5 GB (Y2 + Vd2 = 36.6) and reads 34.5 GB for 9.1 GB "
+           "of Vd3 + 0.9 GB of bit words: the same tap re-fetch as conv3 forward (18.5 GB) plus what 36 GB of write-allocated lines push out of the "
+           "L2s on their way through (section 7 of `r05_kernel_notes.md` has the store cache-policy experiment).\n")
+open(P("r05_c3_step_summary.md"), "w").write("\n".join(out) + "\n")
+print("\n".join(out)[:3000])
