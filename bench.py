@@ -37,6 +37,8 @@ Objects on the JSON line beside the contract fields:
 The timed region carries no instrumentation: the per-kernel HIP-event timers behind ``roofline`` are
 collected in a second, untimed pass (--timer-steps, default 3).
   c2_lite      BASELINE config C2 (SynthesisLite 32 ch x 200, batch 64) on the same GPU.
+  c5           BASELINE config C5 rehearsed on this GPU at its per-rank batch (64): signal stage -> deep classifiers (train
+               mode) -> the headline model's train step; step and classifier milliseconds.
   signal_c5    the preprocess/signal stage of config C5 (256 ch x 24 000 samples @ 400 Hz): Hilbert
                envelope, filtfilt, FIR - kernel time by HIP events, algorithmic GB/s against the HBM
                peak and (Hilbert: the bound that applies) fp64 vector FLOP/s against its peak.
@@ -414,6 +416,57 @@ def signal_subresult(dev, with_cpu: bool):
     return out
 
 
+def c5_subresult(dev, model, steps: int = 3):
+    """BASELINE config C5 rehearsed on ONE GPU at the per-rank batch of its 8-GPU run (512 / 8 = 64): raw 256-channel ECoG
+    (24 000 samples @ 400 Hz) -> frequency_filter.run (Hilbert 70-150 Hz envelope) -> 400-sample windows -> CNNClassifier
+    (syllable) + CNNRNNClassifier (tone, lstm_dim 800) on 64 + 64 channels, in train mode as the reference CLI runs them
+    (train_synthesizer.py:275-284) -> the SynthesisModelCNN train step on 128 channels.  Uses the headline model (its weights
+    move on by `steps` + 1 updates: this runs after everything that is timed) with a trainer of its own."""
+    import torch
+    from argparse import Namespace
+    from decode_tonal_langauge_amd.models import CNNClassifier, CNNRNNClassifier, SynthesisTrainer
+    from decode_tonal_langauge_amd.preprocess.signal import frequency_filter as ff
+    B, T = 64, 400
+    g = torch.Generator(device=dev).manual_seed(0)
+    raw = torch.randn(256, 24000, device=dev, generator=g)
+    prm = Namespace(signal_freq=400, bands=[{"method": "hilbert", "params": {"freq_ranges": [70., 150.], "envelope": True}}])
+    ff.run(raw, prm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hg = ff.run(raw, prm)
+    torch.cuda.synchronize()
+    t_sig = time.perf_counter() - t0
+    starts = torch.arange(B, device=dev) * ((24000 - T) // (B - 1))
+    win = torch.stack([hg[:, int(s):int(s) + T] for s in starts.tolist()]).float()
+    x_non, x_syl, x_tone = win[:, :128].contiguous(), win[:, 128:192].contiguous(), win[:, 192:].contiguous()
+    tgt = 10 * torch.randn(B, 80, device=dev, generator=g)
+    torch.manual_seed(0)
+    syl = CNNClassifier(input_channels=64, input_length=T, n_classes=2)
+    tone = CNNRNNClassifier(input_channels=64, input_length=T, n_classes=4, lstm_dim=800)
+    tr = SynthesisTrainer(model, tone, syl, TONE_MAP, device=dev, verbose=False, train_classifiers=True)
+    model.train()
+    tr.train_step(x_non, x_syl, x_tone, tgt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(x_non, x_syl, x_tone, tgt)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / steps
+    with torch.no_grad():
+        tr._labels(x_tone, x_syl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr._labels(x_tone, x_syl)
+        torch.cuda.synchronize()
+        t_cls = (time.perf_counter() - t0) / steps
+    return {"workload": "C5 rehearsal on 1 GPU at the per-rank batch 64 of the 8-GPU run: 256 ch x 24 000 raw -> Hilbert envelope -> "
+                        "CNNClassifier + CNNRNNClassifier (train mode, 64 + 64 ch) -> SynthesisModelCNN 128 ch x 400 train step",
+            "per_gpu_batch": B, "steps": steps, "train_step_ms": round(t_step * 1e3, 2),
+            "of_which_classifier_forwards_ms": round(t_cls * 1e3, 2), "signal_ms_256x24000": round(t_sig * 1e3, 3),
+            "value": round(B / t_step, 1), "unit": "mel-frames/s", "loss": float(tr._stats[2])}
+
+
 def step_issued_flops(eng, B: int, U: int, L: int) -> float:
     """MFMA FLOPs one train step issues (forward + input gradient + weight gradient)."""
     tot = 0.0
@@ -730,7 +783,8 @@ def main():
         extras = {}
         if world == 1 and args.model == "full" and not args.no_extras:
             for key, fn in (("c2_lite", lambda: lite_subresult(dev)),
-                            ("signal_c5", lambda: signal_subresult(dev, not args.no_cpu_baseline))):
+                            ("signal_c5", lambda: signal_subresult(dev, not args.no_cpu_baseline)),
+                            ("c5", lambda: c5_subresult(dev, model))):
                 try:
                     extras[key] = fn()
                 except Exception as e:      # noqa: BLE001 - a sub-result must not kill the headline line
