@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _kernels, _lib
-from ._lib import (EPI_C1WGRAD, EPI_LRELU, EPI_MASK, EPI_MASKY, EPI_POOL, EPI_POOLV, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, LOAD_V,
+from ._lib import (EPI_C1WGRAD, EPI_GY, EPI_LRELU, EPI_MASK, EPI_MASKY, EPI_POOL, EPI_POOLV, EPI_STORE, LOAD_DIRECT, LOAD_UNPOOL, LOAD_V,
                    LOAD_Y, NtParams, TnParams, check, ptr)
 
 
@@ -441,6 +441,56 @@ class CnnEngine:
               "tl_wino63_wgrad_finalize")
         self._permute(bias_part, gb, (1, 1, 1, st.cout), (0, 0, 0, 1), nz=sk, zs=nd)
 
+    def _gy_stage(self, st) -> bool:
+        """The one-tap pooled stage right behind F(6,3) stage 3 (conv4 of the reference stack) whose input gradient runs on the
+        NT63 kernel and writes stage 3's backward operands Y3 / Vd3 itself (tl_conv1_wino63v_dgrad_nt; TONAL_KERNELS
+        conv4_dgrad=gemm: the one-tap GEMM + tl_wino63_unpool_yvd of round 4)."""
+        if not (self.wino63 and self.f63_yprod3 and st.idx == 4 and len(self.stages) >= 3):
+            return False
+        below = self.stages[1]
+        return (_kernels.get("conv4_dgrad") == "nt63" and st.k == 1 and st.pool and self._f63(below)
+                and st.cout % 32 == 0 and st.cout >= 40 and st.cin % 32 == 0 and (below.tp_in // 2) % 3 == 0)
+
+    def _stage_dgrad_gy(self, st, w):
+        S = self.S
+        below = self.stages[1]                                   # the 3-tap stage whose pooled output this stage reads
+        tpg = below.tp_in // 2                                   # gradient rows per sequence in ITS hex geometry (3 per hex)
+        rows = S * tpg
+        f32 = dict(dtype=torch.float32, device=self._dev)
+        nh = -(-rows // 6)
+        nh_pad = (nh + 127) // 128 * 128
+        A = getattr(self, "_gy_A", None)
+        if A is None or A.shape[0] != nh_pad or A.shape[2] != st.cout:
+            A = self._gy_A = torch.zeros(nh_pad, 8, st.cout, **f32)   # slots 6, 7 and the pad hexes stay zero
+        Gs = self.G[st.idx]
+        ev = self._tick(f"conv{st.idx}_dgrad")
+        check(self.lib.tl_wino63_unpool_rows6(ptr(Gs), ptr(self.bits[st.idx]), ptr(A), rows, Gs.shape[0], tpg, st.tp_out,
+                                              2 * st.tout, st.cout, Gs.shape[1], st.cout // 32, st.cout, 0, self._stream()),
+              "tl_wino63_unpool_rows6")
+        taps = torch.empty(st.cout // 8, 8, st.cin, 8, **f32)
+        check(self.lib.tl_wino63_weights1(ptr(w), ptr(taps), st.cout, st.cin, st.cout, self._stream()), "tl_wino63_weights1")
+        rows3 = S * below.tp_in                                  # conv rows of the stage below: six per hex of ITS geometry
+        Y3 = self._v_hex_buffer(self.Yt, below.idx, rows3, below.cout)
+        Vd3 = self._v_hex_buffer(self.Vd, below.idx, rows3, below.cout)
+        ntm = -(-rows // self._nt63_rows())
+        if not hasattr(self, "_vhalo"):
+            self._vhalo = {}
+        halo = self._vhalo.get("d3")
+        if halo is None or halo.shape[0] != ntm or halo.shape[2] != below.cout:
+            halo = self._vhalo["d3"] = torch.zeros(ntm, 2, below.cout, **f32)
+        self._nt(tag=None, fn="tl_conv1_wino63v_dgrad_nt", A=ptr(A), A_rows=A.shape[0], lda=A.shape[2], loader=LOAD_V,
+                 Bw=ptr(taps), M=rows, N=st.cin, K=st.cout, ldb=st.cout, ldo=st.cin, J=1, row_shift=0, Tp=tpg, slope=self.slope,
+                 auxbits=ptr(self.sbits[below.idx]), ld_auxbits=self.sbits[below.idx].shape[1], abits=ptr(self.bits[below.idx]),
+                 ld_abits=below.cout // 32, out_tp=below.tp_out, Tvalid_in=2 * below.tout, epilogue=EPI_GY, out=None,
+                 vout=ptr(Y3), vout2=ptr(Vd3), vhalo=ptr(halo), vout_quads=Y3.shape[0], ld_vout=Y3.shape[2])
+        check(self.lib.tl_wino63_vd_fixup(ptr(Vd3), ptr(halo), rows // 3, ntm, below.tp_in // 6, below.cout, Vd3.shape[2],
+                                          self._stream()), "tl_wino63_vd_fixup")
+        if ev:
+            ev[1].record()
+        self._y_ready[below.idx] = self.generation
+        self._vd_ready[below.idx] = self.generation
+        return None
+
     def _stage_dgrad63(self, st, w):
         S = self.S
         rows_in = S * st.tp_in
@@ -577,8 +627,10 @@ class CnnEngine:
                     f"wino63v_nt_kernel<C1WGRAD> (conv2 input gradient + conv1 weight gradient, {f6})": ["conv2_dgrad"],
                     }
             if self.f63_yprod3:
+                gy = len(self.stages) >= 3 and self._gy_stage(self.stages[2])
+                src = "the epilogue of conv4's input gradient" if gy else "wino63_unpool_yvd_kernel"
                 fams[f"wino63v_tn4y_kernel (conv3 weight gradient, {f6}: both operands by LDS-DMA, no transform in the kernel; Y3 / Vd3 "
-                     "from wino63_unpool_yvd_kernel)"] = ["conv3_wgrad"]
+                     f"from {src})"] = ["conv3_wgrad"]
             else:
                 fams[f"{tn} (conv3 weight gradient, {f6}; also writes Vd)"] = ["conv3_wgrad"]
             if self.f63_yprod:
@@ -863,6 +915,8 @@ class CnnEngine:
         returned (shape (tiles, (k1 + 1) * c1), layout of ``tl_conv1_wgrad``'s partials)."""
         if self._f63(st):
             return self._stage_dgrad63(st, w)
+        if self._gy_stage(st):
+            return self._stage_dgrad_gy(st, w)
         S = self.S
         Xin = self._pin(st)
         Gs = self.G[st.idx]

@@ -43,6 +43,9 @@ KEYS: Dict[str, Tuple[str, _Allowed, str, str]] = {
     "tn_target": ("TONAL_TN_TARGET", _int(64, 1 << 20), "", "split-K target of the Winograd weight-gradient kernels"),
     "f63_yprod": ("TONAL_F63_YPROD", _B, "1", "F(6,3): stage 3's input gradient writes Y2 / Vd2 instead of G2"),
     "f63_yprod3": ("TONAL_F63_YPROD3", _B, "1", "F(6,3): Y3 / Vd3 from tl_wino63_unpool_yvd"),
+    "conv4_dgrad": ("TONAL_CONV4_DGRAD", frozenset({"nt63", "gemm"}), "nt63",
+                    "F(6,3): the one-tap stage behind conv3 - nt63: its input gradient on the NT63 kernel, writing Y3 / Vd3 "
+                    "(no gradient rows, no tl_wino63_unpool_yvd); gemm: one-tap GEMM + tl_wino63_unpool_yvd"),
     "fuse_c1": ("TONAL_FUSE_C1", _B, "1", "conv1 weight gradient fused into the conv2 input-gradient epilogue"),
     "store_p1": ("TONAL_STORE_P1", _B, "0", "keep the raw pooled rows of stages 1 / 2 beside V (tests)"),
     "overlap": ("TONAL_OVERLAP", _B, "0", "label LSTM / W_hh update on a side stream (measured: does not pay)"),

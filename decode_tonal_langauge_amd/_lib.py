@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("TONAL_HIP_LIB", os.path.join(_HERE, "libtonal_hip.so"
 
 # epilogue / loader codes of tl_gemm_nt_window (include/tonal_hip.h)
 LOAD_DIRECT, LOAD_UNPOOL, LOAD_V = 0, 1, 2
-EPI_STORE, EPI_LRELU, EPI_POOL, EPI_MASK, EPI_C1WGRAD, EPI_POOLV, EPI_MASKY = 0, 1, 2, 3, 4, 5, 6
+EPI_STORE, EPI_LRELU, EPI_POOL, EPI_MASK, EPI_C1WGRAD, EPI_POOLV, EPI_MASKY, EPI_GY = 0, 1, 2, 3, 4, 5, 6, 7
 LOAD_Y = 3
 
 
@@ -74,6 +74,9 @@ SIGNATURES = {
     "tl_wino63_xform2": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "tl_wino63_weights7": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_conv7_wino63v_nt": (_I, [C.POINTER(NtParams), _P]),
+    "tl_wino63_unpool_rows6": (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "tl_wino63_weights1": (_I, [_P, _P, _I, _I, _I, _P]),
+    "tl_conv1_wino63v_dgrad_nt": (_I, [C.POINTER(NtParams), _P]),
     "tl_conv3_wino_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_conv3_wino43_tn": (_I, [C.POINTER(TnParams), _P]),

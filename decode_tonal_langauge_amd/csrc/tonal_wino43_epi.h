@@ -9,7 +9,7 @@
 namespace tl {
 
 enum { W_LOAD_DIRECT = 0, W_LOAD_UNPOOL = 1, W_LOAD_V = 2 };
-enum { W_EPI_LRELU = 1, W_EPI_POOL = 2, W_EPI_MASK = 3, W_EPI_C1W = 4, W_EPI_POOLV = 5, W_EPI_MASKY = 6 };   // numbering of tl_nt_params.epilogue
+enum { W_EPI_LRELU = 1, W_EPI_POOL = 2, W_EPI_MASK = 3, W_EPI_C1W = 4, W_EPI_POOLV = 5, W_EPI_MASKY = 6, W_EPI_GY = 7 };   // numbering of tl_nt_params.epilogue
 
 // ------------------------------------------------------------------------------------------
 // Fused first-stage weight gradient (epilogue 4).  The input gradient of conv2 is G1 = dL/dZ of conv1

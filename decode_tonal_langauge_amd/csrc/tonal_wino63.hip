@@ -265,7 +265,7 @@ __device__ unsigned long long v6_stamp_buf[256 * V6_STAMP_TILES * V6_STAMP_SLOTS
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p) {
-  __shared__ __attribute__((aligned(1024))) char lds[3 * V6_STAGE + ((EPI == W_EPI_POOLV || EPI == W_EPI_MASKY) ? 4096 : EPI == W_EPI_C1W ? 16384 : 0)];
+  __shared__ __attribute__((aligned(1024))) char lds[3 * V6_STAGE + ((EPI == W_EPI_POOLV || EPI == W_EPI_MASKY || EPI == W_EPI_GY) ? 4096 : EPI == W_EPI_C1W ? 16384 : 0)];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -451,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
       if constexpr (EPI == W_EPI_POOL || EPI == W_EPI_POOLV || EPI == W_EPI_LRELU) return v5_prefetch_pool(p, cur.n0, wn, lr);
       else if constexpr (EPI == W_EPI_MASK) return v6_prefetch_mask(p, cur.R0, cur.n0, wm, wn, lr, lh);
       else if constexpr (EPI == W_EPI_MASKY) return v6_prefetch_masky(p, cur.R0, cur.n0, wm, wn, lr, lh);
+      else if constexpr (EPI == W_EPI_GY) return v6_prefetch_masky<true>(p, cur.R0, cur.n0, wm, wn, lr, lh);
       else return v6_prefetch_c1w(p, cur.R0, cur.n0, wm, wn, lr, lh);
     };
     decltype(prefetch()) pre;
@@ -535,6 +536,10 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
       float* xch = reinterpret_cast<float*>(lds + 3 * V6_STAGE);
       if (full) v6_epilogue_masky<true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
       else v6_epilogue_masky<false>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
+    } else if constexpr (EPI == W_EPI_GY) {
+      float* xch = reinterpret_cast<float*>(lds + 3 * V6_STAGE);
+      if (full) v6_epilogue_masky<true, true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
+      else v6_epilogue_masky<false, true>(p, acc, pre, xch, done.R0, done.n0, wm, wn, lr, lh, done.tm, est);
     } else {
       v6_epilogue_c1w(p, acc, pre, reinterpret_cast<float*>(lds + 3 * V6_STAGE) + wave * 512, scratch, done.R0, done.n0, wm, wn,
                       lr, lh, done.tm);
@@ -1620,6 +1625,67 @@ __global__ __launch_bounds__(256, 4) void wino63_unpool_yvd_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 5: the input gradient of a ONE-tap pooled stage whose input comes out of a pooled 3-tap F(6,3) stage (conv4 of the
+// reference stack, models/synthesis_models.py:99-101) on the NT63 kernel, so that its epilogue can hand that stage the operands of
+// its backward pass (Y, Vd: epilogue 7) instead of gradient rows which a kernel of its own (wino63_unpool_yvd_kernel: 21.7 GB)
+// then has to un-pool and transform.  The eight batched GEMMs of the kernel take the SIX rows of a hex: A[hex H][slot i < 6] =
+// un-pooled gradient row 6 H + i of the one-tap stage (row geometry [seq * Tp + t], the hexes of the 3-tap stage below: three of
+// its pooled rows each, two of its hexes per hex here), slots 6, 7 zero, against the same taps W^T in every slot.
+//   wino63_unpool_rows6_kernel: (G rows [seq * g_tp + t / 2], arg-max bits) -> A, pair layout; thread = 4 channels x one hex,
+//   lanes ordered like wino63_unpool_yvd_kernel (64-byte runs); slots 6, 7 are written (zeros) only when `pad` is set.
+//   wino63_weights1_kernel: w (O, I) -> taps [ldb / 8][8][I][8], slot t < 6: w[o][n], slots 6, 7 and o >= O: zero.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void wino63_unpool_rows6_kernel(const float* __restrict__ G, const uint32_t* __restrict__ bits,
+                                                                   float* __restrict__ A, long long nhex, long long rows,
+                                                                   long long g_rows, int Tp, int g_tp, int Tvalid, int C, int ldg,
+                                                                   int ld_bits, int lda, int pad) {
+  const int tpp = C >> 1;                                    // threads per hex pair
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long pair = idx / tpp;
+  const int tl_ = (int)(idx - pair * tpp);
+  const int half = tl_ & 1, hpar = (tl_ >> 1) & 1, kc = tl_ >> 2;
+  const int c = 8 * kc + 4 * half;
+  const long long hg = 2 * pair + hpar;
+  if (hg >= nhex) return;
+  float* dst = A + v6_at(hg, 0, c, lda >> 3);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const long long R = 6 * hg + i;
+    f32x4 v = zero;
+    if (R < rows) {
+      const long long seq = R / Tp;
+      const int t = (int)(R - seq * Tp);
+      const long long row = seq * g_tp + (t >> 1);
+      if (t < Tvalid && row < g_rows) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(G + row * (long long)ldg + c);
+        const uint32_t w = bits[row * (long long)ld_bits + (c >> 5)] >> (c & 31);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (int)((w >> k) & 1u) == (t & 1) ? g[k] : 0.f;
+      }
+    }
+    *reinterpret_cast<f32x4*>(dst + 16 * i) = v;
+  }
+  if (pad) {
+    *reinterpret_cast<f32x4*>(dst + 16 * 6) = zero;
+    *reinterpret_cast<f32x4*>(dst + 16 * 7) = zero;
+  }
+}
+
+__global__ void wino63_weights1_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int ldb) {
+  const long long n_all = (long long)ldb * 8 * I;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_all) return;
+  const int k8 = (int)(idx & 7);
+  const long long q = idx >> 3;
+  const int n = (int)(q % I);
+  const long long q2 = q / I;
+  const int t = (int)(q2 & 7);
+  const int o = (int)(q2 >> 3) * 8 + k8;
+  out[idx] = (t < 6 && o < O) ? w[(long long)o * I + n] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
 // conv1 (C_in = 1) + LeakyReLU + max-pool writing V of its pooled output in HEX form, pair layout (conv1_fwd_vq_kernel of
 // tonal_misc.hip with six rows per unit).  HBM-write bound, so the thread mapping follows the layout: four adjacent lanes
 // = (one 8-channel chunk) x (the two hexes of a pair) write the 64-byte run of a transform, two transforms = one cache line;
@@ -1939,6 +2005,62 @@ extern "C" int tl_conv3_wino63v_nt(const tl_nt_params* pp, void* stream) {
     return TL_EINVAL;
   }
   return check_launch("wino63v_nt");
+}
+
+// Input gradient of a one-tap pooled stage on the NT63 kernel, epilogue 7 (kernel comment above wino63_unpool_rows6_kernel)
+extern "C" int tl_wino63_unpool_rows6(const float* G, const uint32_t* bits, float* A, int64_t rows, int64_t g_rows, int Tp, int g_tp,
+                                      int Tvalid, int C, int ldg, int ld_bits, int lda, int pad, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(G && bits && A, "wino63_unpool_rows6: null pointer");
+  TL_REQUIRE(rows > 0 && Tp > 0 && rows % Tp == 0 && Tvalid > 0 && Tvalid <= Tp, "wino63_unpool_rows6: whole sequences of Tp rows, 0 < Tvalid <= Tp needed");
+  TL_REQUIRE(g_tp > 0 && 2 * g_tp >= Tvalid && g_rows >= (rows / Tp) * (long long)g_tp, "wino63_unpool_rows6: G holds fewer rows than sequences x g_tp");
+  TL_REQUIRE(C > 0 && C % 8 == 0 && ldg >= C && ldg % 4 == 0 && lda >= C && lda % 8 == 0 && ld_bits * 32 >= C,
+             "wino63_unpool_rows6: C %% 8, ldg %% 4, lda %% 8 needed, bits row must cover C");
+  const long long nhex = (rows + 5) / 6;
+  const long long n = (nhex + 1) / 2 * (C >> 1);
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_unpool_rows6: grid too large");
+  hipLaunchKernelGGL(wino63_unpool_rows6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G, bits, A,
+                     nhex, (long long)rows, (long long)g_rows, Tp, g_tp, Tvalid, C, ldg, ld_bits, lda, pad);
+  return check_launch("wino63_unpool_rows6");
+}
+
+extern "C" int tl_wino63_weights1(const float* w, float* taps, int O, int I, int ldb, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(w && taps && O > 0 && I > 0 && ldb >= O && ldb % 8 == 0, "wino63_weights1: w, taps, O, I > 0 and ldb %% 8 == 0, ldb >= O needed");
+  const long long n = (long long)ldb * 8 * I;
+  TL_REQUIRE((n + 255) / 256 < (1LL << 31), "wino63_weights1: too large");
+  hipLaunchKernelGGL(wino63_weights1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, taps, O, I, ldb);
+  return check_launch("wino63_weights1");
+}
+
+extern "C" int tl_conv1_wino63v_dgrad_nt(const tl_nt_params* pp, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(pp != nullptr, "conv1_wino63v_dgrad_nt: null params");
+  const tl_nt_params& p = *pp;
+  TL_REQUIRE(p.A && p.Bw, "conv1_wino63v_dgrad_nt: null A / taps");
+  TL_REQUIRE(p.loader == W_LOAD_V && p.epilogue == W_EPI_GY && p.J == 1 && p.row_shift == 0 && p.splitk <= 1,
+             "conv1_wino63v_dgrad_nt: loader 2, epilogue 7, one tap, row_shift 0, no split-K");
+  TL_REQUIRE(p.M > 0 && p.N > 0 && p.K >= 40 && p.K % 8 == 0, "conv1_wino63v_dgrad_nt: K %% 8, K >= 40 needed");
+  TL_REQUIRE(p.Tp > 0 && p.Tp % 3 == 0 && p.M % p.Tp == 0, "conv1_wino63v_dgrad_nt: Tp (rows per sequence) must be a multiple of 3, M whole sequences");
+  TL_REQUIRE(p.lda >= p.K && p.ldb >= p.K && p.lda % 8 == 0 && p.ldb % 8 == 0, "conv1_wino63v_dgrad_nt: bad leading dimensions (multiples of 8)");
+  TL_REQUIRE(p.A_rows % 2 == 0, "conv1_wino63v_dgrad_nt: A holds hex pairs");
+  TL_REQUIRE(8LL * p.N * p.ldb * 4 < (1LL << 31), "conv1_wino63v_dgrad_nt: tap set larger than a buffer resource");
+  TL_REQUIRE(128LL * 8 * p.lda * 4 + 4LL * p.K < (1LL << 31), "conv1_wino63v_dgrad_nt: tile span too large");
+  const long long ntm = (p.M + V6_ROWS - 1) / V6_ROWS;
+  const long long nwg = ntm * ((p.N + V6_BN - 1) / V6_BN);
+  TL_REQUIRE(nwg < (1LL << 31), "conv1_wino63v_dgrad_nt: grid too large");
+  TL_REQUIRE(p.N % 32 == 0 && p.M + V6_ROWS < (1LL << 31), "conv1_wino63v_dgrad_nt: N %% 32 == 0 and M < 2^31 - 768 needed");
+  TL_REQUIRE(p.slope >= 0.f && p.slope <= 1.f, "conv1_wino63v_dgrad_nt: LeakyReLU slope must lie in [0, 1]");
+  TL_REQUIRE(p.A_rows >= ntm * V6_BH, "conv1_wino63v_dgrad_nt: A must hold whole 128-hex tiles (pad it with zero hexes)");
+  TL_REQUIRE(p.auxbits != nullptr && p.abits != nullptr, "conv1_wino63v_dgrad_nt: needs auxbits (sign) and abits (arg-max) of the stage below");
+  TL_REQUIRE(p.out_tp > 0 && p.out_tp <= p.Tp && 2 * p.out_tp >= p.Tvalid_in, "conv1_wino63v_dgrad_nt: out_tp = rows per sequence of the bit arrays (0 < out_tp <= Tp, covering Tvalid_in / 2)");
+  TL_REQUIRE(p.ld_abits * 32 >= p.N && p.ld_auxbits * 32 >= p.N && p.Tvalid_in % 2 == 0 && p.Tvalid_in <= 2 * p.Tp, "conv1_wino63v_dgrad_nt: bad abits / auxbits / Tvalid_in");
+  TL_REQUIRE(p.vout && p.vout2 && p.vhalo && p.ld_vout >= p.N && p.ld_vout % 8 == 0 && p.vout_quads >= p.M / 3 && p.vout_quads % 2 == 0,
+             "conv1_wino63v_dgrad_nt: needs vout / vout2 (>= M / 3 hexes, whole pairs, ld_vout %% 8 == 0) and vhalo");
+  TL_REQUIRE(128LL * 8 * p.ld_vout * 4 < (1LL << 31), "conv1_wino63v_dgrad_nt: ld_vout too large");
+  const long long ngrid = nwg < 256 ? nwg : 256;
+  hipLaunchKernelGGL((wino63v_nt_kernel<W_EPI_GY>), dim3((unsigned)ngrid), dim3(512), 0, (hipStream_t)stream, p);
+  return check_launch("conv1_wino63v_dgrad_nt");
 }
 
 // weight gradient on V: A = V[hex][8][lda], A_rows = hexes held by V (a whole number of 6-hex K-steps)

@@ -363,7 +363,7 @@ __device__ __forceinline__ void v6_epilogue_pool(const tl_nt_params& p, const f3
 // Vector-memory stores every wave issues per tile (lower bound where a branch adds some), see v5_stores
 template <int EPI>
 constexpr int v6_stores() {
-  return EPI == W_EPI_POOL ? 52 : EPI == W_EPI_POOLV ? 70 : (EPI == W_EPI_MASK || EPI == W_EPI_LRELU) ? 96 : EPI == 6 ? 63 : 0;
+  return EPI == W_EPI_POOL ? 52 : EPI == W_EPI_POOLV ? 70 : (EPI == W_EPI_MASK || EPI == W_EPI_LRELU) ? 96 : (EPI == W_EPI_MASKY || EPI == W_EPI_GY) ? 63 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -467,6 +467,9 @@ __device__ __forceinline__ void v6_epilogue_lrelu(const tl_nt_params& p, const f
 struct v6_pre_masky {
   uint32_t s[3], a[3];         // sign words (auxbits) and arg-max words (abits) of the half's rows lr, 32 + lr, 64 + lr
 };
+// GTP: the bit arrays keep p.out_tp rows per sequence, [seq * out_tp + t], where the rows of this GEMM count p.Tp (the one-tap
+// stage behind a POOL epilogue with out_tp: epilogue 7); rows t >= out_tp have no words (and are never valid)
+template <bool GTP = false>
 __device__ __forceinline__ v6_pre_masky v6_prefetch_masky(const tl_nt_params& p, long long R0, int n0, int wm, int wn, int lr, int lh) {
   const int colbase = n0 + wn * 32;
   const long long ra = R0 + wm * 192 + 96 * lh + lr;
@@ -475,13 +478,24 @@ __device__ __forceinline__ v6_pre_masky v6_prefetch_masky(const tl_nt_params& p,
   for (int k = 0; k < 3; ++k) {
     r.s[k] = r.a[k] = 0u;
     if (colbase < p.N && ra + 32 * k < p.M) {
-      r.s[k] = p.auxbits[(ra + 32 * k) * (long long)p.ld_auxbits + (colbase >> 5)];
-      r.a[k] = p.abits[(ra + 32 * k) * (long long)p.ld_abits + (colbase >> 5)];
+      long long row = ra + 32 * k;
+      bool have = true;
+      if constexpr (GTP) {
+        const unsigned R = (unsigned)row, sq = R / (unsigned)p.Tp, t = R - sq * (unsigned)p.Tp;       // host-checked: M < 2^31
+        have = t < (unsigned)p.out_tp;
+        row = (long long)sq * p.out_tp + t;
+      }
+      if (have) {
+        r.s[k] = p.auxbits[row * (long long)p.ld_auxbits + (colbase >> 5)];
+        r.a[k] = p.abits[row * (long long)p.ld_abits + (colbase >> 5)];
+      }
     }
   }
   return r;
 }
-template <bool FULL>
+// DIRECT (epilogue 7): the accumulators ARE the rows - batch i < 6 of the kernel's eight GEMMs is row 6 H + i of hex H (a
+// one-tap stage: tl_conv1_wino63v_dgrad_nt) - where the 3-tap form takes them from the inverse transform.
+template <bool FULL, bool DIRECT = false>
 __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f32x16 (&acc)[8], const v6_pre_masky& pre, float* xch,
                                                   long long R0, int n0, int wm, int wn, int lr_in, int lh, long long tm,
                                                   unsigned long long* st = nullptr) {
@@ -545,7 +559,12 @@ __device__ __forceinline__ void v6_epilogue_masky(const tl_nt_params& p, const f
     if (e == 8) v6_stamp(st, 11);
     if (e == 12) v6_stamp(st, 12);
     float y[6];
-    wino63_rows(acc, e, y);
+    if constexpr (DIRECT) {
+#pragma unroll
+      for (int h = 0; h < 6; ++h) y[h] = acc[h][e];
+    } else {
+      wino63_rows(acc, e, y);
+    }
     float dzr[12];                                          // the six pooled rows of accumulator element e, un-pooled
 #pragma unroll
     for (int h = 0; h < 6; ++h) {

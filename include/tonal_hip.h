@@ -245,6 +245,25 @@ int tl_conv1_fwd_v6(const float* x, const float* w, const float* b, float* P, fl
 int tl_wino63_xform2(const float* P, float* V0, float* V1, int64_t rows, int Tp, int Tvalid, int C, int ldp, int ldv, void* stream);
 int tl_wino63_weights7(const float* w, float* fwd, int O, int I, int taps, void* stream);
 int tl_conv7_wino63v_nt(const tl_nt_params* p, void* stream);
+/* Round 5 - the input gradient of a ONE-tap pooled stage whose input is the pooled output of a 3-tap F(6,3) stage (conv4 of the
+ * reference stack: nn.Conv2d(512, 256, (1,1)) + LeakyReLU + MaxPool behind conv3, models/synthesis_models.py:96-101, backward in
+ * loss.backward(), models/synthesis_trainer.py:226) on the F(6,3) NT kernel: its eight batched GEMMs take the six rows of a hex
+ * (same taps W^T in each; two batches idle), so the accumulators are the gradient rows G of the stage below and the MASKY epilogue
+ * (epilogue 7 = epilogue 6 without the inverse transform) writes that stage's Y / Vd directly - tl_wino63_unpool_yvd and the
+ * gradient rows themselves go.  Row geometry: [seq * Tp + t], Tp % 3 == 0 rows per sequence = the hexes of the stage below
+ * (three of its pooled rows each); hex H here = rows 6 H .. 6 H + 5 (may straddle two sequences).
+ *   tl_wino63_unpool_rows6     G (the stage's pooled output gradient, rows [seq * g_tp + t / 2], ldg) + its arg-max bits ->
+ *                              A[ceil(rows / 6)][8][lda], pair layout: slot i < 6 = un-pooled row 6 H + i (zero from Tvalid on),
+ *                              slots 6, 7 zero (written only when pad != 0: a zero-filled buffer stays valid)
+ *   tl_wino63_weights1         w (O, I) -> taps [ldb / 8][8][I][8]: slot t < 6 = w[o][n], slots 6, 7 zero
+ *   tl_conv1_wino63v_dgrad_nt  A as above (A_rows hexes, whole 128-hex tiles), Bw = the taps, M = sequences x Tp rows, N = I,
+ *                              K = O (K % 8 == 0, K >= 40), J = 1, loader 2, epilogue 7; auxbits / abits = sign / arg-max words
+ *                              of the stage below in the layout [seq * out_tp + t] (out_tp <= Tp), Tvalid_in its valid conv
+ *                              rows; vout / vout2 / vhalo / vout_quads / ld_vout as epilogue 6; then tl_wino63_vd_fixup       */
+int tl_wino63_unpool_rows6(const float* G, const uint32_t* bits, float* A, int64_t rows, int64_t g_rows, int Tp, int g_tp, int Tvalid,
+                           int C, int ldg, int ld_bits, int lda, int pad, void* stream);
+int tl_wino63_weights1(const float* w, float* taps, int O, int I, int ldb, void* stream);
+int tl_conv1_wino63v_dgrad_nt(const tl_nt_params* p, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
 int tl_sizeof_nt_params(void);
 int tl_sizeof_tn_params(void);

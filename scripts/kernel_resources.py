@@ -23,6 +23,10 @@ def main():
         flt = args[i + 1]
         del args[i:i + 2]
     src, extra = args[0], args[1:]
+    if not extra and src.endswith(("tonal_wino63.hip", "tonal_wino43_tn.hip")):
+        # the Makefile builds these two files without packed fp32 arithmetic: with the default target features the allocator's
+        # result is a different one (MASKY: 63 spilled registers instead of none)
+        extra = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
            "-c", src, "-o", "/dev/null"] + extra
     err = subprocess.run(cmd, capture_output=True, text=True).stderr

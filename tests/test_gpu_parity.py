@@ -1537,3 +1537,97 @@ def test_first_stage_gradient_partials_reduce_to_torch_layout(dev, nblk):
     ref_w = tot[:eng.k1 * eng.c1].view(eng.k1, eng.c1).t()
     assert float((gw.view(eng.c1, eng.k1).double() - ref_w).abs().max()) < 1e-5 * float(ref_w.abs().max())
     assert float((gb.double() - tot[eng.k1 * eng.c1:]).abs().max()) < 1e-5 * float(tot.abs().max())
+
+
+@pytest.mark.parametrize("shape", [
+    # (sequences, conv rows per sequence of the 3-tap stage below (hexes of 6), its valid pooled rows, rows per sequence of its
+    #  bit arrays, its channels = N, channels of the one-tap stage = K)
+    (256, 102, 48, 50, 512, 256),          # the timed geometry per 2 windows: 17 hexes per sequence (odd: hexes here straddle sequences)
+    (5, 102, 48, 50, 128, 64),             # odd sequence count: the last hex is half empty (M % 6 == 3)
+    (3, 12, 5, 6, 64, 64),                 # two hexes per sequence, an odd number of valid pooled rows
+    (37, 30, 14, 15, 96, 96),              # K / N that are not powers of two; bit arrays as wide as the hex geometry
+    (700, 54, 26, 27, 64, 64),             # more than one row tile per workgroup column: the tile walk
+])
+def test_one_tap_input_gradient_on_the_f63_nt_kernel_writes_y_and_vd(dev, shape):
+    """Round 5: conv4's input gradient (reference models/synthesis_models.py:99-101, backward of loss.backward(),
+    synthesis_trainer.py:226) as ``tl_wino63_unpool_rows6`` + ``tl_wino63_weights1`` + ``tl_conv1_wino63v_dgrad_nt`` +
+    ``tl_wino63_vd_fixup``: Y3 = A dz3 and Vd3 = B^T dz3 of the 3-tap stage below, against a float64 restatement
+    (un-pool the one-tap stage's pooled gradient, multiply by W, LeakyReLU' from the sign words, un-pool by the stage's own
+    arg-max words, transform).  Pad hexes stay zero; a second launch into the same buffers is bit-identical."""
+    from decode_tonal_langauge_amd import _lib
+    from decode_tonal_langauge_amd._lib import EPI_GY, LOAD_V, check, ptr
+    from tests.wino63_ref import hex_transform, logical, unpool, y_transform
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    S, tp3, tout3, gtp3, c3, c4 = shape
+    slope = 0.01
+    tpg = tp3 // 2                                     # gradient rows per sequence in the hex geometry (3 per hex)
+    tin4 = tout3                                       # the one-tap stage: rows in = conv rows
+    tout4, gtp4 = tin4 // 2, (gtp3 + 1) // 2
+    g = torch.Generator(device=dev).manual_seed(77 + S)
+    G4 = torch.randn(S * gtp4, c4, device=dev, generator=g)
+    G4.view(S, gtp4, c4)[:, tout4:] = 0
+    rnd = lambda *s: torch.randint(-2 ** 31, 2 ** 31 - 1, s, device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+    bits4, bits3, sbits3 = rnd(S * gtp4, c4 // 32), rnd(S * gtp3, c3 // 32), rnd(S * gtp3, c3 // 32)
+    W = torch.randn(c4, c3, device=dev, generator=g) / c4 ** 0.5
+    # ---- float64 restatement
+    dz4 = unpool(G4, bits4, S, gtp4, 2 * tout4, c4)[:, :gtp3]                         # (S, gtp3, c4): rows of the stage's input
+    if dz4.shape[1] < gtp3:
+        dz4 = torch.nn.functional.pad(dz4, (0, 0, 0, gtp3 - dz4.shape[1]))
+    g3 = dz4 @ W.double()                                                              # (S, gtp3, c3)
+    sh = torch.arange(32, device=dev, dtype=torch.int32)
+    pos = ((sbits3.view(S, gtp3, c3 // 32, 1) >> sh) & 1).reshape(S, gtp3, c3).bool()
+    g3 = g3 * torch.where(pos, 1.0, slope)
+    dz3 = unpool(g3.reshape(-1, c3), bits3, S, gtp3, 2 * tout3, c3)                    # (S, 2 gtp3, c3)
+    if 2 * gtp3 < tp3:
+        dz3 = torch.nn.functional.pad(dz3, (0, 0, 0, tp3 - 2 * gtp3))
+    dz3 = dz3[:, :tp3].reshape(-1, c3)
+    Yref, Vdref = y_transform(dz3, S, tp3), hex_transform(dz3, S, tp3, shift=-2)
+    # ---- the HIP path
+    rows = S * tpg
+    nh = -(-rows // 6)
+    nh_pad = (nh + 127) // 128 * 128
+    A = torch.zeros(nh_pad, 8, c4, device=dev)
+    nh3 = S * (tp3 // 6)
+    nh3_pad = (nh3 + 24 + 127) // 128 * 128
+    tile_rows = lib.tl_wino63_nt_tile_rows()
+    ntm = -(-rows // tile_rows)
+    taps = torch.empty(c4 // 8, 8, c3, 8, device=dev)
+    outs = []
+    for _ in range(2):
+        Y, Vd = torch.zeros(nh3_pad, 8, c3, device=dev), torch.zeros(nh3_pad, 8, c3, device=dev)
+        halo = torch.zeros(ntm, 2, c3, device=dev)
+        check(lib.tl_wino63_unpool_rows6(ptr(G4), ptr(bits4), ptr(A), rows, G4.shape[0], tpg, gtp4, 2 * tout4, c4, c4, c4 // 32, c4, 0,
+                                         st), "tl_wino63_unpool_rows6")
+        check(lib.tl_wino63_weights1(ptr(W), ptr(taps), c4, c3, c4, st), "tl_wino63_weights1")
+        p = _lib.NtParams()
+        p.splitk, p.bm = 1, 128
+        for k, v in dict(A=ptr(A), A_rows=nh_pad, lda=c4, loader=LOAD_V, Bw=ptr(taps), M=rows, N=c3, K=c4, ldb=c4, ldo=c3, J=1,
+                         row_shift=0, Tp=tpg, slope=slope, auxbits=ptr(sbits3), ld_auxbits=c3 // 32, abits=ptr(bits3),
+                         ld_abits=c3 // 32, out_tp=gtp3, Tvalid_in=2 * tout3, epilogue=EPI_GY, vout=ptr(Y), vout2=ptr(Vd),
+                         vhalo=ptr(halo), vout_quads=nh3_pad, ld_vout=c3).items():
+            setattr(p, k, v)
+        check(lib.tl_conv1_wino63v_dgrad_nt(C_.byref(p), st), "tl_conv1_wino63v_dgrad_nt")
+        check(lib.tl_wino63_vd_fixup(ptr(Vd), ptr(halo), rows // 3, ntm, tp3 // 6, c3, c3, st), "tl_wino63_vd_fixup")
+        torch.cuda.synchronize()
+        outs.append((Y, Vd))
+    (Y, Vd), (Y2, Vd2) = outs
+    assert torch.equal(Y, Y2) and torch.equal(Vd, Vd2)
+    # slots 0..5 of A are the un-pooled rows in hex order, slots 6, 7 zero
+    Al = logical(A)[:nh]
+    want = torch.nn.functional.pad(dz4[:, :tpg] if dz4.shape[1] >= tpg else torch.nn.functional.pad(dz4, (0, 0, 0, tpg - dz4.shape[1])),
+                                   (0, 0, 0, 0)).reshape(-1, c4)
+    want = torch.nn.functional.pad(want, (0, 0, 0, 6 * nh - want.shape[0])).view(nh, 6, c4)
+    assert torch.equal(Al[:, :6].double(), want) and float(Al[:, 6:].abs().max()) == 0.0
+    near = lambda a, b: float((a.double() - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    assert near(logical(Y)[:nh3], Yref), float((logical(Y)[:nh3].double() - Yref).abs().max())
+    assert near(logical(Vd)[:nh3], Vdref), float((logical(Vd)[:nh3].double() - Vdref).abs().max())
+    # (an odd hex count ends inside a pair of the pair layout: slice the logical view, not the memory order)
+    assert float(logical(Y)[nh3:].abs().max()) == 0.0 and float(logical(Vd)[nh3:].abs().max()) == 0.0
+    # ---- what the entry refuses
+    p.K = 32
+    assert lib.tl_conv1_wino63v_dgrad_nt(C_.byref(p), st) != 0 and b"K" in lib.tl_last_error()
+    p.K, p.Tp = c4, tpg + 1
+    assert lib.tl_conv1_wino63v_dgrad_nt(C_.byref(p), st) != 0 and b"Tp" in lib.tl_last_error()
+    p.Tp, p.epilogue = tpg, 6
+    assert lib.tl_conv1_wino63v_dgrad_nt(C_.byref(p), st) != 0
