@@ -87,8 +87,9 @@ class Seq:
         return f"#define {name} \\\n{body}\n"
 
 
-def kstep(kind, early=True):
-    """kind: first | step1 | norm | prelast | prelast_z | last"""
+def kstep(kind, early=True, nh=4):
+    """kind: first | step1 | norm | prelast | prelast_z | last;  nh: transforms in half-set H (4; 2 for the six-batch form of
+    tl_conv1_wino63v_dgrad_nt, whose transforms 6 and 7 are zero: 24 MFMAs per K-step instead of 32)"""
     s = Seq()
     dma = kind in ("first", "step1", "norm")
     zero_h = kind in ("step1", "prelast_z")
@@ -100,7 +101,7 @@ def kstep(kind, early=True):
             s.read("bL", i)
         s.emit("s_mov_b32 m0, %[m0a]")
         order = [(q, i) for q in range(4) for i in range(4)]
-        hreads = [(k, i) for i in range(4) for k in ("aH", "bH")]
+        hreads = [(k, i) for i in range(nh) for k in ("aH", "bH")]
         piece = 0
         for n, (q, i) in enumerate(order):
             s.mfma("L", i, q, zero=(q == 0))
@@ -123,16 +124,19 @@ def kstep(kind, early=True):
         s.emit("s_mov_b32 m0, %[m0a]")
     piece = 0
     order = [(q, i) for q in range(4) for i in range(4)]
+    order_h = [(q, i) for q in range(4) for i in range(nh)]
     # (the reads of L are in flight: H's fragments were waited for before the closing barrier of the step in front)
-    for n, (q, i) in enumerate(order):
+    for n, (q, i) in enumerate(order_h):
         a, b = frag("aH", i), frag("bH", i)
         d = acc(i + 4)
         s.emit(f"v_mfma_f32_32x32x2_f32 {d}, v{a + q}, v{b + q}, {'0' if (zero_h and q == 0) else d}")
-        if dma and n % 2 == 1 and piece < 6:
+        # (nh = 2: eight carried MFMAs - a piece behind every one from the second on)
+        if dma and (n % 2 == 1 or (nh < 4 and n >= 1)) and piece < 6:
             s.dma(piece)
             piece += 1
+    assert not dma or piece == 6
     # ---- L(s): 16 MFMAs, the reads of H(s) between them; the closing wait + barrier after the eighth
-    hreads = [(k, i) for i in range(4) for k in ("aH", "bH")]
+    hreads = [(k, i) for i in range(nh) for k in ("aH", "bH")]
     for n, (q, i) in enumerate(order):
         s.mfma("L", i, q)
         if early or n % 2 == 1:
@@ -148,7 +152,7 @@ def kstep(kind, early=True):
         while hreads:
             s.read(*hreads.pop(0))
         # the tile's last half-set: nothing carries it
-        for q, i in order:
+        for q, i in order_h:
             s.mfma("H", i, q)
         # the epilogue's first vector instruction may read an accumulator: XDL write -> VALU read hazard (the compiler's
         # hazard recogniser does not look into asm statements)
@@ -168,33 +172,41 @@ def issue_only():
 def main():
     out = ["// GENERATED by gen_wino63_kloop.py - do not edit (the generator's docstring has the register map and the reasons)",
            "#pragma once", ""]
-    def accs(lo, hi, mode):
-        return [f'"{mode}{{{acc(i)}}}"((A)[{i}])' for i in range(lo, hi)]
 
-    def frags(mode):
-        r = []
-        for kind, var in (("aL", "FAL"), ("bL", "FBL"), ("aH", "FAH"), ("bH", "FBH")):
-            for i in range(4):
-                b = frag(kind, i)
-                r.append(f'"{mode}{{v[{b}:{b + 3}]}}"(({var})[{i}])')
-        return r
+    def emit_set(prefix, nh):
+        na = 4 + nh
 
-    def define(name, regs, comment):
-        out.append("// " + comment)
-        out.append(f"#define {name}(A, FAL, FBL, FAH, FBH) \\\n  " + ", \\\n  ".join(regs) + "\n")
+        def accs(lo, hi, mode):
+            return [f'"{mode}{{{acc(i)}}}"((A)[{i}])' for i in range(lo, hi)]
 
-    # What a statement declares decides what the allocator must keep alive ACROSS THE EPILOGUE: an operand that is read
-    # ("+") by the first statement of a tile would hold its register through the whole epilogue of the tile in front.
-    define("V6K_REGS", accs(0, 8, "+") + frags("+"), "steady state: every accumulator and fragment is read and written")
-    define("V6K_REGS_FIRST", accs(0, 4, "=&") + frags("=&"),
-           "first K-step of a tile: accumulators 0-3 start from zero, all fragments are (re)read - nothing is live on entry")
-    define("V6K_REGS_STEP1", accs(0, 4, "+") + accs(4, 8, "=&") + frags("+"),
-           "second K-step: accumulators 4-7 start from zero")
-    for early in (True, False):
-        sfx = "_E" if early else "_L"
-        for kind in ("step1", "norm", "prelast", "prelast_z", "last"):
-            out.append(kstep(kind, early).text(f"V6K_{kind.upper()}{sfx}"))
-    out.append(kstep("first").text("V6K_FIRST"))
+        def frags(mode):
+            r = []
+            for kind, var in (("aL", "FAL"), ("bL", "FBL"), ("aH", "FAH"), ("bH", "FBH")):
+                for i in range(4 if kind[1] == "L" else nh):
+                    b = frag(kind, i)
+                    r.append(f'"{mode}{{v[{b}:{b + 3}]}}"(({var})[{i}])')
+            return r
+
+        def define(name, regs, comment):
+            out.append("// " + comment)
+            out.append(f"#define {name}(A, FAL, FBL, FAH, FBH) \\\n  " + ", \\\n  ".join(regs) + "\n")
+
+        # What a statement declares decides what the allocator must keep alive ACROSS THE EPILOGUE: an operand that is read
+        # ("+") by the first statement of a tile would hold its register through the whole epilogue of the tile in front.
+        define(f"{prefix}_REGS", accs(0, na, "+") + frags("+"), "steady state: every accumulator and fragment is read and written")
+        define(f"{prefix}_REGS_FIRST", accs(0, 4, "=&") + frags("=&"),
+               "first K-step of a tile: accumulators 0-3 start from zero, all fragments are (re)read - nothing is live on entry")
+        define(f"{prefix}_REGS_STEP1", accs(0, 4, "+") + accs(4, na, "=&") + frags("+"),
+               "second K-step: the accumulators of half-set H start from zero")
+        for early in (True, False):
+            sfx = "_E" if early else "_L"
+            for kind in ("step1", "norm", "prelast", "prelast_z", "last"):
+                out.append(kstep(kind, early, nh).text(f"{prefix}_{kind.upper()}{sfx}"))
+        out.append(kstep("first", True, nh).text(f"{prefix}_FIRST"))
+
+    emit_set("V6K", 4)
+    out.append("// ---- the six-batch form (transforms 6, 7 are zero: tl_conv1_wino63v_dgrad_nt): half-set H = transforms 4, 5")
+    emit_set("V6K6", 2)
     out.append(issue_only().text("V6K_ISSUE"))
     print("\n".join(out))
 

@@ -263,6 +263,9 @@ __device__ unsigned long long v6_stamp_buf[256 * V6_STAMP_TILES * V6_STAMP_SLOTS
 #define V6_STAMP_AT(k) do { } while (0)
 #endif
 
+#ifndef V6_GY_SIX
+#define V6_GY_SIX 1          // 0: the eight-batch K loop for epilogue 7 as well (A/B partner)
+#endif
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p) {
   __shared__ __attribute__((aligned(1024))) char lds[3 * V6_STAGE + ((EPI == W_EPI_POOLV || EPI == W_EPI_MASKY || EPI == W_EPI_GY) ? 4096 : EPI == W_EPI_C1W ? 16384 : 0)];
@@ -284,6 +287,9 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   // loop runs over 3 K channels - segment 0 = V0 (A), hex H; segment 1 = V1 (aux: the transform of the rows shifted by 3);
   // segment 2 = V0 again, hex H + 1 (rows shifted by 6 ARE the next hex) - against taps [3 K / 8][8][N][8]
   constexpr bool SEG3 = EPI == W_EPI_LRELU;
+  // EPI == GY (tl_conv1_wino63v_dgrad_nt): transforms 6, 7 of both operands are zero - the six-batch K loop (V6K6_*: half-set H =
+  // transforms 4, 5; 24 MFMAs per K-step), and waves 6, 7 fetch through empty resources (their planes are never read)
+  constexpr bool SIX = EPI == W_EPI_GY && V6_GY_SIX;
   const int kseg = p.K / V6_BK;                            // K-steps per segment (host-checked: K % 8 == 0)
   const int nsteps = SEG3 ? 3 * kseg : kseg;               // host-checked: >= 5
   // Accumulators and fragments live in FIXED registers (tonal_wino63_kloop.h: v0 - v127, v128 - v191): every K-step is one asm
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
   // for B - M0 of the first piece of each kind, + 1 KB per further piece.
   const int prow = lane >> 1;
   const int src_chunk = (lane & 1) ^ ((lane >> 4) & 1);
-  const v6_i32x4 rsB = v6_rsrc_words(p.Bw, 8LL * p.N * p.ldb * 4);
+  const v6_i32x4 rsB = v6_rsrc_words(p.Bw, (SIX && wave >= 6) ? 0 : 8LL * p.N * p.ldb * 4);
   const unsigned lds0 = (unsigned)(unsigned long long)(lds_void6_t*)lds;        // LDS byte address of the first stage
   const unsigned dst_a0 = lds0 + (unsigned)(wave * V6_BH * V6_ROWB);
   const unsigned dst_b0 = lds0 + (unsigned)(V6_A_BYTES + wave * V6_BN * V6_ROWB);
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     t.R0 = tm * V6_ROWS;
     t.n0 = tn * V6_BN;
     const long long ab = tm * a_tile_bytes;
-    t.rsA = v6_rsrc_words(reinterpret_cast<const char*>(p.A) + ab, a_total_bytes - ab);
+    t.rsA = v6_rsrc_words(reinterpret_cast<const char*>(p.A) + ab, (SIX && wave >= 6) ? 0 : a_total_bytes - ab);
     t.rsA1 = SEG3 ? v6_rsrc_words(reinterpret_cast<const char*>(p.aux) + ab, a_total_bytes - ab) : t.rsA;
     if (t.n0 + V6_BN <= p.N) {
       const unsigned nb4 = (unsigned)t.n0 * 32u;
@@ -459,30 +465,35 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
     // 1, which starts 4-7 from zero); a step issues the pieces of the step two ahead into the stage released by the barrier in
     // front of it; the pieces of step 1 went out in front of the previous tile's epilogue: between them and step 0's pieces
     // sit that epilogue's stores, which the closing wait of step 0 leaves in flight (first_wait).
-    V6K_STMT_R(V6K_REGS_FIRST, V6K_FIRST, cur, 2, stg == 0 ? 2 : stg - 1, first_wait);
+    // (V6K_RUN: the statement of one K-step in the form this instantiation runs - six-batch, early or late fragment reads)
+#define V6K_RUN(KIND, RSFX, tl_, step, dst, wimm)                                                                              \
+  do {                                                                                                                         \
+    if constexpr (SIX) V6K_STMT_R(V6K6_REGS##RSFX, V6K6_##KIND##_L, tl_, step, dst, wimm);                                     \
+    else if constexpr (early) V6K_STMT_R(V6K_REGS##RSFX, V6K_##KIND##_E, tl_, step, dst, wimm);                                \
+    else V6K_STMT_R(V6K_REGS##RSFX, V6K_##KIND##_L, tl_, step, dst, wimm);                                                     \
+  } while (0)
+    if constexpr (SIX) V6K_STMT_R(V6K6_REGS_FIRST, V6K6_FIRST, cur, 2, stg == 0 ? 2 : stg - 1, first_wait);
+    else V6K_STMT_R(V6K_REGS_FIRST, V6K_FIRST, cur, 2, stg == 0 ? 2 : stg - 1, first_wait);
     stg = next3(stg);
     // (straight-line control flow between the statements - nsteps >= 5 is host-checked, the steady-state loop runs at least
     // once: across a branch with two successors the allocator moves the pinned values out of their registers and back)
-    if constexpr (early) V6K_STMT_R(V6K_REGS_STEP1, V6K_STEP1_E, cur, 3, stg == 0 ? 2 : stg - 1, 0);
-    else V6K_STMT_R(V6K_REGS_STEP1, V6K_STEP1_L, cur, 3, stg == 0 ? 2 : stg - 1, 0);
+    V6K_RUN(STEP1, _STEP1, cur, 3, stg == 0 ? 2 : stg - 1, 0);
     stg = next3(stg);
     V6_STAMP_AT(2);
     {
       int s = 2;
       do {
-        if constexpr (early) V6K_STMT(V6K_NORM_E, cur, s + 2, stg == 0 ? 2 : stg - 1, 0);
-        else V6K_STMT(V6K_NORM_L, cur, s + 2, stg == 0 ? 2 : stg - 1, 0);
+        V6K_RUN(NORM, , cur, s + 2, stg == 0 ? 2 : stg - 1, 0);
         stg = next3(stg);
       } while (++s + 2 < nsteps);
     }
     V6_STAMP_AT(3);
-    if constexpr (early) V6K_STMT(V6K_PRELAST_E, cur, 0, 0, 0);
-    else V6K_STMT(V6K_PRELAST_L, cur, 0, 0, 0);
+    V6K_RUN(PRELAST, , cur, 0, 0, 0);
     stg = next3(stg);
     pre = prefetch();
-    if constexpr (early) V6K_STMT(V6K_LAST_E, cur, 0, 0, 0);
-    else V6K_STMT(V6K_LAST_L, cur, 0, 0, 0);
+    V6K_RUN(LAST, , cur, 0, 0, 0);
     stg = next3(stg);
+#undef V6K_RUN
     V6_STAMP_AT(4);
 
 #if V6_ABL & 2
