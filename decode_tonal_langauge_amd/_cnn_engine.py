@@ -98,6 +98,7 @@ class CnnEngine:
                 st.tp_out = tp1_default // 4               # the default geometry's rows per sequence behind stage 3
             self.stages.append(st)
             cin, tin, tp = cout, st.tout, st.tp_out
+        self.gy4 = self._gy_applies()          # (fixed here: _alloc_bwd leaves out the gradient rows this path never stores)
         self.lat = tin
         self.tp5 = tp
         self.H = self.lat * n_channels * lstm_channels
@@ -212,7 +213,8 @@ class CnnEngine:
         if not self.wino63 and not (self.fuse_c1 and self._c1_fusable() and self._use_wino(self.stages[0])):
             self.G[1] = z(S * self.tp1, self.c1)      # otherwise G1 never leaves the stage-2 epilogue
         for st in self.stages:
-            if not (self.f63_yprod and st.idx == 2):          # (with f63_yprod G2 is never stored)
+            # (with f63_yprod G2 is never stored; with the NT63 form of stage 4's input gradient neither is G3)
+            if not (self.f63_yprod and st.idx == 2) and not (self.gy4 and st.idx == 3):
                 self.G[st.idx] = z(S * st.tp_out, st.cout if st.pool else self.ld5)
         self.GY = [z(self.rows5, d[3]) for d in self.concat_dims]
         self.dXc = z(self.rows5, self.ldx)
@@ -445,9 +447,12 @@ class CnnEngine:
         """The one-tap pooled stage right behind F(6,3) stage 3 (conv4 of the reference stack) whose input gradient runs on the
         NT63 kernel and writes stage 3's backward operands Y3 / Vd3 itself (tl_conv1_wino63v_dgrad_nt; TONAL_KERNELS
         conv4_dgrad=gemm: the one-tap GEMM + tl_wino63_unpool_yvd of round 4)."""
-        if not (self.wino63 and self.f63_yprod3 and st.idx == 4 and len(self.stages) >= 3):
+        return self.gy4 and st.idx == 4
+
+    def _gy_applies(self) -> bool:
+        if not (self.wino63 and self.f63_yprod3 and len(self.stages) >= 3):
             return False
-        below = self.stages[1]
+        below, st = self.stages[1], self.stages[2]
         return (_kernels.get("conv4_dgrad") == "nt63" and st.k == 1 and st.pool and self._f63(below)
                 and st.cout % 32 == 0 and st.cout >= 40 and st.cin % 32 == 0 and (below.tp_in // 2) % 3 == 0)
 
@@ -627,7 +632,7 @@ class CnnEngine:
                     f"wino63v_nt_kernel<C1WGRAD> (conv2 input gradient + conv1 weight gradient, {f6})": ["conv2_dgrad"],
                     }
             if self.f63_yprod3:
-                gy = len(self.stages) >= 3 and self._gy_stage(self.stages[2])
+                gy = self.gy4
                 src = "the epilogue of conv4's input gradient" if gy else "wino63_unpool_yvd_kernel"
                 fams[f"wino63v_tn4y_kernel (conv3 weight gradient, {f6}: both operands by LDS-DMA, no transform in the kernel; Y3 / Vd3 "
                      f"from {src})"] = ["conv3_wgrad"]

@@ -597,6 +597,31 @@ def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
     assert b"wino_nt" in lib.tl_last_error()
 
 
+def test_conv4_input_gradient_forms_agree_on_the_whole_model(dev, monkeypatch):
+    """Round 5: conv4's input gradient on the NT63 kernel (the default: its epilogue writes conv3's backward operands) against
+    the one-tap GEMM + ``tl_wino63_unpool_yvd`` form of round 4, whole model, identical forward (the bit words are the same, so
+    no tie can be decided differently): every gradient to 1e-5.  15 sequences: the last hex of the NT63 form is half empty."""
+    from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
+    for (B, C, T) in ((3, 5, 400), (2, 4, 200)):
+        g = torch.Generator().manual_seed(T + 1)
+        x = torch.randn(B, C, T, generator=g)
+        lab = torch.randint(0, 4, (B, 2, 5), generator=g).float()
+        tgt = torch.randn(B, 80, generator=g)
+        grads = {}
+        for form in ("gemm", "nt63"):
+            monkeypatch.setenv("TONAL_CONV4_DGRAD", form)
+            torch.manual_seed(1)
+            model = SynthesisModelCNN(80, C, T, dropout=0.0).to(dev).train()
+            eng = model._engine
+            assert eng.wino63 and eng.gy4 == (form == "nt63")
+            out = model(x.to(dev), lab.to(dev))
+            (out - tgt.to(dev)).abs().mean().backward()
+            assert (3 in eng.G) == (form == "gemm")                     # the NT63 form never stores conv3's gradient rows
+            grads[form] = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
+        for k in grads["gemm"]:
+            assert rel_l2(grads["nt63"][k], grads["gemm"][k]) < 1e-5, (B, C, T, k)
+
+
 def test_cnn_classifier_hip_forward_matches_module_graph(dev):
     """CNNClassifier inference on the HIP conv kernels vs the same module's stock PyTorch graph."""
     from decode_tonal_langauge_amd.models import CNNClassifier
