@@ -12,8 +12,8 @@ ck = json.load(open(P("effective_clock.json")))["effective_clock_ghz"]
 line = json.loads([l for l in open(P("r05_c3_bench_line.log")) if l.startswith("{")][-1])
 roof = line["roofline"]
 pl = roof["per_launch"]
-out = ["# Round 5 - C3 train step, 1x MI355X, rocprofv3 --kernel-trace --stats (asm K loop build, `gpurun_out/r05f`)\n",
-       "Command (GPU box, `R05TAG=r05f scripts/collect_r05_profiles.sh bench c3stats c3fetch c3write c3clock sq c5`, one call, one box): "
+out = ["# Round 5 - C3 train step, 1x MI355X, rocprofv3 --kernel-trace --stats (final build of the round, `gpurun_out/r05n`)\n",
+       "Command (GPU box, `R05TAG=r05n scripts/collect_r05_profiles.sh bench c3stats c3fetch c3write c3clock`, one call, one box): "
        "`rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -o r3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
        "--no-kernel-timers --no-extras`\n",
        f"4 train steps (1 warm-up incl. the one-time zero-fills + 3 timed) of SynthesisModelCNN 128ch x 400t, batch 256, fp32.  Total kernel time "
@@ -27,10 +27,10 @@ for r in rows[:28]:
 out.append("")
 out.append("Kernel names: `wino63v_nt_kernel<5>` = <POOLV> conv2 forward (writes V2), `<4>` = <C1WGRAD> conv2 input gradient + fused conv1 weight "
            "gradient, `<2>` = <POOL> conv3 forward, `<6>` = <MASKY> conv3 input gradient writing Y2 / Vd2; `wino63v_tn4y_kernel`: both weight "
-           "gradients; `wino63_unpool_yvd_kernel`: Y3 / Vd3 from G3; `conv1_fwd_vh_kernel`: conv1 writing V1.  Since this round the K loop of "
+           "gradients; `<7>` = <GY> conv4's input gradient on the same kernel (six batches, writes Y3 / Vd3) behind `wino63_unpool_rows6_kernel`; `conv1_fwd_vh_kernel`: conv1 writing V1.  Since this round the K loop of "
            "`wino63v_nt_kernel` is asm with pinned registers: `Scratch_Size` of all its launches in the trace is 0 (`r05_kernel_resources.md`).\n")
 out.append("HIP-event timers of the bench line (second, untimed pass) against the rocprof averages above: "
-           + ", ".join(f"{k} {v['ms']:.2f}" for k, v in sorted(pl.items()) if k.startswith(("conv2", "conv3"))) + " ms.\n")
+           + ", ".join(f"{k} {v['ms']:.2f}" for k, v in sorted(pl.items()) if k.startswith(("conv2", "conv3", "conv4"))) + " ms.\n")
 out.append("| family | ms (HIP events) | issued TFLOP/s | of 157.3 nominal | held clock GHz (GRBM pass) | at the held clock | HBM-side read GB | write GB |\n|---|---|---|---|---|---|---|---|")
 for fam, v in roof["families"].items():
     t = tr.get(fam, {})
@@ -41,11 +41,22 @@ for fam, v in roof["families"].items():
                )
     out[-1] += f" {t.get('read_bytes', 0)/1e9:.1f} | {t.get('write_bytes', 0)/1e9:.1f} |"
 out.append("")
+def gb(fam_key, what):
+    for k, v in tr.items():
+        if fam_key in k:
+            return v[what] / 1e9
+    return float("nan")
+
+
 out.append("Traffic: separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes of the same bench command, FETCH_SIZE x 2 (gfx950 tallies the 128-B "
-           "requests of 16-B/lane streaming reads at 64 B), per launch.  Against the algorithmic bytes: conv2 forward writes 9.6 GB for 9.1 GB of V2 + 0.4 GB "
-           "of bit words (round 4: 14.2 GB - the difference was spill traffic), reads 39.8 GB for 18.3 GB of V1 (V once + the 8.4 MB tap set per round of "
-           "tiles against a 4 MB L2: Infinity-Cache traffic, `r04_kernel_notes.md` 4); `<MASKY>` writes 36.5 GB (Y2 + Vd2 = 36.6) and reads 34.5 GB for 9.1 GB "
-           "of Vd3 + 0.9 GB of bit words: the same tap re-fetch as conv3 forward (18.5 GB) plus what 36 GB of write-allocated lines push out of the "
-           "L2s on their way through (section 7 of `r05_kernel_notes.md` has the store cache-policy experiment).\n")
+           "requests of 16-B/lane streaming reads at 64 B), per launch.  Against the algorithmic bytes: conv2 forward writes "
+           f"{gb('<POOLV>', 'write_bytes'):.1f} GB for 9.1 GB of V2 + 0.4 GB of bit words (round 4: 14.2 GB - the difference was spill traffic), reads "
+           f"{gb('<POOLV>', 'read_bytes'):.1f} GB for 18.3 GB of V1 (V once + the 8.4 MB tap set per round of tiles against a 4 MB L2: Infinity-Cache traffic, "
+           f"`r04_kernel_notes.md` 4); `<MASKY>` writes {gb('<MASKY>', 'write_bytes'):.1f} GB (Y2 + Vd2 = 36.6) and reads {gb('<MASKY>', 'read_bytes'):.1f} GB for "
+           "9.1 GB of Vd3 + 0.9 GB of bit words: the same tap re-fetch as conv3 forward plus what 36 GB of write-allocated lines push out of the "
+           "L2s on their way through (section 7 of `r05_kernel_notes.md` has the store cache-policy experiment); `<GY>` (conv4's input gradient) writes "
+           f"{gb('<GY>', 'write_bytes'):.1f} GB (Y3 + Vd3 = 18.3) and reads {gb('<GY>', 'read_bytes'):.1f} GB for 1.7 GB of operand + 0.4 GB of bit words "
+           f"(its 0.5 MB tap set stays in the L2), behind `wino63_unpool_rows6_kernel` ({gb('rows6', 'read_bytes'):.1f} GB read, {gb('rows6', 'write_bytes'):.1f} GB "
+           "written); the stand-alone producer they replace moved 21.7 GB and the one-tap GEMM in front of it another 4.4 GB.\n")
 open(P("r05_c3_step_summary.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out)[:3000])

@@ -21,6 +21,8 @@ FAMILIES = {
     "wino63v_nt_kernel<4>": f"wino63v_nt_kernel<C1WGRAD> (conv2 input gradient + conv1 weight gradient, {F6})",
     "wino63v_nt_kernel<6>": f"wino63v_nt_kernel<MASKY> (conv3 input gradient, {F6}; writes Y and Vd of conv2 instead of the gradient rows)",
     "wino63v_nt_kernel<3>": f"wino63v_nt_kernel<MASK> (conv3 input gradient, {F6})",
+    "wino63v_nt_kernel<7>": "wino63v_nt_kernel<GY> (conv4 input gradient as six batched GEMMs of the NT63 kernel; writes Y and Vd of conv3 instead of the gradient rows)",
+    "wino63_unpool_rows6_kernel": "wino63_unpool_rows6_kernel (conv4's pooled output gradient un-pooled into the hex-slot operand of its input gradient)",
     "wino63v_tn4y_kernel": f"wino63v_tn4y_kernel (conv2 / conv3 weight gradient, {F6}: both operands by LDS-DMA, no transform in the kernel; average of the two launches)",
     "wino63_unpool_yvd_kernel": "wino63_unpool_yvd_kernel (Y3 / Vd3 of conv3 from G3 and its arg-max bits)",
     "conv1_fwd_vh_kernel": "conv1_fwd_vh_kernel (conv1 + LeakyReLU + pool writing V1 in hex form)",
