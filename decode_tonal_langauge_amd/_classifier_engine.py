@@ -34,6 +34,84 @@ class CnnClassifierEngine(CnnEngine):
         self.ld_last = last.cout if last.pool else self.ld5
         self.kflat_cls = n_electrodes * self.tp_last * self.ld_last
         self._packed: Dict[str, Tuple[int, torch.Tensor]] = {}
+        # Round 5: the leading pooled 3-tap stages on the F(6,3) V-form kernels of the synthesis stack (tonal_wino63.hip: conv1
+        # writes V1 in hex form, every stage but the last writes the next stage's V from its forward epilogue, the last one
+        # pooled rows in this engine's own row geometry through out_tp) - forward only.  n63 = how many stages after the first
+        # run that way (0: none - TONAL_KERNELS wino != 6, or a shape the kernels do not take).
+        self.n63, self.tp63 = self._plan63(stage_defs, n_timepoints)
+
+    def _plan63(self, stage_defs, T):
+        from . import _kernels
+        if _kernels.get("wino") != "6" or _kernels.get("clf_f63") == "0":
+            return 0, []
+        c1, k1, p1 = stage_defs[0]
+        if not (p1 and 1 <= k1 <= 3 and c1 in (128, 256, 512, 1024) and T >= 2 * self.tout1 + 2 and T * 4 <= 64 * 1024):
+            return 0, []
+        n, cin = 0, c1
+        for st in self.stages:
+            if not (st.k == 3 and st.pool and cin % 128 == 0 and st.cout % 64 == 0 and cin >= 40 and st.tout >= 1):
+                break
+            n, cin = n + 1, st.cout
+        n = min(n, 3)
+        if n == 0:
+            return 0, []
+        unit = 6 << (n - 1)                                  # every stage but the last: Tp % 12 == 0, halved by its pool
+        tp = (self.tout1 + unit - 1) // unit * unit
+        tps = []
+        for _ in range(n):
+            tps.append(tp)
+            tp //= 2
+        return n, tps
+
+    def _forward63(self, convs, x, S, T):
+        """Stages 1 .. 1 + n63 on the F(6,3) kernels; leaves the pooled rows of stage 1 + n63 in self.P (row geometry of this
+        engine) and returns the number of conv layers consumed."""
+        from ._lib import EPI_POOL, EPI_POOLV, LOAD_V
+        lib, st_ = self.lib, self._stream()
+        dev = x.device
+        z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
+        zi = lambda *sh: torch.zeros(*sh, dtype=torch.int32, device=dev)
+        buf = self._buf63
+        w1, b1 = convs[0]
+        tp1 = self.tp63[0]
+        if "V1" not in buf:
+            nh = S * tp1 // 6
+            buf["V1"] = z((nh + 24 + 127) // 128 * 128, 8, self.c1)
+            buf["b1"] = zi(S * tp1, self.c1 // 32)
+        check(lib.tl_conv1_fwd_v6(ptr(x), ptr(w1.reshape(self.c1, self.k1).contiguous()), ptr(b1), None, ptr(buf["V1"]),
+                                  ptr(buf["b1"]), None, S, T, self.k1, self.c1, tp1, self.tout1, self.slope, st_), "tl_conv1_fwd_v6")
+        V = buf["V1"]
+        tile_rows = self._nt63_rows()
+        for i in range(self.n63):
+            st, (w, b) = self.stages[i], convs[1 + i]
+            tp_in = self.tp63[i]
+            last = i == self.n63 - 1
+            wp = self._cached(f"conv{st.idx}w63", w, lambda w=w: self._pack_wino63(w, True))
+            rows_in = S * tp_in
+            kb = f"bits{st.idx}"
+            if kb not in buf:
+                buf[kb] = zi(S * (st.tp_out if last else tp_in // 2), st.cout // 32)
+            kw = dict(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], loader=LOAD_V, Bw=ptr(wp), bias=ptr(b), M=rows_in, N=st.cout,
+                      K=st.cin, ldb=st.cin, J=3, row_shift=0, Tp=tp_in, slope=self.slope, obits=ptr(buf[kb]),
+                      ld_obits=st.cout // 32, Tvalid=2 * st.tout)
+            if last:
+                dst = self.P[st.idx]
+                self._nt(fn="tl_conv3_wino63v_nt", out=ptr(dst), ldo=dst.shape[1], epilogue=EPI_POOL, out_tp=st.tp_out, **kw)
+            else:
+                rows_out = S * (tp_in // 2)
+                kv, kh = f"V{st.idx}", f"halo{st.idx}"
+                ntm = -(-rows_in // tile_rows)
+                if kv not in buf:
+                    nh = rows_out // 6
+                    buf[kv] = z((nh + 24 + 127) // 128 * 128, 8, st.cout)
+                    buf[kh] = z(ntm, 2, st.cout)
+                Vn, halo = buf[kv], buf[kh]
+                self._nt(fn="tl_conv3_wino63v_nt", out=None, ldo=st.cout, epilogue=EPI_POOLV, vout=ptr(Vn), vhalo=ptr(halo),
+                         vout_quads=Vn.shape[0], ld_vout=Vn.shape[2], **kw)
+                check(lib.tl_wino63_v_fixup(ptr(Vn), ptr(halo), rows_out // 6, ntm, tp_in // 2, st.cout, Vn.shape[2], st_),
+                      "tl_wino63_v_fixup")
+                V = Vn
+        return 1 + self.n63
 
     def _alloc(self, B: int, dev):
         if self._B == B and getattr(self, "_dev", None) == dev:
@@ -41,6 +119,7 @@ class CnnClassifierEngine(CnnEngine):
         self._B, self._dev = B, dev
         S = B * self.C
         self.S = S
+        self._buf63 = {}
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
         self.P = {1: z(S * self.tp1, self.c1)}
@@ -72,10 +151,14 @@ class CnnClassifierEngine(CnnEngine):
         lib, st_ = self.lib, self._stream()
         S = self.S
         w1, b1 = convs[0]
-        check(lib.tl_conv1_fwd(ptr(x), ptr(w1.reshape(self.c1, self.k1).contiguous()), ptr(b1), ptr(self.P[1]),
-                               ptr(self.bits[1]), None, S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_),
-              "tl_conv1_fwd")
-        for st, (w, b) in zip(self.stages, convs[1:]):
+        done = 1
+        if self.n63:
+            done = self._forward63(convs, x, S, T)
+        else:
+            check(lib.tl_conv1_fwd(ptr(x), ptr(w1.reshape(self.c1, self.k1).contiguous()), ptr(b1), ptr(self.P[1]),
+                                   ptr(self.bits[1]), None, S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_),
+                  "tl_conv1_fwd")
+        for st, (w, b) in list(zip(self.stages, convs[1:]))[done - 1:]:
             # pooled 3-tap stages run on the Winograd kernels of the synthesis engine (same TONAL_WINO switch)
             wino, f43 = self._use_wino(st), self._use_wino43(st)
             if wino:

@@ -50,6 +50,7 @@ KEYS: Dict[str, Tuple[str, _Allowed, str, str]] = {
     "store_p1": ("TONAL_STORE_P1", _B, "0", "keep the raw pooled rows of stages 1 / 2 beside V (tests)"),
     "overlap": ("TONAL_OVERLAP", _B, "0", "label LSTM / W_hh update on a side stream (measured: does not pay)"),
     # ---- deep classifiers (_classifier_engine.py)
+    "clf_f63": ("TONAL_CLF_F63", _B, "1", "CNN classifier: its leading pooled 3-tap stages on the F(6,3) V-form kernels (0: in-loop F(4,3))"),
     "conv7": ("TONAL_CONV7", frozenset({"wino63", "wino43", "wino43+1", "direct"}), "wino63", "the CNN-RNN classifier's 7-tap convolutions"),
     "lstm_fused": ("TONAL_LSTM_FUSED", _B, "1", "classifier LSTMs: one fused launch per step"),
     "lstm_sk": ("TONAL_LSTM_SK", _int(0, 1024), "0", "classifier LSTMs (unfused form): split-K of the W_hh product (0 = auto)"),

@@ -622,19 +622,24 @@ def test_conv4_input_gradient_forms_agree_on_the_whole_model(dev, monkeypatch):
             assert rel_l2(grads["nt63"][k], grads["gemm"][k]) < 1e-5, (B, C, T, k)
 
 
-def test_cnn_classifier_hip_forward_matches_module_graph(dev):
-    """CNNClassifier inference on the HIP conv kernels vs the same module's stock PyTorch graph."""
+@pytest.mark.parametrize("f63", ["1", "0"])
+def test_cnn_classifier_hip_forward_matches_module_graph(dev, f63, monkeypatch):
+    """CNNClassifier inference on the HIP conv kernels vs the same module's stock PyTorch graph: with its leading pooled 3-tap
+    stages on the F(6,3) V-form kernels (round 5, the default) and on the in-loop F(4,3) kernels."""
     from decode_tonal_langauge_amd.models import CNNClassifier
+    monkeypatch.setenv("TONAL_CLF_F63", f63)
     torch.manual_seed(0)
-    for (C, T, B) in ((4, 160, 5), (3, 233, 9)):
+    for (C, T, B) in ((4, 160, 5), (3, 233, 9), (8, 400, 7)):
         clf = CNNClassifier(input_channels=C, input_length=T, n_classes=3).to(dev).eval()
         x = torch.randn(B, C, T, device=dev)
         with torch.no_grad():
             hip = clf(x)
+            hip2 = clf(x)                                   # (a second pass through the cached buffers / packed weights)
         assert clf._hip is not None, "HIP path was not taken"
+        assert clf._hip.n63 == (3 if f63 == "1" else 0)
         ref = clf.classifier(clf.feature_extractor(x.unsqueeze(1).permute(0, 1, 3, 2)))
         assert hip.shape == ref.shape == (B, 3)
-        assert float((hip - ref.detach()).abs().max()) < 1e-5
+        assert float((hip - ref.detach()).abs().max()) < 1e-5 and torch.equal(hip, hip2)
 
 
 def test_downsample_matches_reference_golden(dev):
