@@ -12,8 +12,8 @@ ck = json.load(open(P("effective_clock.json")))["effective_clock_ghz"]
 line = json.loads([l for l in open(P("r05_c3_bench_line.log")) if l.startswith("{")][-1])
 roof = line["roofline"]
 pl = roof["per_launch"]
-out = ["# Round 5 - C3 train step, 1x MI355X, rocprofv3 --kernel-trace --stats (final build of the round, `gpurun_out/r05n`)\n",
-       "Command (GPU box, `R05TAG=r05n scripts/collect_r05_profiles.sh bench c3stats c3fetch c3write c3clock`, one call, one box): "
+out = ["# Round 5 - C3 train step, 1x MI355X, rocprofv3 --kernel-trace --stats (final build of the round, `gpurun_out/r05r`)\n",
+       "Command (GPU box, `R05TAG=r05r scripts/collect_r05_profiles.sh bench c3stats c3fetch c3write c3clock`, one call, one box): "
        "`rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -o r3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
        "--no-kernel-timers --no-extras`\n",
        f"4 train steps (1 warm-up incl. the one-time zero-fills + 3 timed) of SynthesisModelCNN 128ch x 400t, batch 256, fp32.  Total kernel time "
