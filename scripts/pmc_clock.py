@@ -9,11 +9,13 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.py")).read()
 ns = {}
-exec(src[src.index("F6 ="):src.index("def collect")], ns)            # the family table of pmc_traffic.py
-FAMILIES = ns["FAMILIES"]
+exec(src[src.index("F6 ="):src.index("def collect")], ns)            # the family table of pmc_traffic.py (+ the tn4y split)
+FAMILIES, TN4Y, tn4y_split = ns["FAMILIES"], ns["TN4Y"], ns["tn4y_split"]
 acc = defaultdict(list)
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    which = tn4y_split(rows)
+    for r in rows:
         if r["Counter_Name"] != "GRBM_GUI_ACTIVE":
             continue
         dt = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])           # ns
@@ -22,6 +24,8 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
         for key, fam in FAMILIES.items():
             if key in r["Kernel_Name"]:
                 acc[fam].append(float(r["Counter_Value"]) / 8.0 / dt)           # cycles per ns = GHz
+        if r["Dispatch_Id"] in which:
+            acc[TN4Y[which[r["Dispatch_Id"]]]].append(float(r["Counter_Value"]) / 8.0 / dt)
 out = {"effective_clock_ghz": {k: round(sum(v) / len(v), 3) for k, v in acc.items() if 1.0 < sum(v) / len(v) < 2.6},
        "launches_averaged": {k: len(v) for k, v in acc.items()},
        "source": "one rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace pass of `bench.py --steps 3 --warmup 1 --no-cpu-baseline "

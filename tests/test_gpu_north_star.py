@@ -3,8 +3,10 @@
 
 * golden G11: one train step of the REFERENCE at that shape, B = 2 (oracle/make_golden_r2.py):
   per-stage activations, LSTM state, output, loss, MCD, every parameter gradient and the parameters
-  after one NAdam step, against the HIP path with its defaults (Winograd F(4,3) / F(2,3), fused conv1
-  weight gradient, low-rank NAdam on W_hh).
+  after one NAdam step, against the HIP path with its defaults (Winograd F(6,3) on pre-transformed
+  operands for conv2 / conv3, conv4's input gradient on the same kernel, fused conv1 weight gradient,
+  low-rank NAdam on W_hh); golden G11b: three steps at the same shape; the F(6,3) kernels against the
+  direct MFMA kernels at the timed batch.  Observed deviations go to profiles/parity_observed.json.
 * batch 256 (the timed batch; no CPU oracle fits it): the loss is a mean over independent windows, so
   the gradient of the whole batch is the mean of the gradients of its two halves - a size-independent
   property that crosses every batch-dependent code path (6.5 M-row split-K reductions, U = 8 label
