@@ -174,6 +174,8 @@ class CnnEngine:
         z = lambda *s: torch.zeros(*s, **f32)
         zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
         self._v_ready = {}     # V tensors already written by the producing kernel in this forward
+        self._gy_A = None      # (per-batch / per-device scratch of the NT63 input-gradient paths: re-created on demand)
+        self._vhalo = {}
         self.P = {}
         if not (self.wino63 or self._conv1_writes_v()) or self.store_p1:
             self.P[1] = z(S * self.tp1, self.c1)
