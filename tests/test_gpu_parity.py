@@ -1579,6 +1579,10 @@ def test_first_stage_gradient_partials_reduce_to_torch_layout(dev, nblk):
     (700, 54, 26, 27, 64, 64),             # more than one row tile per workgroup column: the tile walk
 ])
 def test_one_tap_input_gradient_on_the_f63_nt_kernel_writes_y_and_vd(dev, shape):
+    one_tap_gy_check(dev, shape, refusals=True)
+
+
+def one_tap_gy_check(dev, shape, refusals=False):
     """Round 5: conv4's input gradient (reference models/synthesis_models.py:99-101, backward of loss.backward(),
     synthesis_trainer.py:226) as ``tl_wino63_unpool_rows6`` + ``tl_wino63_weights1`` + ``tl_conv1_wino63v_dgrad_nt`` +
     ``tl_wino63_vd_fixup``: Y3 = A dz3 and Vd3 = B^T dz3 of the 3-tap stage below, against a float64 restatement
@@ -1654,6 +1658,8 @@ def test_one_tap_input_gradient_on_the_f63_nt_kernel_writes_y_and_vd(dev, shape)
     assert near(logical(Vd)[:nh3], Vdref), float((logical(Vd)[:nh3].double() - Vdref).abs().max())
     # (an odd hex count ends inside a pair of the pair layout: slice the logical view, not the memory order)
     assert float(logical(Y)[nh3:].abs().max()) == 0.0 and float(logical(Vd)[nh3:].abs().max()) == 0.0
+    if not refusals:
+        return
     # ---- what the entry refuses
     p.K = 32
     assert lib.tl_conv1_wino63v_dgrad_nt(C_.byref(p), st) != 0 and b"K" in lib.tl_last_error()

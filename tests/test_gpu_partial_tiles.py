@@ -13,7 +13,7 @@ import pytest
 import torch
 from hypothesis import HealthCheck, given, settings, strategies as st
 
-from tests.test_gpu_parity import f63_stage_check, rel, rel_l2
+from tests.test_gpu_parity import f63_stage_check, one_tap_gy_check, rel, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -133,3 +133,22 @@ def test_partial_tile_stores_of_the_nt_kernels_on_random_shapes(dev, data):
             f43_stage_check(dev, (B, C, T, c1, c2, c3))
         finally:
             env.undo()
+
+
+@settings(max_examples=int(os.environ.get("TONAL_SWEEP_CASES_GY", "200")), deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
+@given(st.data())
+def test_one_tap_input_gradient_on_the_nt_kernel_on_random_shapes(dev, data):
+    """Round 5: ``tl_conv1_wino63v_dgrad_nt`` (conv4's input gradient as six batched GEMMs of the NT63 kernel, epilogue 7 writing Y / Vd
+    of the 3-tap stage below) on drawn geometries - sequence counts whose last hex is half empty, hexes that straddle sequences
+    (an odd number of hexes per sequence), valid lengths short of the padding, bit arrays narrower than the hex geometry, column
+    tails - against the float64 restatement of ``one_tap_gy_check``; every launch twice, bit-identical."""
+    S = data.draw(st.integers(1, 300), label="sequences")
+    hexes = data.draw(st.integers(2, 17), label="hexes per sequence of the stage below")
+    tp3 = 6 * hexes
+    tpg = tp3 // 2
+    gtp3 = data.draw(st.integers(max(2, tpg - 2), tpg), label="rows per sequence of the bit arrays")
+    tout3 = data.draw(st.integers(2, gtp3), label="valid pooled rows")
+    c3 = data.draw(st.sampled_from([64, 96, 128, 256]), label="N")
+    c4 = data.draw(st.sampled_from([64, 96, 128]), label="K")
+    one_tap_gy_check(dev, (S, tp3, tout3, gtp3, c3, c4))
