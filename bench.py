@@ -575,6 +575,11 @@ def main():
     from decode_tonal_langauge_amd.models.synthesis_models import SynthesisLite, SynthesisModelCNN
     from decode_tonal_langauge_amd.models.synthesis_trainer import SynthesisTrainer
 
+    if os.environ.get("TONAL_BENCH_SHARE_GPU") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # rehearsal on a one-GPU box (also under `python -m torch.distributed.run`, the driver's launch form): every rank on
+        # device 0, collectives over gloo (RCCL refuses two ranks per device)
+        os.environ["LOCAL_RANK"] = "0"
+        os.environ.setdefault("TONAL_DIST_BACKEND", "gloo")
     rank, world, local = parallel.init_from_env()
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)

@@ -293,6 +293,33 @@ def test_bench_two_rank_launch_at_the_headline_shape():
         assert line["step0"]["ok"], line["step0"]
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's launch form for N > 1 - ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`` - with three ranks on the test GPU over gloo (TONAL_BENCH_SHARE_GPU=1): RANK /
+    LOCAL_RANK / WORLD_SIZE come from the launcher, rank 0 prints the one JSON line, the replicas end identical."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TONAL_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2",
+                        "--warmup", "1", "--batch", "9", "--channels", "8", "--timepoints", "100", "--no-cpu-baseline",
+                        "--no-extras"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 3 and line["config"]["parallelism"] == "dp3" and line["config"]["backend"] == "gloo"
+    assert line["config"]["per_gpu_batch"] == 3 and line["config"]["global_batch"] == 9
+    assert line["dp_check"]["ok"] and line["dp_check"]["ranks_seen"] == 3 and line["dp_check"]["param_checksum_spread"] == 0.0
+
+
 def test_bench_ends_non_zero_when_a_rank_dies():
     r, line = _bench({"TONAL_BENCH_SHARE_GPU": "1", "TONAL_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "1",
                      "--warmup", "0", "--batch", "8", "--channels", "8", "--timepoints", "100", "--no-cpu-baseline",
