@@ -83,6 +83,9 @@ for k in eng.G:
 if eng.f63_yprod:         # stage 2's backward operands come out of stage 3's input gradient: give the isolated passes something to read
     for store in (eng.Yt, eng.Vd):
         eng._v_hex_buffer(store, 2, S * eng.tp1, 512).normal_(generator=g)
+if eng.gy4:               # ... and stage 3's out of stage 4's
+    for store in (eng.Yt, eng.Vd):
+        eng._v_hex_buffer(store, 3, S * eng.stages[1].tp_in, 512).normal_(generator=g)
 for k in eng.bits:
     eng.bits[k].random_(-2**31, 2**31 - 1, generator=g)
     eng.sbits[k].random_(-2**31, 2**31 - 1, generator=g)
@@ -92,6 +95,22 @@ for si in [int(s) for s in args.stages.split(",")]:
         V2 = eng._v_hex_buffer(eng.V, 2, S * st.tp_in, 512)
         V2.normal_(generator=g)
         eng._v_ready[2] = V2
+    if si == 4:
+        # the one-tap stage behind conv3: only its input gradient runs on the NT63 kernel (six batched GEMMs, epilogue 7)
+        assert eng.gy4, "stage 4's input gradient is not on the NT63 kernel (TONAL_KERNELS conv4_dgrad)"
+        w = torch.randn(st.cout, st.cin, 1, 1, device=dev, generator=g) * 0.02
+        fl = 2.0 * B * eng.C * st.tc * st.cin * st.cout
+        eng.stage_dgrad(st, w); torch.cuda.synchronize()
+        eng.enable_timers(True)
+        for _ in range(args.iters):
+            eng.stage_dgrad(st, w)
+        ts = eng.timer_summary(); eng.enable_timers(False)
+        ms = ts["conv4_dgrad"][1]
+        print(f"F63 conv4_dgrad  {ms:8.3f} ms (operand producer + NT63 launch + fix-up)  {fl / ms / 1e9:7.2f} TFLOP/s algorithmic "
+              f"({100 * fl / ms / 1e9 / 157.3:.1f}% of fp32 MFMA peak)", flush=True)
+        if args.stamps:
+            stamp_report(eng, "conv4_dgrad")
+        continue
     w = torch.randn(st.cout, st.cin, 3, 1, device=dev, generator=g) * 0.02
     b = torch.randn(st.cout, device=dev, generator=g) * 0.1
     gw, gb = torch.empty_like(w), torch.empty_like(b)
@@ -103,8 +122,8 @@ for si in [int(s) for s in args.stages.split(",")]:
         eng.stage_dgrad(st, w)
 
     def wgrad():
-        if eng.f63_yprod and st.idx == 2:
-            eng._y_ready[2] = eng.generation
+        if (eng.f63_yprod and st.idx == 2) or (eng.gy4 and st.idx == 3):
+            eng._y_ready[st.idx] = eng.generation
         eng.stage_wgrad(st, gw, gb)
     for name, fn in (("fwd", lambda: eng.stage_forward(st, w, b)), ("wgrad", wgrad), ("dgrad", dgrad)):
         if name not in args.passes.split(","):
