@@ -13,7 +13,7 @@ for sec in "$@"; do
     c3write) rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o w -- $BENCH > $O/c3_write_run.log 2>&1 ;;
     c3clock) rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_c -o c -- $BENCH > $O/c3_clock_run.log 2>&1 ;;
     sq)      # the default F(6,3) kernels of both stages, all three passes (POOLV, C1WGRAD, tn4y; POOL, MASKY, tn4y + the Y / Vd producer)
-             rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/sq -o sq -- python3 $R/scripts/bench_conv63.py --iters 2 > $O/sq.log 2>&1 ;;
+             rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/sq -o sq -- python3 $R/scripts/bench_conv63.py --iters 2 --stages 2,3,4 > $O/sq.log 2>&1 ;;
     c2)      rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -o l -- python3 $R/bench.py --model lite --channels 32 --timepoints 200 --batch 64 --steps 200 --warmup 20 --no-extras > $O/c2_run.log 2>&1 ;;
     c5)      rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -o c5 -- python3 $R/scripts/bench_c5.py --train-classifiers --no-stock-compare > $O/c5_run.log 2>&1 ;;
     signal)  rocprofv3 --kernel-trace --stats --output-format csv -d $O/sig -o s -- python3 $R/scripts/bench_signal.py > $O/sig_run.log 2>&1 ;;
