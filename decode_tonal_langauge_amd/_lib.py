@@ -77,6 +77,12 @@ SIGNATURES = {
     "tl_wino63_unpool_rows6": (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tl_wino63_weights1": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_conv1_wino63v_dgrad_nt": (_I, [C.POINTER(NtParams), _P]),
+    "tl_comm_unique_id": (_I, [_P]),
+    "tl_comm_init": (_I, [C.POINTER(C.c_void_p), _I, _I, _P]),
+    "tl_comm_destroy": (_I, [_P]),
+    "tl_allreduce": (_I, [_P, _P, _P, _L, _I, _P]),
+    "tl_reduce_scatter": (_I, [_P, _P, _P, _L, _P]),
+    "tl_all_gather": (_I, [_P, _P, _P, _L, _P]),
     "tl_conv3_wino_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_conv3_wino43_tn": (_I, [C.POINTER(TnParams), _P]),

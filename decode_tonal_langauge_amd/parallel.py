@@ -37,10 +37,60 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("TONAL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend == "nccl":
+        if backend in ("nccl", "tl"):
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # "tl": the RCCL handle of the C ABI (include/tonal_hip.h, tl_comm_*) carries every fp32 device buffer; the process
+        # group (gloo) is the control plane - rendezvous, the 128-byte id, host-side objects
+        dist.init_process_group(backend="gloo" if backend == "tl" else backend, rank=rank, world_size=world)
+        if backend == "tl":
+            tl_comm_init(rank, world)
     return rank, world, local
+
+
+# ---- the C-ABI RCCL handle as the data path (TONAL_DIST_BACKEND=tl) --------------------------------------------------------
+_TL = None          # (library, communicator, side stream for the asynchronous all-reduce)
+
+
+def tl_comm_init(rank: int, nranks: int) -> None:
+    """Create this process's communicator through ``tl_comm_init``: rank 0 draws the id, the process group carries its 128
+    bytes to the others.  From here on the helpers below hand contiguous fp32 device tensors to ``tl_allreduce`` /
+    ``tl_all_gather`` on torch's current stream; everything else keeps the process group."""
+    global _TL
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        _lib.check(lib.tl_comm_unique_id(buf), "tl_comm_unique_id")
+    box = [bytes(buf.raw) if rank == 0 else None]
+    if nranks > 1:
+        dist.broadcast_object_list(box, src=0)
+    handle = C.c_void_p()
+    _lib.check(lib.tl_comm_init(C.byref(handle), rank, nranks, box[0]), "tl_comm_init")
+    _TL = (lib, handle, torch.cuda.Stream())
+
+
+def tl_comm_destroy() -> None:
+    global _TL
+    if _TL is not None:
+        from . import _lib
+        torch.cuda.synchronize()
+        _lib.check(_TL[0].tl_comm_destroy(_TL[1]), "tl_comm_destroy")
+        _TL = None
+
+
+def _tl_ok(*ts: torch.Tensor) -> bool:
+    return _TL is not None and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+
+
+def _tl_allreduce(t: torch.Tensor, opcode: int) -> None:
+    from . import _lib
+    _lib.check(_TL[0].tl_allreduce(_TL[1], t.data_ptr(), t.data_ptr(), t.numel(), opcode, torch.cuda.current_stream().cuda_stream),
+               "tl_allreduce")
+
+
+def _tl_opcode(op):
+    return {dist.ReduceOp.SUM: 0, dist.ReduceOp.MAX: 1, dist.ReduceOp.MIN: 2}.get(op)
 
 
 def world() -> Tuple[int, int]:
@@ -67,7 +117,9 @@ def _staged() -> bool:
 def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
     """In-place all-reduce (sum by default) of a tensor on any device."""
     op = dist.ReduceOp.SUM if op is None else op
-    if t.is_cuda and _staged():
+    if _tl_ok(t) and _tl_opcode(op) is not None and t.numel() > 0:
+        _tl_allreduce(t, _tl_opcode(op))
+    elif t.is_cuda and _staged():
         h = t.detach().cpu()
         dist.all_reduce(h, op=op)
         t.copy_(h)
@@ -77,7 +129,11 @@ def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
 
 
 def _all_gather_rows(out: torch.Tensor, t: torch.Tensor) -> None:
-    if t.is_cuda and _staged():
+    if _tl_ok(out, t) and t.numel() > 0:
+        from . import _lib
+        _lib.check(_TL[0].tl_all_gather(_TL[1], t.data_ptr(), out.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream),
+                   "tl_all_gather")
+    elif t.is_cuda and _staged():
         ho = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(ho, t.detach().cpu().contiguous())
         out.copy_(ho)
@@ -96,7 +152,11 @@ def all_gather_param_rows_(p: torch.Tensor, row0: int, rows: int) -> torch.Tenso
     """In place: every rank contributes rows [row0, row0 + rows) of ``p`` (equal, rank-ordered row shards) and
     receives all others - re-assembles a parameter whose rows were updated shard-wise."""
     mine = p[row0:row0 + rows]
-    if p.is_cuda and _staged():
+    if _tl_ok(p, mine) and mine.numel() > 0:
+        from . import _lib                       # in place: this rank's rows sit where its block of the result belongs
+        _lib.check(_TL[0].tl_all_gather(_TL[1], mine.data_ptr(), p.data_ptr(), mine.numel(), torch.cuda.current_stream().cuda_stream),
+                   "tl_all_gather")
+    elif p.is_cuda and _staged():
         ho = torch.empty(p.shape, dtype=p.dtype)
         dist.all_gather_into_tensor(ho, mine.detach().cpu().contiguous())
         p.copy_(ho)
@@ -177,6 +237,16 @@ class FlatGrads:
         return self.flat[lo:hi]
 
 
+class _EventWork:
+    """``work.wait()`` of a collective issued on a side stream: torch's current stream waits for the event behind it."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class _Pending:
     """An all-reduce in flight.  ``wait()`` makes torch's current stream wait for it; with ``wait_events`` (a list) the
     time that stream actually spends blocked is measured by a pair of HIP events around the wait."""
@@ -205,6 +275,16 @@ def all_reduce_async(t: torch.Tensor) -> _Pending:
     ranks sharing one GPU, collectives staged through host memory): done synchronously."""
     if not active():
         return _Pending(None, t)
+    if _tl_ok(t) and t.numel() > 0:
+        # the C-ABI handle: on a stream of its own, behind what torch's current stream has enqueued so far
+        side, cur = _TL[2], torch.cuda.current_stream()
+        side.wait_stream(cur)
+        t.record_stream(side)
+        with torch.cuda.stream(side):
+            _tl_allreduce(t, 0)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return _Pending(_EventWork(ev), t)
     if t.is_cuda and _staged():
         all_reduce_(t)
         return _Pending(None, t)
@@ -238,7 +318,11 @@ def broadcast_parameters_(module: torch.nn.Module, src: int = 0) -> None:
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            if t.is_cuda and _staged():
+            if _tl_ok(t.data) and t.numel() > 0:
+                if dist.get_rank() != src:       # (a sum whose other terms are zero: the handle has no broadcast entry)
+                    t.data.zero_()
+                _tl_allreduce(t.data, 0)
+            elif t.is_cuda and _staged():
                 h = t.detach().cpu()
                 dist.broadcast(h, src=src)
                 t.copy_(h)

@@ -264,6 +264,24 @@ int tl_wino63_unpool_rows6(const float* G, const uint32_t* bits, float* A, int64
                            int C, int ldg, int ld_bits, int lda, int pad, void* stream);
 int tl_wino63_weights1(const float* w, float* taps, int O, int I, int ldb, void* stream);
 int tl_conv1_wino63v_dgrad_nt(const tl_nt_params* p, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * RCCL handle (round 5; SURVEY 8b names it): the exchange step of the data-parallel trainer - between loss.backward() and
+ * optimizer.step(), models/synthesis_trainer.py:226-227 - on plain fp32 device buffers.  One communicator per process (= per GPU);
+ * rank 0 draws the id, the host side broadcasts its 128 bytes out of band (the Python host: through the torch.distributed store).
+ * librccl is resolved at first use (the copy the process has loaded, else librccl.so.1): the library loads without it.
+ *   tl_comm_unique_id   id128 <- ncclGetUniqueId
+ *   tl_comm_init        *comm <- ncclCommInitRank(nranks, id, rank) on the current HIP device; tl_comm_destroy frees it
+ *   tl_allreduce        recv[i] = op over ranks of send[i], i < count (op 0 sum, 1 max, 2 min; send == recv allowed)
+ *   tl_reduce_scatter   recv[recv_count] = this rank's block of the sum over ranks of send[nranks * recv_count]
+ *   tl_all_gather       recv[nranks * send_count] = the ranks' send[send_count] in rank order
+ * all asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------ */
+int tl_comm_unique_id(void* id128);
+int tl_comm_init(void** comm, int rank, int nranks, const void* id128);
+int tl_comm_destroy(void* comm);
+int tl_allreduce(void* comm, const float* send, float* recv, int64_t count, int op, void* stream);
+int tl_reduce_scatter(void* comm, const float* send, float* recv, int64_t recv_count, void* stream);
+int tl_all_gather(void* comm, const float* send, float* recv, int64_t send_count, void* stream);
 /* sizeof() of the two parameter structs as compiled into the library (binding self-check) */
 int tl_sizeof_nt_params(void);
 int tl_sizeof_tn_params(void);

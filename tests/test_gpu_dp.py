@@ -146,6 +146,80 @@ def _rccl_worker(port, q):
     dist.destroy_process_group()
 
 
+def _tl_worker(port, q):
+    """One rank whose exchange step runs through the RCCL handle of the C ABI (TONAL_DIST_BACKEND=tl: tl_comm_init /
+    tl_allreduce / tl_all_gather on device buffers, the process group only as control plane), forced on with one rank; then
+    the six entry points directly."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      TONAL_DP_FORCE="1", TONAL_DIST_BACKEND="tl")
+    import ctypes as C
+    from decode_tonal_langauge_amd import _lib, parallel
+    import torch.distributed as dist
+    rank, world, local = parallel.init_from_env()
+    assert (rank, world) == (0, 1) and parallel.active() and parallel._TL is not None and dist.get_backend() == "gloo"
+    dev = torch.device("cuda:0")
+    model, tr, batches = _build(dev)
+    assert tr.dp and tr.world == 1
+    model.train()
+    for b in batches:
+        tr.train_step(*b)
+    torch.cuda.synchronize()
+    out = ({k: v.detach().cpu().numpy() for k, v in model.named_parameters()}, tr._stats.cpu().numpy())
+    # ---- the entry points themselves (one rank: every collective is the identity)
+    lib, comm, _ = parallel._TL
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(1000, device=dev)
+    for op in (0, 1, 2):
+        y = torch.empty_like(x)
+        _lib.check(lib.tl_allreduce(comm, x.data_ptr(), y.data_ptr(), x.numel(), op, st), "tl_allreduce")
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+    y = torch.empty_like(x)
+    _lib.check(lib.tl_all_gather(comm, x.data_ptr(), y.data_ptr(), x.numel(), st), "tl_all_gather")
+    z = torch.empty_like(x)
+    _lib.check(lib.tl_reduce_scatter(comm, x.data_ptr(), z.data_ptr(), x.numel(), st), "tl_reduce_scatter")
+    torch.cuda.synchronize()
+    assert torch.equal(x, y) and torch.equal(x, z)
+    t = torch.arange(12, device=dev, dtype=torch.float32).view(3, 4)
+    assert torch.equal(parallel.all_gather_param_rows_(t.clone(), 0, 3), t)          # in place through the handle
+    pend = parallel.all_reduce_async(x.clone())
+    pend.wait()
+    assert lib.tl_allreduce(None, x.data_ptr(), x.data_ptr(), 4, 0, st) != 0 and b"allreduce" in lib.tl_last_error()
+    assert lib.tl_allreduce(comm, x.data_ptr(), x.data_ptr(), 4, 7, st) != 0
+    assert lib.tl_comm_init(None, 0, 1, None) != 0 and lib.tl_comm_destroy(None) != 0
+    parallel.tl_comm_destroy()
+    assert parallel._TL is None
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def test_exchange_step_over_the_c_abi_rccl_handle_single_rank():
+    """SURVEY 8b's RCCL handle (tl_comm_* / tl_allreduce / tl_reduce_scatter / tl_all_gather): a training run whose exchange
+    step goes through it ends on the single-process parameters; RCCL refuses two ranks per device, so one rank with the
+    exchange forced on is what a one-GPU box can run."""
+    dev = torch.device("cuda:0")
+    model, tr, batches = _build(dev)
+    model.train()
+    for b in batches:
+        tr.train_step(*b)
+    ref = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_tl_worker, args=(31500 + (os.getpid() % 1000), q))
+    p.start()
+    params, stats = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    torch.manual_seed(0)
+    from decode_tonal_langauge_amd.models import SynthesisModelCNN
+    init = {k: v.detach().clone() for k, v in SynthesisModelCNN(80, 8, 100, dropout=0.0).named_parameters()}
+    for k in ref:
+        upd = (ref[k] - init[k]).double()
+        err = float((torch.from_numpy(params[k]).double() - ref[k].double()).norm() / max(float(upd.norm()), 1e-30))
+        assert err < 2e-2, (k, err)
+    assert abs(float(stats[0]) - float(tr._stats[0])) < 1e-3 * abs(float(tr._stats[0]))
+
+
 def test_exchange_step_over_rccl_single_rank():
     dev = torch.device("cuda:0")
     model, tr, batches = _build(dev)
