@@ -268,6 +268,50 @@ def test_c3_batch256_gradient_is_mean_of_half_batches(dev, c3):
         assert err < 2e-4, (k, err)
 
 
+def test_c3_batch256_conv4_input_gradient_forms_agree(dev, c3):
+    """Round 5, at the TIMED batch: conv4's input gradient on the NT63 kernel (six batched GEMMs, epilogue 7 writing conv3's
+    Y3 / Vd3: 17 408 tiles, 68 per persistent workgroup) against the round-4 form (one-tap GEMM writing G3 +
+    ``tl_wino63_unpool_yvd``) on the same forward pass: every gradient to 1e-5 (the bit words are shared, so the two forms
+    differ by the rounding of one K = 256 reduction only)."""
+    model, tr, _ = c3
+    eng = model._engine
+    assert eng.gy4
+    gen = torch.Generator(device=dev).manual_seed(123)
+    B = 256
+    x = torch.randn(B, 128, 400, device=dev, generator=gen)
+    tones = torch.randint(0, 4, (B,), generator=torch.Generator().manual_seed(3))
+    syls = torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(4))
+    lab = gi.tone_dynamics(tones, syls).to(dev)
+    tgt = 10 * torch.randn(B, 80, device=dev, generator=gen)
+    prm = {k: p.detach() for k, p in model.named_parameters()}
+    model.train()
+    out = eng.forward(prm, x, lab, training=True, save=True, seed=0)
+    dout = torch.zeros(B, eng.ldd, device=dev)
+    stats = torch.zeros(4, device=dev)
+    from decode_tonal_langauge_amd._lib import check, ptr
+    check(eng.lib.tl_l1_mcd(ptr(out), ptr(tgt), ptr(dout), ptr(stats), B, 80, eng.ldd, 1, 1.0,
+                            torch.cuda.current_stream().cuda_stream), "tl_l1_mcd")
+    res = {}
+    try:
+        for form in ("nt63", "gemm"):
+            eng.gy4 = form == "nt63"
+            if not eng.gy4 and 3 not in eng.G:                      # (the default path never allocates conv3's gradient rows)
+                st3 = eng.stages[1]
+                eng.G[3] = torch.zeros(eng.S * st3.tp_out, st3.cout, device=dev)
+            g = {k: torch.empty_like(v) for k, v in prm.items() if k != eng.lowrank_param}
+            eng.backward(prm, dout, g, whh_factors=True)
+            res[form] = {k: v.clone() for k, v in g.items()}
+    finally:
+        eng.gy4 = True
+        eng.G.pop(3, None)
+    worst = {}
+    for k in res["gemm"]:
+        a, b = res["nt63"][k].double(), res["gemm"][k].double()
+        worst[k] = float((a - b).norm() / max(float(b.norm()), 1e-30))
+        assert worst[k] < 1e-5, (k, worst[k])
+    record("conv4 input gradient on the NT63 kernel vs one-tap GEMM + producer, whole model at batch 256 (rel L2 per gradient)", worst)
+
+
 def test_f63_kernels_at_the_timed_batch_match_direct_kernels(dev, monkeypatch):
     """Round 5: the F(6,3) default against the direct MFMA kernels (TONAL_WINO=0) at the TIMED row count - batch 256,
     128 ch x 400 samples, 512 channels: 6.68 M conv rows per stage-2 pass, 8 704 row tiles, the 4 096-way split-K of the
