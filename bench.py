@@ -517,6 +517,37 @@ def replica_spread(modules, parallel, dist) -> float:
     return float((hi[:-1] - lo).abs().max().item())
 
 
+def replica_spread_tl(modules, parallel) -> float:
+    """The same equality check carried by the C-ABI RCCL handle (``tl_allreduce`` MIN / MAX, fp32 only): every fp64 checksum
+    travels as three fp32 pieces (x = hi + mid + lo exactly, a deterministic function of x), so the ranks hold the same
+    checksums exactly when every piece has spread 0.  The value returned is the largest piece spread - a yes / no figure
+    (0.0 or not), not the size of the disagreement; non-finite checksums return NaN.  Validates the handle's MIN / MAX
+    path on the first real multi-GPU run (review item 9a)."""
+    import torch
+    sums = []
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            t = t.detach()
+            if not t.is_floating_point():
+                t = t.double()
+            sums.append(torch.sum(t, dtype=torch.float64))
+            sums.append(torch.linalg.vector_norm(t.reshape(-1), dtype=torch.float64))
+    v = torch.stack(sums)
+    bad = (~torch.isfinite(v)).any().to(torch.float32).reshape(1)
+    v = torch.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0)
+    hi = v.float()
+    mid = (v - hi.double()).float()
+    lo_ = (v - hi.double() - mid.double()).float()
+    pieces = torch.cat([hi, mid, lo_]).contiguous()
+    mn, mx = pieces.clone(), torch.cat([pieces, bad]).contiguous()
+    import torch.distributed as dist
+    parallel.all_reduce_(mn, op=dist.ReduceOp.MIN)
+    parallel.all_reduce_(mx, op=dist.ReduceOp.MAX)
+    if float(mx[-1].item()) != 0.0:
+        return float("nan")
+    return float((mx[:-1] - mn).abs().max().item())
+
+
 def choose_lstm_mode(trainer, data, want: str, sync, parallel, dist, dev) -> dict:
     """--lstm-shard: run the label LSTM sharded by gate rows or whole on every rank.  ``auto`` times both for two steps
     each (after one step that allocates), max over ranks, and keeps the faster - DESIGN.md section 7's falsifier (i): the
@@ -628,6 +659,9 @@ def main():
         # every rank must start from the same bits (model AND classifiers), whichever way they were initialised
         spread0 = replica_spread([model, trainer.tone_model, trainer.syllable_model], parallel, dist)
         dp_check = {"init_checksum_spread": spread0}
+        if parallel.tl_active():
+            dp_check["init_checksum_spread_tl_handle"] = replica_spread_tl([model, trainer.tone_model, trainer.syllable_model], parallel)
+            spread0 = spread0 if dp_check["init_checksum_spread_tl_handle"] == 0.0 else float("nan")
         if spread0 != 0.0:
             raise SystemExit(f"bench.py: rank {rank}: initial parameters differ between the ranks (checksum spread {spread0})")
 
@@ -694,6 +728,11 @@ def main():
         # not stay in lockstep and the throughput above is not that of the single-process computation.
         trainer.sync_parameters()
         dp_check["param_checksum_spread"] = replica_spread([model], parallel, dist)
+        if parallel.tl_active():
+            # the same verdict through tl_allreduce MIN / MAX: a wrong result of the handle's reductions shows here
+            dp_check["param_checksum_spread_tl_handle"] = replica_spread_tl([model], parallel)
+            if dp_check["param_checksum_spread_tl_handle"] != 0.0:
+                dp_check["param_checksum_spread"] = float("nan")
         dp_check["ranks_seen"] = dist.get_world_size()
         dp_check["backend"] = dist.get_backend()
         dp_check["lstm"] = lstm_mode
@@ -830,6 +869,7 @@ def main():
     bad = dp_check is not None and not (dp_check.get("param_checksum_spread") == 0.0)
     if dist.is_initialized():
         dist.barrier()
+        parallel.tl_comm_destroy()                 # (no-op unless TONAL_DIST_BACKEND=tl created the C-ABI communicator)
         dist.destroy_process_group()
     if bad:
         print(f"bench.py: rank {rank}: replicas diverged (parameter checksum spread {dp_check.get('param_checksum_spread')})",

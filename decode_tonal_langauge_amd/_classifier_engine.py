@@ -389,6 +389,13 @@ class CnnRnnConvEngine:
             V1 = self.V7[1].view(-1)[: self.V7[1].shape[0] * 8 * cin].view(-1, 8, cin)
             # rows from the valid length of THIS layer's input on enter as zeros (they only feed rows nobody reads)
             tvalid = self.t1 if cin == 1024 else self.ta
+            if V0.shape[2] != self.V7[0].shape[2]:
+                # a narrower layer re-views the storage: its pad hexes (whole pairs behind the last hex, which the third
+                # segment and the rows past M of the last tile read) overlay the wider layer's transform data - zero them, as
+                # tl_conv7_wino63v_nt's contract says ("zero hexes appended"); ~2 MB per array
+                h0 = (nhex + 1) // 2 * 2
+                V0[h0:].zero_()
+                V1[h0:].zero_()
             check(self.lib.tl_wino63_xform2(ptr(src), ptr(V0), ptr(V1), rows, self.Tp, tvalid, cin, src.shape[1], cin, st_),
                   "tl_wino63_xform2")
 

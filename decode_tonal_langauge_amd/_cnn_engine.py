@@ -1154,12 +1154,27 @@ class CnnEngine:
             else:
                 sk_h = self._splitk((ldt + 127) // 128 * ((H + 127) // 128), (kloc + 31) // 32, 1024)
             slab_h = torch.empty(sk_h, ldt, H, **f32)
+        # single process, factored update: the last BPTT product dh_1 = dgates_2 . W_hh comes out of the W_hh NAdam pass itself
+        # (tl_nadam_lowrank_dh): the factors are complete one step before the BPTT ends - h_0 = 0, the gradient has no term for the
+        # first step - and that product needs only the OLD weight.  One 5.4 GB stream of W_hh less per step
+        fuse_dh = (L > 1 and not sh and gather_whh is None and whh_factors and (L - 1) * U <= 64 and U <= 8
+                   and on_factors is not None and getattr(on_factors, "fuse_dh", False) and _kernels.get("whh_dh") != "0")
+        fused_done = False
         for t in range(L - 1, -1, -1):
             check(lib.tl_lstm_cell_bwd(ptr(dh_ext) if t == L - 1 else None, ptr(dhrec) if t < L - 1 else None,
                                        ptr(dc[(t + 1) & 1]) if t < L - 1 else None, ptr(self._act[t]), ptr(self._c[t]),
                                        ptr(self._c[t - 1]) if t > 0 else None, ptr(dg[t]),
                                        ptr(dgt) if t > 0 else None, ptr(dc[t & 1]), U, H, ldt, st_), "tl_lstm_cell_bwd")
-            if t > 0 and sh:
+            if t == 1 and fuse_dh:
+                kr = (L - 1) * U
+                self.whh_factors = (dg[1:].reshape(kr, 4 * H), self._h[:L - 1].reshape(kr, H))
+                row_tiles = 16
+                nslab = -(-(-(-4 * H // 32)) // row_tiles)
+                slab_d = torch.empty(nslab, U, H, **f32)
+                on_factors(dh=(slab_d, U, row_tiles))
+                self._permute(slab_d, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=nslab, zs=U * H)
+                fused_done = True
+            elif t > 0 and sh:
                 # partial dgates . W_hh over this rank's gate rows, summed over the ranks
                 r0, R, _wd = sh
                 self._tn(A=dgt.data_ptr() + 4 * r0 * ldt, B=w_hh.data_ptr() + 4 * r0 * H, slab=ptr(slab_h), Krows=R,
@@ -1175,7 +1190,9 @@ class CnnEngine:
             if "label_lstm.weight_hh_l0" not in grads:
                 grads["label_lstm.weight_hh_l0"] = torch.empty(4 * H, H, **f32)
             return grads["label_lstm.weight_hh_l0"]
-        if L > 1:
+        if fused_done:
+            pass                                   # factors handed over and consumed inside the loop
+        elif L > 1:
             kr = (L - 1) * U
             fa, fb = dg[1:].reshape(kr, 4 * H), self._h[:L - 1].reshape(kr, H)
             if sh:
@@ -1215,7 +1232,7 @@ class CnnEngine:
         check(lib.tl_lstm_ih_grad(ptr(dg), ptr(self._xu), ptr(grads["label_lstm.weight_ih_l0"]), ptr(gb),
                                   ptr(grads["label_lstm.bias_hh_l0"]), L, U, H, 2, st_), "tl_lstm_ih_grad")
         del dg, dgt
-        if on_factors is not None:
+        if on_factors is not None and not fused_done:
             on_factors()
 
     # ------------------------------------------------------------------ backward

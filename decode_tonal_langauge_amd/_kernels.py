@@ -56,6 +56,8 @@ KEYS: Dict[str, Tuple[str, _Allowed, str, str]] = {
     "lstm_sk": ("TONAL_LSTM_SK", _int(0, 1024), "0", "classifier LSTMs (unfused form): split-K of the W_hh product (0 = auto)"),
     # ---- optimiser / trainer
     "nadam_multi": ("TONAL_NADAM_MULTI", _B, "1", "one NAdam launch for all dense tensors"),
+    "whh_dh": ("TONAL_WHH_DH", _B, "1", "single process: the W_hh NAdam pass also produces the last BPTT product dh_1 = dgates_2 . W_hh "
+                                        "(0: a W_hh stream of its own for it)"),
     "graph": ("TONAL_GRAPH", _B, "1", "SynthesisLite step replayed as a HIP graph"),
     "lstm_shard": ("TONAL_LSTM_SHARD", _B, "1", "data parallel: label LSTM sharded by gate rows"),
     # ---- preprocess/signal

@@ -127,6 +127,7 @@ SIGNATURES = {
     "tl_stage_step": (_I, [_P, _P, _F, _F, _F, C.c_uint64, _P, _P, _P, _I, _P]),
     "tl_nadam_multi_dev": (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _F, _P]),
     "tl_nadam_lowrank": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "tl_nadam_lowrank_dh": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _F, _F, _F, _F, _P, _I, _I, _P]),
     "tl_tone_dynamics": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "tl_splitk_bias_lrelu": (_I, [_P, _P, _P, _I, _L, _I, _F, _P]),
     "tl_labels_from_scores": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

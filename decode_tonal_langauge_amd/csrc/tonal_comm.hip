@@ -38,26 +38,41 @@ int find_loaded(struct dl_phdr_info* info, size_t, void* data) {
   return 0;
 }
 
-const api* rccl() {
-  static api a = {};
-  static bool tried = false;
-  if (tried) return a.ok ? &a : nullptr;
-  tried = true;
+// state: 0 loaded, 1 no librccl in the process or on the loader path, 2 a librccl without one of the entry points
+struct loaded { api a; int state; const char* missing; };
+
+loaded load_rccl() {
+  loaded l = {};
   char path[1024] = {0};
   dl_iterate_phdr(find_loaded, path);
   void* h = path[0] ? dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD) : nullptr;
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!h) return nullptr;
-  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
-  a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
-  a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
-  a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
-  a.ReduceScatter = (decltype(a.ReduceScatter))dlsym(h, "ncclReduceScatter");
-  a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
-  a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-  a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.ReduceScatter && a.AllGather && a.GetErrorString;
-  return a.ok ? &a : nullptr;
+  if (!h) {
+    l.state = 1;
+    return l;
+  }
+  api& a = l.a;
+#define TL_SYM(field, name)                                              \
+  a.field = (decltype(a.field))dlsym(h, name);                           \
+  if (!a.field && !l.missing) l.missing = name;
+  TL_SYM(GetUniqueId, "ncclGetUniqueId")
+  TL_SYM(CommInitRank, "ncclCommInitRank")
+  TL_SYM(CommDestroy, "ncclCommDestroy")
+  TL_SYM(AllReduce, "ncclAllReduce")
+  TL_SYM(ReduceScatter, "ncclReduceScatter")
+  TL_SYM(AllGather, "ncclAllGather")
+  TL_SYM(GetErrorString, "ncclGetErrorString")
+#undef TL_SYM
+  a.ok = l.missing == nullptr;
+  l.state = a.ok ? 0 : 2;
+  return l;
+}
+
+// resolved once, by whichever thread comes first (C++11 function-local static: concurrent first calls wait for it)
+const loaded& rccl_state() {
+  static const loaded l = load_rccl();
+  return l;
 }
 
 int fail(const api* a, const char* what, int rc) {
@@ -69,11 +84,16 @@ int fail(const api* a, const char* what, int rc) {
 }  // namespace tl
 
 #define TL_RCCL(a)                                                                                     \
-  const tl::api* a = tl::rccl();                                                                       \
-  if (a == nullptr) {                                                                                  \
+  const tl::loaded& a##_l = tl::rccl_state();                                                          \
+  if (a##_l.state == 1) {                                                                              \
     tl::set_error("RCCL is not available in this process (librccl.so.1 could not be loaded)");         \
     return TL_ENODEV;                                                                                  \
-  }
+  }                                                                                                    \
+  if (a##_l.state == 2) {                                                                              \
+    tl::set_error("the librccl of this process has no %s (RCCL 2.x entry points needed)", a##_l.missing); \
+    return TL_ENODEV;                                                                                  \
+  }                                                                                                    \
+  const tl::api* a = &a##_l.a;
 
 extern "C" int tl_comm_unique_id(void* id128) {
   using namespace tl;

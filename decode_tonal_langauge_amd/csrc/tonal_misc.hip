@@ -937,60 +937,136 @@ __global__ __launch_bounds__(256) void nadam_multi_kernel(const tl_nadam_entry* 
 // parameters): kr <= (L-1) * U = 32 distinct (step, label) rows, so the 5.4 GB gradient tensor and
 // its write + read disappear from the step.  Block tile 32 rows x 256 columns; a thread owns 8 rows
 // x 4 columns; the factor tiles sit in LDS ([k][32] and [k][256]).
-constexpr int LR_TR = 32, LR_TC = 256, LR_MAXK = 64;
+constexpr int LR_TR = 32, LR_TC = 256, LR_MAXK = 64, LR_MAXU = 8;
+// DH (round 6): the same pass also produces dh = fa[0:U] . p_OLD (U x cols) - the last step of the label LSTM's BPTT,
+// dh_1 = dgates_2 . W_hh, which needs only the weight as it was before this update and whose result the W_hh gradient does
+// not depend on (h_0 = 0: the gradient has no term for the first step; rows 0..U-1 of fa ARE dgates_2).  A workgroup walks
+// `row_tiles` consecutive 32-row tiles with the column factor tile resident, accumulates its U x 4 partial sums per thread in
+// registers over the rows, reduces its four row groups through LDS in a fixed order and writes one partial slab
+// dh_slab[blockIdx.x][U][cols]; the caller sums the slabs (deterministic: no atomics).  One 5.4 GB stream of W_hh less per step.
+template <bool DH>
 __global__ __launch_bounds__(256) void nadam_lowrank_kernel(float* __restrict__ p, float* __restrict__ m,
                                                             float* __restrict__ v, const float* __restrict__ fa,
                                                             const float* __restrict__ fb, int kr, int rows, int cols,
                                                             int ldfa, int ldfb, float cg, float cm, float b1, float b2,
-                                                            float bc2, float eps, float wd, float gscale) {
+                                                            float bc2, float eps, float wd, float gscale,
+                                                            float* __restrict__ dh_slab, int U, int row_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lr_lds[];
   float* sa = lr_lds;                        // [kr][LR_TR]
   float* sb = lr_lds + kr * LR_TR;           // [kr][LR_TC]
-  const int r0 = blockIdx.x * LR_TR, c0 = blockIdx.y * LR_TC;
-  for (int i = threadIdx.x; i < kr * LR_TR; i += 256) {
-    const int k = i / LR_TR, r = i % LR_TR;
-    sa[i] = (r0 + r) < rows ? fa[(long long)k * ldfa + r0 + r] : 0.f;
-  }
+  const int c0 = blockIdx.y * LR_TC;
   for (int i = threadIdx.x; i < kr * (LR_TC / 4); i += 256) {
     const int k = i / (LR_TC / 4), c4 = (i % (LR_TC / 4)) * 4;
     f32x4 val = {0.f, 0.f, 0.f, 0.f};
     if (c0 + c4 < cols) val = *reinterpret_cast<const f32x4*>(fb + (long long)k * ldfb + c0 + c4);
     *reinterpret_cast<f32x4*>(sb + k * LR_TC + c4) = val;
   }
-  __syncthreads();
   const int cg4 = (threadIdx.x & 63) * 4, rg = (threadIdx.x >> 6) * 8;
-  f32x4 g[8];
+  const int col = c0 + cg4;
+  const bool colok = col < cols;
+  f32x4 dh[DH ? LR_MAXU : 1];
+  if constexpr (DH) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) g[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < kr; ++k) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + k * LR_TC + cg4);
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + k * LR_TR + rg);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + k * LR_TR + rg + 4);
+    for (int u = 0; u < LR_MAXU; ++u) dh[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nt = DH ? row_tiles : 1;
+#pragma unroll 1
+  for (int it = 0; it < nt; ++it) {
+    const int r0 = (blockIdx.x * nt + it) * LR_TR;
+    if (r0 >= rows) break;                   // (uniform over the workgroup)
+    if (it > 0) __syncthreads();             // the row factor tile of the tile before is still being read
+    for (int i = threadIdx.x; i < kr * LR_TR; i += 256) {
+      const int k = i / LR_TR, r = i % LR_TR;
+      sa[i] = (r0 + r) < rows ? fa[(long long)k * ldfa + r0 + r] : 0.f;
+    }
+    // DH: the weight rows of this thread are fetched ahead of the gradient arithmetic (they are in flight while it runs) and
+    // meet the first U factor rows - the dgates of the product - inside that loop, where those are in registers anyway
+    f32x4 pold[DH ? 8 : 1];
+    if constexpr (DH) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      g[r] += a0[r] * bv;
-      g[r + 4] += a1[r] * bv;
+      for (int r = 0; r < 8; ++r) {
+        const int row = r0 + rg + r;
+        pold[r] = (colok && row < rows) ? reinterpret_cast<const f32x4*>(p)[((long long)row * cols + col) >> 2]
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __syncthreads();
+    f32x4 g[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) g[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    if constexpr (DH) {
+#pragma unroll
+      for (int u = 0; u < LR_MAXU; ++u) {
+        if (u < U) {                         // (U <= kr, uniform)
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + u * LR_TC + cg4);
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + u * LR_TR + rg);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + u * LR_TR + rg + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            g[r] += a0[r] * bv;
+            g[r + 4] += a1[r] * bv;
+            dh[u] += a0[r] * pold[r];        // the weight BEFORE the update
+            dh[u] += a1[r] * pold[r + 4];
+          }
+        }
+      }
+      k = U;
+    }
+    for (; k < kr; ++k) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + k * LR_TC + cg4);
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + k * LR_TR + rg);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + k * LR_TR + rg + 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        g[r] += a0[r] * bv;
+        g[r + 4] += a1[r] * bv;
+      }
+    }
+    if (colok) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = r0 + rg + r;
+        if (row >= rows) break;
+        const long long at = ((long long)row * cols + col) >> 2;
+        f32x4 pv, mv = reinterpret_cast<f32x4*>(m)[at], vv = reinterpret_cast<f32x4*>(v)[at];
+        if constexpr (DH) pv = pold[r];
+        else pv = reinterpret_cast<f32x4*>(p)[at];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float pq = pv[q], mq = mv[q], vq = vv[q];
+          nadam_one(pq, g[r][q], mq, vq, cg, cm, b1, b2, bc2, eps, wd, gscale);
+          pv[q] = pq;
+          mv[q] = mq;
+          vv[q] = vq;
+        }
+        reinterpret_cast<f32x4*>(p)[at] = pv;
+        reinterpret_cast<f32x4*>(m)[at] = mv;
+        reinterpret_cast<f32x4*>(v)[at] = vv;
+      }
     }
   }
-  const int col = c0 + cg4;
-  if (col >= cols) return;
+  if constexpr (DH) {
+    // the four row groups of the workgroup hold partial sums for the same 256 columns: summed in the order 0, 1, 2, 3
+    // (the scratch overlays the factor tiles, which nobody reads any more behind the barrier)
+    __syncthreads();
+    float* red = lr_lds;                                 // [3][LR_MAXU][LR_TC]
+    const int w = threadIdx.x >> 6;
+    if (w > 0) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int row = r0 + rg + r;
-    if (row >= rows) break;
-    const long long at = ((long long)row * cols + col) >> 2;
-    f32x4 pv = reinterpret_cast<f32x4*>(p)[at], mv = reinterpret_cast<f32x4*>(m)[at], vv = reinterpret_cast<f32x4*>(v)[at];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float pq = pv[q], mq = mv[q], vq = vv[q];
-      nadam_one(pq, g[r][q], mq, vq, cg, cm, b1, b2, bc2, eps, wd, gscale);
-      pv[q] = pq;
-      mv[q] = mq;
-      vv[q] = vq;
+      for (int u = 0; u < LR_MAXU; ++u) *reinterpret_cast<f32x4*>(red + ((w - 1) * LR_MAXU + u) * LR_TC + cg4) = dh[u];
     }
-    reinterpret_cast<f32x4*>(p)[at] = pv;
-    reinterpret_cast<f32x4*>(m)[at] = mv;
-    reinterpret_cast<f32x4*>(v)[at] = vv;
+    __syncthreads();
+    if (w == 0 && colok) {
+#pragma unroll
+      for (int u = 0; u < LR_MAXU; ++u) {
+        if (u >= U) break;
+        f32x4 s = dh[u];
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww) s += *reinterpret_cast<const f32x4*>(red + (ww * LR_MAXU + u) * LR_TC + cg4);
+        *reinterpret_cast<f32x4*>(dh_slab + ((long long)blockIdx.x * U + u) * cols + col) = s;
+      }
+    }
   }
 }
 
@@ -1481,34 +1557,62 @@ extern "C" int tl_nadam_multi_dev(const tl_nadam_entry* entries_dev, int count, 
 
 extern "C" int tl_nadam_multi_chunk(void) { return NM_CHUNK; }
 
-extern "C" int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
+static int nadam_lowrank_launch(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
                                 int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
-                                float bias_corr2, float eps, float weight_decay, float grad_scale, void* stream) {
+                                float bias_corr2, float eps, float weight_decay, float grad_scale, float* dh_slab, int U,
+                                int row_tiles, void* stream) {
   TL_REQUIRE(p && m && v && rows > 0 && cols > 0, "nadam_lowrank: bad arguments");
   TL_REQUIRE(kr >= 0 && kr <= LR_MAXK && (kr == 0 || (fa && fb)), "nadam_lowrank: rank must be 0..%d with both factors", LR_MAXK);
   TL_REQUIRE(cols % 4 == 0 && ldfb % 4 == 0 && ldfa >= rows && ldfb >= cols, "nadam_lowrank: cols / ldfb must be multiples of 4, ld >= extent");
   TL_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)fb) & 15) == 0, "nadam_lowrank: pointers must be 16-byte aligned");
-  const unsigned gx = (unsigned)((rows + LR_TR - 1) / LR_TR), gy = (unsigned)((cols + LR_TC - 1) / LR_TC);
+  const bool dh = dh_slab != nullptr;
+  if (dh) {
+    TL_REQUIRE(U >= 1 && U <= LR_MAXU && U <= kr && row_tiles >= 1, "nadam_lowrank_dh: 1 <= U <= min(%d, rank) and row_tiles >= 1 needed", LR_MAXU);
+    TL_REQUIRE(((uintptr_t)dh_slab & 15) == 0, "nadam_lowrank_dh: dh_slab must be 16-byte aligned");
+  }
+  const int tiles = (rows + LR_TR - 1) / LR_TR;
+  const unsigned gx = (unsigned)(dh ? (tiles + row_tiles - 1) / row_tiles : tiles), gy = (unsigned)((cols + LR_TC - 1) / LR_TC);
   TL_REQUIRE(gy <= 65535u, "nadam_lowrank: more than 16.7 M columns");
-  const size_t lds = (size_t)kr * (LR_TR + LR_TC) * 4;
-  if (lds > 64 * 1024) {      // ranks 57..64 need 64.1 - 72 KB of the CU's 160 KB: raise the per-block limit once
-    static thread_local int raised_on = -1;
+  size_t lds = (size_t)kr * (LR_TR + LR_TC) * 4;
+  if (dh && lds < (size_t)3 * LR_MAXU * LR_TC * 4) lds = (size_t)3 * LR_MAXU * LR_TC * 4;      // (the reduction scratch overlays the tiles)
+  const void* fn = dh ? reinterpret_cast<const void*>(nadam_lowrank_kernel<true>) : reinterpret_cast<const void*>(nadam_lowrank_kernel<false>);
+  if (lds > 64 * 1024) {      // ranks 57..64 need more than 64 KB of the CU's 160 KB: raise the per-block limit once
+    static thread_local int raised_on[2] = {-1, -1};
     int devid = 0;
     (void)hipGetDevice(&devid);
-    if (raised_on != devid) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nadam_lowrank_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LR_MAXK * (LR_TR + LR_TC) * 4);
+    if (raised_on[dh] != devid) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LR_MAXK * (LR_TR + LR_TC) * 4);
       if (e != hipSuccess) {
         set_error("nadam_lowrank: cannot raise the dynamic LDS limit for rank %d: %s", kr, hipGetErrorString(e));
         return TL_ELAUNCH;
       }
-      raised_on = devid;
+      raised_on[dh] = devid;
     }
   }
-  hipLaunchKernelGGL(nadam_lowrank_kernel, dim3(gx, gy), dim3(256), lds, (hipStream_t)stream, p,
-                     m, v, fa, fb, kr, rows, cols, ldfa, ldfb, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps,
-                     weight_decay, grad_scale);
+  if (dh)
+    hipLaunchKernelGGL(nadam_lowrank_kernel<true>, dim3(gx, gy), dim3(256), lds, (hipStream_t)stream, p, m, v, fa, fb, kr, rows,
+                       cols, ldfa, ldfb, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps, weight_decay, grad_scale, dh_slab, U,
+                       row_tiles);
+  else
+    hipLaunchKernelGGL(nadam_lowrank_kernel<false>, dim3(gx, gy), dim3(256), lds, (hipStream_t)stream, p, m, v, fa, fb, kr, rows,
+                       cols, ldfa, ldfb, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps, weight_decay, grad_scale, nullptr, 0, 1);
   return check_launch("nadam_lowrank");
+}
+
+extern "C" int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
+                                int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
+                                float bias_corr2, float eps, float weight_decay, float grad_scale, void* stream) {
+  return nadam_lowrank_launch(p, m, v, fa, fb, kr, rows, cols, ldfa, ldfb, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps,
+                              weight_decay, grad_scale, nullptr, 0, 1, stream);
+}
+
+extern "C" int tl_nadam_lowrank_dh(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
+                                   int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
+                                   float bias_corr2, float eps, float weight_decay, float grad_scale, float* dh_slab, int U,
+                                   int row_tiles, void* stream) {
+  TL_REQUIRE(dh_slab != nullptr, "nadam_lowrank_dh: dh_slab needed (ceil(rows / (32 row_tiles)) x U x cols floats)");
+  return nadam_lowrank_launch(p, m, v, fa, fb, kr, rows, cols, ldfa, ldfb, coef_grad, coef_mom, beta1, beta2, bias_corr2, eps,
+                              weight_decay, grad_scale, dh_slab, U, row_tiles, stream);
 }
 
 extern "C" int tl_splitk_bias_lrelu(const float* slab, const float* bias, float* out, int nz, int64_t n, int ncols, float slope,

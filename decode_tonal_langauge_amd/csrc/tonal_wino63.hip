@@ -418,18 +418,22 @@ __global__ __launch_bounds__(512, 2) void wino63v_nt_kernel(const tl_nt_params p
       [vb1] "v"((src).vb[1]), [ra] "s"((src).ra), [rb] "s"(rsB), [m0a] "s"(dst_a0 + (unsigned)(dst) * (unsigned)V6_STAGE),     \
       [m0b] "s"(dst_b0 + (unsigned)(dst) * (unsigned)V6_STAGE), [sa] "s"((src).sa), [sb] "s"((src).sb), [w] "n"(wimm)
   // (clobbers: the statements advance M0 with s_add_u32, which writes SCC - a compare the compiler placed in front of a
-  // statement must not be consumed behind it; M0 itself is only ever written inside these statements)
+  // statement must not be consumed behind it.  M0 is written inside the statements and named as a clobber too, so that an
+  // M0 initialisation the compiler makes for a consumer of its own is never assumed to survive one of them;
+  // clang remarks that M0 is a reserved register - the clobber is recorded all the same and the generated code is unchanged,
+  // profiles/r05_kernel_resources.md - hence the diagnostic pragma)
+#pragma clang diagnostic ignored "-Winline-asm"
 #define V6K_STMT_R(REGS, TEXT, tl_, step, dst, wimm)                                                                     \
   do {                                                                                                                   \
     const dma_src src_ = src_of(tl_, step);                                                                              \
-    asm volatile(TEXT : REGS(acc, faL, fbL, faH, fbH) : V6K_INPUTS(src_, dst, wimm) : "memory", "scc");                  \
+    asm volatile(TEXT : REGS(acc, faL, fbL, faH, fbH) : V6K_INPUTS(src_, dst, wimm) : "memory", "scc", "m0");                  \
   } while (0)
 #define V6K_STMT(TEXT, tl_, step, dst, wimm) V6K_STMT_R(V6K_REGS, TEXT, tl_, step, dst, wimm)
   // the six LDS-DMA pieces of K-step `step` of tile tl_ into stage `dst` (no MFMAs, no vector operands: the first two stages
   // of a tile, issued in front of the epilogue of the tile before - which must not see fragments or accumulators as live)
   auto issue = [&](const tile_t& tl_, int step, int dst) {
     const dma_src src_ = src_of(tl_, step);
-    asm volatile(V6K_ISSUE : : V6K_INPUTS(src_, dst, 0) : "memory", "scc");
+    asm volatile(V6K_ISSUE : : V6K_INPUTS(src_, dst, 0) : "memory", "scc", "m0");
   };
   // The reads of H between L's MFMAs: one per MFMA in the first half of L's window, so that the last eight MFMAs cover their
   // latency behind the barrier - for the conv2 launches (POOLV, fused conv1 gradient: -0.5 / -0.4 ms, same-call A/B, twice);

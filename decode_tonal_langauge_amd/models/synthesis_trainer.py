@@ -270,13 +270,15 @@ class SynthesisTrainer:
         scale = 1.0          # the 1/N of the global mean is already in dout (weight of this rank's rows)
         early = []
 
-        def on_factors():
+        def on_factors(dh=None):
             # single process: the W_hh update (33 GB of HBM traffic) is issued as soon as its gradient factors exist, on the
-            # stream the LSTM backward runs on - beside the convolution backward instead of behind it
+            # stream the LSTM backward runs on - beside the convolution backward instead of behind it.  ``dh``: the engine
+            # asks for the last BPTT product out of the same pass (they exist one step early: h_0 = 0)
             factors = getattr(eng, "whh_factors", None)
             if factors is not None and not self.dp:
-                self.optimizer.step_lowrank({params[skip]: factors}, grad_scale=scale)
+                self.optimizer.step_lowrank({params[skip]: factors}, grad_scale=scale, dh=dh)
                 early.append(params[skip])
+        on_factors.fuse_dh = not self.dp
         flat = getattr(self, "_flat", None) if self.dp else None
         pending = []
 
@@ -358,10 +360,11 @@ class SynthesisTrainer:
 
     def set_lstm_shard(self, on: bool) -> bool:
         """Switch the gate-row sharding of the label LSTM on or off BETWEEN steps (data parallel only; a collective: every
-        rank must call it with the same value).  The weight is re-assembled first; the NAdam moments of ``weight_hh_l0``
-        change shape with the mode (row shard <-> whole matrix), so they - and the flat gradient layout - start afresh:
-        this is for choosing the faster mode during warm-up (bench.py ``--lstm-shard auto``), not for mid-training use.
-        Returns whether the LSTM will run sharded (False where the model / label table does not allow it)."""
+        rank must call it with the same value).  The weight is re-assembled first; the NAdam state of ``weight_hh_l0``
+        follows the mode - its moments are cut to this rank's rows (whole -> shard: every rank holds the same full
+        moments) or all-gathered (shard -> whole), its step count and mu product stay - so the parameter keeps the
+        single-process trajectory across a switch (bench.py ``--lstm-shard auto`` switches during warm-up).  The flat gradient
+        layout is rebuilt.  Returns whether the LSTM will run sharded (False where the model / label table does not allow it)."""
         eng = getattr(self.model, "_engine", None)
         if not self.dp or eng is None or not hasattr(eng, "lstm_shard"):
             return False
@@ -370,7 +373,18 @@ class SynthesisTrainer:
         if want != eng.lstm_shard:
             eng.lstm_shard = want
             p = dict(self.model.named_parameters())[eng.lowrank_param]
-            self.optimizer.state.pop(p, None)
+            st = self.optimizer.state.get(p)
+            if st:
+                rows = p.shape[0] // self.world
+                r0 = self.rank * rows
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if want is not None:                      # whole -> this rank's rows
+                        st[key] = st[key][r0:r0 + rows].clone()
+                    else:                                     # row shards -> the whole matrix on every rank
+                        full = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        full[r0:r0 + rows].copy_(st[key])
+                        st[key] = parallel.all_gather_param_rows_(full, r0, rows)
+                st["shard_rows"] = (r0, rows) if want is not None else None
             self._grads, self._flat = None, None
             if want is not None and not getattr(self, "_guard_hooked", False):
                 self.model.register_state_dict_pre_hook(self._state_dict_guard)

@@ -56,17 +56,23 @@ class FusedNAdam(torch.optim.Optimizer):
     LOWRANK_MAX = 64          # largest factor rank tl_nadam_lowrank takes
 
     @torch.no_grad()
-    def step_lowrank(self, lowrank: Dict[torch.nn.Parameter, tuple], grad_scale: float = 1.0) -> None:
+    def step_lowrank(self, lowrank: Dict[torch.nn.Parameter, tuple], grad_scale: float = 1.0, dh=None) -> None:
         """The low-rank part of ``step`` alone, on torch's current stream: lets the caller update such a parameter as soon
         as its factors exist (the trainer runs it on a side stream beside the convolution backward) and hand the same
-        parameters to ``step(..., skip=...)`` afterwards."""
+        parameters to ``step(..., skip=...)`` afterwards.
+
+        ``dh = (slab (n, U, cols), U, row_tiles)`` (one parameter only): the same pass writes the partial sums of
+        ``fa[0:U] . p_old`` - the product of the factor's first U rows with the parameter as it was BEFORE this update
+        (``tl_nadam_lowrank_dh``: the label LSTM's last BPTT step rides in the W_hh update); ``slab.sum(0)`` is the product."""
         stream = torch.cuda.current_stream().cuda_stream
+        if dh is not None and len(lowrank) != 1:
+            raise RuntimeError("FusedNAdam.step_lowrank: the fused product takes exactly one parameter")
         for group in self.param_groups:
             for p in group["params"]:
                 if p in lowrank:
-                    self._step_lowrank(p, group, lowrank[p], grad_scale, stream)
+                    self._step_lowrank(p, group, lowrank[p], grad_scale, stream, dh)
 
-    def _step_lowrank(self, p, group, spec, grad_scale, stream) -> None:
+    def _step_lowrank(self, p, group, spec, grad_scale, stream, dh=None) -> None:
         b1, b2 = group["betas"]
         fa, fb = spec[0], spec[1]
         shard = (int(spec[2]), int(spec[3])) if len(spec) > 2 else None
@@ -84,6 +90,18 @@ class FusedNAdam(torch.optim.Optimizer):
         st["step"] += 1
         cg, cm, bc2, st["mu_product"] = nadam_scalars(st["step"], st["mu_product"], group["lr"], b1, b2,
                                                       group["momentum_decay"])
+        if dh is not None:
+            slab, U, row_tiles = dh
+            nslab = -(-(-(-rows // 32)) // row_tiles)
+            if (shard is not None or not kr or U > kr or tuple(slab.shape) != (nslab, U, p.shape[1]) or not slab.is_contiguous()
+                    or slab.dtype != torch.float32):
+                raise RuntimeError("FusedNAdam: the fused product needs the whole parameter, U <= rank and a contiguous fp32 slab "
+                                   f"({nslab}, {U}, {p.shape[1]})")
+            check(self._lib.tl_nadam_lowrank_dh(p.data_ptr(), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(fa), ptr(fb), kr, rows,
+                                                p.shape[1], fa.stride(0), fb.stride(0), cg, cm, b1, b2, bc2, group["eps"],
+                                                group["weight_decay"], grad_scale, ptr(slab), U, row_tiles, stream),
+                  "tl_nadam_lowrank_dh")
+            return
         check(self._lib.tl_nadam_lowrank(p.data_ptr() + 4 * row0 * p.shape[1], ptr(st["exp_avg"]),
                                          ptr(st["exp_avg_sq"]), ptr(fa), ptr(fb),
                                          kr, rows, p.shape[1], fa.stride(0) if kr else rows,

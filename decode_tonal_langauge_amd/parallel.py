@@ -79,6 +79,11 @@ def tl_comm_destroy() -> None:
         _TL = None
 
 
+def tl_active() -> bool:
+    """The C-ABI RCCL handle carries the fp32 device buffers of this process (``TONAL_DIST_BACKEND=tl``)."""
+    return _TL is not None
+
+
 def _tl_ok(*ts: torch.Tensor) -> bool:
     return _TL is not None and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
 
@@ -151,6 +156,11 @@ def all_gather_blocks(out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
 def all_gather_param_rows_(p: torch.Tensor, row0: int, rows: int) -> torch.Tensor:
     """In place: every rank contributes rows [row0, row0 + rows) of ``p`` (equal, rank-ordered row shards) and
     receives all others - re-assembles a parameter whose rows were updated shard-wise."""
+    rank_, world_ = world()
+    if row0 != rank_ * rows or rows * world_ != p.shape[0]:
+        # (both in-place forms below put rank r's block at rows [r * rows, (r + 1) * rows) of the result)
+        raise ValueError(f"all_gather_param_rows_: rank {rank_} of {world_} must own rows [{rank_ * rows}, {(rank_ + 1) * rows}) of "
+                         f"{p.shape[0]}, got row0 = {row0}, rows = {rows}")
     mine = p[row0:row0 + rows]
     if _tl_ok(p, mine) and mine.numel() > 0:
         from . import _lib                       # in place: this rank's rows sit where its block of the result belongs
@@ -276,7 +286,10 @@ def all_reduce_async(t: torch.Tensor) -> _Pending:
     if not active():
         return _Pending(None, t)
     if _tl_ok(t) and t.numel() > 0:
-        # the C-ABI handle: on a stream of its own, behind what torch's current stream has enqueued so far
+        # the C-ABI handle: on a stream of its own, behind what torch's current stream has enqueued so far.  (One communicator
+        # serves this stream and the blocking collectives on the current stream: RCCL orders the operations of a communicator
+        # by issue order, which is the same program order on every rank - single host thread, no data-dependent branches
+        # between collectives - so the two streams cannot cross them.)
         side, cur = _TL[2], torch.cuda.current_stream()
         side.wait_stream(cur)
         t.record_stream(side)

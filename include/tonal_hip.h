@@ -401,6 +401,16 @@ int tl_nadam_multi_dev(const tl_nadam_entry* entries_dev, int count, int64_t tot
 int tl_nadam_lowrank(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
                      int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
                      float bias_corr2, float eps, float weight_decay, float grad_scale, void* stream);
+/* ... and, in the same pass over p, dh = fa[0:U] . p_OLD (U x cols): the last step of the label LSTM's BPTT
+ * (dh_1 = dgates_2 . W_hh reads the weight as it was BEFORE this update, and the W_hh gradient has no term for the first step,
+ * so the update does not wait for it; torch's LSTM backward inside loss.backward(), models/synthesis_trainer.py:226, followed by
+ * optimizer.step(), :227).  Rows 0..U-1 of fa must be the dgates of that step (U <= 8, U <= kr).  The kernel writes
+ * ceil(rows / (32 row_tiles)) partial slabs dh_slab[slab][U][cols] (caller-owned, 16-byte aligned); their sum over `slab`
+ * (tl_permute_reduce) is dh.  One 5.4 GB stream of W_hh less per train step.                                                 */
+int tl_nadam_lowrank_dh(float* p, float* m, float* v, const float* fa, const float* fb, int kr, int rows, int cols,
+                        int ldfa, int ldfb, float coef_grad, float coef_mom, float beta1, float beta2,
+                        float bias_corr2, float eps, float weight_decay, float grad_scale, float* dh_slab, int U,
+                        int row_tiles, void* stream);
 
 /* ---- tone dynamics gather (data_loading/utils.py:32-79) ----------------------------------- */
 /* labels[b][0][l] = syl[b]; labels[b][1][l] = table[tone[b]][l]; err flag set if tone out of range */

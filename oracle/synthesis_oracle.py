@@ -121,22 +121,80 @@ def lstm_last_hidden(x: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor,
     return h
 
 
+class _ActPoolDecided(torch.autograd.Function):
+    """LeakyReLU (+ MaxPool2d((2, 1))) with the reference's forward values (models/synthesis_models.py:88-104,
+    118-130) and a backward whose two DISCRETE decisions come from outside: ``pos`` - the (pooled) output is positive, so
+    LeakyReLU' is 1, else ``slope`` - and ``odd`` - the second row of the pool pair is the arg-max and receives the
+    gradient.  With the decisions torch itself takes (``pos = y > 0``, ``odd = z[2t+1] > z[2t]``) the result is
+    ``F.leaky_relu`` + ``F.max_pool2d`` bit for bit; with the decisions another implementation took on pre-activations
+    that differ from these by rounding, every remaining difference between the two gradients is arithmetic, not a
+    flipped branch on a near-tie.  Test infrastructure (tests/test_gpu_north_star.py)."""
+
+    @staticmethod
+    def forward(ctx, z, slope, pos, odd):
+        y = F.leaky_relu(z, slope)
+        if odd is not None:
+            y = F.max_pool2d(y, kernel_size=(2, 1), stride=(2, 1))
+        ctx.slope, ctx.rows = slope, z.shape[2]
+        ctx.save_for_backward(pos, odd if odd is not None else pos)
+        ctx.pooled = odd is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, odd = ctx.saved_tensors
+        gp = g * torch.where(pos, torch.ones((), dtype=g.dtype), torch.full((), ctx.slope, dtype=g.dtype))
+        if not ctx.pooled:
+            return gp, None, None, None
+        gz = g.new_zeros(g.shape[0], g.shape[1], ctx.rows, g.shape[3])      # a trailing odd row gets no gradient
+        n = g.shape[2]
+        gz[:, :, 0:2 * n:2] = torch.where(odd, torch.zeros((), dtype=g.dtype), gp)
+        gz[:, :, 1:2 * n:2] = torch.where(odd, gp, torch.zeros((), dtype=g.dtype))
+        return gz, None, None, None
+
+
+def own_decisions(z: torch.Tensor, pool: bool) -> Dict[str, torch.Tensor]:
+    """The decisions torch takes on pre-activations ``z`` (B, ch, t, C): ``pos`` and, for a pooled stage, ``odd``
+    (``max_pool2d`` keeps the FIRST maximum of a tie; LeakyReLU' is ``slope`` at exactly 0)."""
+    if not pool:
+        return {"pos": z > 0}
+    n = z.shape[2] // 2
+    a, b = z[:, :, 0:2 * n:2], z[:, :, 1:2 * n:2]
+    return {"pos": torch.maximum(a, b) > 0, "odd": b > a}
+
+
 def cnn_forward(p: Dict[str, torch.Tensor], inputs_ecog: torch.Tensor, inputs_labels: torch.Tensor,
                 dropout_mask: Optional[torch.Tensor] = None, negative_slope: float = 0.01,
-                return_intermediates: bool = False):
+                return_intermediates: bool = False, decisions: Optional[Dict[str, torch.Tensor]] = None,
+                own: Optional[Dict[str, torch.Tensor]] = None):
     """``SynthesisModelCNN.forward`` (models/synthesis_models.py:137-176).
 
     ``dropout_mask`` (B, conv_channels, latent, C) holds the already scaled keep mask
     (0 or 1/(1-p)); ``None`` = eval mode / dropout 0.
+
+    ``decisions`` (test infrastructure): ``{"ecog<i>.pos", "ecog<i>.odd" (i = 1..4), "ecog5.pos", "concat<i>.pos"}`` bool
+    tensors in the layout of the activation they belong to - the LeakyReLU' / arg-max branches the BACKWARD pass takes
+    (``_ActPoolDecided``); forward values are unchanged.  Layers without an entry decide for themselves.  ``own``: a dict
+    that receives the decisions this forward pass would take by itself (for counting how many differ).
     """
     B, C, T = inputs_ecog.shape
     x = inputs_ecog.unsqueeze(1).permute(0, 1, 3, 2)        # (B, 1, T, C)  :157-158
     inter = {}
+    dec = decisions or {}
+
+    def act(z, slope, pool, key):
+        if own is not None:
+            with torch.no_grad():
+                for k, v in own_decisions(z, pool).items():
+                    own[f"{key}.{k}"] = v
+        if f"{key}.pos" in dec:
+            return _ActPoolDecided.apply(z, slope, dec[f"{key}.pos"], dec[f"{key}.odd"] if pool else None)
+        y = F.leaky_relu(z, slope)
+        return F.max_pool2d(y, kernel_size=(2, 1), stride=(2, 1)) if pool else y
+
     for si, (idx, (_, _k, pool)) in enumerate(zip((0, 3, 6, 9, 12), ECOG_STAGES)):
         x = F.conv2d(x, p[f"ecog_conv_block.{idx}.weight"], p[f"ecog_conv_block.{idx}.bias"])
-        x = F.leaky_relu(x, negative_slope)
-        if pool:
-            x = F.max_pool2d(x, kernel_size=(2, 1), stride=(2, 1))
+        x = act(x, negative_slope, pool, f"ecog{si + 1}")
         inter[f"ecog{si + 1}"] = x
     if dropout_mask is not None:                              # :107,160
         x = x * dropout_mask
@@ -149,7 +207,7 @@ def cnn_forward(p: Dict[str, torch.Tensor], inputs_ecog: torch.Tensor, inputs_la
     x = torch.cat((x, x2), dim=1)                             # :170
     for si, idx in enumerate((0, 2, 4, 6, 8)):                # :116-131 (slope 0.1)
         x = F.conv2d(x, p[f"concat_conv_block.{idx}.weight"], p[f"concat_conv_block.{idx}.bias"])
-        x = F.leaky_relu(x, 0.1)
+        x = act(x, 0.1, False, f"concat{si + 1}")
         inter[f"concat{si + 1}"] = x
     x = x.flatten(1)                                          # :174
     out = x @ p["output_layer.weight"].t() + p["output_layer.bias"]   # :175

@@ -22,6 +22,7 @@ import pytest
 import torch
 
 from tests import golden_inputs as gi
+from tests.branch_planes import count_differing, hip_decisions
 from tests.parity_record import record
 from tests.test_gpu_parity import rel, rel_l2, _trainer
 
@@ -161,9 +162,9 @@ def test_c3_shape_train_step_matches_reference_golden(dev, c3):
             absum = float(grads[k].double().abs().sum())
         assert got.shape == ref.reshape(-1).shape, k
         observed["grad." + k] = rel_l2(got, ref.reshape(-1))
-        assert observed["grad." + k] < 5e-3, k
+        assert observed["grad." + k] < grad_bound(k), (k, observed["grad." + k])
         if sums is not None:
-            assert abs(absum - sums[1]) < 5e-3 * sums[1], k
+            assert abs(absum - sums[1]) < max(grad_bound(k), 1e-4) * sums[1], k
     # parameters after the step (NAdam, low-rank path for W_hh): the update vector against the reference's
     upd = {}
     for k, p in model.named_parameters():
@@ -177,6 +178,73 @@ def test_c3_shape_train_step_matches_reference_golden(dev, c3):
         # tensor below UPD_OBSERVED) - round 2's bounds were 5e-2 / 2e-2
         tol = 2 * UPD_OBSERVED_BIAS if k in ("ecog_conv_block.9.bias", "concat_conv_block.4.bias") else 2 * UPD_OBSERVED
         assert v < tol, (k, v)
+
+
+# gradient deviation from the reference golden G11 observed on the MI355X with the default kernels (profiles/parity_observed.json,
+# "G11 one step"): the five conv-stack tensors sit at 1.2e-3 - 2.8e-3 because a handful of LeakyReLU' / arg-max branches on
+# pre-activations that agree to 2e-6 fall the other way (test_c3_gradients_match_the_oracle_given_the_same_branches holds
+# the arithmetic itself to 2e-5); everything else below 2e-6.  The unconditional test allows twice the observed value
+GRAD_OBSERVED = {"ecog_conv_block.0": 2.8e-3, "ecog_conv_block.3": 2.6e-3, "ecog_conv_block.6": 2.4e-3,
+                 "ecog_conv_block.9": 1.4e-3}
+GRAD_OBSERVED_ELSEWHERE = 2.5e-6
+
+
+def grad_bound(name: str) -> float:
+    return 2 * GRAD_OBSERVED.get(name.rsplit(".", 1)[0], GRAD_OBSERVED_ELSEWHERE)
+
+
+def test_c3_gradients_match_the_oracle_given_the_same_branches(dev, c3):
+    """The 2e-3 deviation of the conv-stack gradients from golden G11 is explained, not tolerated: the HIP path's sign and
+    arg-max bit planes are read back and handed to the CPU oracle's backward pass (oracle.synthesis_oracle._ActPoolDecided,
+    as the dropout mask already is) on the reference's G11 parameters and inputs.  With the branches shared EVERY parameter
+    gradient must agree to 2e-5 relative L2 - a 0.3 % error in any conv kernel cannot hide behind a near-tie any more.  The
+    branches that differ from the ones the oracle takes by itself are counted and recorded."""
+    from oracle import synthesis_oracle as so
+    model, _tr, _chk = c3
+    g = np.load(os.path.join(GOLD, "g11_c3_step.npz"))
+    D, Cn, T, B = (int(v) for v in g["dims"])
+    xs, _t, _s, labs, tg = gi.train_batches(1, B, Cn, T, seed=int(g["data_seed"]))
+    x, lab, tgt = xs[0], labs[0], tg[0]
+    tr = _pristine(model, dev)
+    eng = model._engine
+    assert eng.wino63 and eng.gy4 and eng.H == 18432                # the default kernels bench.py times
+    model.train()
+    tr._stats.zero_()
+    tr._fused_step(x.to(dev), lab.to(dev), tgt.to(dev))
+    torch.cuda.synchronize()
+    grads = dict(tr._grads)
+    fa, fb = eng.whh_factors
+    dec = hip_decisions(eng, B, Cn)
+    # ---- the oracle on the reference's parameters (host copy of the seeded state), its backward on the HIP path's branches ----
+    leaves = {k: _INIT["state"][k].clone().requires_grad_(True) for k, _ in model.named_parameters()}
+    own = {}
+    ref = so.cnn_forward(leaves, x, lab, decisions=dec, own=own)
+    ref_loss = so.l1_loss(ref, tgt.long())
+    ref_grads = dict(zip(leaves, torch.autograd.grad(ref_loss, list(leaves.values()))))
+    obs = {"loss": abs(float(tr._stats[2]) - float(ref_loss)) / float(ref_loss)}
+    differ, total = count_differing(dec, own)
+    for k, p in model.named_parameters():
+        rg = ref_grads[k]
+        if k == eng.lowrank_param:                                  # gradient = fa^T . fb: compared in row blocks on the GPU
+            num = den = 0.0
+            for r0 in range(0, 4 * eng.H, 4096):
+                blk = (fa[:, r0:r0 + 4096].t() @ fb).double()
+                rb = rg[r0:r0 + 4096].to(dev).double()
+                num += float(((blk - rb) ** 2).sum())
+                den += float((rb ** 2).sum())
+            obs["grad." + k] = (num / den) ** 0.5
+        else:
+            obs["grad." + k] = rel_l2(grads[k].cpu().numpy(), rg.numpy())
+    worst = max(v for k, v in obs.items() if k.startswith("grad."))
+    print("gradients against the oracle on shared branches: worst", f"{worst:.2e}", "branches that differ from the oracle's own:",
+          {k: v for k, v in differ.items() if v})
+    record("G11 gradients, oracle backward on the HIP path's sign / arg-max planes",
+           dict(obs, **{"differ." + k: v for k, v in differ.items()}, **{"of." + k: v for k, v in total.items()}))
+    for k, v in obs.items():
+        assert v < 2e-5, (k, v)
+    # near-ties only: a handful of branches out of 10^8
+    assert sum(differ.values()) <= 1e-5 * sum(total.values()), differ
+    _pristine(model, dev)
 
 
 def test_c3_shape_three_steps_follow_reference_golden(dev, c3):
@@ -463,6 +531,7 @@ def test_train_mode_dropout_mask_forward_and_gradients_against_oracle(dev):
     loss.backward()
     assert eng._p_drop_used == 0.5
     seed = eng._seed_used
+    dec = hip_decisions(eng, B, Cn)
 
     def read_mask(seed_, row0=0, nb=B):
         # keep mask * 1/(1-p): the concat kernel applied to an all-ones stage-5 activation
@@ -488,13 +557,13 @@ def test_train_mode_dropout_mask_forward_and_gradients_against_oracle(dev):
     assert eng._seed_used != seed and not torch.equal(read_mask(eng._seed_used), mask)
     # oracle with the HIP-generated mask
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    ref = so.cnn_forward(leaves, xs[0], labs[0], dropout_mask=mask.cpu())
+    ref = so.cnn_forward(leaves, xs[0], labs[0], dropout_mask=mask.cpu(), decisions=dec)
     ref_loss = so.l1_loss(ref, tg[0].long())
     ref_grads = dict(zip(leaves, torch.autograd.grad(ref_loss, list(leaves.values()))))
     assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
     assert abs(float(loss.detach()) - float(ref_loss)) < 1e-5 * float(ref_loss)
-    for k, p in model.named_parameters():
-        assert rel_l2(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 5e-3, k
+    for k, p in model.named_parameters():              # the oracle's backward takes the HIP path's LeakyReLU' / arg-max branches
+        assert rel_l2(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 5e-5, k
 
 
 def test_dropout_backward_uses_the_forward_mask(dev):
@@ -566,3 +635,31 @@ def test_lowrank_nadam_at_the_rank_limit(dev):
             oa.step(grads={pa: (fa.t() @ fb).contiguous()})
             ob.step(grads={}, lowrank={pb: (fa, fb)})
         assert float((pa - pb).detach().abs().max()) < 1e-5 * max(1.0, float(pa.detach().abs().max())), kr
+
+
+def test_lowrank_nadam_pass_also_yields_the_last_bptt_product(dev):
+    """tl_nadam_lowrank_dh: parameter and moments bit-identical to tl_nadam_lowrank's (same arithmetic, same order), and the
+    slab sum equals fa[0:U] . p_OLD - the product with the weight as it was before the update - over ragged rows / columns,
+    every U the kernel takes, ranks up to the LDS limit and several row-tile counts."""
+    from decode_tonal_langauge_amd.optim import FusedNAdam
+    g = torch.Generator(device=dev).manual_seed(9)
+    for rows, cols, kr, U, row_tiles in ((1000, 520, 32, 8, 16), (96, 256, 5, 1, 1), (4099, 1028, 64, 8, 3), (33, 4, 8, 5, 2)):
+        w0 = torch.randn(rows, cols, device=dev, generator=g)
+        pa, pb = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(w0.clone())
+        oa, ob = FusedNAdam([pa], lr=5e-3, weight_decay=0.004), FusedNAdam([pb], lr=5e-3, weight_decay=0.004)
+        for _ in range(2):
+            fa = torch.randn(kr, rows, device=dev, generator=g)
+            fb = torch.randn(kr, cols, device=dev, generator=g)
+            old = pb.detach().clone()
+            nslab = -(-(-(-rows // 32)) // row_tiles)
+            slab = torch.full((nslab, U, cols), float("nan"), device=dev)
+            oa.step_lowrank({pa: (fa, fb)})
+            ob.step_lowrank({pb: (fa, fb)}, dh=(slab, U, row_tiles))
+            assert torch.equal(pa.detach(), pb.detach())
+            assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+            assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+            ref = fa[:U].double() @ old.double()
+            got = slab.double().sum(0)
+            assert float((got - ref).abs().max()) < 1e-5 * float(ref.abs().max()), (rows, cols, kr, U, row_tiles)
+    with pytest.raises(RuntimeError):           # U above the factor rank / a slab of the wrong shape
+        ob.step_lowrank({pb: (fa[:2], fb[:2])}, dh=(torch.empty(1, 5, cols, device=dev), 5, 2))

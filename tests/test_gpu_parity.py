@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from tests import golden_inputs as gi
+from tests.branch_planes import hip_decisions
 
 pytestmark = pytest.mark.gpu
 
@@ -135,12 +136,13 @@ def test_cnn_autograd_path_equals_fused_path(dev):
     loss = (out - tg[0].to(dev).long()).abs().mean()
     loss.backward()
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    ref = so.cnn_forward(leaves, xs[0], labs[0])
+    # (the oracle's backward takes the LeakyReLU' / arg-max branches the HIP path took: tests/branch_planes.py)
+    ref = so.cnn_forward(leaves, xs[0], labs[0], decisions=hip_decisions(model._engine, 5, 4))
     ref_loss = so.l1_loss(ref, tg[0].long())
     ref_grads = dict(zip(leaves, torch.autograd.grad(ref_loss, list(leaves.values()))))
     assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
     for k, p in model.named_parameters():
-        assert rel_l2(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 5e-3, k
+        assert rel_l2(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 5e-5, k
 
 
 def test_cnn_random_labels_no_dedup(dev):
@@ -156,11 +158,11 @@ def test_cnn_random_labels_no_dedup(dev):
     out = model(x.to(dev), lab.to(dev))
     out.square().mean().backward()
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    ref = so.cnn_forward(leaves, x, lab)
+    ref = so.cnn_forward(leaves, x, lab, decisions=hip_decisions(model._engine, 70, 8))
     ref_grads = dict(zip(leaves, torch.autograd.grad(ref.square().mean(), list(leaves.values()))))
     assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
     for k, p in model.named_parameters():
-        assert rel_l2(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 5e-3, k
+        assert rel_l2(p.grad.cpu().numpy(), ref_grads[k].numpy()) < 5e-5, k
 
 
 def test_signal_filters_match_reference_golden(dev):
@@ -470,15 +472,15 @@ def test_cnn_edge_shapes_against_oracle(dev, cfg):
     ((out - tgt.to(dev)) ** 2).mean().backward()
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     # oracle with the model's widths (its helper assumes the reference's names/shapes only)
-    ref = so.cnn_forward(leaves, x, lab)
+    ref = so.cnn_forward(leaves, x, lab, decisions=hip_decisions(model._engine, B, C))
     ref_grads = dict(zip(leaves, torch.autograd.grad(((ref - tgt) ** 2).mean(), list(leaves.values()))))
     assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
     for k, p in model.named_parameters():
         gref = ref_grads[k].numpy()
         if np.abs(gref).max() < 1e-12:
             assert float(p.grad.abs().max()) < 1e-9, k
-        else:
-            assert rel_l2(p.grad.cpu().numpy(), gref) < 5e-3, k
+        else:                                         # (shared LeakyReLU' / arg-max branches: tests/branch_planes.py)
+            assert rel_l2(p.grad.cpu().numpy(), gref) < 5e-5, k
 
 
 def test_cnn_rejects_bad_inputs(dev):

@@ -330,3 +330,33 @@ def test_f63_matrices_of_the_kernels_are_the_exact_cook_toom_construction():
     pair = lin.reshape(nh // 2, 2, 8, Cc // 8, 8).permute(0, 3, 2, 1, 4).reshape(nh, 8, Cc)       # store channels-last data pair-wise
     assert torch.equal(logical(pair), lin)
     assert np.isfinite(float(ident.sum()))
+
+
+def test_decided_backward_is_torchs_own_given_torchs_own_branches():
+    """oracle.synthesis_oracle._ActPoolDecided (the backward pass on externally supplied LeakyReLU' / arg-max branches, used
+    by the GPU tests to separate flipped near-ties from arithmetic): with the branches torch takes by itself it reproduces
+    F.leaky_relu + F.max_pool2d bit for bit - forward and every gradient - and a flipped arg-max plane moves the gradients
+    upstream of it only."""
+    from oracle import synthesis_oracle as so
+    torch.manual_seed(0)
+    p = so.init_cnn_params(80, 4, 100)
+    x, lab, tg = torch.randn(3, 4, 100), torch.randn(3, 2, 5), torch.randn(3, 80)
+
+    def run(dec=None, own=None):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        out = so.cnn_forward(leaves, x, lab, decisions=dec, own=own)
+        return out, dict(zip(leaves, torch.autograd.grad(so.l1_loss(out, tg), list(leaves.values()))))
+
+    o1, g1 = run()
+    own = {}
+    run(own=own)
+    assert sorted(own) == sorted([f"ecog{i}.{k}" for i in (1, 2, 3, 4) for k in ("odd", "pos")] + ["ecog5.pos"]
+                                 + [f"concat{i}.pos" for i in (1, 2, 3, 4, 5)])
+    o2, g2 = run(dec=own)
+    assert torch.equal(o1, o2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+    flipped = dict(own, **{"ecog3.odd": ~own["ecog3.odd"]})
+    o3, g3 = run(dec=flipped)
+    assert torch.equal(o1, o3)                                   # forward values never depend on the supplied branches
+    for k in g1:
+        upstream = k.startswith("ecog_conv_block.") and int(k.split(".")[1]) <= 6
+        assert torch.equal(g1[k], g3[k]) != upstream, k
