@@ -361,6 +361,8 @@ def signal_subresult(dev, with_cpu: bool):
              ("hilbert_f32_math", hilbert_f32, 8),               # opt-in: fp32 transforms end to end (ols_bank_bl_kernel<float,8,float>)
              ("hilbert_dft_domain_path", hilbert_dft, 8),       # the path long (low-band / raw-rate) kernels take
              ("butter_filtfilt", lambda: ff.butter_filter(x, [0.3, 100], FS), 8),
+             # opt-in (TONAL_KERNELS=butter=scan): time-parallel block scan, 2e-8 - 5e-8 from the sequential kernel
+             ("butter_filtfilt_scan", lambda: with_kernels("butter=scan", lambda: ff.butter_filter(x, [0.3, 100], FS)), 8),
              ("fir390", lambda: ff.fir_bandpass_filter(x, FS, 390, [100.]), 4)]
     for name, fn, s_out in cases:
         ms = event_ms(fn, 10)
@@ -397,11 +399,34 @@ def signal_subresult(dev, with_cpu: bool):
             rec["bound"] = ("HBM / L2 (Bluestein chirp-z over radix-2 Stockham passes in fp64: 18 FFTs of 65 536 points per "
                             "channel, one pass over a 1 MB buffer per radix-2 stage); not the default for this band")
         elif name == "butter_filtfilt":
-            rec["bound"] = "latency (fp64 IIR recurrence, sequential in time)"
+            rec["bound"] = "latency (fp64 IIR recurrence, sequential in time; bit-identical to scipy's loop: the default)"
+        elif name == "butter_filtfilt_scan":
+            rec["bound"] = ("fp64 VALU issue of the per-block recurrences (two passes over every block) + the per-channel scan of the "
+                            "block-start states (compensated 8 x 8 products); opt-in, 2e-8 - 5e-8 from the default")
+            rec["speedup_over_sequential"] = round(out["butter_filtfilt"]["ms"] / ms, 1)
         else:
             rec["bound"] = ("LDS round trips and barriers of the in-LDS FFT (391-tap causal FIR by overlap-save on the 1024-point "
                             "fp64 transform of tl_hilbert_ols; the time-domain kernel: 0.32 ms, fp64-VALU bound)")
         out[name] = rec
+    # ---- the same kernels where occupancy is not the limit: 256 ch x 2.4 M samples (100 minutes at 400 Hz), 7.4 GB algorithmic ----
+    try:
+        TL = 2_400_000
+        xl = torch.randn(C, TL, device=dev, dtype=torch.float32, generator=torch.Generator(device=dev).manual_seed(1))
+        long_cases = [("hilbert", lambda: ff.hilbert_filter(xl, FS, [70., 150.]), 8, "fp64 VALU issue + LDS round trips of the in-LDS FFTs"),
+                      ("fir390", lambda: ff.fir_bandpass_filter(xl, FS, 390, [100.]), 4, "LDS round trips and barriers of the in-LDS FFT"),
+                      ("butter_filtfilt_scan", lambda: with_kernels("butter=scan", lambda: ff.butter_filter(xl, [0.3, 100], FS)), 8,
+                       "fp64 VALU issue of the block recurrences; time-major work buffers (2 x 9.8 GB) written and read twice")]
+        lg = {"shape": [C, TL], "dtype_in": "f32"}
+        for name, fn, s_out, bound in long_cases:
+            ms = event_ms(fn, 3)
+            gb = C * TL * (4 + s_out) / 1e9
+            lg[name] = {"ms": round(ms, 3), "algorithmic_GBps": round(gb / ms * 1e3, 1),
+                        "frac_of_hbm_peak": round(gb / ms * 1e3 / PEAK_HBM_GBPS, 4), "binding_unit": bound}
+        out["signal_long"] = lg
+        del xl
+        torch.cuda.empty_cache()
+    except Exception as e:                          # noqa: BLE001 - optional sub-result (a smaller card, a path with a size limit)
+        out["signal_long"] = {"skipped": f"{type(e).__name__}: {str(e)[:200]}"}
     if with_cpu:
         from oracle import signal_oracle as sg
         rows = 32                                   # bounded sample: 32 of the 256 channels

@@ -153,6 +153,7 @@ SIGNATURES = {
     "tl_hilbert_ols_bl": (_I, [_P, _I, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_hilbert_fft": (_I, [_P, _I, _P, _I, _L, _P, _I, _P, _P, _P, _I, _I, _P, _P]),
     "tl_filtfilt_f64": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _L, _I, _P]),
+    "tl_filtfilt_scan_f64": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _L, _I, _I, _P]),
     "tl_sosfilt_f64": (_I, [_P, _I, _P, _P, _I, _L, _I, _P]),
     "tl_fir_bank": (_I, [_P, _I, _P, _P, _I, _I, _L, _I, _I, _P]),
     "tl_fir_bank_ols": (_I, [_P, _I, _P, _P, _P, _I, _I, _L, _I, _I, _P]),

@@ -782,6 +782,155 @@ __global__ __launch_bounds__(256) void filtfilt_out_kernel(const double* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// filtfilt, TIME-PARALLEL (opt-in: TONAL_KERNELS=butter=scan).  The recurrence is linear, so a pass over the extended signal
+// splits exactly into blocks of L samples: (1) every (channel, block) runs the recurrence from a ZERO state and keeps the
+// state it ends in, s_j; (2) the states at the block starts follow z_{j+1} = A^L z_j + s_j - a prefix "sum" over the blocks,
+// evaluated per channel by a Hillis-Steele scan with the host-supplied matrices A^(L 2^m) (one workgroup per channel, a
+// thread per block, log2 steps); (3) every (channel, block) re-runs the recurrence from its true start state and writes the
+// outputs.  Steps (1) and (3) are scipy's loop (same operations, same order); step (2) is where the arithmetic differs from
+// the sequential kernel: the direct-form states of this filter are ~1e6 x the output with cancellation (eight poles
+// clustered at z = 1), so the matrices come as double-double pairs (exact powers rounded once, from the host) and every
+// matrix-vector product is a compensated dot product (two_prod / two_sum: the result is the correctly rounded exact value up
+// to ~1e-31 of the terms) - in plain fp64 the same scheme lands 6e-3 from the reference (round 2).  What is left against
+// the sequential kernel is 2e-8 - 5e-8 relative, the size of the reference's OWN rounding: scipy's loop differs from the
+// same loop in 64-bit-mantissa arithmetic by 1e-8 - 3e-8 (tests/test_signal_scan_notes.py), so no re-association can
+// promise 1e-9.  Hence opt-in; the default stays the bit-exact sequential kernel.  ntaps <= 9.
+// ------------------------------------------------------------------------------------------
+constexpr int FS_NS = 8;
+
+template <bool APPLY>
+__global__ __launch_bounds__(64) void filtfilt_scan_block_kernel(const double* __restrict__ b, const double* __restrict__ a,
+                                                                 const double* __restrict__ in, double* __restrict__ out,
+                                                                 const double* __restrict__ Z, double* __restrict__ S, int C,
+                                                                 long long next, int ntaps, int L, long long first,
+                                                                 long long dir) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const long long j = blockIdx.y;
+  const long long n0 = j * L, n1 = (n0 + L < next) ? n0 + L : next;
+  double bb[FS_NS + 1], aa[FS_NS + 1], z[FS_NS + 1];
+#pragma unroll
+  for (int k = 0; k <= FS_NS; ++k) {
+    bb[k] = k < ntaps ? b[k] : 0.0;
+    aa[k] = k < ntaps ? a[k] : 0.0;
+    z[k] = 0.0;
+  }
+  if constexpr (APPLY) {
+#pragma unroll
+    for (int k = 0; k < FS_NS; ++k) z[k] = Z[(j * FS_NS + k) * C + c];
+  }
+  const double* __restrict__ ip = in + c;
+  double* __restrict__ op = out + c;
+  constexpr int U = 8;
+  double cur[U], nxt[U];
+  long long n = n0;
+  if (n1 - n0 >= U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = ip[(first + dir * (n0 + u)) * C];
+  }
+  for (; n + U <= n1; n += U) {
+    const bool more = n + 2 * U <= n1;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) nxt[u] = ip[(first + dir * (n + U + u)) * C];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // scipy lfilter order: y = z0 + b0*x;  z_k = (z_{k+1} + x*b_{k+1}) - y*a_{k+1}
+      const double yv = z[0] + bb[0] * cur[u];
+#pragma unroll
+      for (int k = 0; k < FS_NS; ++k) z[k] = (z[k + 1] + cur[u] * bb[k + 1]) - yv * aa[k + 1];
+      if constexpr (APPLY) op[(first + dir * (n + u)) * C] = yv;
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+  }
+  for (; n < n1; ++n) {
+    const double xs = ip[(first + dir * n) * C];
+    const double yv = z[0] + bb[0] * xs;
+#pragma unroll
+    for (int k = 0; k < FS_NS; ++k) z[k] = (z[k + 1] + xs * bb[k + 1]) - yv * aa[k + 1];
+    if constexpr (APPLY) op[(first + dir * n) * C] = yv;
+  }
+  if constexpr (!APPLY) {
+#pragma unroll
+    for (int k = 0; k < FS_NS; ++k) S[(j * FS_NS + k) * C + c] = z[k];
+  }
+}
+
+// r = M u + v with M = Mh + Ml (double-double) in a compensated dot product per row; M: [FS_NS][FS_NS][2] (hi, lo)
+__device__ __forceinline__ void scan_matvec(const double* __restrict__ M, const double (&u)[FS_NS], double (&v)[FS_NS]) {
+#pragma unroll
+  for (int i = 0; i < FS_NS; ++i) {
+    double s = v[i], e = 0.0;
+#pragma unroll
+    for (int k = 0; k < FS_NS; ++k) {
+      const double mh = M[(i * FS_NS + k) * 2], ml = M[(i * FS_NS + k) * 2 + 1];
+      const double pr = mh * u[k];
+      const double pe = fma(mh, u[k], -pr);               // two_prod: mh * u = pr + pe exactly
+      const double s2 = s + pr;                           // two_sum: s + pr = s2 + se exactly
+      const double bv = s2 - s;
+      const double se = (s - (s2 - bv)) + (pr - bv);
+      s = s2;
+      e += (pe + se) + ml * u[k];
+    }
+    v[i] = s + e;
+  }
+}
+
+// one workgroup per channel, a thread per block (chunks of blockDim.x blocks, the state carried from chunk to chunk)
+__global__ __launch_bounds__(512) void filtfilt_scan_prefix_kernel(const double* __restrict__ S, double* __restrict__ Z,
+                                                                   const double* __restrict__ M, const double* __restrict__ zi,
+                                                                   const double* __restrict__ in, int C, long long nb, int ntaps,
+                                                                   long long first) {
+  extern __shared__ __attribute__((aligned(16))) double fs_sh[];       // [2][blockDim.x][FS_NS]
+  const int c = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  double carry[FS_NS], v[FS_NS], u[FS_NS];
+  const double x0 = in[first * C + c];
+#pragma unroll
+  for (int k = 0; k < FS_NS; ++k) carry[k] = k < ntaps - 1 ? zi[k] * x0 : 0.0;       // scipy: zi * x_ext[0]
+  for (long long chunk0 = 0; chunk0 < nb; chunk0 += nthr) {
+    const long long j = chunk0 + tid;
+#pragma unroll
+    for (int k = 0; k < FS_NS; ++k) v[k] = j < nb ? S[(j * FS_NS + k) * C + c] : 0.0;
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < FS_NS; ++k) Z[(chunk0 * FS_NS + k) * C + c] = carry[k];
+      scan_matvec(M, carry, v);                                         // state at the END of the chunk's first block
+    }
+    int buf = 0, lev = 0;
+    for (int d = 1; d < nthr; d <<= 1, ++lev) {
+      double* sh = fs_sh + (size_t)buf * nthr * FS_NS;
+#pragma unroll
+      for (int k = 0; k < FS_NS; ++k) sh[tid * FS_NS + k] = v[k];
+      __syncthreads();
+      if (tid >= d) {
+#pragma unroll
+        for (int k = 0; k < FS_NS; ++k) u[k] = sh[(tid - d) * FS_NS + k];
+        scan_matvec(M + (size_t)lev * FS_NS * FS_NS * 2, u, v);
+      }
+      buf ^= 1;
+    }
+    // v = state at the end of block j = at the start of block j + 1
+    if (j + 1 < nb) {
+#pragma unroll
+      for (int k = 0; k < FS_NS; ++k) Z[((j + 1) * FS_NS + k) * C + c] = v[k];
+    }
+    double* sh = fs_sh + (size_t)buf * nthr * FS_NS;
+    if (tid == nthr - 1) {
+#pragma unroll
+      for (int k = 0; k < FS_NS; ++k) sh[k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FS_NS; ++k) carry[k] = sh[k];
+    __syncthreads();
+  }
+}
+
 constexpr int MAX_SEC = 8;
 template <typename TIN>
 __global__ __launch_bounds__(64) void sosfilt_kernel(const void* __restrict__ x, const double* __restrict__ sos,
@@ -972,6 +1121,47 @@ extern "C" int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, con
   hipLaunchKernelGGL(filtfilt_out_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, st, work, y, C,
                      (long long)T, edge);
   return check_launch("filtfilt");
+}
+
+extern "C" int tl_filtfilt_scan_f64(const void* x, int x_is_f64, const double* b, const double* a, const double* zi,
+                                    const double* M, int nlev, double* y, double* work, double* swork, int C, int64_t T,
+                                    int ntaps, int L, void* stream) {
+  TL_REQUIRE(x && b && a && zi && M && y && work && swork, "filtfilt_scan: null pointer");
+  TL_REQUIRE(ntaps >= 2 && ntaps <= FS_NS + 1, "filtfilt_scan: ntaps must be 2..%d", FS_NS + 1);
+  TL_REQUIRE(C > 0 && C <= 65535 && T > 3LL * ntaps && L >= 8, "filtfilt_scan: bad sizes (the input must be longer than padlen = %d)", 3 * ntaps);
+  hipStream_t st = (hipStream_t)stream;
+  const int edge = 3 * ntaps;
+  const long long next = T + 2LL * edge;
+  const long long nb = (next + L - 1) / L;
+  TL_REQUIRE(nb <= 65535, "filtfilt_scan: more than 65 535 blocks of %d samples (raise L)", L);
+  int nthr = 64;
+  while (nthr < 512 && nthr < nb) nthr <<= 1;
+  int need = 0;
+  while ((1 << need) < nthr) ++need;
+  TL_REQUIRE(nlev >= need && nlev >= 1, "filtfilt_scan: %d matrix levels A^(L 2^m) needed for %d blocks per chunk", need, nthr);
+  long long g = (next * C + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (x_is_f64)
+    hipLaunchKernelGGL((filtfilt_build_kernel<double>), dim3((unsigned)g), dim3(256), 0, st, x, work, C, (long long)T, edge);
+  else
+    hipLaunchKernelGGL((filtfilt_build_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, x, work, C, (long long)T, edge);
+  double* S = swork;
+  double* Z = swork + nb * FS_NS * C;
+  const dim3 grid((unsigned)((C + 63) / 64), (unsigned)nb);
+  for (int pass = 0; pass < 2; ++pass) {
+    const double* in = work + (long long)pass * next * C;
+    double* out = work + (long long)(1 - pass) * next * C;
+    const long long first = pass == 0 ? 0 : next - 1, dir = pass == 0 ? 1 : -1;
+    hipLaunchKernelGGL((filtfilt_scan_block_kernel<false>), grid, dim3(64), 0, st, b, a, in, out, nullptr, S, C, next, ntaps, L,
+                       first, dir);
+    hipLaunchKernelGGL(filtfilt_scan_prefix_kernel, dim3((unsigned)C), dim3(nthr), (size_t)2 * nthr * FS_NS * sizeof(double), st,
+                       S, Z, M, zi, in, C, nb, ntaps, first);
+    hipLaunchKernelGGL((filtfilt_scan_block_kernel<true>), grid, dim3(64), 0, st, b, a, in, out, Z, nullptr, C, next, ntaps, L,
+                       first, dir);
+  }
+  hipLaunchKernelGGL(filtfilt_out_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0, st, work, y, C,
+                     (long long)T, edge);
+  return check_launch("filtfilt_scan");
 }
 
 extern "C" int tl_sosfilt_f64(const void* x, int x_is_f64, const double* sos, double* y, int C, int64_t T, int nsec,

@@ -298,7 +298,7 @@ def butter_filter(data, freqs: Union[Tuple[float, float], float], fs: float, ord
     C, T = x.shape
     lib = _lib.load()
     y = torch.empty(C, T, dtype=torch.float64, device=x.device)
-    key = (int(order), tuple(np.atleast_1d(wn).tolist()), str(filter_type), bool(causal), str(x.device))
+    key = (int(order), tuple(np.atleast_1d(wn).tolist()), str(filter_type), bool(causal), str(x.device), _kernels.get("butter"))
     coef = _BUTTER_CACHE.get(key)
     if coef is None:
         # coefficient design (scipy, as the reference calls it) and its host-to-device copies, once per filter
@@ -314,6 +314,8 @@ def butter_filter(data, freqs: Union[Tuple[float, float], float], fs: float, ord
             aa[:len(a)] = a / a[0]
             zi = lfilter_zi(bb, aa)
             coef = tuple(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(x.device) for v in (bb, aa, zi)) + (ntaps,)
+            if _kernels.get("butter") == "scan" and ntaps <= 9:
+                coef = coef + (torch.from_numpy(_scan_matrices(aa, _SCAN_L, _SCAN_LEVELS)).to(x.device),)
         if len(_BUTTER_CACHE) > 32:
             _BUTTER_CACHE.clear()
         _BUTTER_CACHE[key] = coef
@@ -322,11 +324,25 @@ def butter_filter(data, freqs: Union[Tuple[float, float], float], fs: float, ord
         check(lib.tl_sosfilt_f64(ptr(x), int(x.dtype == torch.float64), ptr(sd), ptr(y), C, T, nsec, _stream()),
               "tl_sosfilt_f64")
     else:
-        bd, ad, zd, ntaps = coef
+        bd, ad, zd, ntaps = coef[:4]
         edge = 3 * ntaps
         if T <= edge:
             raise ValueError(f"The length of the input vector x must be greater than padlen, which is {edge}.")
         work = torch.empty(2, T + 2 * edge, C, dtype=torch.float64, device=x.device)
+        if len(coef) > 4:
+            # opt-in (TONAL_KERNELS=butter=scan): time-parallel form, 2e-8 - 5e-8 from the sequential kernel - the size of the
+            # reference's own rounding (tl_filtfilt_scan_f64's header comment); blocks of _SCAN_L samples, longer blocks for
+            # recordings beyond 65 535 of them
+            L = _SCAN_L
+            while (T + 2 * edge + L - 1) // L > 65535:
+                L *= 2
+            md = coef[4] if L == _SCAN_L else torch.from_numpy(_scan_matrices(ad.cpu().numpy(), L, _SCAN_LEVELS)).to(x.device)
+            nb = (T + 2 * edge + L - 1) // L
+            swork = torch.empty(2, nb, 8, C, dtype=torch.float64, device=x.device)
+            check(lib.tl_filtfilt_scan_f64(ptr(x), int(x.dtype == torch.float64), ptr(bd), ptr(ad), ptr(zd), ptr(md), _SCAN_LEVELS,
+                                           ptr(y), ptr(work), ptr(swork), C, T, ntaps, L, _stream()), "tl_filtfilt_scan_f64")
+            out = _ret(y, was_np)
+            return out[0] if squeeze else out
         check(lib.tl_filtfilt_f64(ptr(x), int(x.dtype == torch.float64), ptr(bd), ptr(ad), ptr(zd), ptr(y), ptr(work),
                                   C, T, ntaps, _stream()), "tl_filtfilt_f64")
     out = _ret(y, was_np)
@@ -334,6 +350,51 @@ def butter_filter(data, freqs: Union[Tuple[float, float], float], fs: float, ord
 
 
 _BUTTER_CACHE = {}
+_SCAN_L = 128            # samples per block of the time-parallel filtfilt
+_SCAN_LEVELS = 9         # A^(L 2^m), m < 9: chunks of up to 512 blocks per workgroup
+
+
+def _scan_matrices(aa: np.ndarray, L: int, nlev: int) -> np.ndarray:
+    """(nlev, 8, 8, 2) double-double pairs of A^(L 2^m), m < nlev: the m-fold squared L-step transition matrix of the
+    direct-form-II-transposed recurrence scipy's ``lfilter`` runs (homogeneous part: y = z_0, z_k <- z_{k+1} - a_{k+1} z_0) for
+    the normalised denominator ``aa``.  The powers are formed in 600-bit fixed point on Python integers (the entries stay
+    below ~1e7, the coefficients are exact binary fractions), then each entry is rounded ONCE to a (hi, lo) pair: the
+    device's compensated products see the exact matrix to ~1e-32."""
+    from fractions import Fraction
+    F = 600
+    ns = 8
+    one = 1 << F
+
+    def fx(v: float) -> int:
+        fr = Fraction(float(v))
+        return (fr.numerator << F) // fr.denominator
+
+    A = [[0] * ns for _ in range(ns)]
+    for k in range(min(ns, len(aa) - 1)):
+        A[k][0] -= fx(aa[k + 1])
+        if k + 1 < ns:
+            A[k][k + 1] += one
+
+    def mul(X, Y):
+        return [[sum(X[i][k] * Y[k][j] for k in range(ns)) >> F for j in range(ns)] for i in range(ns)]
+
+    P = [[one if i == j else 0 for j in range(ns)] for i in range(ns)]
+    base, e = A, L
+    while e:
+        if e & 1:
+            P = mul(P, base)
+        base = mul(base, base)
+        e >>= 1
+    out = np.zeros((nlev, ns, ns, 2))
+    for m in range(nlev):
+        for i in range(ns):
+            for j in range(ns):
+                fr = Fraction(P[i][j], one)
+                hi = float(fr)
+                out[m, i, j, 0] = hi
+                out[m, i, j, 1] = float(fr - Fraction(hi))
+        P = mul(P, P)
+    return out
 
 
 def fir_bandpass_filter(data, fs: float, order: int, center_frequencies: List[float]):
