@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void filtfilt_out_kernel(const double* __restr
 // splits exactly into blocks of L samples: (1) every (channel, block) runs the recurrence from a ZERO state and keeps the
 // state it ends in, s_j; (2) the states at the block starts follow z_{j+1} = A^L z_j + s_j - a prefix "sum" over the blocks,
 // evaluated per channel by a Hillis-Steele scan with the host-supplied matrices A^(L 2^m) (one workgroup per channel, a
-// thread per block, log2 steps); (3) every (channel, block) re-runs the recurrence from its true start state and writes the
+// thread per (block, state row), log2 steps); (3) every (channel, block) re-runs the recurrence from its true start state and writes the
 // outputs.  Steps (1) and (3) are scipy's loop (same operations, same order); step (2) is where the arithmetic differs from
 // the sequential kernel: the direct-form states of this filter are ~1e6 x the output with cancellation (eight poles
 // clustered at z = 1), so the matrices come as double-double pairs (exact powers rounded once, from the host) and every
@@ -861,73 +861,92 @@ __global__ __launch_bounds__(64) void filtfilt_scan_block_kernel(const double* _
   }
 }
 
-// r = M u + v with M = Mh + Ml (double-double) in a compensated dot product per row; M: [FS_NS][FS_NS][2] (hi, lo)
-__device__ __forceinline__ void scan_matvec(const double* __restrict__ M, const double (&u)[FS_NS], double (&v)[FS_NS]) {
+// One workgroup per channel; a thread per (block, state row): FS_BLK blocks x 8 rows = 1024 threads per chunk of blocks, the
+// state carried from chunk to chunk.  Row i of v <- M u + v is ONE compensated dot product of 8 terms (two_prod by fma,
+// two_sum, the low words of M and all rounding errors in a second accumulator): correctly rounded up to ~1e-31 of the terms.
+// The matrices of all levels sit in LDS (a lane reads its own row), the vectors are exchanged through LDS.
+constexpr int FS_BLK = 128;
+__device__ __forceinline__ double scan_row(const double* __restrict__ Mrow, const double* __restrict__ u, double v) {
+  double s = v, e = 0.0;
 #pragma unroll
-  for (int i = 0; i < FS_NS; ++i) {
-    double s = v[i], e = 0.0;
-#pragma unroll
-    for (int k = 0; k < FS_NS; ++k) {
-      const double mh = M[(i * FS_NS + k) * 2], ml = M[(i * FS_NS + k) * 2 + 1];
-      const double pr = mh * u[k];
-      const double pe = fma(mh, u[k], -pr);               // two_prod: mh * u = pr + pe exactly
-      const double s2 = s + pr;                           // two_sum: s + pr = s2 + se exactly
-      const double bv = s2 - s;
-      const double se = (s - (s2 - bv)) + (pr - bv);
-      s = s2;
-      e += (pe + se) + ml * u[k];
+  for (int k = 0; k < FS_NS; ++k) {
+    const double mh = Mrow[2 * k], ml = Mrow[2 * k + 1], uk = u[k];
+    const double pr = mh * uk;
+    const double pe = fma(mh, uk, -pr);                   // two_prod: mh * uk = pr + pe exactly
+    const double s2 = s + pr;                             // two_sum: s + pr = s2 + se exactly
+    const double bv = s2 - s;
+    const double se = (s - (s2 - bv)) + (pr - bv);
+    s = s2;
+    e += (pe + se) + ml * uk;
+  }
+  return s + e;
+}
+
+__global__ __launch_bounds__(FS_BLK * FS_NS) void filtfilt_scan_prefix_kernel(const double* __restrict__ S, double* __restrict__ Z,
+                                                                              const double* __restrict__ M, int nlev,
+                                                                              const double* __restrict__ zi,
+                                                                              const double* __restrict__ in, int C, long long nb,
+                                                                              int ntaps, long long first) {
+  __shared__ __attribute__((aligned(16))) double sm[7 * FS_NS * FS_NS * 2];      // levels 0..6 of A^(L 2^m): 7 KB
+  __shared__ __attribute__((aligned(16))) double sv[2][FS_BLK][FS_NS];           // 16 KB
+  __shared__ double scar[FS_NS];
+  const int c = blockIdx.x, tid = threadIdx.x, i = tid & 7, jl = tid >> 3;
+  for (int q = tid; q < 7 * FS_NS * FS_NS * 2; q += FS_BLK * FS_NS) sm[q] = q < nlev * FS_NS * FS_NS * 2 ? M[q] : 0.0;
+  if (tid < FS_NS) scar[tid] = tid < ntaps - 1 ? zi[tid] * in[first * C + c] : 0.0;     // scipy: zi * x_ext[0]
+  __syncthreads();
+  for (long long chunk0 = 0; chunk0 < nb; chunk0 += FS_BLK) {
+    const long long j = chunk0 + jl;
+    double v = j < nb ? S[(j * FS_NS + i) * C + c] : 0.0;
+    if (jl == 0) {
+      Z[(chunk0 * FS_NS + i) * C + c] = scar[i];
+      v = scan_row(sm + i * FS_NS * 2, scar, v);          // state at the END of the chunk's first block
     }
-    v[i] = s + e;
+    int buf = 0;
+    const int nact = (nb - chunk0 < FS_BLK) ? (int)(nb - chunk0) : FS_BLK;      // blocks of this chunk (uniform)
+#pragma unroll 1
+    for (int lev = 0, d = 1; d < nact; ++lev, d <<= 1) {
+      sv[buf][jl][i] = v;
+      __syncthreads();
+      if (jl >= d) v = scan_row(sm + (lev * FS_NS + i) * FS_NS * 2, sv[buf][jl - d], v);
+      buf ^= 1;
+    }
+    // v = row i of the state at the end of block j = at the start of block j + 1
+    if (j + 1 < nb) Z[((j + 1) * FS_NS + i) * C + c] = v;
+    __syncthreads();                                       // (scar is still being read by the first block's lanes above)
+    if (jl == nact - 1) scar[i] = v;
+    __syncthreads();
   }
 }
 
-// one workgroup per channel, a thread per block (chunks of blockDim.x blocks, the state carried from chunk to chunk)
-__global__ __launch_bounds__(512) void filtfilt_scan_prefix_kernel(const double* __restrict__ S, double* __restrict__ Z,
-                                                                   const double* __restrict__ M, const double* __restrict__ zi,
-                                                                   const double* __restrict__ in, int C, long long nb, int ntaps,
-                                                                   long long first) {
-  extern __shared__ __attribute__((aligned(16))) double fs_sh[];       // [2][blockDim.x][FS_NS]
-  const int c = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  double carry[FS_NS], v[FS_NS], u[FS_NS];
-  const double x0 = in[first * C + c];
+// the odd-extended recording TIME-MAJOR, like filtfilt_build_kernel, with both sides coalesced: 64 x 64 tiles through LDS
+// for the centre part, the 2 x edge extension rows directly
+template <typename TIN>
+__global__ __launch_bounds__(256) void filtfilt_build_tiled_kernel(const void* __restrict__ x, double* __restrict__ work, int C,
+                                                                   long long T, int edge) {
+  __shared__ double tile[64][65];
+  const long long t0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;       // 64 x 4
 #pragma unroll
-  for (int k = 0; k < FS_NS; ++k) carry[k] = k < ntaps - 1 ? zi[k] * x0 : 0.0;       // scipy: zi * x_ext[0]
-  for (long long chunk0 = 0; chunk0 < nb; chunk0 += nthr) {
-    const long long j = chunk0 + tid;
+  for (int r = 0; r < 16; ++r) {
+    const int c = c0 + ly + 4 * r;
+    const long long t = t0 + lx;
+    if (t < T && c < C) tile[ly + 4 * r][lx] = ld_as_f64<TIN>(x, (long long)c * T + t);
+  }
+  __syncthreads();
 #pragma unroll
-    for (int k = 0; k < FS_NS; ++k) v[k] = j < nb ? S[(j * FS_NS + k) * C + c] : 0.0;
-    if (tid == 0) {
-#pragma unroll
-      for (int k = 0; k < FS_NS; ++k) Z[(chunk0 * FS_NS + k) * C + c] = carry[k];
-      scan_matvec(M, carry, v);                                         // state at the END of the chunk's first block
+  for (int r = 0; r < 16; ++r) {
+    const long long t = t0 + ly + 4 * r;
+    const int c = c0 + lx;
+    if (t < T && c < C) work[(t + edge) * C + c] = tile[lx][ly + 4 * r];
+  }
+  if (blockIdx.x == 0) {                                         // the extension rows of this channel tile
+    for (int q = threadIdx.x; q < 2 * edge * 64; q += 256) {
+      const int c = c0 + (q & 63), e = q >> 6;
+      if (c >= C) continue;
+      const long long ti = e < edge ? e : T + edge + (e - edge);
+      work[ti * C + c] = ext_sample<TIN>(x, (long long)c * T, T, edge, ti);
     }
-    int buf = 0, lev = 0;
-    for (int d = 1; d < nthr; d <<= 1, ++lev) {
-      double* sh = fs_sh + (size_t)buf * nthr * FS_NS;
-#pragma unroll
-      for (int k = 0; k < FS_NS; ++k) sh[tid * FS_NS + k] = v[k];
-      __syncthreads();
-      if (tid >= d) {
-#pragma unroll
-        for (int k = 0; k < FS_NS; ++k) u[k] = sh[(tid - d) * FS_NS + k];
-        scan_matvec(M + (size_t)lev * FS_NS * FS_NS * 2, u, v);
-      }
-      buf ^= 1;
-    }
-    // v = state at the end of block j = at the start of block j + 1
-    if (j + 1 < nb) {
-#pragma unroll
-      for (int k = 0; k < FS_NS; ++k) Z[((j + 1) * FS_NS + k) * C + c] = v[k];
-    }
-    double* sh = fs_sh + (size_t)buf * nthr * FS_NS;
-    if (tid == nthr - 1) {
-#pragma unroll
-      for (int k = 0; k < FS_NS; ++k) sh[k] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < FS_NS; ++k) carry[k] = sh[k];
-    __syncthreads();
   }
 }
 
@@ -1134,17 +1153,12 @@ extern "C" int tl_filtfilt_scan_f64(const void* x, int x_is_f64, const double* b
   const long long next = T + 2LL * edge;
   const long long nb = (next + L - 1) / L;
   TL_REQUIRE(nb <= 65535, "filtfilt_scan: more than 65 535 blocks of %d samples (raise L)", L);
-  int nthr = 64;
-  while (nthr < 512 && nthr < nb) nthr <<= 1;
-  int need = 0;
-  while ((1 << need) < nthr) ++need;
-  TL_REQUIRE(nlev >= need && nlev >= 1, "filtfilt_scan: %d matrix levels A^(L 2^m) needed for %d blocks per chunk", need, nthr);
-  long long g = (next * C + 255) / 256;
-  if (g > 8192) g = 8192;
+  TL_REQUIRE(nlev >= 7, "filtfilt_scan: 7 matrix levels A^(L 2^m), m < 7, needed (chunks of %d blocks)", FS_BLK);
+  const dim3 tgrid((unsigned)((T + 63) / 64), (unsigned)((C + 63) / 64));
   if (x_is_f64)
-    hipLaunchKernelGGL((filtfilt_build_kernel<double>), dim3((unsigned)g), dim3(256), 0, st, x, work, C, (long long)T, edge);
+    hipLaunchKernelGGL((filtfilt_build_tiled_kernel<double>), tgrid, dim3(256), 0, st, x, work, C, (long long)T, edge);
   else
-    hipLaunchKernelGGL((filtfilt_build_kernel<float>), dim3((unsigned)g), dim3(256), 0, st, x, work, C, (long long)T, edge);
+    hipLaunchKernelGGL((filtfilt_build_tiled_kernel<float>), tgrid, dim3(256), 0, st, x, work, C, (long long)T, edge);
   double* S = swork;
   double* Z = swork + nb * FS_NS * C;
   const dim3 grid((unsigned)((C + 63) / 64), (unsigned)nb);
@@ -1154,8 +1168,8 @@ extern "C" int tl_filtfilt_scan_f64(const void* x, int x_is_f64, const double* b
     const long long first = pass == 0 ? 0 : next - 1, dir = pass == 0 ? 1 : -1;
     hipLaunchKernelGGL((filtfilt_scan_block_kernel<false>), grid, dim3(64), 0, st, b, a, in, out, nullptr, S, C, next, ntaps, L,
                        first, dir);
-    hipLaunchKernelGGL(filtfilt_scan_prefix_kernel, dim3((unsigned)C), dim3(nthr), (size_t)2 * nthr * FS_NS * sizeof(double), st,
-                       S, Z, M, zi, in, C, nb, ntaps, first);
+    hipLaunchKernelGGL(filtfilt_scan_prefix_kernel, dim3((unsigned)C), dim3(FS_BLK * FS_NS), 0, st, S, Z, M, nlev, zi, in, C, nb,
+                       ntaps, first);
     hipLaunchKernelGGL((filtfilt_scan_block_kernel<true>), grid, dim3(64), 0, st, b, a, in, out, Z, nullptr, C, next, ntaps, L,
                        first, dir);
   }

@@ -351,7 +351,7 @@ def butter_filter(data, freqs: Union[Tuple[float, float], float], fs: float, ord
 
 _BUTTER_CACHE = {}
 _SCAN_L = 128            # samples per block of the time-parallel filtfilt
-_SCAN_LEVELS = 9         # A^(L 2^m), m < 9: chunks of up to 512 blocks per workgroup
+_SCAN_LEVELS = 7         # A^(L 2^m), m < 7: the scan runs over chunks of 128 blocks per workgroup
 
 
 def _scan_matrices(aa: np.ndarray, L: int, nlev: int) -> np.ndarray:

@@ -511,7 +511,7 @@ int tl_filtfilt_f64(const void* x, int x_is_f64, const double* b, const double* 
 /* the same zero-phase filter evaluated TIME-PARALLEL (opt-in; frequency_filter.py:226-227): blocks of L samples run scipy's
  * recurrence from a zero state, the block-start states follow from a per-channel scan with the matrices
  * M[m] = A^(L 2^m) (nlev x 8 x 8 x (hi, lo) double-double pairs, from the host: exact powers of the recurrence's transition
- * matrix rounded once; nlev >= log2(min(512, blocks))), and the blocks are re-run from their true start states.  Agrees with
+ * matrix rounded once; nlev >= 7: the scan takes chunks of 128 blocks), and the blocks are re-run from their true start states.  Agrees with
  * tl_filtfilt_f64 to 2e-8 - 5e-8 relative - the size of the reference's own rounding error - not to the last bit.
  * ntaps <= 9, L >= 8, at most 65 535 blocks.  work: 2*C*(T + 6*ntaps) doubles; swork: 2 * blocks * 8 * C doubles.        */
 int tl_filtfilt_scan_f64(const void* x, int x_is_f64, const double* b, const double* a, const double* zi, const double* M,
