@@ -74,10 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--channels", type=int, default=128)
     ap.add_argument("--timepoints", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4, help="micro-batch of the CPU-oracle leg")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="smaller micro-batch of the CPU-oracle leg (the larger is twice it)")
     ap.add_argument("--cpu-budget", type=float, default=130.0,
-                    help="seconds of host time the CPU-oracle leg aims at (default 130: five timed steps at micro-batch 12 - "
-                         "always - then 2-5 at micro-batch 4 for the extrapolation); >= 400 times micro-batches 32 and 64")
+                    help="seconds of host time the CPU-oracle leg aims at (default 130: five timed steps at micro-batch 16 - "
+                         "always - then 2-5 at micro-batch 8 for the extrapolation); >= 400 times micro-batches 32 and 64")
     ap.add_argument("--no-kernel-timers", action="store_true",
                     help="skip the untimed second pass that collects the per-kernel HIP-event timers")
     ap.add_argument("--timer-steps", type=int, default=3, help="steps of that second pass")
@@ -213,6 +213,18 @@ def host_ram_gb() -> float:
     return float("nan")
 
 
+def cpu_baseline_at_256():
+    """profiles/cpu_baseline_b256.json (scripts/cpu_baseline_b256.py, one gpurun session): the oracle at batch 256, or None."""
+    path = os.path.join(ROOT, "profiles", "cpu_baseline_b256.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    rec["source"] = "profiles/cpu_baseline_b256.json (static: measured once on a GPU box's host cores, not in this run)"
+    return rec
+
+
 def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0, budget_s: float = 130.0):
     """The oracle's train step on the host cores, timed at two micro-batches so that the batch-independent part of
     a step (5.5 GB of LSTM weights streamed per LSTM step + NAdam over 1.38 G parameters, ~9 s) is separated from the
@@ -228,7 +240,7 @@ def cpu_baseline(model, B_cpu: int, C: int, T: int, out_dim: int, B_big: int = 0
     min_steps = 2
     if budget_s >= 400.0 and not B_big:        # opt-in (--cpu-budget): larger micro-batches, >= 5 timed steps each
         B_cpu, B_big, min_steps = 32, 64, 5
-    B_big = B_big or 3 * B_cpu
+    B_big = B_big or 2 * B_cpu                 # powers of two: 8 and 16 by default
     params = {k: v.detach().to("cpu", copy=True) for k, v in model.named_parameters()}
     state = so.NAdamState(params)
     gen = torch.Generator().manual_seed(1234)
@@ -439,6 +451,25 @@ def signal_subresult(dev, with_cpu: bool):
                                "hilbert_channel_samples_per_s": round(rows * T / (t1 - t0)),
                                "butter_channel_samples_per_s": round(rows * T / (t2 - t1))}
     return out
+
+
+def rank_batch_probe(trainer, data, batches=(128, 64, 32), steps: int = 3):
+    """Single-GPU train-step time at the per-rank batches of the 2 / 4 / 8-GPU strong-scaling points (the whole label LSTM on
+    the rank, no exchange): what a measured scaling curve decomposes into - per-rank compute here, exchange + sharding effects as
+    the difference (review item 9b).  Runs after everything that is timed; the model moves on by a few updates."""
+    import torch
+    out = {}
+    for b in batches:
+        shard = tuple(t[:b].contiguous() for t in data[0])
+        trainer.train_step(*shard)                         # (re-allocates the engine's workspaces at this batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.train_step(*shard)
+        torch.cuda.synchronize()
+        out[str(b)] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+    return {"ms_per_step_at_batch": out, "steps": steps,
+            "note": "one GPU, whole LSTM on the rank, no exchange step: the compute part of the N = 256 / batch strong-scaling point"}
 
 
 def c5_subresult(dev, model, steps: int = 3):
@@ -851,7 +882,8 @@ def main():
                     "per_stage_frac": {k: round(v[0] * iss / (v[1] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) for k, v in sorted(ops.items())}}}
         extras = {}
         if world == 1 and args.model == "full" and not args.no_extras:
-            for key, fn in (("c2_lite", lambda: lite_subresult(dev)),
+            for key, fn in (("rank_batch_probe", lambda: rank_batch_probe(trainer, data)),
+                            ("c2_lite", lambda: lite_subresult(dev)),
                             ("signal_c5", lambda: signal_subresult(dev, not args.no_cpu_baseline)),
                             ("c5", lambda: c5_subresult(dev, model))):
                 try:
@@ -859,11 +891,22 @@ def main():
                 except Exception as e:      # noqa: BLE001 - a sub-result must not kill the headline line
                     extras[key] = {"error": repr(e)}
         cpu = None
-        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the 1-GPU run only
+        if not args.no_cpu_baseline and world == 1:      # the LIVE CPU leg runs on rank 0 of the 1-GPU run only
             try:
                 cpu = cpu_baseline(model, args.cpu_batch, C, T, D, budget_s=args.cpu_budget)
             except Exception as e:      # noqa: BLE001 - the baseline leg must not kill the bench line
                 cpu = {"value": None, "error": repr(e)}
+        static256 = cpu_baseline_at_256()
+        if static256 is not None and args.model == "full" and not args.no_cpu_baseline:
+            # the same oracle timed ONCE at the metric's own batch on a GPU box's host (static, committed file): carried on every
+            # line, multi-GPU ones included (the live leg is skipped there)
+            if cpu is None:
+                cpu = {"value": None, "unit": "mel-frames/s", "kind": "port", "cores": static256.get("cores"),
+                       "sample": "live leg skipped (world > 1): see measured_at_batch_256"}
+            cpu["measured_at_batch_256"] = static256
+            ex = cpu.get("extrapolated_to_batch_256")
+            if isinstance(ex, dict) and static256.get("value"):
+                ex["vs_measured_at_batch_256"] = round(ex["value"] / static256["value"], 3)
         line = {
             "metric": "mel-frames/sec (train step) SynthesisModelCNN, 128ch x 400t batch256" if args.model == "full"
                       else "mel-frames/sec (train step) SynthesisLite",

@@ -19,7 +19,7 @@ from ._lib import EPI_LRELU, EPI_STORE, LOAD_DIRECT, check, ptr
 
 
 class CnnClassifierEngine(CnnEngine):
-    F63_CAPABLE = False        # this engine enqueues its stages itself on the F(4,3) / F(2,3) / direct kernels
+    F63_CAPABLE = False        # this engine enqueues its stages itself (F(6,3) prefix, then F(4,3) V form / direct kernels)
 
     def __init__(self, n_electrodes: int, n_timepoints: int, stage_defs, hidden: int, n_classes: int,
                  negative_slope: float):
@@ -42,7 +42,7 @@ class CnnClassifierEngine(CnnEngine):
 
     def _plan63(self, stage_defs, T):
         from . import _kernels
-        if _kernels.get("wino") != "6" or _kernels.get("clf_f63") == "0":
+        if _kernels.get("wino") != "6":
             return 0, []
         c1, k1, p1 = stage_defs[0]
         if not (p1 and 1 <= k1 <= 3 and c1 in (128, 256, 512, 1024) and T >= 2 * self.tout1 + 2 and T * 4 <= 64 * 1024):
@@ -120,6 +120,7 @@ class CnnClassifierEngine(CnnEngine):
         S = B * self.C
         self.S = S
         self._buf63 = {}
+        self.V = {}
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         zi = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
         self.P = {1: z(S * self.tp1, self.c1)}
@@ -159,10 +160,11 @@ class CnnClassifierEngine(CnnEngine):
                                    ptr(self.bits[1]), None, S, T, self.k1, self.c1, self.tp1, self.tout1, self.slope, st_),
                   "tl_conv1_fwd")
         for st, (w, b) in list(zip(self.stages, convs[1:]))[done - 1:]:
-            # pooled 3-tap stages run on the Winograd kernels of the synthesis engine (same TONAL_WINO switch)
-            wino, f43 = self._use_wino(st), self._use_wino43(st)
-            if wino:
-                wp = self._cached(f"conv{st.idx}w{int(f43)}", w, lambda w=w, f43=f43: self._pack_wino(w, True, f43))
+            # pooled 3-tap stages the F(4,3) V form covers: one transform pass over the stage's input, then the transform-free
+            # kernel of the synthesis engine (half the direct form's MFMA work); everything else on the direct MFMA kernel
+            v43 = self._v43(st)
+            if v43:
+                wp = self._cached(f"conv{st.idx}w43", w, lambda w=w: self._pack_wino43(w, True))
             else:
                 wp = self._cached(f"conv{st.idx}", w, lambda w=w, st=st: self._pack_conv(w, st.cin, False))
             src, dst = self.P[st.idx - 1], self.P[st.idx]
@@ -174,7 +176,11 @@ class CnnClassifierEngine(CnnEngine):
                 kw.update(epilogue=EPI_POOL, obits=ptr(self.bits[st.idx]), ld_obits=st.cout // 32, Tvalid=2 * st.tout)
             else:
                 kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
-            self._nt(fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino else "tl_gemm_nt_window", **kw)
+            if v43:
+                from ._lib import LOAD_V
+                V = self._input_transform(st)
+                kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], loader=LOAD_V)
+            self._nt(fn="tl_conv3_wino43v_nt" if v43 else "tl_gemm_nt_window", **kw)
         feat = self.P[self.stages[-1].idx]                       # [S*tp_last][ld_last] == [B][kflat_cls]
         if p_drop > 0.0:
             check(lib.tl_dropout_scale(ptr(feat), feat.numel(), float(p_drop), int(seed), st_), "tl_dropout_scale")
@@ -233,13 +239,11 @@ class LstmInferEngine:
     the two LSTMs of ``CNNRNNClassifier`` (reference models/deep_classifiers.py:230-233, 263-264, 294-296,
     316-318), which the synthesis trainer runs once per train step without gradients.
 
-    Two phases, both on the fp32 MFMA GEMM kernel:
-      1. the input projection of EVERY time step in one GEMM:  Xp = X W_ih^T + (b_ih + b_hh)   (B*T rows);
-      2. per time step  h_{t-1} W_hh^T  as a skinny split-K GEMM (32-row tiles, about one workgroup per CU:
-         W_hh - 10 MB for hidden 800 - streams from L2) and one
-         ``tl_lstm_cell_infer`` launch that sums the split-K slabs, adds Xp[t] and updates c, h in place -
-         all T steps enqueued by one C call (``tl_lstm_infer_seq``).
-    The sequence is latency bound (T dependent steps); two small launches per step.  Hidden and input widths
+    Two phases:
+      1. the input projection of EVERY time step in one fp32-MFMA GEMM:  Xp = X W_ih^T + (b_ih + b_hh)   (B*T rows);
+      2. per time step ONE fused launch - h_{t-1} W_hh^T on the matrix cores (W_hh, 10 MB for hidden 800, streams from L2)
+         and the cell update in its epilogue - all T steps enqueued by one C call (``tl_lstm_infer_seq_fused``).
+    The sequence is latency bound (T dependent steps); one launch per step.  Hidden and input widths
     that are not multiples of 4 are zero-padded in the packed weights (a padded unit has i = f = o = 1/2,
     g = 0, so its c and h stay exactly 0 and feed nothing)."""
 
@@ -249,8 +253,6 @@ class LstmInferEngine:
         self.in_dim, self.H = in_dim, hidden
         self.Kp, self.Hp = _r4(in_dim), (hidden + 7) // 8 * 8
         self._packed = None
-        # "1": one fused launch per step (tl_lstm_infer_seq_fused); "0": split-K GEMM + cell launch per step
-        self.fused = _kernels.get("lstm_fused") != "0"
 
     def _weights(self, w_ih, w_hh, b_ih, b_hh):
         ver = tuple((t._version, t.data_ptr()) for t in (w_ih, w_hh, b_ih, b_hh))
@@ -289,24 +291,13 @@ class LstmInferEngine:
                    lda=Kp, ldb=Kp, ldo=4 * Hp, loader=LOAD_DIRECT, epilogue=EPI_STORE)
         h = torch.empty(B, Hp, **f32)
         c = torch.empty(B, Hp, **f32)
-        if self.fused:
-            import ctypes as C
-            h2 = torch.empty(B, Hp, **f32)
-            in_b = C.c_int(0)
-            check(self.lib.tl_lstm_infer_seq_fused(ptr(xp), T * 4 * Hp, ptr(whp), ptr(h), ptr(h2), ptr(c), B, Hp, T,
-                                                   C.byref(in_b), torch.cuda.current_stream().cuda_stream),
-                  "tl_lstm_infer_seq_fused")
-            h = h2 if in_b.value else h
-            return h[:, :H] if Hp != H else h
-        tiles = ((B + 31) // 32) * ((4 * Hp + 127) // 128)
-        # split factor: about one workgroup per CU.  Measured on the C5 shapes (hidden 800, batch 64, 400 steps):
-        # 2 -> 9.2 ms, 4 -> 8.0, 6 -> 8.4, 10 -> 10.4, 20 (whole rounds of 512) -> 16.3; MIOpen 9.0 ms
-        sk = int(_kernels.get("lstm_sk")) or max(1, 224 // tiles)
-        sk = max(1, min(sk, (Hp + 31) // 32))
-        slab = torch.empty(sk, B, 4 * Hp, **f32)
-        # phase 2: the T dependent steps, enqueued from C in one call (tl_lstm_infer_seq)
-        check(self.lib.tl_lstm_infer_seq(ptr(xp), T * 4 * Hp, ptr(wh), ptr(h), ptr(c), ptr(slab), sk, B, Hp, T,
-                                         torch.cuda.current_stream().cuda_stream), "tl_lstm_infer_seq")
+        import ctypes as C
+        h2 = torch.empty(B, Hp, **f32)
+        in_b = C.c_int(0)
+        check(self.lib.tl_lstm_infer_seq_fused(ptr(xp), T * 4 * Hp, ptr(whp), ptr(h), ptr(h2), ptr(c), B, Hp, T,
+                                               C.byref(in_b), torch.cuda.current_stream().cuda_stream),
+              "tl_lstm_infer_seq_fused")
+        h = h2 if in_b.value else h
         return h[:, :H] if Hp != H else h
 
 
@@ -337,9 +328,8 @@ class CnnRnnConvEngine:
             raise ValueError("input_length too small for the CNN-RNN convolution stack")
         # 7-tap stack: "wino63" (default since round 5) three F(6,3) segments summed in the transform domain by ONE launch of
         # the V-form NT kernel of the synthesis stack (tl_conv7_wino63v_nt: segment 2 re-reads V0 one hex on, so only two
-        # transformed arrays exist); "wino43+1" two F(4,3) segments (taps 0..5) plus tap 6 as a one-tap GEMM added in the
-        # epilogue; "wino43" three F(4,3) segments; "direct" the 7-tap window GEMM.  CNN-RNN forward at C5 (batch 64), rounds
-        # 2-4: 57.0 (wino43+1) / 60.3 / 72.8 ms
+        # transformed arrays exist); "direct" the 7-tap window GEMM (72.8 ms for the CNN-RNN forward at C5, batch 64, against
+        # 46 ms).  The segmented F(4,3) forms of rounds 2-4 were retired in round 6
         _kernels.validate()
         self.conv7_form = _kernels.get("conv7")
         # rows per sequence: whole hexes for the F(6,3) form, whole quads for the others
@@ -369,7 +359,6 @@ class CnnRnnConvEngine:
         nb = B * self.w1 * self.Tp
         self.Pb, self.Pa = self.P[:nb], self.P[nb:rows]
         self.bits_a, self.bits_b = zi(B * self.C * self.Tp, 32), zi(B * self.w1 * self.Tp, 32)
-        self.Tap = z(rows, 512) if self.conv7_form == "wino43+1" else None
         self.V7 = None
         if self.conv7_form == "wino63":
             # V0 / V1 of a 7-tap layer's input (hex transforms of the rows and of the rows shifted by 3, pair layout, whole
@@ -410,39 +399,17 @@ class CnnRnnConvEngine:
                        bias=ptr(b.detach()), out=ptr(dst), M=rows, N=cout, K=cin, ldb=3 * cin, ldo=dst.shape[1], J=self.K,
                        row_shift=0, Tp=self.Tp, Tvalid=self.Tp, slope=self.slope, loader=LOAD_V, epilogue=EPI_LRELU)
             return
-        wino = self.conv7_form not in ("direct", "wino63") and cin % 32 == 0
-        nseg = 2 if self.conv7_form == "wino43+1" else 3
-        # the segmented kernel reads A rows up to A_rows + 3 (nseg - 1) = rows + 2 + 3 (nseg - 1); the direct form rows + 8
-        if src.shape[0] < rows + max(8, 2 + 3 * (nseg - 1)):
-            raise RuntimeError("conv7: the input buffer is shorter than the rows the segmented convolution reads")
-
-        def pack():
-            if not wino:
-                return w.detach().reshape(cout, cin, self.K).permute(2, 0, 1).contiguous()   # [J][O][I]
-            wp = torch.empty(6, cout, nseg * cin, dtype=torch.float32, device=w.device)
-            check(self.lib.tl_wino43_weights7(ptr(w.detach().reshape(cout, cin, self.K).contiguous()), ptr(wp), cout, cin,
-                                              self.K, nseg, st_), "tl_wino43_weights7")
-            return wp
-        wp = self._cached(key + self.conv7_form, w, pack)
-        if wino and nseg == 2:
-            w6 = self._cached(key + "tap6", w, lambda: w.detach().reshape(cout, cin, self.K)[:, :, 6].contiguous())
-            tap = self.Tap[:, :cout]
-            _launch_nt(self.lib, A=src.data_ptr() + 4 * 6 * cin, Bw=ptr(w6), out=ptr(tap), M=rows, A_rows=rows + 2, N=cout,
-                       K=cin, lda=cin, ldb=cin, ldo=tap.stride(0), loader=LOAD_DIRECT, epilogue=EPI_STORE)
+        # "direct" (or a width the F(6,3) form does not take): the 7-tap window GEMM, which reads rows + 8 input rows
+        if src.shape[0] < rows + 8:
+            raise RuntimeError("conv7: the input buffer is shorter than the rows the 7-tap window reads")
+        wp = self._cached(key + "direct", w, lambda: w.detach().reshape(cout, cin, self.K).permute(2, 0, 1).contiguous())   # [J][O][I]
         p = NtParams()
         p.A, p.Bw, p.bias, p.out = ptr(src), ptr(wp), ptr(b.detach()), ptr(dst)
-        p.M, p.A_rows = rows, rows + 2
-        p.N, p.K, p.lda, p.ldo = cout, cin, cin, cout
+        p.M, p.A_rows = rows, rows + 8
+        p.N, p.K, p.lda, p.ldb, p.ldo = cout, cin, cin, cin, cout
         p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = self.K, 0, self.Tp, self.Tp, self.slope
         p.loader, p.epilogue, p.splitk, p.bm = LOAD_DIRECT, EPI_LRELU, 1, 128
-        if wino:
-            p.ldb = nseg * cin
-            if nseg == 2:
-                p.J, p.aux, p.ldaux = 6, ptr(self.Tap), self.Tap.stride(0)
-            check(self.lib.tl_conv7_wino43_nt(C.byref(p), st_), "tl_conv7_wino43_nt")
-        else:
-            p.ldb, p.A_rows = cin, rows + 8
-            check(self.lib.tl_gemm_nt_window(C.byref(p), st_), "tl_gemm_nt_window")
+        check(self.lib.tl_gemm_nt_window(C.byref(p), st_), "tl_gemm_nt_window")
 
     @torch.no_grad()
     def linear(self, a: torch.Tensor, w: torch.Tensor, b: torch.Tensor, sigmoid: bool = False) -> torch.Tensor:

@@ -87,7 +87,7 @@ class CnnEngine:
                           and self.tp1 >= 12)
         # ... and stage 3's (whose gradient rows no Winograd epilogue produces) from a kernel of its own, tl_wino63_unpool_yvd
         # (TONAL_F63_YPROD3=0: its weight-gradient kernel un-pools and transforms G3 itself and writes Vd3)
-        self.f63_yprod3 = (self.wino63 and _kernels.get("f63_yprod3") != "0" and stage_defs[1][0] % 256 == 0)
+        self.f63_yprod3 = (self.wino63 and _kernels.get("f63_yprod") != "0" and stage_defs[1][0] % 256 == 0)
         self.stages: List[_Stage] = []
         cin, tin, tp = self.c1, self.tout1, self.tp1
         for i, (cout, k, pool) in enumerate(stage_defs[1:], start=2):
@@ -118,46 +118,23 @@ class CnnEngine:
         self.lstm_shard = None
         self._sh = None
         self.timers = None
-        # Winograd kernels for the pooled 3-tap stages.  TONAL_WINO selects the form:
-        #   6  default (round 4): F(6,3) on pre-transformed operands for all three passes of stages 2 and 3 where the stack
-        #      allows it (_f63_covers; 4/9 of the direct-form MFMA work), the F(4,3) forms below everywhere else
-        #   0  direct-form MFMA kernels (the parity partner)
-        #   1  F(2,3) for all three passes (2/3 of the direct-form MFMA work)
-        #   4  (default until round 3) F(4,3) for the forward and input-gradient passes (1/2 of the MFMA work), F(2,3)
-        #      for the weight gradient: 3 % faster per step than F(2,3) (304.5 vs 314 ms at the
-        #      north-star shape); rounding error against the direct kernels 1.4e-6 vs 8e-7.  Against the
-        #      reference golden all three forms sit at the same noise floor (scripts/update_parity.py,
-        #      DESIGN.md section 6)
+        # Kernels for the pooled 3-tap stages (TONAL_KERNELS wino):
+        #   6  default: Winograd F(6,3) on pre-transformed operands for all three passes of stages 2 and 3 where the stack
+        #      allows it (_f63_covers; 4/9 of the direct-form MFMA work); the F(4,3) V form below, stage by stage, elsewhere
+        #   4  Winograd F(4,3) on pre-transformed operands (tonal_wino43v.hip; 1/2 of the MFMA work): the A/B partner
+        #   0  direct-form MFMA kernels (the parity partner, and the fallback for every shape neither V form covers)
+        # (the in-loop-transform F(2,3) / F(4,3) kernels of rounds 1-2 were retired in round 6)
         mode = _kernels.get("wino")
-        if mode == "6":
-            mode = "4"                          # (the F(4,3) predicates describe the fallback; wino63 overrides stages 2, 3)
-        self.wino = mode != "0"
-        self.wino43 = mode == "4"
-        # weight gradient: F(4,3) with the transforms applied at LDS-staging time (tonal_wino43_tn.hip; half
-        # the direct-form MFMA work) under TONAL_WINO=4 unless TONAL_WINO_TN=2 asks for the F(2,3) kernel
-        self.wino43_tn = self.wino43 and _kernels.get("wino_tn") == "4"
-        # round 3: the F(4,3) input transform V = B^T d is written once by the producer of an activation and the
-        # forward / weight-gradient GEMMs read it by LDS-DMA (tonal_wino43v.hip).  TONAL_WINO_V: 0 off, 1 on
-        self.wino_v = self.wino43 and _kernels.get("wino_v") != "0"
+        self.wino43 = mode != "0"
         # with V written by the first stage the raw pooled rows P1 (13.4 GB at the north-star shape) have no reader
         # left (the LeakyReLU' mask of the backward pass comes from the 1-bit sign array); store_p1 keeps them anyway
         self.store_p1 = _kernels.get("store_p1") == "1"
-        # round 4: the forward epilogue of a pooled 3-tap stage whose successor reads V writes that V itself (epilogue 5 of
-        # tl_conv3_wino43v_nt + tl_wino43_v_fixup): the stand-alone transform kernel and the raw pooled rows of stage 2
-        # (6.6 GB written, 6.6 GB re-read at the north-star shape) go; store_p1 keeps the raw rows as well (tests).  0: off
-        self.wino_vout = _kernels.get("wino_vout") != "0"
         # fold the first stage's weight gradient into the stage-2 input-gradient epilogue (Winograd kernels)
-        self.fuse_c1 = _kernels.get("fuse_c1") != "0"
-        # TONAL_OVERLAP=1: run the label LSTM (forward and BPTT: HBM-bound streams of the 5.4 GB W_hh) and the W_hh update
-        # on a side stream beside the MFMA-bound convolution stack they do not depend on.  Measured equal to one stream
-        # (251.1 vs 250.7 ms): a conv workgroup holds 144 KB of LDS and both waves' worth of registers of every SIMD, so
-        # the streaming kernels (which stage through LDS too) find no free CU and the two streams serialise.  Off.
-        self.overlap = _kernels.get("overlap") == "1"
-        self.vd_mode = _kernels.get("wino_vd")
-        # C_in tile of the V-form weight-gradient kernel: 0 = 128 (8 waves, wino43v_tn8_kernel) where the shape allows, else
-        # 64; 64 / 127 force the 4-wave kernel / the 8-wave kernel that stages Y through registers (the A/B partners: same
-        # results bit for bit)
-        self.tn_bm = int(_kernels.get("tn_bm"))
+        self.fuse_c1 = True                    # (tests clear it to reach the stand-alone tl_conv1_wgrad)
+        # test hooks of the F(4,3) V form (no TONAL_KERNELS keys): wino_vout False - forward epilogues write raw rows, every
+        # stage transforms its own input; tn_bm 64 / 127 / 128 - force a C_in tile of the weight-gradient kernel (0: auto)
+        self.wino_vout = True
+        self.tn_bm = 0
         self._side = None
         self._B = None
         self.generation = 0
@@ -212,7 +189,7 @@ class CnnEngine:
         z = lambda *s: torch.zeros(*s, **f32)
         S = self.S
         self.G = {}
-        if not self.wino63 and not (self.fuse_c1 and self._c1_fusable() and self._use_wino(self.stages[0])):
+        if not self.wino63 and not (self.fuse_c1 and self._c1_fusable() and self._v43(self.stages[0])):
             self.G[1] = z(S * self.tp1, self.c1)      # otherwise G1 never leaves the stage-2 epilogue
         for st in self.stages:
             # (with f63_yprod G2 is never stored; with the NT63 form of stage 4's input gradient neither is G3)
@@ -323,7 +300,7 @@ class CnnEngine:
         """The F(6,3) kernels cover the stack: stages 2 and 3 are pooled 3-tap convolutions with C_in % 128 == 0 and
         C_out % 64 == 0, the first stage has 1..3 taps, one input channel and a width tl_conv1_fwd_v6 takes, and the fused
         first-stage weight gradient can read its sample windows."""
-        if len(stage_defs) < 4 or _kernels.get("fuse_c1") == "0":
+        if len(stage_defs) < 4:
             return False
         (c1, k1, p1), (c2, k2, p2), (c3, k3, p3) = stage_defs[0], stage_defs[1], stage_defs[2]
         tout1 = (T - k1 + 1) // 2
@@ -402,7 +379,7 @@ class CnnEngine:
         ldg = nd
         V = self._v_ready[st.idx - 1]
         tiles = (st.cin // 64) * (nd // 64)
-        sk = self._splitk(tiles, (rows_in + 35) // 36, int(_kernels.get("tn_target") or "4096"))
+        sk = self._splitk(tiles, (rows_in + 35) // 36, 4096)
         slab = torch.empty(sk, 8 * st.cin, ldg, **f32)
         bias_part = torch.empty(sk, nd, **f32)
         if (st.idx == 3 and self.f63_yprod3 and self._y_ready.get(3) != self.generation):
@@ -537,46 +514,32 @@ class CnnEngine:
                  c1bits=ptr(self.bits[1]), c1partial=ptr(part), c1T=self.T, c1kt=self.k1, Tvalid=self.tout1, **kw)
         return part
 
-    def _use_wino(self, st) -> bool:
-        return (self.wino and st.k == 3 and st.pool and st.cin % 32 == 0 and st.cout % 32 == 0
-                and st.tp_in % 2 == 0)
-
     def _c1_fusable(self) -> bool:
         # the epilogue reads x[2t + a + j] for j < 3 unconditionally (4 floats from 2t)
         return self.k1 <= 3 and self.T >= 2 * self.tout1 + 2
 
-    def _use_wino43(self, st) -> bool:
-        return self.wino43 and self._use_wino(st) and st.tp_in % 4 == 0
-
-    def _use_wino43_tn(self, st) -> bool:
-        return self.wino43_tn and self._use_wino43(st)
-
-    def _use_wino_v(self, st) -> bool:
-        return self.wino_v and self._use_wino43(st) and st.cin % 64 == 0
-
-    def _use_wino_vd(self, st) -> bool:
-        """The stage's input gradient runs on the transform-free V-form kernel, reading Vd = the F(4,3) input transform of
-        the un-pooled dZ.  TONAL_WINO_VD: "tn" (default) - the first C_in tile of the stage's weight-gradient kernel writes
-        Vd (it already holds those dZ rows for its own transform); "side" - Vd comes from the stand-alone, LDS-free
-        ``tl_wino43_unpool_transform`` launched on a side stream beside the weight-gradient kernel (measured: the two share
-        the CUs but the sum of their times stays the serial one - 249.9 vs 245.4 ms per step); "0" - off."""
-        return (self._use_wino_v(st) and self._use_wino43_tn(st) and _r4(st.cout) % 16 == 0 and self.vd_mode != "0")
+    def _v43(self, st) -> bool:
+        """The stage runs on the F(4,3) V-form kernels, all three passes: forward and weight gradient on V (the input transform
+        its producer wrote), input gradient on Vd (the transformed un-pooled dZ its weight-gradient launch writes).  Every
+        other shape runs on the direct MFMA kernels."""
+        return (self.wino43 and st.k == 3 and st.pool and st.cin % 64 == 0 and st.cout % 32 == 0 and st.tp_in % 4 == 0
+                and _r4(st.cout) % 16 == 0)
 
     def _tn_bm(self, st) -> int:
-        """64: 64 x 64 tile, 4 waves; 128: 128 x 64 tile, 8 waves, the Y side by LDS-DMA (wino43v_tn8_kernel: needs C_in % 128 ==
-        0, C_out % 64 == 0); 127: the 128-wide tile on the kernel that stages Y through registers."""
+        """C_in tile of the V-form weight-gradient kernel: 128 (8 waves, the Y side by LDS-DMA: C_in % 128 == 0,
+        C_out % 64 == 0) where the shape allows it, else 64 (4 waves)."""
         wide = st.cin % 128 == 0
         dma8 = wide and _r4(st.cout) % 64 == 0 and (st.cout // 32) % 2 == 0
-        if self.tn_bm == 127:
+        if self.tn_bm == 127:                  # (the 8-wave kernel that stages Y through registers: bit-identical A/B partner)
             return 127 if wide else 64
-        if self.tn_bm == 128 or not self.tn_bm:
+        if self.tn_bm in (0, 128):
             return 128 if dma8 else 64
         return 64
 
     def _conv1_writes_v(self) -> bool:
         """The first stage hands its output to stage 2 as V (tl_conv1_fwd_v) - nothing else reads P1 then."""
-        return (self._use_wino_v(self.stages[0]) and self._use_wino43_tn(self.stages[0]) and self.tp1 % 4 == 0
-                and self.c1 in (128, 256, 512, 1024) and (self.fuse_c1 and self._c1_fusable()))
+        return (self._v43(self.stages[0]) and self.tp1 % 4 == 0 and self.c1 in (128, 256, 512, 1024)
+                and (self.fuse_c1 and self._c1_fusable()))
 
     def _writes_v(self, st) -> bool:
         """The forward pass of this stage writes V of its own output for the next stage (nothing else reads the raw rows:
@@ -584,8 +547,7 @@ class CnnEngine:
         if not (self.wino_vout and st.pool and st.idx - 1 < len(self.stages)):
             return False
         nxt = self.stages[st.idx - 1]                      # stages[k] has idx k + 2
-        return (self._use_wino_v(st) and self._use_wino_v(nxt) and self._use_wino43_tn(nxt) and st.tp_in % 8 == 0
-                and nxt.cin == st.cout)
+        return self._v43(st) and self._v43(nxt) and st.tp_in % 8 == 0 and nxt.cin == st.cout
 
     def _pin(self, st):
         """Input activation of a stage, or None when only its V form exists (stage 2 behind tl_conv1_fwd_v)."""
@@ -616,9 +578,7 @@ class CnnEngine:
         """MFMA FLOPs the weight-gradient kernel of a stage issues per direct-convolution FLOP."""
         if self._f63(st):
             return self.f63_issue_factor(st)
-        if self._use_wino43_tn(st):
-            return 0.5
-        return 2.0 / 3.0 if self._use_wino(st) else 1.0
+        return 0.5 if self._v43(st) else 1.0
 
     def kernel_families(self):
         """({rocprofv3 kernel family: [timer tags]}, {family: MFMA FLOPs issued per algorithmic FLOP})
@@ -648,66 +608,48 @@ class CnnEngine:
                 fams[f"{tn2} (conv2 weight gradient, {f6}; also writes Vd)"] = ["conv2_wgrad"]
             issued = {k: self.f63_issue_factor(st2 if "conv2" in k else st3) for k in fams}
             return fams, issued
-        if not self.wino:
+        self._fam_share = {}         # family -> share of its stages' algorithmic FLOPs it computes (default 1)
+        if not all(self._v43(st) for st in self.stages[:2]):
             fams = {"nt_window_kernel<128,UNPOOL,MASK> (conv input-gradient)": ["conv2_dgrad", "conv3_dgrad", "conv4_dgrad"],
                     "nt_window_kernel<128,DIRECT,POOL> (conv forward)": ["conv2_fwd", "conv3_fwd", "conv4_fwd"],
                     "tn3_kernel<UNPOOL> (conv weight-gradient)": ["conv2_wgrad", "conv3_wgrad"]}
-            return fams, {k: 1.0 for k in fams}
-        nt, form = ("wino43_nt_kernel", "F(4,3)") if self.wino43 else ("wino_nt_kernel", "F(2,3)")
+            return fams, {k: 1.0 for k in fams}      # (mixed shapes: a stage the V form does not cover runs direct)
+        form = "Winograd F(4,3) on pre-transformed operands, LDS-DMA"
         fused = self.fuse_c1 and self._c1_fusable()
-        tn = "wino43_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3))" if self.wino43_tn else \
-            "wino_tn_kernel (conv2/conv3 weight gradient, Winograd F(2,3))"
-        fwd = f"{nt}<DIRECT,POOL> (conv2/conv3 forward, Winograd {form})"
+        bm = self._tn_bm(self.stages[0])
         extra = {}
-        self._fam_share = {}         # family -> share of its stages' algorithmic FLOPs it computes (default 1)
-        if self.wino_v and all(self._use_wino_v(st) for st in self.stages[:2]):
-            fwd = "wino43v_nt_kernel<POOL> (conv2/conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)"
-            if self.wino43_tn:
-                tn = "wino43v_tn_kernel (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA)"
-                if self.vd_mode == "tn" and all(self._use_wino_vd(st) for st in self.stages[:2]):
-                    bm = self._tn_bm(self.stages[0])
-                    if bm == 128:
-                        # one launch: its workgroups take turns at writing Vd, the operand of the input gradient
-                        tn = ("wino43v_tn8_kernel<true> (conv2/conv3 weight gradient, Winograd F(4,3) on V, LDS-DMA; also "
-                              "writes Vd for the input gradient)")
-                    else:
-                        # the op is two launches, named apart by rocprofv3: the first C_in tile (1 / ntm of the MFMA work)
-                        # also writes Vd, the operand of the input gradient; the plain instantiation does the other tiles
-                        ntm = (self.stages[0].cin + (64 if bm == 64 else 128) - 1) // (64 if bm == 64 else 128)
-                        kn = {64: "wino43v_tn_kernel<{}, 2>", 127: "wino43v_tn_kernel<{}, 4>"}[bm]
-                        tn = f"{kn.format('false')} (conv2/conv3 weight gradient, C_in tiles 1..{ntm - 1} of {ntm}, Winograd F(4,3) on V, LDS-DMA)"
-                        vdn = f"{kn.format('true')} (conv2/conv3 weight gradient, C_in tile 0 of {ntm}, Winograd F(4,3) on V, + writes Vd for the input gradient)"
-                        extra[vdn] = ["conv2_wgrad_vd", "conv3_wgrad_vd"]
-                        self._fam_share = {tn: (ntm - 1) / ntm, vdn: 1.0 / ntm}
-        fams = {fwd: ["conv2_fwd", "conv3_fwd"], tn: ["conv2_wgrad", "conv3_wgrad"]}
-        if self.wino_v and self._writes_v(self.stages[0]) and all(self._use_wino_v(st) for st in self.stages[:2]):
-            # round 4: stage 2's forward launch also writes V of its output for stage 3 (epilogue 5): its own kernel name
-            del fams[fwd]
-            fams["wino43v_nt_kernel<POOLV> (conv2 forward, Winograd F(4,3) on V, LDS-DMA; writes V of its pooled output for "
-                 "conv3 instead of the raw rows)"] = ["conv2_fwd"]
-            fams["wino43v_nt_kernel<POOL> (conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)"] = ["conv3_fwd"]
-        fams.update(extra)
-        if all(self._use_wino_vd(st) for st in self.stages[:2]):
-            nt = "wino43v_nt_kernel"
-            form = "F(4,3) on the pre-transformed dZ, LDS-DMA"
-        if fused:       # the stage-2 launch carries the fused conv1 weight-gradient epilogue: its own kernel name
-            fams[f"{nt}<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, Winograd {form})"] = ["conv2_dgrad"]
-            fams[f"{nt}<UNPOOL,MASK> (conv3 input gradient, Winograd {form})"] = ["conv3_dgrad"]
+        if bm == 128:
+            # one launch: its workgroups take turns at writing Vd, the operand of the input gradient
+            tn = f"wino43v_tn8_kernel<true> (conv2/conv3 weight gradient, {form}; also writes Vd for the input gradient)"
         else:
-            fams[f"{nt}<UNPOOL,MASK> (conv2/conv3 input gradient, Winograd {form})"] = ["conv2_dgrad", "conv3_dgrad"]
-        issued = {k: (0.5 if "F(4,3)" in k else 2.0 / 3.0) for k in fams}
-        return fams, issued          # (mixed shapes: a stage the F(4,3) forms do not cover falls back per stage)
+            # the op is two launches, named apart by rocprofv3: the first C_in tile (1 / ntm of the MFMA work) also writes Vd
+            ntm = (self.stages[0].cin + 63) // 64
+            tn = f"wino43v_tn_kernel<false, 2> (conv2/conv3 weight gradient, C_in tiles 1..{ntm - 1} of {ntm}, {form})"
+            vdn = f"wino43v_tn_kernel<true, 2> (conv2/conv3 weight gradient, C_in tile 0 of {ntm}, {form}, + writes Vd for the input gradient)"
+            extra[vdn] = ["conv2_wgrad_vd", "conv3_wgrad_vd"]
+            self._fam_share = {tn: (ntm - 1) / ntm, vdn: 1.0 / ntm}
+        fams = {tn: ["conv2_wgrad", "conv3_wgrad"]}
+        if self._writes_v(self.stages[0]):
+            # stage 2's forward launch also writes V of its output for stage 3 (epilogue 5): its own kernel name
+            fams[f"wino43v_nt_kernel<POOLV> (conv2 forward, {form}; writes V of its pooled output for conv3 instead of the raw rows)"] = ["conv2_fwd"]
+            fams[f"wino43v_nt_kernel<POOL> (conv3 forward, {form})"] = ["conv3_fwd"]
+        else:
+            fams[f"wino43v_nt_kernel<POOL> (conv2/conv3 forward, {form})"] = ["conv2_fwd", "conv3_fwd"]
+        fams.update(extra)
+        if fused:       # the stage-2 launch carries the fused conv1 weight-gradient epilogue: its own kernel name
+            fams[f"wino43v_nt_kernel<UNPOOL,C1WGRAD> (conv2 input gradient + conv1 weight gradient, {form})"] = ["conv2_dgrad"]
+            fams[f"wino43v_nt_kernel<UNPOOL,MASK> (conv3 input gradient, {form})"] = ["conv3_dgrad"]
+        else:
+            fams[f"wino43v_nt_kernel<UNPOOL,MASK> (conv2/conv3 input gradient, {form})"] = ["conv2_dgrad", "conv3_dgrad"]
+        return fams, {k: 0.5 for k in fams}
 
-    def _pack_wino(self, w, forward: bool, f43: bool = False):
-        """torch (O, I, 3, 1) -> the 4 (F(2,3)) or 6 (F(4,3)) Winograd taps: forward [n][O][I] or
-        input-gradient [n][I][O]."""
+    def _pack_wino43(self, w, forward: bool):
+        """torch (O, I, 3, 1) -> the 6 F(4,3) taps: forward [6][O][I] or input-gradient [6][I][O]."""
         O, I = w.shape[0], w.shape[1]
-        n = 6 if f43 else 4
-        dst = torch.empty(n, O, I, dtype=torch.float32, device=w.device) if forward else \
-            torch.empty(n, I, O, dtype=torch.float32, device=w.device)
-        fn = self.lib.tl_wino43_weights if f43 else self.lib.tl_wino_weights
-        check(fn(ptr(w), ptr(dst) if forward else None, None if forward else ptr(dst), O, I, I, O, self._stream()),
-              "tl_wino_weights")
+        dst = torch.empty(6, O, I, dtype=torch.float32, device=w.device) if forward else \
+            torch.empty(6, I, O, dtype=torch.float32, device=w.device)
+        check(self.lib.tl_wino43_weights(ptr(w), ptr(dst) if forward else None, None if forward else ptr(dst), O, I, I, O,
+                                         self._stream()), "tl_wino43_weights")
         return dst
 
     # ------------------------------------------------------------------ one ecog stage (2..5)
@@ -718,9 +660,8 @@ class CnnEngine:
         if self._f63(st):
             return self._stage_forward63(st, w, bia)
         S = self.S
-        wino = self._use_wino(st)
-        f43 = self._use_wino43(st)
-        wp = self._pack_wino(w, True, f43) if wino else self._pack_conv(w, st.cin, False)
+        v43 = self._v43(st)
+        wp = self._pack_wino43(w, True) if v43 else self._pack_conv(w, st.cin, False)
         src = self._pin(st)
         vout = self._writes_v(st)
         if vout and self.store_p1 and st.idx not in self.P:
@@ -735,30 +676,27 @@ class CnnEngine:
                       ld_obits=st.cout // 32, Tvalid=2 * st.tout)
         else:
             kw.update(epilogue=EPI_LRELU, Tvalid=st.tout)
-        if self._use_wino_v(st):
-            V = self._v_ready.get(st.idx - 1)
-            if V is None:
-                V = self._v_ready[st.idx - 1] = self._input_transform(st)
-            kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], loader=LOAD_V)
-            if vout:
-                rows_out = S * st.tp_out
-                Vn = self._v_buffer(st.idx, rows_out, st.cout)
-                ntm = (S * st.tp_in + 511) // 512
-                halo = getattr(self, "_vhalo", {}).get(st.idx)
-                if halo is None or halo.shape[0] != ntm or halo.shape[2] != st.cout:
-                    if not hasattr(self, "_vhalo"):
-                        self._vhalo = {}
-                    halo = self._vhalo[st.idx] = torch.zeros(ntm, 2, st.cout, dtype=torch.float32, device=self._dev)
-                kw.update(epilogue=EPI_POOLV, vout=ptr(Vn), vhalo=ptr(halo), vout_quads=Vn.shape[0], ld_vout=Vn.shape[2])
-                self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino43v_nt", **kw)
-                check(self.lib.tl_wino43_v_fixup(ptr(Vn), ptr(halo), rows_out // 4, ntm, st.tp_out, st.cout, Vn.shape[2],
-                                                 self._stream()), "tl_wino43_v_fixup")
-                self._v_ready[st.idx] = Vn
-                return
-            self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino43v_nt", **kw)
+        if not v43:
+            self._nt(tag=f"conv{st.idx}_fwd", fn="tl_gemm_nt_window", **kw)
             return
-        self._nt(tag=f"conv{st.idx}_fwd", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino
-                 else "tl_gemm_nt_window", **kw)
+        V = self._v_ready.get(st.idx - 1)
+        if V is None:
+            V = self._v_ready[st.idx - 1] = self._input_transform(st)
+        kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], loader=LOAD_V)
+        if vout:
+            rows_out = S * st.tp_out
+            Vn = self._v_buffer(st.idx, rows_out, st.cout)
+            ntm = (S * st.tp_in + 511) // 512
+            halo = self._vhalo.get(st.idx)
+            if halo is None or halo.shape[0] != ntm or halo.shape[2] != st.cout:
+                halo = self._vhalo[st.idx] = torch.zeros(ntm, 2, st.cout, dtype=torch.float32, device=self._dev)
+            kw.update(epilogue=EPI_POOLV, vout=ptr(Vn), vhalo=ptr(halo), vout_quads=Vn.shape[0], ld_vout=Vn.shape[2])
+            self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino43v_nt", **kw)
+            check(self.lib.tl_wino43_v_fixup(ptr(Vn), ptr(halo), rows_out // 4, ntm, st.tp_out, st.cout, Vn.shape[2],
+                                             self._stream()), "tl_wino43_v_fixup")
+            self._v_ready[st.idx] = Vn
+            return
+        self._nt(tag=f"conv{st.idx}_fwd", fn="tl_conv3_wino43v_nt", **kw)
 
     def _colsum(self, Gm, rows, ncols, ld, Tp, Tvalid, dst):
         nc4 = _r4(ncols)                       # pad columns of G are zero by construction
@@ -800,59 +738,32 @@ class CnnEngine:
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
         nd = _r4(st.cout)
-        if self._use_wino43_tn(st):
-            # F(4,3): 64 x 64 tiles, 6 transform accumulators.  Many short reduction splits (16 rounds of the 512
-            # resident workgroups) rather than few long ones: the 64 workgroups of one split re-read each
-            # other's activation / gradient panels through their XCD's L2, which only works while they stay
-            # in step - measured HBM-side reads per conv2 launch 64.6 GB at 4 rounds, 31.4 GB at 16, 27.4 GB
-            # (+ 3.2 GB of slab reduction) at 64; the time is the same (50.3 - 51.1 ms)
+        if self._v43(st):
+            # F(4,3) on V: 6 transform accumulators; split-K slabs summed afterwards.  (Measured at conv2: the 8-wave kernel,
+            # one workgroup per CU, runs 0.3 ms better with 8 rounds of 256 workgroups than with 16 - 42.2 / 42.55 ms)
             tiles = ((st.cin + 63) // 64) * ((nd + 63) // 64)
-            # (the 8-wave kernel, one workgroup per CU: 8 rounds of 256 measure 0.3 ms better at conv2 than 16 - 42.2 / 42.55 ms)
-            tn8 = self._use_wino_v(st) and self._tn_bm(st) == 128
-            sk = self._splitk(tiles, (rows_in + 31) // 32, int(_kernels.get("tn_target") or ("4096" if tn8 else "8192")))
+            bm = self._tn_bm(st)
+            sk = self._splitk(tiles, (rows_in + 31) // 32, 4096 if bm in (127, 128) else 8192)
             slab = torch.empty(sk, 6 * st.cin, ldg, **f32)
             bias_part = torch.empty(sk, nd, **f32)     # the kernel's Y1 = sum of the quad's dZ rows doubles as the bias gradient
-            kw = dict(A=ptr(Xin), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=rows_in, B_rows=Gs.shape[0],
-                      Mdim=st.cin, Ndim=nd, lda=st.cin, ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk,
+            V = self._v_ready.get(st.idx - 1)          # normally written in the forward pass
+            if V is None:
+                V = self._v_ready[st.idx - 1] = self._input_transform(st)
+            nq_pad = (rows_in // 4 + 127) // 128 * 128
+            Vd = self.Vd.get(st.idx)
+            if Vd is None or Vd.shape[0] != nq_pad or Vd.shape[2] != nd:
+                Vd = self.Vd[st.idx] = torch.zeros(nq_pad, 6, nd, **f32)
+            kw = dict(A=ptr(V), B=ptr(Gs), slab=ptr(slab), Krows=rows_in, A_rows=V.shape[0], B_rows=Gs.shape[0],
+                      Mdim=st.cin, Ndim=nd, lda=V.shape[2], ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk,
                       slab_stride=6 * st.cin * ldg, loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]),
-                      ld_bbits=st.cout // 32, Tvalid=2 * st.tout, colsum=ptr(bias_part))
-            fn = "tl_conv3_wino43_tn"
-            if self._use_wino_v(st) and st.cin % 64 == 0:
-                V = self._v_ready.get(st.idx - 1)      # normally written in the forward pass
-                if V is None:
-                    V = self._v_ready[st.idx - 1] = self._input_transform(st)
-                kw.update(A=ptr(V), A_rows=V.shape[0], lda=V.shape[2], bm=self._tn_bm(st))
-                fn = "tl_conv3_wino43v_tn"
-                if self._use_wino_vd(st):
-                    nq_pad = (rows_in // 4 + 127) // 128 * 128
-                    Vd = self.Vd.get(st.idx)
-                    if Vd is None or Vd.shape[0] != nq_pad or Vd.shape[2] != nd:
-                        Vd = self.Vd[st.idx] = torch.zeros(nq_pad, 6, nd, **f32)
-                    if self.vd_mode == "tn":
-                        kw.update(vd=ptr(Vd), ld_vd=nd)
-                    else:
-                        # HBM-bound (26 GB at conv2) and LDS-free: on the side stream it shares the CUs with the
-                        # weight-gradient kernel launched below (two 4-wave workgroups per CU leave every SIMD the
-                        # registers for one more light wave)
-                        side = self._side_stream(self._dev)
-                        side.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(side):
-                            ev = self._tick(f"conv{st.idx}_vdxform")
-                            check(self.lib.tl_wino43_unpool_transform(ptr(Gs), ptr(self.bits[st.idx]), ptr(Vd), rows_in,
-                                                                      Gs.shape[0], st.tp_in, 2 * st.tout, nd, ldg,
-                                                                      st.cout // 32, nd, self._stream()),
-                                  "tl_wino43_unpool_transform")
-                            if ev:
-                                ev[1].record()
-                    self._vd_ready[st.idx] = self.generation
-            # (measured and not kept: the Vd-writing launch on a side stream beside the launch of the other seven C_in tiles
-            # - tl_tn_params.part - 249.4 vs 244.9 ms per step)
-            if kw.get("vd") and self.timers is not None and kw.get("bm") != 128:
+                      ld_bbits=st.cout // 32, Tvalid=2 * st.tout, colsum=ptr(bias_part), bm=bm, vd=ptr(Vd), ld_vd=nd)
+            self._vd_ready[st.idx] = self.generation
+            if self.timers is not None and bm != 128:
                 # two calls so that the two launches of the op get their own HIP-event timers (rocprofv3 names them apart too)
-                self._tn(tag=f"conv{st.idx}_wgrad_vd", fn=fn, part=1, **kw)
-                self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, part=2, **kw)
+                self._tn(tag=f"conv{st.idx}_wgrad_vd", fn="tl_conv3_wino43v_tn", part=1, **kw)
+                self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino43v_tn", part=2, **kw)
             else:
-                self._tn(tag=f"conv{st.idx}_wgrad", fn=fn, **kw)
+                self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino43v_tn", **kw)
             if sk > 1:
                 red = torch.empty(6 * st.cin, ldg, **f32)
                 n = 6 * st.cin * ldg
@@ -862,24 +773,6 @@ class CnnEngine:
             check(self.lib.tl_wino43_wgrad_finalize(ptr(red), ptr(gw), st.cout, st.cin, ldg, self._stream()),
                   "tl_wino43_wgrad_finalize")
             self._permute(bias_part, gb, (1, 1, 1, st.cout), (0, 0, 0, 1), nz=sk, zs=nd)
-            return
-        if self._use_wino(st):
-            tiles = ((st.cin + 127) // 128) * ((nd + 63) // 64)
-            sk = self._splitk(tiles, (rows_in + 31) // 32, 1024)
-            slab = torch.empty(sk, 4 * st.cin, ldg, **f32)
-            self._tn(tag=f"conv{st.idx}_wgrad", fn="tl_conv3_wino_tn", A=ptr(Xin), B=ptr(Gs), slab=ptr(slab),
-                     Krows=rows_in, A_rows=Xin.shape[0], B_rows=Gs.shape[0], Mdim=st.cin, Ndim=nd, lda=st.cin,
-                     ldb=ldg, ldc=ldg, J=3, Tp=st.tp_in, splitk=sk, slab_stride=4 * st.cin * ldg,
-                     loader=LOAD_UNPOOL, bbits=ptr(self.bits[st.idx]), ld_bbits=st.cout // 32, Tvalid=2 * st.tout)
-            if sk > 1:
-                red = torch.empty(4 * st.cin, ldg, **f32)
-                n = 4 * st.cin * ldg
-                self._permute(slab, red, (1, 1, 1, n), (0, 0, 0, 1), nz=sk, zs=n)
-            else:
-                red = slab
-            check(self.lib.tl_wino_wgrad_finalize(ptr(red), ptr(gw), st.cout, st.cin, ldg, self._stream()),
-                  "tl_wino_wgrad_finalize")
-            self._colsum(Gs, Gs.shape[0], st.cout, ldg, st.tp_out, st.tout, gb)
             return
         if st.k == 3:      # all-taps kernel: 128 x 64 tiles
             tiles = ((st.cin + 127) // 128) * ((nd + 63) // 64)
@@ -929,11 +822,10 @@ class CnnEngine:
         Gs = self.G[st.idx]
         rows_in = S * st.tp_in
         ldg = Gs.shape[1]
-        wino = self._use_wino(st)
-        f43 = self._use_wino43(st)
-        wd = self._pack_wino(w, False, f43) if wino else self._pack_conv(w, st.cin, True)   # [J, 4 or 6][cin][r4(cout)]
+        v43 = self._v43(st)
+        wd = self._pack_wino43(w, False) if v43 else self._pack_conv(w, st.cin, True)   # [6 or J][cin][r4(cout)]
         kd = wd.shape[2]
-        fuse = st.idx == 2 and wino and self.fuse_c1 and self._c1_fusable()
+        fuse = st.idx == 2 and v43 and self.fuse_c1 and self._c1_fusable()
         kw = dict(A=ptr(Gs), Bw=ptr(wd), aux=ptr(Xin), out=None if fuse else ptr(self.G[st.idx - 1]), M=rows_in,
                   A_rows=Gs.shape[0], N=st.cin, K=kd, lda=ldg, ldb=kd, ldo=st.cin, ldaux=st.cin, J=st.k,
                   row_shift=-(st.k - 1), Tp=st.tp_in, epilogue=EPI_MASK, slope=self.slope)
@@ -944,24 +836,22 @@ class CnnEngine:
                       Tvalid_in=2 * st.tout)
         else:
             kw.update(loader=LOAD_DIRECT)
+        if not v43:
+            self._nt(tag=f"conv{st.idx}_dgrad", fn="tl_gemm_nt_window", **kw)
+            return None
         part = None
         if fuse:
-            tile_rows = 512 if f43 else 256
-            ntm = (rows_in + tile_rows - 1) // tile_rows
+            ntm = (rows_in + 511) // 512
             part = torch.empty(ntm, (self.k1 + 1) * self.c1, dtype=torch.float32, device=self._dev)
             kw.update(epilogue=EPI_C1WGRAD, out=None, c1x=ptr(self._x), c1bits=ptr(self.bits[1]), c1partial=ptr(part),
                       c1T=self.T, c1kt=self.k1, Tvalid=self.tout1)
-        if self._use_wino_vd(st) and self._vd_ready.get(st.idx) == self.generation and st.idx in self.Vd:
-            # the weight-gradient kernel of this stage (run just before) left Vd = B^T (un-pooled dZ rows 4q-2 .. 4q+3)
-            Vd = self.Vd[st.idx]
-            if self.vd_mode != "tn":
-                torch.cuda.current_stream().wait_stream(self._side_stream(self._dev))
-            kw.update(A=ptr(Vd), A_rows=Vd.shape[0], lda=Vd.shape[2], loader=LOAD_V)
-            self._vd_ready[st.idx] = -1
-            self._nt(tag=f"conv{st.idx}_dgrad", fn="tl_conv3_wino43v_nt", **kw)
-            return part
-        self._nt(tag=f"conv{st.idx}_dgrad", fn=("tl_conv3_wino43_nt" if f43 else "tl_conv3_wino_nt") if wino
-                 else "tl_gemm_nt_window", **kw)
+        if self._vd_ready.get(st.idx) != self.generation or st.idx not in self.Vd:
+            raise RuntimeError("F(4,3) input gradient: the stage's weight-gradient pass (which writes Vd) must run first")
+        # the weight-gradient kernel of this stage (run just before) left Vd = B^T (un-pooled dZ rows 4q-2 .. 4q+3)
+        Vd = self.Vd[st.idx]
+        kw.update(A=ptr(Vd), A_rows=Vd.shape[0], lda=Vd.shape[2], loader=LOAD_V)
+        self._vd_ready[st.idx] = -1
+        self._nt(tag=f"conv{st.idx}_dgrad", fn="tl_conv3_wino43v_nt", **kw)
         return part
 
     def _lstm_forward(self, prm, xu, U, L, dev, training, label_table) -> None:
@@ -1080,7 +970,7 @@ class CnnEngine:
         f32 = dict(dtype=torch.float32, device=dev)
         # the LSTM does not depend on the convolution stack: it runs on a side stream beside it (HBM-bound next to
         # MFMA-bound), joined in front of the concat kernel.  Not under the row-sharded data-parallel LSTM (collectives).
-        side = self._side_stream(dev) if (self.overlap and self.lstm_shard is None) else None
+        side = None         # (a side stream for the LSTM beside the convolutions measured equal to one stream - round 3; retired)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -1332,7 +1222,7 @@ class CnnEngine:
                                        st_), "tl_concat_unpack_bwd")
         # ---- LSTM BPTT on the distinct rows: independent of the convolution backward below - on the side stream beside it
         # when nothing in it is a collective (single process); the trainer's W_hh update rides along (on_factors) ----
-        side = self._side_stream(self._dev) if (self.overlap and gather_whh is None and self._sh is None) else None
+        side = None         # (the same for the BPTT beside the convolution backward)
         if side is not None:
             dh_ext.record_stream(side)
             side.wait_stream(torch.cuda.current_stream())

@@ -32,43 +32,31 @@ _B = frozenset({"0", "1"})
 #: key -> (legacy variable, allowed values, default, what it selects)
 KEYS: Dict[str, Tuple[str, _Allowed, str, str]] = {
     # ---- SynthesisModelCNN conv stack (_cnn_engine.py)
-    "wino": ("TONAL_WINO", frozenset({"6", "4", "1", "0"}), "6",
-             "conv2 / conv3: 6 Winograd F(6,3) on pre-transformed operands (F(4,3) where the stack does not allow it), 4 F(4,3), "
-             "1 F(2,3), 0 direct MFMA kernels"),
-    "wino_tn": ("TONAL_WINO_TN", frozenset({"4", "2"}), "4", "weight gradient under wino=4: 4 F(4,3), 2 the F(2,3) kernel"),
-    "wino_v": ("TONAL_WINO_V", _B, "1", "F(4,3): operands pre-transformed by their producer (0: transforms inside the GEMM loops)"),
-    "wino_vout": ("TONAL_WINO_VOUT", _B, "1", "F(4,3): the forward epilogue writes the next stage's V"),
-    "wino_vd": ("TONAL_WINO_VD", frozenset({"tn", "side", "0"}), "tn", "F(4,3): who writes the input-gradient operand Vd"),
-    "tn_bm": ("TONAL_TN_BM", frozenset({"0", "64", "127", "128"}), "0", "F(4,3) weight-gradient tiling (0 = auto)"),
-    "tn_target": ("TONAL_TN_TARGET", _int(64, 1 << 20), "", "split-K target of the Winograd weight-gradient kernels"),
-    "f63_yprod": ("TONAL_F63_YPROD", _B, "1", "F(6,3): stage 3's input gradient writes Y2 / Vd2 instead of G2"),
-    "f63_yprod3": ("TONAL_F63_YPROD3", _B, "1", "F(6,3): Y3 / Vd3 from tl_wino63_unpool_yvd"),
+    "wino": ("TONAL_WINO", frozenset({"6", "4", "0"}), "6",
+             "conv2 / conv3: 6 Winograd F(6,3) on pre-transformed operands (F(4,3) V form where the stack does not allow it), "
+             "4 the F(4,3) V form, 0 direct MFMA kernels (also the fallback for every shape neither form covers)"),
+    "f63_yprod": ("TONAL_F63_YPROD", _B, "1", "F(6,3): the backward operands Y / Vd of stages 2 and 3 come pre-transformed out of the "
+                                              "input-gradient epilogue of the stage above (0: the weight-gradient kernels un-pool and "
+                                              "transform the gradient rows themselves)"),
     "conv4_dgrad": ("TONAL_CONV4_DGRAD", frozenset({"nt63", "gemm"}), "nt63",
                     "F(6,3): the one-tap stage behind conv3 - nt63: its input gradient on the NT63 kernel, writing Y3 / Vd3 "
                     "(no gradient rows, no tl_wino63_unpool_yvd); gemm: one-tap GEMM + tl_wino63_unpool_yvd"),
-    "fuse_c1": ("TONAL_FUSE_C1", _B, "1", "conv1 weight gradient fused into the conv2 input-gradient epilogue"),
     "store_p1": ("TONAL_STORE_P1", _B, "0", "keep the raw pooled rows of stages 1 / 2 beside V (tests)"),
-    "overlap": ("TONAL_OVERLAP", _B, "0", "label LSTM / W_hh update on a side stream (measured: does not pay)"),
     # ---- deep classifiers (_classifier_engine.py)
-    "clf_f63": ("TONAL_CLF_F63", _B, "1", "CNN classifier: its leading pooled 3-tap stages on the F(6,3) V-form kernels (0: in-loop F(4,3))"),
-    "conv7": ("TONAL_CONV7", frozenset({"wino63", "wino43", "wino43+1", "direct"}), "wino63", "the CNN-RNN classifier's 7-tap convolutions"),
-    "lstm_fused": ("TONAL_LSTM_FUSED", _B, "1", "classifier LSTMs: one fused launch per step"),
-    "lstm_sk": ("TONAL_LSTM_SK", _int(0, 1024), "0", "classifier LSTMs (unfused form): split-K of the W_hh product (0 = auto)"),
+    "conv7": ("TONAL_CONV7", frozenset({"wino63", "direct"}), "wino63", "the CNN-RNN classifier's 7-tap convolutions"),
     # ---- optimiser / trainer
-    "nadam_multi": ("TONAL_NADAM_MULTI", _B, "1", "one NAdam launch for all dense tensors"),
     "whh_dh": ("TONAL_WHH_DH", _B, "1", "single process: the W_hh NAdam pass also produces the last BPTT product dh_1 = dgates_2 . W_hh "
                                         "(0: a W_hh stream of its own for it)"),
     "graph": ("TONAL_GRAPH", _B, "1", "SynthesisLite step replayed as a HIP graph"),
     "lstm_shard": ("TONAL_LSTM_SHARD", _B, "1", "data parallel: label LSTM sharded by gate rows"),
     # ---- preprocess/signal
-    "hilbert": ("TONAL_HILBERT", frozenset({"auto", "ols", "sym", "taps", "fft"}), "auto", "Hilbert bank: force a path"),
-    "hilbert_bl": ("TONAL_HILBERT_BL", _B, "1", "band-limited overlap-save (0: all 1024 bins per band)"),
+    "hilbert": ("TONAL_HILBERT", frozenset({"auto", "ols", "ols_full", "sym", "taps", "fft"}), "auto",
+                "Hilbert bank: force a path (ols band-limited overlap-save, ols_full all 1024 bins per band, sym / taps the "
+                "time-domain kernels with / without Hermitian symmetry, fft the DFT-domain form)"),
     "hilbert_f32": ("TONAL_HILBERT_F32", _B, "0", "float32 recordings: fp32 transforms end to end (default: fp64 math)"),
-    "hilbert_sym": ("TONAL_HILBERT_SYM", _B, "1", "Hermitian-symmetric time-domain kernel"),
     "butter": ("TONAL_BUTTER", frozenset({"seq", "scan"}), "seq",
                "zero-phase Butterworth: seq the sequential recurrence (bit-identical to scipy's loop), scan the time-parallel "
                "block scan (2e-8 - 5e-8 from it: the size of the reference's own rounding; ~20 x faster)"),
-    "fir": ("TONAL_FIR", frozenset({"ols", "taps"}), "ols", "FIR bank by overlap-save (taps: time domain)"),
 }
 _LEGACY = {v[0]: k for k, v in KEYS.items()}
 _cache: Tuple[str, Dict[str, str]] = ("", {})

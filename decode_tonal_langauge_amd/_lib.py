@@ -65,12 +65,7 @@ SIGNATURES = {
     "tl_device_count": (_I, []),
     "tl_gemm_nt_window": (_I, [C.POINTER(NtParams), _P]),
     "tl_gemm_tn_window": (_I, [C.POINTER(TnParams), _P]),
-    "tl_wino_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_wino43_weights": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "tl_conv3_wino_nt": (_I, [C.POINTER(NtParams), _P]),
-    "tl_conv3_wino43_nt": (_I, [C.POINTER(NtParams), _P]),
-    "tl_wino43_weights7": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "tl_conv7_wino43_nt": (_I, [C.POINTER(NtParams), _P]),
     "tl_wino63_xform2": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "tl_wino63_weights7": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_conv7_wino63v_nt": (_I, [C.POINTER(NtParams), _P]),
@@ -83,9 +78,6 @@ SIGNATURES = {
     "tl_allreduce": (_I, [_P, _P, _P, _L, _I, _P]),
     "tl_reduce_scatter": (_I, [_P, _P, _P, _L, _P]),
     "tl_all_gather": (_I, [_P, _P, _P, _L, _P]),
-    "tl_conv3_wino_tn": (_I, [C.POINTER(TnParams), _P]),
-    "tl_wino_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
-    "tl_conv3_wino43_tn": (_I, [C.POINTER(TnParams), _P]),
     "tl_wino43_wgrad_finalize": (_I, [_P, _P, _I, _I, _I, _P]),
     "tl_wino43_input_transform": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "tl_conv3_wino43v_nt": (_I, [C.POINTER(NtParams), _P]),
@@ -110,9 +102,7 @@ SIGNATURES = {
     "tl_permute_reduce": (_I, [_P, _P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _L, _P, _P]),
     "tl_colsum": (_I, [_P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "tl_lstm_cell_infer": (_I, [_P, _I, _L, _P, _L, _P, _P, _I, _I, _I, _P]),
     "tl_lstm_infer_seq_fused": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, C.POINTER(C.c_int), _P]),
-    "tl_lstm_infer_seq": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "tl_lstm_ih_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tl_concat_pack": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint64, _L, _P]),

@@ -622,32 +622,6 @@ __global__ __launch_bounds__(64) void lstm_ih_grad_wave_kernel(const float* __re
   }
 }
 
-// Inference step of a one-layer LSTM whose input projection x_t W_ih^T + b_ih + b_hh was pre-computed
-// for all time steps by one GEMM (xp), and whose recurrent product h_{t-1} W_hh^T arrives as nsplit
-// split-K slabs of the NT GEMM (summed here: no separate reduction launch).  c and h are updated in
-// place; nothing is kept for a backward pass (the classifiers run forward-only inside the synthesis
-// train step, models/synthesis_trainer.py:207-210).  Gate order i, f, g, o as torch.nn.LSTM.
-__global__ __launch_bounds__(256) void lstm_cell_infer_kernel(const float* __restrict__ slab, int nsplit,
-                                                              long long slab_stride, const float* __restrict__ xp,
-                                                              long long xp_row_stride, float* __restrict__ c,
-                                                              float* __restrict__ h, int U, int H, int first) {
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i >= (long long)U * H) return;
-  const int u = (int)(i / H), k = (int)(i % H);
-  float pre[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const long long col = (long long)q * H + k;
-    float v = xp[(long long)u * xp_row_stride + col];
-    for (int z = 0; z < nsplit; ++z) v += slab[z * slab_stride + (long long)u * 4 * H + col];
-    pre[q] = v;
-  }
-  const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-  const float cn = (first ? 0.f : fg * c[i]) + ig * gg;
-  c[i] = cn;
-  h[i] = og * tanhf(cn);
-}
-
 // One inference step of the LSTM in ONE launch (instead of split-K GEMM + cell): a workgroup owns 32
 // batch rows and 8 hidden units = 32 gate columns (the recurrent weight is packed unit-major, row 4 u + g,
 // so a tile holds whole cells); gates = h_prev . Wp^T + xp[t], then the cell update.  8 interleaved K slices
@@ -1396,47 +1370,7 @@ extern "C" int tl_lstm_cell_fwd(const float* hh, const float* x_t, const float* 
   return check_launch("lstm_cell_fwd");
 }
 
-extern "C" int tl_lstm_cell_infer(const float* slab, int nsplit, int64_t slab_stride, const float* xp,
-                                  int64_t xp_row_stride, float* c, float* h, int U, int H, int first, void* stream) {
-  TL_REQUIRE(xp && c && h && U > 0 && H > 0, "lstm_cell_infer: bad arguments");
-  TL_REQUIRE(nsplit >= 0 && (nsplit == 0 || (slab != nullptr && slab_stride >= (int64_t)U * 4 * H)), "lstm_cell_infer: bad slabs");
-  TL_REQUIRE(first || nsplit > 0, "lstm_cell_infer: a later step needs the recurrent product");
-  TL_REQUIRE(xp_row_stride >= 4LL * H, "lstm_cell_infer: xp row stride smaller than 4H");
-  const long long total = (long long)U * H;
-  hipLaunchKernelGGL(lstm_cell_infer_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     slab, nsplit, (long long)slab_stride, xp, (long long)xp_row_stride, c, h, U, H, first);
-  return check_launch("lstm_cell_infer");
-}
-
-// Whole-sequence inference driver: the T dependent steps (skinny split-K GEMM + cell update) are enqueued
-// from C in one call - the per-launch cost of the Python binding (struct fill + foreign call, ~20 us) would
-// otherwise dominate a 400-step sequence whose kernels take a few microseconds each.
-extern "C" int tl_lstm_infer_seq(const float* xp, int64_t xp_row_stride, const float* w_hh, float* h, float* c,
-                                 float* slab, int nsplit, int B, int H, int T, void* stream) {
-  TL_REQUIRE(xp && w_hh && h && c && slab && B > 0 && H > 0 && T > 0 && nsplit >= 1, "lstm_infer_seq: bad arguments");
-  TL_REQUIRE(H % 4 == 0, "lstm_infer_seq: hidden width must be a multiple of 4 (pad the packed weights)");
-  TL_REQUIRE(xp_row_stride >= (int64_t)T * 4 * H, "lstm_infer_seq: xp rows are (b, t): row stride must cover T steps");
-  tl_nt_params g;
-  memset(&g, 0, sizeof(g));
-  g.A = h; g.Bw = w_hh; g.out = slab;
-  g.M = B; g.A_rows = B; g.N = 4 * H; g.K = H; g.lda = H; g.ldb = H; g.ldo = 4 * H;
-  g.J = 1; g.Tp = 1; g.Tvalid = 1; g.loader = 0; g.epilogue = 0; g.bm = 32; g.splitk = nsplit;
-  g.slab_stride = (int64_t)B * 4 * H;
-  const long long total = (long long)B * H;
-  const unsigned grid = (unsigned)((total + 255) / 256);
-  for (int t = 0; t < T; ++t) {
-    if (t > 0) {
-      const int rc = tl_gemm_nt_window(&g, stream);
-      if (rc) return rc;
-    }
-    hipLaunchKernelGGL(lstm_cell_infer_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, t > 0 ? nsplit : 0,
-                       (long long)g.slab_stride, xp + (long long)t * 4 * H, (long long)xp_row_stride, c, h, B, H,
-                       t == 0 ? 1 : 0);
-  }
-  return check_launch("lstm_infer_seq");
-}
-
-// The same sequence with one fused launch per step (lstm_step_fused_kernel).  wp: the recurrent weight packed
+// All T steps of an inference LSTM, one fused launch per step (lstm_step_fused_kernel).  wp: the recurrent weight packed
 // unit-major, row 4 u + g = W_hh row g H + u; xp keeps the torch gate-major columns.  h_a / h_b: ping-pong
 // buffers; the final state is in h_a when T is odd, h_b when T is even (returned through *last_in_b).
 extern "C" int tl_lstm_infer_seq_fused(const float* xp, int64_t xp_row_stride, const float* wp, float* h_a, float* h_b,

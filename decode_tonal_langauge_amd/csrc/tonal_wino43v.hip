@@ -1338,7 +1338,79 @@ __global__ __launch_bounds__(512, 1) void wino43v_tn8_kernel(const tl_tn_params 
     }
 }
 
+// F(4,3) taps of a 3-tap filter, torch (O, I, 3) -> forward [6][O][ld_f] / input-gradient [6][I][ld_d] (taps flipped)
+__global__ void wino43_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ dgr,
+                                      int O, int I, int ld_f, int ld_d) {
+  const long long n_f = (long long)O * ld_f, n_d = (long long)I * ld_d;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  auto emit = [](float* dst, long long n, long long at, float g0, float g1, float g2) {
+    const float s = g0 + g2;
+    dst[at] = 0.25f * g0;
+    dst[n + at] = (-1.f / 6.f) * (s + g1);
+    dst[2 * n + at] = (-1.f / 6.f) * (s - g1);
+    dst[3 * n + at] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    dst[4 * n + at] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    dst[5 * n + at] = g2;
+  };
+  if (fwd != nullptr && idx < n_f) {
+    const int o = (int)(idx / ld_f), i = (int)(idx % ld_f);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (i < I) {
+      const float* s = w + ((long long)o * I + i) * 3;
+      g0 = s[0], g1 = s[1], g2 = s[2];
+    }
+    emit(fwd, n_f, idx, g0, g1, g2);
+  }
+  if (dgr != nullptr && idx < n_d) {
+    const int i = (int)(idx / ld_d), o = (int)(idx % ld_d);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (o < O) {
+      const float* s = w + ((long long)o * I + i) * 3;
+      g0 = s[2], g1 = s[1], g2 = s[0];          // flipped taps
+    }
+    emit(dgr, n_d, idx, g0, g1, g2);
+  }
+}
+
+
+// dW (O, I, 3) = G^T M from the reduced transforms red[6][I][ld]:
+//   G^T = [ 1/4 -1/6 -1/6 1/24  1/24 0 ;  0 -1/6 1/6 1/12 -1/12 0 ;  0 -1/6 -1/6 1/6 1/6 1 ]
+__global__ void wino43_wgrad_finalize_kernel(const float* __restrict__ red, float* __restrict__ gw, int O, int I, int ld) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)O * I) return;
+  const int i = (int)(idx / O), o = (int)(idx % O);
+  const long long plane = (long long)I * ld;
+  const float* s = red + (long long)i * ld + o;
+  const float m0 = s[0], m1 = s[plane], m2 = s[2 * plane], m3 = s[3 * plane], m4 = s[4 * plane], m5 = s[5 * plane];
+  const float a12 = m1 + m2, s12 = m2 - m1, a34 = m3 + m4, s34 = m3 - m4;
+  float* d = gw + ((long long)o * I + i) * 3;
+  d[0] = 0.25f * m0 - (1.f / 6.f) * a12 + (1.f / 24.f) * a34;
+  d[1] = (1.f / 6.f) * s12 + (1.f / 12.f) * s34;
+  d[2] = (1.f / 6.f) * (a34 - a12) + m5;
+}
+
 }  // namespace tl
+
+extern "C" int tl_wino43_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(w != nullptr && (fwd != nullptr || dgr != nullptr), "wino43_weights: null pointer");
+  TL_REQUIRE(O > 0 && I > 0, "wino43_weights: bad sizes");
+  TL_REQUIRE((fwd == nullptr || ld_f >= I) && (dgr == nullptr || ld_d >= O), "wino43_weights: leading dimension too small");
+  const long long nf = fwd ? (long long)O * ld_f : 0, nd = dgr ? (long long)I * ld_d : 0;
+  const long long n = nf > nd ? nf : nd;
+  hipLaunchKernelGGL(wino43_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, fwd,
+                     dgr, O, I, ld_f, ld_d);
+  return check_launch("wino43_weights");
+}
+
+extern "C" int tl_wino43_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream) {
+  using namespace tl;
+  TL_REQUIRE(red && gw && O > 0 && I > 0 && ld >= O, "wino43_wgrad_finalize: bad arguments");
+  const long long n = (long long)O * I;
+  hipLaunchKernelGGL(wino43_wgrad_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     red, gw, O, I, ld);
+  return check_launch("wino43_wgrad_finalize");
+}
 
 extern "C" int tl_wino43_input_transform(const float* P, float* V, int64_t rows, int Tp, int C, int ldp, int ldv,
                                          void* stream) {

@@ -257,26 +257,27 @@ def hilbert_filter(data, sampling_rate: int, freq_ranges: Union[List[Tuple[float
     mode = _kernels.get("hilbert")
     tp, ntap, half, sym, ols = (None, 0, 0, None, None) if mode == "fft" else _device_taps(T, sampling_rate, cfs, sds, x.device)
     if mode == "fft" or ntap > _MAX_TAPS_LDS:
-        if mode == "taps":
+        if mode in ("taps", "sym"):
             raise ValueError(f"hilbert_filter: the band kernels need {ntap} taps at this sampling rate; the time-domain "
-                             f"kernel supports up to {_MAX_TAPS_LDS} (TONAL_HILBERT=taps forbids the DFT-domain path)")
+                             f"kernel supports up to {_MAX_TAPS_LDS} (TONAL_KERNELS hilbert={mode} forbids the DFT-domain path)")
         return _ret(_hilbert_dft(x, sampling_rate, cfs, sds, bool(envelope)), was_np)
     y = torch.empty(C, T, dtype=torch.float64, device=x.device)
-    if ols is not None and ols[3] is not None and mode in ("auto", "ols") and _kernels.get("hilbert_bl") != "0":
-        # float32 recordings: fp64 math on the fp32 samples by default.  In the reference only the forward transform stays
-        # single precision (scipy.fft(float32) -> complex64, frequency_filter.py:167); the product with the float64 kernel
-        # promotes to complex128 and the inverse transform, |.| and the band mean run in fp64 (:170-184).  fp64 throughout
-        # is at least that precise.  TONAL_HILBERT_F32=1 opts into fp32 transforms end to end (0.135 instead of ~0.16 ms
-        # at 256 x 24 000; ~1e-6 relative, golden G6 hilbert_f32_odd holds it to 1e-5)
+    # hilbert = auto: the first form below that the bank / recording allows; ols, ols_full, sym, taps force one
+    if ols is not None and ols[3] is not None and mode in ("auto", "ols"):
+        # band-limited overlap-save.  float32 recordings: fp64 math on the fp32 samples by default.  In the reference only
+        # the forward transform stays single precision (scipy.fft(float32) -> complex64, frequency_filter.py:167); the product
+        # with the float64 kernel promotes to complex128 and the inverse transform, |.| and the band mean run in fp64
+        # (:170-184).  fp64 throughout is at least that precise.  hilbert_f32=1 opts into fp32 transforms end to end (0.135
+        # instead of ~0.16 ms at 256 x 24 000; ~1e-6 relative, golden G6 hilbert_f32_odd holds it to 1e-5)
         mode_x = 1 if x.dtype == torch.float64 else (0 if _kernels.get("hilbert_f32") == "1" else 2)
         check(_lib.load().tl_hilbert_ols_bl(ptr(x), mode_x, ptr(ols[3][0]), ptr(ols[3][1]), ptr(ols[1]), ptr(y),
                                             C, T, len(cfs), half, ols[2], int(bool(envelope)), _stream()), "tl_hilbert_ols_bl")
         return _ret(y, was_np)
-    if ols is not None and mode in ("auto", "ols"):
+    if ols is not None and mode in ("auto", "ols", "ols_full"):          # overlap-save with all 1024 bins per band
         check(_lib.load().tl_hilbert_ols(ptr(x), int(x.dtype == torch.float64), ptr(ols[0]), ptr(ols[1]), ptr(y), C, T, len(cfs),
                                          half, ols[2], int(bool(envelope)), _stream()), "tl_hilbert_ols")
         return _ret(y, was_np)
-    if sym is not None and _kernels.get("hilbert_sym") != "0":
+    if sym is not None and mode != "taps":                               # Hermitian-symmetric time-domain kernel
         check(_lib.load().tl_gauss_envelope_sym(ptr(x), int(x.dtype == torch.float64), ptr(sym), ptr(y), C, T, len(cfs), half,
                                                 int(bool(envelope)), _stream()), "tl_gauss_envelope_sym")
         return _ret(y, was_np)
@@ -406,7 +407,7 @@ def fir_bandpass_filter(data, fs: float, order: int, center_frequencies: List[fl
         squeeze = True
     x, was_np = _to_device(data)
     C, T = x.shape
-    use_ols = T >= _OLS_N and _kernels.get("fir") == "ols"
+    use_ols = T >= _OLS_N                      # (shorter recordings: the time-domain kernel, tl_fir_bank)
     coef, nb, ntap, ols = _fir_coefficients(float(fs), int(order), tuple(float(f) for f in center_frequencies), bool(use_ols),
                                             x.device)
     y = torch.empty(C, T, dtype=x.dtype, device=x.device)

@@ -118,7 +118,7 @@ typedef struct {
                          over the rows of A[.][m], Mdim floats (the bias gradient of a Linear layer); tl_gemm_tn_window on its
                          one-tap direct kernel (J == 1, loader 0, Mdim > 32, Krows > 512): colsum[z][n] = sum over the valid
                          rows of split z of B[.][n], Ndim floats per split (the bias gradient of a 1x1 convolution, from the
-                         launch that reads its output gradient anyway); tl_conv3_wino43_tn:
+                         launch that reads its output gradient anyway); tl_conv3_wino43v_tn / tl_conv3_wino63v_tn:
                          colsum[z][n] = sum over split z of the un-pooled
                          dZ column n (the bias gradient partial sums; Ndim floats per split), or null */
   float* vd; int ld_vd; /* optional (tl_conv3_wino43v_tn): also write Vd[quad][6][ld_vd] = the F(4,3) input transform of
@@ -132,55 +132,30 @@ typedef struct {
 int tl_gemm_tn_window(const tl_tn_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Winograd F(2,3) forms of the 3-tap convolutions that are followed by MaxPool (2,1)
+ * Winograd F(4,3) on PRE-TRANSFORMED operands for the 3-tap convolutions that are followed by MaxPool (2,1)
  * (conv2, conv3: models/synthesis_models.py:91-97; their backward in loss.backward(),
- * models/synthesis_trainer.py:226).  Same data contracts as the two windowed GEMMs above with
- * J = 3, but 4 channel contractions per output row pair instead of 6.
- *   tl_wino_weights        w (O, I, 3, 1) -> forward taps fwd [4][O][ld_f] and input-gradient taps
- *                          dgr [4][I][ld_d] (either may be null)
- *   tl_conv3_wino_nt       tl_gemm_nt_window with Bw = the 4 transformed taps; loader/epilogue
- *                          DIRECT/POOL (forward, row_shift 0) or UNPOOL/MASK (input gradient,
- *                          row_shift -2); K % 32 == 0, M even
- *   tl_conv3_wino_tn       tl_gemm_tn_window (UNPOOL) writing the 4 transform accumulators
- *                          slab[z][4][Mdim][ldc] (slab_stride >= 4*Mdim*ldc)
- *   tl_wino_wgrad_finalize red [4][I][ld] (slabs summed by the caller) -> dW (O, I, 3, 1)
- *   tl_wino43_weights / tl_conv3_wino43_nt: the F(4,3) form of the same two NT passes (6 contractions
- *                          per 4 conv rows; taps [6][N][ldb]; M and Tp multiples of 4)
- *   tl_wino43_weights7 / tl_conv7_wino43_nt: a 7..9-tap (k,1) convolution + LeakyReLU (the CNN-RNN
- *                          classifier's 1024 -> 512 -> 256 stack, models/deep_classifiers.py:247-256) as
- *                          nseg = ceil(J / 3) F(4,3) segments accumulated in the same six products:
- *                          w (O, I, taps) -> fwd [6][O][nseg I] (taps 0 .. 3 nseg - 1); DIRECT loader,
- *                          LRELU epilogue, ldb >= nseg K, M % 4 == 0; segment s reads input rows shifted
- *                          by 3 s, so A must hold A_rows + 3 (nseg - 1) rows.  aux (optional, ldaux): a
- *                          pre-activation term added before bias + LeakyReLU - e.g. J = 6 covers taps
- *                          0..5 of a 7-tap filter and aux holds tap 6 from a one-tap tl_gemm_nt_window
- *   tl_conv3_wino43_tn / tl_wino43_wgrad_finalize: the F(4,3) form of the weight gradient (6 outer
- *                          products per 4 conv rows; slab[z][6][Mdim][ldc], slab_stride >= 6*Mdim*ldc;
- *                          Krows and Tp multiples of 4); red [6][I][ld] -> dW (O, I, 3, 1)
- *
- * Round 3 - the F(4,3) INPUT TRANSFORM HOISTED INTO THE PRODUCER of an activation.  Both the forward
- * pass and the weight gradient of a stage consume the same V = B^T d of its input rows; on gfx950 the
+ * models/synthesis_trainer.py:226): 6 channel contractions per 4 conv rows instead of 12.  The A/B partner of the
+ * F(6,3) default below (TONAL_KERNELS wino=4); the in-loop-transform F(2,3) / F(4,3) generation of rounds 1-2 was
+ * retired in round 6 (shapes neither V form covers run on the windowed GEMMs above).
+ * Both the forward pass and the weight gradient of a stage consume the same V = B^T d of its input rows; on gfx950 the
  * fp32 MFMA shares the vector ALU's rate, so transform / staging instructions inside the GEMM kernels
  * displace matrix work one for one.  V[quad][6][ldv] (quad Q = input rows 4Q..4Q+5 of one sequence,
- * rows past the sequence taken as zero) is written once and the GEMM kernels become transform-free:
+ * rows past the sequence taken as zero) is written once and the GEMM kernels are transform-free:
+ *   tl_wino43_weights          w (O, I, 3, 1) -> forward taps fwd [6][O][ld_f] and input-gradient taps dgr [6][I][ld_d]
+ *                              (flipped; either may be null)
  *   tl_wino43_input_transform  P (rows, C; whole sequences of Tp rows, Tp % 4 == 0) -> V (rows / 4 quads)
- *   tl_conv3_wino43v_nt        forward pass of tl_conv3_wino43_nt with loader = 2: A = V, lda = ldv,
- *                              A_rows = quads held by V (>= M / 4); POOL epilogue; K % 16 == 0; both
- *                              operands reach LDS by buffer_load .. lds (no staging registers)
- *   tl_conv3_wino43v_tn        weight gradient of tl_conv3_wino43_tn with A = V (lda = ldv, A_rows = quads
+ *   tl_conv3_wino43v_nt        tl_gemm_nt_window's contract with J = 3, Bw = the 6 transformed taps [6][N][ldb], loader = 2:
+ *                              A = V, lda = ldv, A_rows = quads held by V (>= M / 4); POOL / POOLV epilogue (forward) or
+ *                              MASK / conv1-weight-gradient epilogue on Vd (input gradient, row_shift -2); K % 16 == 0;
+ *                              M and Tp multiples of 4; both operands reach LDS by buffer_load .. lds
+ *   tl_conv3_wino43v_tn        tl_gemm_tn_window's contract (UNPOOL) writing the 6 transform accumulators
+ *                              slab[z][6][Mdim][ldc] (slab_stride >= 6*Mdim*ldc) with A = V (lda = ldv, A_rows = quads
  *                              held by V, a whole number of 8-quad K-steps: pad with zero quads); V by
- *                              LDS-DMA into a 4-slot ring, Y = A dy staged as before; Mdim % 64 == 0
+ *                              LDS-DMA into a 4-slot ring, Y = A dy staged through registers; Mdim % 64 == 0
+ *   tl_wino43_wgrad_finalize   red [6][I][ld] (slabs summed by the caller) -> dW (O, I, 3, 1)
  * tl_conv1_fwd_v (below) writes V of the first stage's output directly.
  * ------------------------------------------------------------------------------------------ */
-int tl_wino_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
 int tl_wino43_weights(const float* w, float* fwd, float* dgr, int O, int I, int ld_f, int ld_d, void* stream);
-int tl_conv3_wino43_nt(const tl_nt_params* p, void* stream);
-int tl_wino43_weights7(const float* w, float* fwd, int O, int I, int taps, int nseg, void* stream);
-int tl_conv7_wino43_nt(const tl_nt_params* p, void* stream);
-int tl_conv3_wino_nt(const tl_nt_params* p, void* stream);
-int tl_conv3_wino_tn(const tl_tn_params* p, void* stream);
-int tl_wino_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
-int tl_conv3_wino43_tn(const tl_tn_params* p, void* stream);
 int tl_wino43_wgrad_finalize(const float* red, float* gw, int O, int I, int ld, void* stream);
 int tl_wino43_input_transform(const float* P, float* V, int64_t rows, int Tp, int C, int ldp, int ldv, void* stream);
 int tl_conv3_wino43v_nt(const tl_nt_params* p, void* stream);
@@ -318,18 +293,10 @@ int tl_colsum(const float* G, float* partial, int nblk, int64_t rows, int ncols,
 int tl_lstm_cell_fwd(const float* hh, const float* x_t, const float* w_ih, const float* b_ih,
                      const float* b_hh, const float* c_prev, float* act, float* c, float* h,
                      int U, int H, int in_dim, int ld_hh, void* stream);
-/* inference-only step (models/deep_classifiers.py:230-233,294-296,316-318: the CNN-RNN classifier's two
- * LSTMs, run forward-only by the synthesis trainer): pre = xp[u*xp_row_stride + gate*H + k] (input
- * projection + both biases, pre-computed for every step by one GEMM) + sum_z slab[z][u][gate*H + k] (the
- * split-K slabs of h_{t-1} W_hh^T; nsplit = 0 with first != 0 for t = 0); c, h (U,H) updated in place. */
-int tl_lstm_cell_infer(const float* slab, int nsplit, int64_t slab_stride, const float* xp,
-                       int64_t xp_row_stride, float* c, float* h, int U, int H, int first, void* stream);
-/* all T steps of such an LSTM enqueued by one call: per step the skinny GEMM h W_hh^T (tl_gemm_nt_window,
- * 32-row tiles, nsplit split-K slabs of (B,4H) in `slab`) and tl_lstm_cell_infer.  xp rows are (b, t):
- * xp_row_stride = T*4H or more.  h, c (B,H) need not be initialised; on return they hold h_T, c_T.   */
-int tl_lstm_infer_seq(const float* xp, int64_t xp_row_stride, const float* w_hh, float* h, float* c,
-                      float* slab, int nsplit, int B, int H, int T, void* stream);
-/* One fused launch per step (recurrent product + cell update; no split-K slabs): wp = the recurrent weight
+/* inference-only sequence (models/deep_classifiers.py:230-233,294-296,316-318: the CNN-RNN classifier's two LSTMs, run
+ * forward-only by the synthesis trainer): xp[u*xp_row_stride + t*4H + gate*H + k] = input projection + both biases of every
+ * step, pre-computed by one GEMM (rows are (b, t): xp_row_stride = T*4H or more).
+ * One fused launch per step (recurrent product + cell update; no split-K slabs): wp = the recurrent weight
  * packed unit-major (row 4 u + g = W_hh row g H + u), H % 8 == 0, h_a / h_b ping-pong state buffers (the
  * first step ignores both); *last_in_b tells which one holds h_T.                                        */
 int tl_lstm_infer_seq_fused(const float* xp, int64_t xp_row_stride, const float* wp, float* h_a, float* h_b, float* c,

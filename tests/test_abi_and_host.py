@@ -42,22 +42,18 @@ def test_abi_argument_validation_without_gpu():
     assert lib.tl_nadam_multi(None, 3, 3, 0., 0., .9, .999, 1., 1e-8, 0., 1., None) == -1 and lib.tl_nadam_multi_chunk() > 0
     assert lib.tl_nadam_lowrank(16, 16, 16, 16, 16, 65, 8, 8, 8, 8, 0., 0., .9, .999, 1., 1e-8, 0., 1., None) == -1
     assert b"rank" in lib.tl_last_error()
-    assert lib.tl_conv3_wino43_nt(None, None) == -1 and lib.tl_conv3_wino_tn(None, None) == -1
-    assert lib.tl_conv7_wino43_nt(None, None) == -1 and lib.tl_wino43_weights7(None, None, 8, 8, 7, 3, None) == -1
-    assert lib.tl_wino43_weights7(16, 16, 8, 8, 3, 2, None) == -1 and b"taps" in lib.tl_last_error()
-    assert lib.tl_wino43_weights7(16, 16, 8, 8, 6, 3, None) == -1 and b"segments" in lib.tl_last_error()
+    assert lib.tl_conv3_wino43v_nt(None, None) == -1 and lib.tl_conv3_wino43v_tn(None, None) == -1
+    assert lib.tl_wino43_weights(None, None, None, 8, 8, 8, 8, None) == -1 and b"null" in lib.tl_last_error()
+    assert lib.tl_nadam_lowrank_dh(16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 0., 0., .9, .999, 1., 1e-8, 0., 1., None, 4, 2, None) == -1
+    assert b"dh_slab" in lib.tl_last_error()
+    assert lib.tl_nadam_lowrank_dh(16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 0., 0., .9, .999, 1., 1e-8, 0., 1., 16, 9, 2, None) == -1
+    assert b"U <=" in lib.tl_last_error()
+    assert lib.tl_filtfilt_scan_f64(16, 1, 16, 16, 16, 16, 7, 16, 16, 16, 2, 5000, 10, 128, None) == -1 and b"ntaps" in lib.tl_last_error()
+    assert lib.tl_filtfilt_scan_f64(16, 1, 16, 16, 16, 16, 3, 16, 16, 16, 2, 5000, 9, 128, None) == -1 and b"levels" in lib.tl_last_error()
     assert lib.tl_filtfilt_f64(16, 1, 16, 16, 16, 16, 16, 2, 20, 9, None) == -1
     assert b"padlen" in lib.tl_last_error()
     assert lib.tl_gauss_envelope(16, 1, 16, 16, 2, 100, 8, 200, 0, 1, None) == -1
-    # round-2 entry points: F(4,3) weight gradient, inference LSTM
-    assert lib.tl_conv3_wino43_tn(None, None) == -1
-    t = _lib.TnParams()
-    t.A = t.B = t.slab = t.bbits = 16
-    t.J, t.loader, t.Krows, t.Mdim, t.Ndim, t.lda, t.ldb, t.ldc, t.Tp, t.Tvalid = 3, 1, 30, 64, 64, 64, 64, 64, 4, 2
-    t.A_rows, t.B_rows, t.ld_bbits = 32, 16, 2
-    assert lib.tl_conv3_wino43_tn(C.byref(t), None) == -1 and b"Krows" in lib.tl_last_error()      # Krows % 4
-    t.Krows, t.Tp = 32, 6
-    assert lib.tl_conv3_wino43_tn(C.byref(t), None) == -1 and b"Tp" in lib.tl_last_error()
+    # F(4,3) weight-gradient epilogue, inference LSTM
     assert lib.tl_wino43_wgrad_finalize(None, None, 4, 4, 4, None) == -1
     # round-4 entry points: Winograd F(6,3) on pre-transformed operands (argument checks only: no GPU call is reached)
     assert lib.tl_conv3_wino63v_nt(None, None) == -1 and lib.tl_conv3_wino63v_tn(None, None) == -1
@@ -76,10 +72,6 @@ def test_abi_argument_validation_without_gpu():
     assert lib.tl_conv3_wino63v_tn(C.byref(t6), None) == -1 and b"Tp" in lib.tl_last_error()                   # Tp % 6
     t6.Tp, t6.Mdim = 12, 64
     assert lib.tl_conv3_wino63v_tn(C.byref(t6), None) == -1 and b"Mdim" in lib.tl_last_error()                 # C_in % 128
-    assert lib.tl_lstm_cell_infer(None, 0, 0, None, 0, None, None, 4, 8, 1, None) == -1
-    assert lib.tl_lstm_cell_infer(None, 0, 0, 16, 16, 16, 16, 4, 8, 0, None) == -1 and b"recurrent" in lib.tl_last_error()
-    assert lib.tl_lstm_infer_seq(16, 10, 16, 16, 16, 16, 1, 4, 6, 3, None) == -1 and b"multiple of 4" in lib.tl_last_error()
-    assert lib.tl_lstm_infer_seq(16, 10, 16, 16, 16, 16, 1, 4, 8, 3, None) == -1 and b"row stride" in lib.tl_last_error()
     import ctypes as C2
     flag = C2.c_int(0)
     assert lib.tl_lstm_infer_seq_fused(16, 100, 16, 16, 16, 16, 4, 12, 3, C2.byref(flag), None) == -1
@@ -358,25 +350,26 @@ def test_kernel_setting_is_one_validated_variable(monkeypatch):
     monkeypatch.delenv("TONAL_KERNELS", raising=False)
     monkeypatch.delenv("TONAL_WINO", raising=False)
     assert _kernels.get("wino") == "6" and _kernels.get("conv7") == "wino63" and _kernels.get("hilbert_f32") == "0"
-    monkeypatch.setenv("TONAL_KERNELS", "wino=4, fuse_c1=0,tn_target=2048")
-    assert _kernels.get("wino") == "4" and _kernels.get("fuse_c1") == "0" and _kernels.get("tn_target") == "2048"
-    assert _kernels.get("wino_v") == "1"                               # not mentioned: the default
-    for bad in ("wino=5", "winograd=4", "wino", "tn_target=abc", "hilbert=fast"):
+    monkeypatch.setenv("TONAL_KERNELS", "wino=4, whh_dh=0,hilbert=ols_full")
+    assert _kernels.get("wino") == "4" and _kernels.get("whh_dh") == "0" and _kernels.get("hilbert") == "ols_full"
+    assert _kernels.get("f63_yprod") == "1"                            # not mentioned: the default
+    assert len(_kernels.KEYS) <= 12                                    # round 6: one switch per decision that still exists
+    for bad in ("wino=5", "wino=1", "winograd=4", "wino", "fuse_c1=0", "hilbert=fast", "butter=fast"):
         monkeypatch.setenv("TONAL_KERNELS", bad)
         with pytest.raises(ValueError):
             _kernels.validate()
     monkeypatch.setenv("TONAL_KERNELS", "wino=0")
-    monkeypatch.setenv("TONAL_WINO", "1")                              # TONAL_KERNELS wins over a legacy variable
+    monkeypatch.setenv("TONAL_WINO", "4")                              # TONAL_KERNELS wins over a legacy variable
     assert _kernels.get("wino") == "0"
     monkeypatch.delenv("TONAL_KERNELS")
     monkeypatch.setenv("TONAL_AB", "1")
-    assert _kernels.get("wino") == "1"
+    assert _kernels.get("wino") == "4"
     monkeypatch.setenv("TONAL_WINO", "7")
     with pytest.raises(ValueError):
         _kernels.get("wino")
-    monkeypatch.setenv("TONAL_WINO", "1")
+    monkeypatch.setenv("TONAL_WINO", "4")
     monkeypatch.delenv("TONAL_AB")
-    with pytest.raises(RuntimeError, match="TONAL_KERNELS=wino=1"):
+    with pytest.raises(RuntimeError, match="TONAL_KERNELS=wino=4"):
         _kernels.get("wino")
     with pytest.raises(RuntimeError):
         _kernels.validate()

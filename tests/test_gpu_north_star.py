@@ -410,7 +410,7 @@ def test_f63_kernels_at_the_timed_batch_match_direct_kernels(dev, monkeypatch):
         eng._alloc_bwd()
         engs[mode] = eng
     e0, e6 = engs["0"], engs["6"]
-    assert e6.wino63 and e6.f63_yprod and e6.f63_yprod3 and not e0.wino63 and not e0.wino
+    assert e6.wino63 and e6.f63_yprod and e6.f63_yprod3 and not e0.wino63 and not e0.wino43
     S = e6.S
     g = torch.Generator(device=dev).manual_seed(17)
     x = torch.randn(B, C, T, device=dev, generator=g)

@@ -176,35 +176,34 @@ def test_signal_filters_match_reference_golden(dev):
     # 8 bands with truncated kernels: short recordings take the Hermitian-symmetry kernel (tl_gauss_envelope_sym), recordings
     # of >= 1024 samples overlap-save on the LDS FFT (tl_hilbert_ols); the plain bank (tl_gauss_envelope) must give the same
     # numbers far below the golden tolerance, and so must the three on a longer recording
-    os.environ["TONAL_HILBERT_SYM"] = "0"
+    os.environ["TONAL_HILBERT"] = "taps"
     try:
         plain = ff.hilbert_filter(x, 400, freq_ranges=[70., 150.])
     finally:
-        os.environ.pop("TONAL_HILBERT_SYM", None)
+        os.environ.pop("TONAL_HILBERT", None)
     assert rel(plain, g["hilbert"]) < 1e-9 and rel(hil, plain) < 1e-13
     xl = np.random.default_rng(5).standard_normal((3, 5003))
     res = {}
-    # (overlap-save comes in two forms: tl_hilbert_ols_bl, the default - it drops the bins of a band's kernel spectrum that lie
-    # below 1e-12 of its peak, outside a 256-bin window - and tl_hilbert_ols with all 1024 bins, TONAL_HILBERT_BL=0)
-    for mode, symflag, bl in (("ols", "1", "1"), ("ols", "1", "0"), ("sym", "1", "1"), ("sym", "0", "1")):
-        os.environ["TONAL_HILBERT"], os.environ["TONAL_HILBERT_SYM"], os.environ["TONAL_HILBERT_BL"] = mode, symflag, bl
+    # (overlap-save comes in two forms: tl_hilbert_ols_bl, hilbert=ols, the default - it drops the bins of a band's kernel
+    # spectrum that lie below 1e-12 of its peak, outside a 256-bin window - and tl_hilbert_ols with all 1024 bins,
+    # hilbert=ols_full; sym / taps: the time-domain kernels with / without Hermitian symmetry)
+    for mode in ("ols", "ols_full", "sym", "taps"):
+        os.environ["TONAL_HILBERT"] = mode
         try:
-            res[mode + symflag + bl] = (ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.]),
-                                        ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.], envelope=False))
+            res[mode] = (ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.]),
+                         ff.hilbert_filter(xl, 400, freq_ranges=[70., 150.], envelope=False))
         finally:
             os.environ.pop("TONAL_HILBERT", None)
-            os.environ.pop("TONAL_HILBERT_SYM", None)
-            os.environ.pop("TONAL_HILBERT_BL", None)
-    for k in ("ols10", "sym11"):
-        assert rel(res[k][0], res["sym01"][0]) < 1e-13 and rel(res[k][1], res["sym01"][1]) < 1e-12
-    assert rel(res["ols11"][0], res["sym01"][0]) < 1e-12 and rel(res["ols11"][1], res["sym01"][1]) < 1e-12
-    assert not np.array_equal(res["ols11"][0], res["ols10"][0])          # (the two forms really are different kernels)
-    for bl in ("1", "0"):                                                # a silent channel stays exactly zero (magnitude guard)
-        os.environ["TONAL_HILBERT_BL"] = bl
+    for k in ("ols_full", "sym"):
+        assert rel(res[k][0], res["taps"][0]) < 1e-13 and rel(res[k][1], res["taps"][1]) < 1e-12
+    assert rel(res["ols"][0], res["taps"][0]) < 1e-12 and rel(res["ols"][1], res["taps"][1]) < 1e-12
+    assert not np.array_equal(res["ols"][0], res["ols_full"][0])         # (the two forms really are different kernels)
+    for mode in ("ols", "ols_full"):                                     # a silent channel stays exactly zero (magnitude guard)
+        os.environ["TONAL_HILBERT"] = mode
         try:
             assert not ff.hilbert_filter(np.zeros((2, 2048)), 400, freq_ranges=[70., 150.]).any()
         finally:
-            os.environ.pop("TONAL_HILBERT_BL", None)
+            os.environ.pop("TONAL_HILBERT", None)
     assert rel(ff.butter_filter(x, [0.3, 100], 400), g["butter"]) < 1e-9
     assert rel(ff.butter_filter(x, [0.3, 100], 400, causal=True), g["butter_causal"]) < 1e-9
     assert rel(ff.fir_bandpass_filter(x, 400, 390, [100.]), g["fir"]) < 1e-9
@@ -212,11 +211,12 @@ def test_signal_filters_match_reference_golden(dev):
     # recordings of >= 1024 samples take the overlap-save form (tl_fir_bank_ols): same numbers as the time-domain kernel
     for order, cfs_ in ((390, [100.]), (64, [60., 120.]), (512, [90.])):
         a_ = ff.fir_bandpass_filter(xl, 400, order, cfs_)
-        os.environ["TONAL_FIR"] = "taps"
+        saved = ff._OLS_N
+        ff._OLS_N = 1 << 60                                              # (no recording is that long: the time-domain kernel)
         try:
             b_ = ff.fir_bandpass_filter(xl, 400, order, cfs_)
         finally:
-            os.environ.pop("TONAL_FIR", None)
+            ff._OLS_N = saved
         assert rel(a_, b_) < 1e-12
     x32 = xl.astype(np.float32)
     a_ = ff.fir_bandpass_filter(x32, 400, 390, [100.])
@@ -353,12 +353,12 @@ def test_hilbert_overlap_save_forms_match_oracle_at_ragged_sizes(dev, monkeypatc
         tol = 1e-9 if dt == np.float64 else 1e-5
         for env in (True, False):
             ref = sg.hilbert_filter(x.astype(np.float64) if dt == np.float64 else x, 400, [70., 150.], envelope=env)
-            for bl in ("1", "0"):
-                monkeypatch.setenv("TONAL_HILBERT_BL", bl)
+            for bl in ("ols", "ols_full"):
+                monkeypatch.setenv("TONAL_HILBERT", bl)
                 out = ff.hilbert_filter(x, 400, freq_ranges=[70., 150.], envelope=env)
                 assert out.dtype == np.float64 and out.shape == (C, T)
                 assert rel(out, ref) < tol, (C, T, dt, env, bl, rel(out, ref))
-                if dt == np.float32 and bl == "1":
+                if dt == np.float32 and bl == "ols":
                     # float32 recordings: fp64 math by default (in the reference only the forward FFT stays complex64, the
                     # product / inverse / |.| / mean run in fp64); TONAL_HILBERT_F32=1 opts into fp32 transforms end to end -
                     # both inside the golden's 1e-5, 1e-5 apart at most, and the default is the closer one to the fp64 result
@@ -368,7 +368,7 @@ def test_hilbert_overlap_save_forms_match_oracle_at_ragged_sizes(dev, monkeypatc
                     assert rel(out32, ref) < tol and rel(out, out32) < tol and not np.array_equal(out, out32)
                     ref64 = sg.hilbert_filter(x.astype(np.float64), 400, [70., 150.], envelope=env)
                     assert rel(out, ref64) < 1e-9 and rel(out, ref64) <= rel(out32, ref64)
-    monkeypatch.delenv("TONAL_HILBERT_BL", raising=False)
+    monkeypatch.delenv("TONAL_HILBERT", raising=False)
 
 
 def test_cnn_full_size_batch_properties(dev):
@@ -557,8 +557,8 @@ def test_one_tap_nt_gemm_forms_match_matmul(dev, shape, monkeypatch):
 
 
 def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
-    """The Winograd conv kernels (F(2,3); default F(4,3) + F(2,3)) against the direct MFMA kernels (TONAL_WINO=0):
-    same forward, same gradients, on a ragged shape (row tiles, time padding and the last
+    """The Winograd conv kernels (F(4,3) and the default F(6,3), both on pre-transformed operands) against the direct MFMA
+    kernels (TONAL_WINO=0): same forward, same gradients, on a ragged shape (row tiles, time padding and the last
     reduction chunk are all partial)."""
     from decode_tonal_langauge_amd.models.synthesis_models import SynthesisModelCNN
     from decode_tonal_langauge_amd import _lib
@@ -569,17 +569,17 @@ def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
         lab = torch.randint(0, 4, (B, 2, 5), generator=g).float()
         tgt = torch.randn(B, 80, generator=g)
         outs, grads = [], []
-        for flag in ("0", "1", "4", "6"):         # direct, F(2,3), F(4,3), default (F(6,3) on pre-transformed operands)
+        for flag in ("0", "4", "6"):              # direct, F(4,3), default (F(6,3)), the last two on pre-transformed operands
             monkeypatch.setenv("TONAL_WINO", flag)
             torch.manual_seed(1)
             model = SynthesisModelCNN(80, C, T, dropout=0.0).to(dev).train()
-            assert model._engine.wino == (flag != "0") and model._engine.wino43 == (flag in "46")
-            assert model._engine.wino63 == (flag == "6")
+            assert model._engine.wino43 == (flag in "46") and model._engine.wino63 == (flag == "6")
+            assert all(model._engine._v43(st) == (flag == "4") or model._engine.wino63 for st in model._engine.stages[:2])
             out = model(x.to(dev), lab.to(dev))
             (out - tgt.to(dev)).abs().mean().backward()
             outs.append(out.detach().cpu().numpy())
             grads.append({k: p.grad.cpu().numpy() for k, p in model.named_parameters()})
-        for v in (1, 2, 3):
+        for v in (1, 2):
             assert rel(outs[v], outs[0]) < 1e-5
             for k in grads[0]:
                 # (the gradients of the ecog stages at this loss are sums over every row that cancel to 1e-9 .. 1e-7: a handful of
@@ -587,16 +587,16 @@ def test_winograd_kernels_match_direct_kernels(dev, monkeypatch):
                 # thousand; the stage tests hold the kernels to 1e-5 on identical inputs, the reference goldens the model)
                 r = rel_l2(grads[v][k], grads[0][k])
                 if r > 2e-3:
-                    print(f"(B, C, T) = {(B, C, T)}, form {('0', '1', '4', '6')[v]}: {k} {r:.2e} from the direct kernels")
+                    print(f"(B, C, T) = {(B, C, T)}, form {('0', '4', '6')[v]}: {k} {r:.2e} from the direct kernels")
                 assert r < (2e-2 if k.startswith("ecog_conv_block.") else 5e-3), k
     # the C ABI refuses shapes the Winograd form does not cover instead of computing garbage
     p = _lib.NtParams()
     dummy = torch.zeros(64, device=dev)
     for k in ("A", "Bw", "out"):
         setattr(p, k, dummy.data_ptr())
-    p.M, p.N, p.K, p.lda, p.ldb, p.J, p.Tp = 4, 32, 24, 24, 24, 3, 2          # K % 32 != 0
-    assert lib.tl_conv3_wino_nt(C_.byref(p), None) != 0
-    assert b"wino_nt" in lib.tl_last_error()
+    p.M, p.N, p.K, p.lda, p.ldb, p.J, p.Tp, p.loader = 4, 32, 24, 24, 24, 3, 4, 2          # K % 16 != 0
+    assert lib.tl_conv3_wino43v_nt(C_.byref(p), None) != 0
+    assert b"wino43v_nt" in lib.tl_last_error()
 
 
 def test_conv4_input_gradient_forms_agree_on_the_whole_model(dev, monkeypatch):
@@ -624,12 +624,13 @@ def test_conv4_input_gradient_forms_agree_on_the_whole_model(dev, monkeypatch):
             assert rel_l2(grads["nt63"][k], grads["gemm"][k]) < 1e-5, (B, C, T, k)
 
 
-@pytest.mark.parametrize("f63", ["1", "0"])
-def test_cnn_classifier_hip_forward_matches_module_graph(dev, f63, monkeypatch):
+@pytest.mark.parametrize("wino", ["6", "4", "0"])
+def test_cnn_classifier_hip_forward_matches_module_graph(dev, wino, monkeypatch):
     """CNNClassifier inference on the HIP conv kernels vs the same module's stock PyTorch graph: with its leading pooled 3-tap
-    stages on the F(6,3) V-form kernels (round 5, the default) and on the in-loop F(4,3) kernels."""
+    stages on the F(6,3) V-form kernels (round 5, the default), on the F(4,3) V form (one transform pass per stage) and on the
+    direct MFMA kernels."""
     from decode_tonal_langauge_amd.models import CNNClassifier
-    monkeypatch.setenv("TONAL_CLF_F63", f63)
+    monkeypatch.setenv("TONAL_WINO", wino)
     torch.manual_seed(0)
     for (C, T, B) in ((4, 160, 5), (3, 233, 9), (8, 400, 7)):
         clf = CNNClassifier(input_channels=C, input_length=T, n_classes=3).to(dev).eval()
@@ -638,7 +639,7 @@ def test_cnn_classifier_hip_forward_matches_module_graph(dev, f63, monkeypatch):
             hip = clf(x)
             hip2 = clf(x)                                   # (a second pass through the cached buffers / packed weights)
         assert clf._hip is not None, "HIP path was not taken"
-        assert clf._hip.n63 == (3 if f63 == "1" else 0)
+        assert clf._hip.n63 == (3 if wino == "6" else 0)
         ref = clf.classifier(clf.feature_extractor(x.unsqueeze(1).permute(0, 1, 3, 2)))
         assert hip.shape == ref.shape == (B, 3)
         assert float((hip - ref.detach()).abs().max()) < 1e-5 and torch.equal(hip, hip2)
@@ -694,17 +695,18 @@ def test_cnnrnn_classifier_hip_trunk_matches_module_graph(dev):
 @pytest.mark.parametrize("widths", [(64, 96, 32), (32, 160, 64), (96, 32, 96), (128, 64, 64)])
 def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
     """Stage kernels at the C-ABI level on channel counts that are not multiples of the column tiles
-    (tile tails in N, one- and two-chunk K loops): all three Winograd forms against the direct kernels."""
+    (tile tails in N, one- and two-chunk K loops): the F(4,3) V form (where a stage's widths allow it; the direct kernels
+    elsewhere) against the direct kernels."""
     from decode_tonal_langauge_amd._cnn_engine import CnnEngine
     c1, c2, c3 = widths
     defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
     B, C, T = 3, 5, 236
     g = torch.Generator(device=dev).manual_seed(sum(widths))
     res = {}
-    for mode in ("0", "1", "4"):
+    for mode in ("0", "4"):
         eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
-        assert not eng.wino63                      # (widths the F(6,3) kernels do not cover: the F(4,3) / F(2,3) / direct forms)
-        eng.wino, eng.wino43, eng.fuse_c1 = mode != "0", mode == "4", False
+        assert not eng.wino63                      # (widths the F(6,3) kernels do not cover: the F(4,3) V form / direct kernels)
+        eng.wino43, eng.fuse_c1 = mode == "4", False
         eng.wino_vout = False          # stage kernels one at a time on random inputs: every stage reads P
         eng._alloc(B, dev)
         eng._alloc_bwd()
@@ -723,14 +725,16 @@ def test_winograd_stage_kernels_on_ragged_widths(dev, widths):
             b = torch.randn(st.cout, device=dev, generator=g) * 0.1
             gw, gb = torch.zeros_like(w), torch.zeros_like(b)
             keep = (eng.P[si].clone(), eng.bits[si].clone(), eng.sbits[si].clone())
+            eng._v_ready = {}
+            eng.stage_wgrad(st, gw, gb)            # (the V form's input gradient reads Vd, which the weight gradient writes)
             eng.stage_dgrad(st, w)
-            eng.stage_wgrad(st, gw, gb)
             dg = eng.G[si - 1].clone()
+            eng._v_ready = {}
             eng.stage_forward(st, w, b)
             out.append((eng.P[si].clone(), eng.bits[si].clone(), dg, gw, gb))
             eng.P[si].copy_(keep[0]); eng.bits[si].copy_(keep[1]); eng.sbits[si].copy_(keep[2])
         res[mode] = out
-    for mode in ("1", "4"):
+    for mode in ("4",):
         for (p0, b0, d0, w0, g0), (p1, b1, d1, w1, g1) in zip(res["0"], res[mode]):
             assert rel(p1.cpu().numpy(), p0.cpu().numpy()) < 2e-5
             flips = (b0 ^ b1)
@@ -808,7 +812,7 @@ def test_weight_gradient_tilings_agree_bit_for_bit(dev, shape, monkeypatch):
         eng.bits[k].random_(-2**31, 2**31 - 1, generator=g)
     for si in (2, 3):
         st = eng.stages[si - 2]
-        assert eng._use_wino_vd(st)
+        assert eng._v43(st)
         eng.P[si - 1].view(eng.S, st.tp_in, -1)[:, st.tin:, :] = 0
         res = {}
         for bm in (64, 127, 128):
@@ -915,7 +919,7 @@ def test_sparse_tone_mapping_keeps_the_label_lstm_finite(dev):
         assert torch.equal(v, finals[0][k]), k
 
 
-@pytest.mark.parametrize("wino", ["6", "4", "1", "0"])
+@pytest.mark.parametrize("wino", ["6", "4", "0"])
 def test_cnn_training_trajectory_matches_reference_golden(dev, monkeypatch, wino):
     """G14: 30 NAdam steps of the reference's SynthesisModelCNN(80, 16, 200, dropout=0) on 30 seeded batches - the HIP
     path's L1 loss, MCD and mel MSE mean((out - target)^2) stay within 1e-3 of the reference at EVERY step (the bound
@@ -929,7 +933,7 @@ def test_cnn_training_trajectory_matches_reference_golden(dev, monkeypatch, wino
     torch.manual_seed(int(g["seed"]))
     model = SynthesisModelCNN(D, C, T, dropout=0.0)
     tr = _trainer(model, dev, T)
-    assert model._engine.wino == (wino != "0") and model._engine.wino43 == (wino in "46") and model._engine.wino63 == (wino == "6")
+    assert model._engine.wino43 == (wino in "46") and model._engine.wino63 == (wino == "6")
     model.train()
     worst = 0.0
     obs = {"loss": 0.0, "mcd": 0.0, "mse": 0.0, "out": 0.0}
@@ -1217,7 +1221,6 @@ def f63_stage_check(dev, shape, yprod, setenv, twice=False, ntail=False):
     from tests.wino63_ref import hex_transform, logical, unpool, y_transform
     B, C, T, c1, c2, c3 = shape
     setenv("TONAL_F63_YPROD", yprod)
-    setenv("TONAL_F63_YPROD3", yprod)
     defs = [(c1, 3, True), (c2, 3, True), (c3, 3, True), (32, 1, True), (8, 1, False)]
     engs = {}
     for mode in ("0", "6"):

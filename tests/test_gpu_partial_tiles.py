@@ -52,8 +52,7 @@ def f43_stage_check(dev, shape):
     for mode in ("0", "4"):
         eng = CnnEngine(80, C, T, 4, 8, 0.0, 0.01, defs, [16, 8])
         assert not eng.wino63
-        eng.wino, eng.wino43, eng.fuse_c1 = mode != "0", mode == "4", False
-        eng.wino43_tn = eng.wino_v = mode == "4"
+        eng.wino43, eng.fuse_c1 = mode == "4", False
         eng.wino_vout = False          # stage kernels one at a time on random inputs: every stage reads P
         eng._alloc(B, dev)
         eng._alloc_bwd()
@@ -69,7 +68,7 @@ def f43_stage_check(dev, shape):
         for si in (2, 3):
             stg = eng.stages[si - 2]
             if mode == "4":
-                assert eng._use_wino_v(stg) and eng._use_wino_vd(stg), (shape, si)
+                assert eng._v43(stg), (shape, si)
             # rows past the valid time of a sequence are zero in every real tensor (the epilogues write them so)
             eng.P[si - 1].view(eng.S, stg.tp_in, -1)[:, stg.tin:, :] = 0
             eng.G[si].view(eng.S, stg.tp_out, -1)[:, stg.tout:, :] = 0

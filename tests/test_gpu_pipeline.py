@@ -71,9 +71,9 @@ def test_deep_classifiers_hip_forward_matches_reference_golden(dev):
 
 @pytest.mark.parametrize("B,T,D,H", [(5, 7, 12, 20), (64, 9, 33, 136), (70, 4, 8, 800), (33, 1, 16, 24)])
 def test_lstm_inference_paths_against_torch_lstm(dev, B, T, D, H, monkeypatch):
-    """Both HIP inference forms of nn.LSTM(batch_first=True)(x)[0][:, -1] (reference models/deep_classifiers.py:294-296,
-    316-318): the fused one-launch-per-step kernel (64- and 32-row tiles, hidden widths padded to 8, ragged row
-    tiles, T = 1 and odd / even T for the ping-pong state) and the split-K GEMM + cell pair, against torch on the CPU."""
+    """The HIP inference form of nn.LSTM(batch_first=True)(x)[0][:, -1] (reference models/deep_classifiers.py:294-296,
+    316-318) - one fused launch per step: 32-row tiles, hidden widths padded to 8, ragged row tiles, T = 1 and odd / even T
+    for the ping-pong state - against torch on the CPU."""
     from decode_tonal_langauge_amd._classifier_engine import LstmInferEngine
     torch.manual_seed(B * 1000 + H)
     lstm = torch.nn.LSTM(D, H, batch_first=True)
@@ -81,76 +81,10 @@ def test_lstm_inference_paths_against_torch_lstm(dev, B, T, D, H, monkeypatch):
     with torch.no_grad():
         ref = lstm(x)[0][:, -1, :].double()
     w = [getattr(lstm, n).detach().to(dev) for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
-    for fused in ("1", "0"):
-        monkeypatch.setenv("TONAL_LSTM_FUSED", fused)
-        eng = LstmInferEngine(D, H)
-        assert eng.fused == (fused == "1")
-        got = eng.last_hidden(x.to(dev), *w).cpu().double()
-        assert got.shape == ref.shape
-        assert float((got - ref).abs().max()) < 2e-6, fused
-
-
-@pytest.mark.parametrize("nseq,Tp,cin,cout,taps,nseg", [(3, 20, 64, 96, 7, 3), (2, 516, 32, 40, 7, 3), (1, 8, 96, 64, 8, 3),
-                                                        (5, 12, 32, 33, 9, 3), (2, 516, 32, 40, 7, 2), (3, 20, 64, 96, 5, 2)])
-def test_segmented_winograd_conv7_against_float64(dev, nseq, Tp, cin, cout, taps, nseg):
-    """tl_conv7_wino43_nt (three F(4,3) segments) vs a float64 sliding-window convolution + LeakyReLU over
-    every row of the buffer, seams between sequences included (the classifier reads only the valid rows
-    but the kernel computes all of them): ragged column tile (cout not a multiple of 64), partial row
-    tile, 7 / 8 / 9 taps in three segments, and two segments with the remaining tap (if any) supplied
-    through ``aux`` by a one-tap window GEMM - the form the CNN-RNN classifier engine uses."""
-    import ctypes as C
-    from decode_tonal_langauge_amd import _lib
-    from decode_tonal_langauge_amd._lib import NtParams, LOAD_DIRECT, EPI_LRELU, check, ptr
-    lib = _lib.load()
-    gen = torch.Generator().manual_seed(100 * nseq + taps)
-    rows = nseq * Tp
-    x = torch.zeros(rows + 8, cin)
-    x[:rows] = torch.randn(rows, cin, generator=gen)
-    x[rows:] = torch.randn(8, cin, generator=gen)         # readable slack rows: must only reach rows >= rows - taps + 1
-    w = torch.randn(cout, cin, taps, generator=gen) / np.sqrt(cin * taps)
-    b = torch.randn(cout, generator=gen)
-    xd, wd, bd = x.to(dev), w.to(dev).contiguous(), b.to(dev)
-    wp = torch.empty(6, cout, nseg * cin, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    check(lib.tl_wino43_weights7(ptr(wd), ptr(wp), cout, cin, taps, nseg, st), "tl_wino43_weights7")
-    out = torch.full((rows, cout), float("nan"), device=dev)
-    p = NtParams()
-    p.A, p.Bw, p.bias, p.out = ptr(xd), ptr(wp), ptr(bd), ptr(out)
-    p.M, p.A_rows, p.N, p.K, p.lda, p.ldb, p.ldo = rows, rows + 2, cout, cin, cin, nseg * cin, cout
-    p.J, p.row_shift, p.Tp, p.Tvalid, p.slope = min(taps, 3 * nseg), 0, Tp, Tp, 0.3
-    p.loader, p.epilogue, p.splitk, p.bm = LOAD_DIRECT, EPI_LRELU, 1, 128
-    if taps > 3 * nseg:                                    # tap 6 of 7 by a one-tap GEMM on the rows shifted by 6
-        assert taps == 3 * nseg + 1
-        from decode_tonal_langauge_amd._lib import EPI_STORE
-        w_last = wd[:, :, taps - 1].contiguous()
-        tap = torch.full((rows, cout + 4), float("nan"), device=dev)
-        q = NtParams()
-        q.A, q.Bw, q.out = xd.data_ptr() + 4 * (taps - 1) * cin, ptr(w_last), ptr(tap)
-        q.M, q.A_rows, q.N, q.K, q.lda, q.ldb, q.ldo = rows, rows + 2, cout, cin, cin, cin, cout + 4
-        q.J, q.Tp, q.Tvalid, q.loader, q.epilogue, q.splitk, q.bm = 1, 1, 1, LOAD_DIRECT, EPI_STORE, 1, 128
-        check(lib.tl_gemm_nt_window(C.byref(q), st), "tl_gemm_nt_window")
-        p.aux, p.ldaux = ptr(tap), cout + 4
-    check(lib.tl_conv7_wino43_nt(C.byref(p), st), "tl_conv7_wino43_nt")
-    torch.cuda.synchronize()
-    x64 = x.double()
-    ref = torch.zeros(rows, cout, dtype=torch.float64)
-    for j in range(taps):
-        xs = torch.zeros(rows, cin, dtype=torch.float64)
-        n = min(rows, rows + 8 - j)
-        xs[:n] = x64[j:j + n]
-        # the kernel reads input row r only while its segment-local row < A_rows = rows + 2
-        seg_local = torch.arange(rows) + (j % 3)
-        xs[seg_local >= rows + 2] = 0
-        ref += xs @ w[:, :, j].double().T
-    ref = torch.nn.functional.leaky_relu(ref + b.double(), 0.3)
-    got = out.cpu().double()
-    assert torch.isfinite(got).all()
-    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
-    # bad arguments are refused
-    p.ldb = (nseg - 1) * cin
-    assert lib.tl_conv7_wino43_nt(C.byref(p), st) != 0 and b"ldb" in lib.tl_last_error()
-    p.ldb, p.J = nseg * cin, 3
-    assert lib.tl_conv7_wino43_nt(C.byref(p), st) != 0
+    eng = LstmInferEngine(D, H)
+    got = eng.last_hidden(x.to(dev), *w).cpu().double()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("nseq,Tp,tvalid,cin,cout,taps", [(3, 24, 21, 64, 96, 7), (2, 516, 516, 32, 64, 7), (700, 198, 197, 64, 64, 7),
