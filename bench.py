@@ -530,13 +530,11 @@ def step_issued_flops(eng, B: int, U: int, L: int) -> float:
         alg = conv_flops(eng, st.idx, B)
         if getattr(eng, "wino63", False) and eng._f63(st):
             f_nt = eng.f63_issue_factor(st)
-        elif eng._use_wino43(st):
+        elif eng._v43(st):
             f_nt = 0.5
-        elif eng._use_wino(st):
-            f_nt = 2.0 / 3.0
         else:
             f_nt = 1.0
-        f_tn = eng.wgrad_issue_factor(st) if hasattr(eng, "wgrad_issue_factor") else (2.0 / 3.0 if eng._use_wino(st) else 1.0)
+        f_tn = eng.wgrad_issue_factor(st)
         tot += alg * (2 * f_nt + f_tn)
     rows5 = B * eng.C * eng.lat
     for cin_t, cin_ld, cout_t, cout_ld in eng.concat_dims:

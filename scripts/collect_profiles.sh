@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 evidence runs on the GPU box (outputs under gpurun_out/$R05TAG/, summaries are then copied into profiles/ by
-# scripts/make_profile_summary_r05.py).  Counter passes run on their own (no trace domains beside --kernel-trace), as the pool
-# requires; the program itself follows `--` (no env / bash -c hop).   usage: scripts/collect_r05_profiles.sh <section> [...]
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${R05TAG:-r05}; mkdir -p $O
+# Evidence runs on the GPU box (outputs under gpurun_out/$RTAG/, default r06; the summaries are then built into profiles/ by
+# scripts/pmc_traffic.py, scripts/pmc_clock.py and scripts/make_profile_summary.py <tag>).  Counter passes run on their own (no trace domains beside --kernel-trace), as the pool
+# requires; the program itself follows `--` (no env / bash -c hop).   usage: [RTAG=r06] scripts/collect_profiles.sh <section> [...]
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${RTAG:-r06}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-extras"
 SQ="SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE"

@@ -26,6 +26,9 @@ FAMILIES = {
     "wino63v_tn4y_kernel": f"wino63v_tn4y_kernel (conv2 / conv3 weight gradient, {F6}: both operands by LDS-DMA, no transform in the kernel; average of the two launches)",
     "wino63_unpool_yvd_kernel": "wino63_unpool_yvd_kernel (Y3 / Vd3 of conv3 from G3 and its arg-max bits)",
     "conv1_fwd_vh_kernel": "conv1_fwd_vh_kernel (conv1 + LeakyReLU + pool writing V1 in hex form)",
+    "nadam_lowrank_kernel<true>": "nadam_lowrank_kernel<true> (NAdam on W_hh from its gradient factors + the last BPTT product dh_1 in the same pass)",
+    "tn_skinny_kernel": "tn_skinny_kernel (dgates . W_hh on the distinct label rows: one 5.4 GB pass)",
+    "nt_window_kernel<32, 0, 0>": "nt_window_kernel<32, 0, 0> (h . W_hh^T on the distinct label rows: one 5.4 GB pass)",
     "wino63v_tn4_kernel<true>": f"wino63v_tn4_kernel<true> (conv3 weight gradient, {F6}; also writes Vd)",
     "wino43v_nt_kernel<5>": "wino43v_nt_kernel<POOLV> (conv2 forward, Winograd F(4,3) on V, LDS-DMA; writes V of its pooled output for conv3 instead of the raw rows)",
     "wino43v_nt_kernel<2>": "wino43v_nt_kernel<POOL> (conv3 forward, Winograd F(4,3) on the pre-transformed input V, LDS-DMA)",
