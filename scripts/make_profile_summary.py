@@ -1,10 +1,11 @@
 """profiles/<tag>_c3_step_summary.md from the committed rocprofv3 kernel stats (profiles/<tag>_c3_step_kernel_stats.csv), the PMC
 traffic / clock reductions (profiles/pmc_traffic.json, effective_clock.json) and the bench line (profiles/<tag>_c3_bench_line.log).
 
-    python scripts/make_profile_summary.py r06
+    python scripts/make_profile_summary.py r06 [raw-dir]
 """
 import csv, json, os, sys
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
+RAW = sys.argv[2] if len(sys.argv) > 2 else TAG          # directory under gpurun_out/ the passes were collected into
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda *a: os.path.join(ROOT, "profiles", *a)
 rows = list(csv.DictReader(open(P(f"{TAG}_c3_step_kernel_stats.csv"))))
@@ -14,8 +15,8 @@ ck = json.load(open(P("effective_clock.json")))["effective_clock_ghz"]
 line = json.loads([l for l in open(P(f"{TAG}_c3_bench_line.log")) if l.startswith("{")][-1])
 roof = line["roofline"]
 pl = roof["per_launch"]
-out = [f"# Round {int(TAG[1:3])} - C3 train step, 1x MI355X, rocprofv3 --kernel-trace --stats (final build of the round, `gpurun_out/{TAG}`)\n",
-       f"Command (GPU box, `RTAG={TAG} scripts/collect_profiles.sh bench c3stats c3fetch c3write c3clock`, one call, one box): "
+out = [f"# Round {int(TAG[1:3])} - C3 train step, 1x MI355X, rocprofv3 --kernel-trace --stats (final build of the round, `gpurun_out/{RAW}`)\n",
+       f"Command (GPU box, `RTAG={RAW} scripts/collect_profiles.sh bench c3stats c3fetch c3write c3clock`, one call, one box): "
        "`rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -o r3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
        "--no-kernel-timers --no-extras`\n",
        f"4 train steps (1 warm-up incl. the one-time zero-fills + 3 timed) of SynthesisModelCNN 128ch x 400t, batch 256, fp32.  Total kernel time "
