@@ -182,6 +182,15 @@ def _tl_worker(port, q):
     assert torch.equal(x, y) and torch.equal(x, z)
     t = torch.arange(12, device=dev, dtype=torch.float32).view(3, 4)
     assert torch.equal(parallel.all_gather_param_rows_(t.clone(), 0, 3), t)          # in place through the handle
+    # bench.py's replica check carried by the handle (fp32 pieces of the fp64 checksums through tl_allreduce MIN / MAX)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert parallel.tl_active() and bench.replica_spread_tl([model, tr.tone_model], parallel) == 0.0
+    bad = torch.nn.Linear(3, 2).to(dev)
+    with torch.no_grad():
+        bad.weight[0, 0] = float("nan")
+    assert bench.replica_spread_tl([bad], parallel) != 0.0                             # a non-finite checksum reads as NaN
     pend = parallel.all_reduce_async(x.clone())
     pend.wait()
     assert lib.tl_allreduce(None, x.data_ptr(), x.data_ptr(), 4, 0, st) != 0 and b"allreduce" in lib.tl_last_error()
@@ -503,6 +512,14 @@ def _tl_worker_multi(rank, world, port, q):
         tr.train_step(*bt)
     tr.sync_parameters()
     torch.cuda.synchronize()
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.replica_spread_tl([model], parallel) == 0.0                           # identical replicas, seen through the handle
+    odd = torch.nn.Linear(3, 2).to(dev)
+    with torch.no_grad():
+        odd.weight.fill_(float(rank))
+    assert bench.replica_spread_tl([odd], parallel) > 0.0                              # ... and a diverged one is caught
     q.put((rank, {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}))
     parallel.tl_comm_destroy()
     dist.destroy_process_group()
