@@ -6,7 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# The A/B tests flip one kernel switch at a time through the per-switch variables (TONAL_WINO, TONAL_WINO_V, ...): the product
+# The A/B tests flip one kernel switch at a time through the per-switch variables (TONAL_WINO, TONAL_HILBERT, ...): the product
 # honours those only under TONAL_AB=1 (decode_tonal_langauge_amd/_kernels.py); its own setting is TONAL_KERNELS.
 os.environ.setdefault("TONAL_AB", "1")
 
