@@ -171,7 +171,14 @@ def all_gather_param_rows_(p: torch.Tensor, row0: int, rows: int) -> torch.Tenso
         dist.all_gather_into_tensor(ho, mine.detach().cpu().contiguous())
         p.copy_(ho)
     else:
-        dist.all_gather_into_tensor(p, mine)        # in place: the input is this rank's chunk of the output
+        try:
+            dist.all_gather_into_tensor(p, mine)    # in place: the input is this rank's chunk of the output (NCCL's in-place form)
+        except (RuntimeError, ValueError):
+            # an argument check that refuses the aliased input fires on every rank alike, before anything is enqueued: take the
+            # out-of-place form (one temporary of the parameter's size) everywhere
+            tmp = torch.empty_like(p)
+            dist.all_gather_into_tensor(tmp, mine.contiguous())
+            p.copy_(tmp)
     return p
 
 
