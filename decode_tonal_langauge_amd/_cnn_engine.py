@@ -1034,10 +1034,11 @@ class CnnEngine:
         w_hh = prm["label_lstm.weight_hh_l0"]
         ldt = (U + 31) // 32 * 32
         dg = torch.empty(L, U, 4 * H, **f32)
-        dgt = torch.zeros(4 * H, ldt, **f32) if L > 1 else None
+        stream_gw = U <= 8 and H % 4 == 0                    # dgates . W_hh on tl_lstm_gw (reads dg[t] itself: no transposed copy)
+        dgt = torch.zeros(4 * H, ldt, **f32) if (L > 1 and not stream_gw) else None
         dc = [torch.empty(U, H, **f32), torch.empty(U, H, **f32)]
         dhrec = torch.empty(U, H, **f32) if L > 1 else None
-        if L > 1:
+        if L > 1 and not stream_gw:
             kloc = sh[1] if sh else 4 * H                      # gate rows this rank contracts over
             if ldt <= 32:        # skinny streaming kernel: 32 x 512 tiles, 16-deep K stages
                 sk_h = self._splitk_rounds((H + 511) // 512, (kloc + 15) // 16)
@@ -1050,11 +1051,13 @@ class CnnEngine:
         fuse_dh = (L > 1 and not sh and gather_whh is None and whh_factors and (L - 1) * U <= 64 and U <= 8
                    and on_factors is not None and getattr(on_factors, "fuse_dh", False) and _kernels.get("whh_dh") != "0")
         fused_done = False
+        slab_g = None
         for t in range(L - 1, -1, -1):
             check(lib.tl_lstm_cell_bwd(ptr(dh_ext) if t == L - 1 else None, ptr(dhrec) if t < L - 1 else None,
                                        ptr(dc[(t + 1) & 1]) if t < L - 1 else None, ptr(self._act[t]), ptr(self._c[t]),
                                        ptr(self._c[t - 1]) if t > 0 else None, ptr(dg[t]),
-                                       ptr(dgt) if t > 0 else None, ptr(dc[t & 1]), U, H, ldt, st_), "tl_lstm_cell_bwd")
+                                       ptr(dgt) if (t > 0 and dgt is not None) else None, ptr(dc[t & 1]), U, H, ldt, st_),
+                  "tl_lstm_cell_bwd")
             if t == 1 and fuse_dh:
                 kr = (L - 1) * U
                 self.whh_factors = (dg[1:].reshape(kr, 4 * H), self._h[:L - 1].reshape(kr, H))
@@ -1067,11 +1070,29 @@ class CnnEngine:
             elif t > 0 and sh:
                 # partial dgates . W_hh over this rank's gate rows, summed over the ranks
                 r0, R, _wd = sh
-                self._tn(A=dgt.data_ptr() + 4 * r0 * ldt, B=w_hh.data_ptr() + 4 * r0 * H, slab=ptr(slab_h), Krows=R,
-                         A_rows=R, B_rows=R, Mdim=ldt, Ndim=H, lda=ldt, ldb=H, ldc=H, loader=LOAD_DIRECT, splitk=sk_h,
-                         slab_stride=ldt * H)
-                self._permute(slab_h, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=sk_h, zs=ldt * H)
+                if stream_gw:
+                    rpb = 512
+                    nb = -(-R // rpb)
+                    if slab_g is None:
+                        slab_g = torch.empty(nb, U, H, **f32)
+                    check(lib.tl_lstm_gw(dg[t].data_ptr() + 4 * r0, w_hh.data_ptr() + 4 * r0 * H, ptr(slab_g), U, R, H, 4 * H, H,
+                                         rpb, st_), "tl_lstm_gw")
+                    self._permute(slab_g, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=nb, zs=U * H)
+                else:
+                    self._tn(A=dgt.data_ptr() + 4 * r0 * ldt, B=w_hh.data_ptr() + 4 * r0 * H, slab=ptr(slab_h), Krows=R,
+                             A_rows=R, B_rows=R, Mdim=ldt, Ndim=H, lda=ldt, ldb=H, ldc=H, loader=LOAD_DIRECT, splitk=sk_h,
+                             slab_stride=ldt * H)
+                    self._permute(slab_h, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=sk_h, zs=ldt * H)
                 parallel.all_reduce_(dhrec)
+            elif t > 0 and stream_gw:
+                # dgates_t . W_hh as a pure stream of the 5.4 GB weight (tl_lstm_gw, round 6): 512-row blocks, the partial
+                # products of the 144 blocks summed behind it
+                rpb = 512
+                nb = -(-4 * H // rpb)
+                if slab_g is None:
+                    slab_g = torch.empty(nb, U, H, **f32)
+                check(lib.tl_lstm_gw(ptr(dg[t]), ptr(w_hh), ptr(slab_g), U, 4 * H, H, 4 * H, H, rpb, st_), "tl_lstm_gw")
+                self._permute(slab_g, dhrec, (1, 1, U, H), (0, 0, H, 1), nz=nb, zs=U * H)
             elif t > 0:
                 self._tn(A=ptr(dgt), B=ptr(w_hh), slab=ptr(slab_h), Krows=4 * H, A_rows=4 * H, B_rows=4 * H, Mdim=ldt,
                          Ndim=H, lda=ldt, ldb=H, ldc=H, loader=LOAD_DIRECT, splitk=sk_h, slab_stride=ldt * H)

@@ -102,6 +102,7 @@ SIGNATURES = {
     "tl_permute_reduce": (_I, [_P, _P, C.POINTER(_L), C.POINTER(_L), C.POINTER(_L), _I, _L, _P, _P]),
     "tl_colsum": (_I, [_P, _P, _I, _L, _I, _I, _I, _I, _P]),
     "tl_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tl_lstm_gw": (_I, [_P, _P, _P, _I, _L, _I, _L, _L, _I, _P]),
     "tl_lstm_infer_seq_fused": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, C.POINTER(C.c_int), _P]),
     "tl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "tl_lstm_ih_grad": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

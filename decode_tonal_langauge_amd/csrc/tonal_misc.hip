@@ -622,6 +622,59 @@ __global__ __launch_bounds__(64) void lstm_ih_grad_wave_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// dgates . W_hh of the label LSTM on its U <= 8 DISTINCT label rows (round 6): W_hh is 5.4 GB at the north-star shape and the
+// product is a pure stream of it - what matters is bytes in flight, not the matrix pipe (the MFMA form it replaces, a skinny TN
+// GEMM through LDS with split-K slabs, ran at 5.2 TB/s; this one at 5.8, a library GEMM on the same operands at 6.0).
+//   lstm_gw_kernel    slab[rb][u][k] = sum_{n in block rb} g[u][n] W[n][k]   (a thread owns 4 consecutive k, a workgroup 1024
+//                     columns x `rpb` rows with g of the row block in LDS as [row][8]; eight 16-byte loads in flight per lane;
+//                     the caller sums the slabs).  Same arithmetic in a different summation order (fp32 FMA chains along n).
+// (The forward product h W_hh^T stays on tl_gemm_nt_window: a row-dot streaming form of it ran at 4.3 TB/s - every wave needs all
+// of h, and a grid of 8-row waves leaves a third of the chip idle in its last round - measured, profiles/r06_kernel_notes.md 7.)
+// ------------------------------------------------------------------------------------------
+constexpr int HW_MAXU = 8;
+constexpr int GW_COLS = 1024, GW_MAXROWS = 1024;
+__global__ __launch_bounds__(256, 2) void lstm_gw_kernel(const float* __restrict__ g, const float* __restrict__ W,
+                                                         float* __restrict__ slab, int U, long long N, int K, long long ldg,
+                                                         long long ldw, int rpb) {
+  __shared__ __attribute__((aligned(16))) float sg[GW_MAXROWS * HW_MAXU];       // [row of the block][u] (rows u >= U: zero)
+  const int k = blockIdx.x * GW_COLS + 4 * threadIdx.x;
+  const long long r0 = (long long)blockIdx.y * rpb;
+  const int nr = (int)(N - r0 < rpb ? N - r0 : rpb);
+  for (int i = threadIdx.x; i < HW_MAXU * rpb; i += 256) {
+    const int u = i / rpb, r = i - u * rpb;                             // (consecutive threads read consecutive n of one u)
+    sg[r * HW_MAXU + u] = (u < U && r < nr) ? g[(long long)u * ldg + r0 + r] : 0.f;
+  }
+  __syncthreads();
+  f32x4 acc[HW_MAXU];
+#pragma unroll
+  for (int u = 0; u < HW_MAXU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (k < K) {                                                          // K % 4 == 0: the float4 is in or out
+    const float* wp = W + r0 * ldw + k;
+    auto row = [&](const f32x4 wv, int r) {
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(sg + r * HW_MAXU), gb = *reinterpret_cast<const f32x4*>(sg + r * HW_MAXU + 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[u] += ga[u] * wv;                                           // (u >= U: a zero factor)
+        acc[u + 4] += gb[u] * wv;
+      }
+    };
+    int r = 0;
+#pragma unroll 1
+    for (; r + 8 <= nr; r += 8) {
+      f32x4 wv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wv[q] = *reinterpret_cast<const f32x4*>(wp + (long long)(r + q) * ldw);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) row(wv[q], r + q);
+    }
+    for (; r < nr; ++r) row(*reinterpret_cast<const f32x4*>(wp + (long long)r * ldw), r);
+#pragma unroll
+    for (int u = 0; u < HW_MAXU; ++u)
+      if (u < U) *reinterpret_cast<f32x4*>(slab + ((long long)blockIdx.y * U + u) * K + k) = acc[u];
+  }
+}
+
 // One inference step of the LSTM in ONE launch (instead of split-K GEMM + cell): a workgroup owns 32
 // batch rows and 8 hidden units = 32 gate columns (the recurrent weight is packed unit-major, row 4 u + g,
 // so a tile holds whole cells); gates = h_prev . Wp^T + xp[t], then the cell update.  8 interleaved K slices
@@ -1368,6 +1421,20 @@ extern "C" int tl_lstm_cell_fwd(const float* hh, const float* x_t, const float* 
   hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      hh, x_t, w_ih, b_ih, b_hh, c_prev, act, c, h, U, H, in_dim, ld_hh);
   return check_launch("lstm_cell_fwd");
+}
+
+extern "C" int tl_lstm_gw(const float* g, const float* W, float* slab, int U, int64_t N, int K, int64_t ldg, int64_t ldw,
+                          int rows_per_block, void* stream) {
+  TL_REQUIRE(g && W && slab, "lstm_gw: null pointer");
+  TL_REQUIRE(U >= 1 && U <= HW_MAXU && N > 0 && K > 0 && K % 4 == 0, "lstm_gw: 1 <= U <= %d, K %% 4 == 0 needed", HW_MAXU);
+  TL_REQUIRE(rows_per_block >= 8 && rows_per_block <= GW_MAXROWS, "lstm_gw: rows_per_block must be 8..%d", GW_MAXROWS);
+  TL_REQUIRE(ldg >= N && ldw >= K && ldw % 4 == 0, "lstm_gw: leading dimensions too small (ldw a multiple of 4)");
+  TL_REQUIRE((((uintptr_t)W | (uintptr_t)slab) & 15) == 0, "lstm_gw: W and slab must be 16-byte aligned");
+  const long long nb = (N + rows_per_block - 1) / rows_per_block;
+  TL_REQUIRE(nb <= 65535, "lstm_gw: more than 65 535 row blocks");
+  hipLaunchKernelGGL(lstm_gw_kernel, dim3((unsigned)((K + GW_COLS - 1) / GW_COLS), (unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, W,
+                     slab, U, (long long)N, K, (long long)ldg, (long long)ldw, rows_per_block);
+  return check_launch("lstm_gw");
 }
 
 // All T steps of an inference LSTM, one fused launch per step (lstm_step_fused_kernel).  wp: the recurrent weight packed

@@ -293,6 +293,12 @@ int tl_colsum(const float* G, float* partial, int nblk, int64_t rows, int ncols,
 int tl_lstm_cell_fwd(const float* hh, const float* x_t, const float* w_ih, const float* b_ih,
                      const float* b_hh, const float* c_prev, float* act, float* c, float* h,
                      int U, int H, int in_dim, int ld_hh, void* stream);
+/* dgates . W of the label LSTM on its U <= 8 distinct label rows as a pure stream of W (N x K, row stride ldw;
+ * label_lstm.weight_hh_l0: 73 728 x 18 432 at the north-star shape) - torch's LSTM backward inside loss.backward(),
+ * models/synthesis_trainer.py:226:  slab[b][u][k] = sum_{n in row block b} g[u][n] W[n][k]; ceil(N / rows_per_block) slabs of
+ * U x K floats, summed by the caller (tl_permute_reduce); rows_per_block 8..1024; K % 4 == 0, 16-byte aligned W / slab.       */
+int tl_lstm_gw(const float* g, const float* W, float* slab, int U, int64_t N, int K, int64_t ldg, int64_t ldw, int rows_per_block,
+               void* stream);
 /* inference-only sequence (models/deep_classifiers.py:230-233,294-296,316-318: the CNN-RNN classifier's two LSTMs, run
  * forward-only by the synthesis trainer): xp[u*xp_row_stride + t*4H + gate*H + k] = input projection + both biases of every
  * step, pre-computed by one GEMM (rows are (b, t): xp_row_stride = T*4H or more).

@@ -48,6 +48,8 @@ def test_abi_argument_validation_without_gpu():
     assert b"dh_slab" in lib.tl_last_error()
     assert lib.tl_nadam_lowrank_dh(16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 0., 0., .9, .999, 1., 1e-8, 0., 1., 16, 9, 2, None) == -1
     assert b"U <=" in lib.tl_last_error()
+    assert lib.tl_lstm_gw(16, 16, 16, 9, 64, 64, 64, 64, 512, None) == -1 and b"U <=" in lib.tl_last_error()
+    assert lib.tl_lstm_gw(16, 16, 16, 8, 64, 64, 64, 64, 2048, None) == -1 and b"rows_per_block" in lib.tl_last_error()
     assert lib.tl_filtfilt_scan_f64(16, 1, 16, 16, 16, 16, 7, 16, 16, 16, 2, 5000, 10, 128, None) == -1 and b"ntaps" in lib.tl_last_error()
     assert lib.tl_filtfilt_scan_f64(16, 1, 16, 16, 16, 16, 3, 16, 16, 16, 2, 5000, 9, 128, None) == -1 and b"levels" in lib.tl_last_error()
     assert lib.tl_filtfilt_f64(16, 1, 16, 16, 16, 16, 16, 2, 20, 9, None) == -1

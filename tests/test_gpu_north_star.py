@@ -663,3 +663,30 @@ def test_lowrank_nadam_pass_also_yields_the_last_bptt_product(dev):
             assert float((got - ref).abs().max()) < 1e-5 * float(ref.abs().max()), (rows, cols, kr, U, row_tiles)
     with pytest.raises(RuntimeError):           # U above the factor rank / a slab of the wrong shape
         ob.step_lowrank({pb: (fa[:2], fb[:2])}, dh=(torch.empty(1, 5, cols, device=dev), 5, 2))
+
+
+def test_recurrent_gradient_stream_matches_float64(dev):
+    """tl_lstm_gw (dgates . W as a stream of W, round 6): ragged row counts (a last block shorter than the others, fewer rows than
+    one block), K that is not a multiple of the 1024-column workgroup tile, every U, a row-offset view (the data-parallel shard form),
+    against a float64 product."""
+    from decode_tonal_langauge_amd._lib import check, load, ptr
+    lib = load()
+    st = torch.cuda.current_stream().cuda_stream
+    g_ = torch.Generator(device=dev).manual_seed(17)
+    for N, K, U, rpb in ((4099, 1028, 8, 512), (300, 2052, 1, 512), (2048, 1024, 5, 8), (1536, 516, 8, 1024)):
+        W = torch.randn(N, K, device=dev, generator=g_)
+        g = torch.randn(U, N, device=dev, generator=g_)
+        nb = -(-N // rpb)
+        slab = torch.full((nb, U, K), float("nan"), device=dev)
+        check(lib.tl_lstm_gw(ptr(g), ptr(W), ptr(slab), U, N, K, N, K, rpb, st), "tl_lstm_gw")
+        ref = g.double() @ W.double()
+        got = slab.double().sum(0)
+        assert float((got - ref).abs().max()) < 2e-6 * float(ref.abs().max()), (N, K, U, rpb)
+    # rows [r0, r0 + R) of a wider gradient / a taller weight
+    N, K, U, r0, R = 4096, 1024, 8, 1024, 2048
+    W = torch.randn(N, K, device=dev, generator=g_)
+    g = torch.randn(U, N, device=dev, generator=g_)
+    slab = torch.empty(-(-R // 512), U, K, device=dev)
+    check(lib.tl_lstm_gw(g.data_ptr() + 4 * r0, W.data_ptr() + 4 * r0 * K, ptr(slab), U, R, K, N, K, 512, st), "tl_lstm_gw")
+    ref = g[:, r0:r0 + R].double() @ W[r0:r0 + R].double()
+    assert float((slab.double().sum(0) - ref).abs().max()) < 2e-6 * float(ref.abs().max())
