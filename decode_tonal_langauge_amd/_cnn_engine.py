@@ -1034,7 +1034,8 @@ class CnnEngine:
         w_hh = prm["label_lstm.weight_hh_l0"]
         ldt = (U + 31) // 32 * 32
         dg = torch.empty(L, U, 4 * H, **f32)
-        stream_gw = U <= 8 and H % 4 == 0                    # dgates . W_hh on tl_lstm_gw (reads dg[t] itself: no transposed copy)
+        # dgates . W_hh on tl_lstm_gw (reads dg[t] itself: no transposed copy)
+        stream_gw = U <= 8 and H % 4 == 0 and _kernels.get("whh_stream") != "0"
         dgt = torch.zeros(4 * H, ldt, **f32) if (L > 1 and not stream_gw) else None
         dc = [torch.empty(U, H, **f32), torch.empty(U, H, **f32)]
         dhrec = torch.empty(U, H, **f32) if L > 1 else None

@@ -47,6 +47,8 @@ KEYS: Dict[str, Tuple[str, _Allowed, str, str]] = {
     # ---- optimiser / trainer
     "whh_dh": ("TONAL_WHH_DH", _B, "1", "single process: the W_hh NAdam pass also produces the last BPTT product dh_1 = dgates_2 . W_hh "
                                         "(0: a W_hh stream of its own for it)"),
+    "whh_stream": ("TONAL_WHH_STREAM", _B, "1", "label LSTM backward: dgates . W_hh as a pure stream of the weight (tl_lstm_gw; 0: the skinny "
+                                                "MFMA GEMM with split-K slabs, also the form for more than 8 distinct label rows)"),
     "graph": ("TONAL_GRAPH", _B, "1", "SynthesisLite step replayed as a HIP graph"),
     "lstm_shard": ("TONAL_LSTM_SHARD", _B, "1", "data parallel: label LSTM sharded by gate rows"),
     # ---- preprocess/signal
