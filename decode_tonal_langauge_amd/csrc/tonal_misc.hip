@@ -629,8 +629,8 @@ __global__ __launch_bounds__(64) void lstm_ih_grad_wave_kernel(const float* __re
 //   lstm_gw_kernel    slab[rb][u][k] = sum_{n in block rb} g[u][n] W[n][k]   (a thread owns 4 consecutive k, a workgroup 1024
 //                     columns x `rpb` rows with g of the row block in LDS as [row][8]; eight 16-byte loads in flight per lane;
 //                     the caller sums the slabs).  Same arithmetic in a different summation order (fp32 FMA chains along n).
-// (The forward product h W_hh^T stays on tl_gemm_nt_window: a row-dot streaming form of it ran at 4.3 TB/s - every wave needs all
-// of h, and a grid of 8-row waves leaves a third of the chip idle in its last round - measured, profiles/r06_kernel_notes.md 7.)
+// (The forward product h W_hh^T stays on tl_gemm_nt_window: two row-dot streaming forms of it - h in registers, h staged in LDS -
+// ran at 4.3 and 3.6 TB/s against the MFMA form's 5.3; measured and removed, profiles/r06_kernel_notes.md 7.)
 // ------------------------------------------------------------------------------------------
 constexpr int HW_MAXU = 8;
 constexpr int GW_COLS = 1024, GW_MAXROWS = 1024;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""The two recurrent products of the label LSTM at the north-star shape (W_hh 73 728 x 18 432, U = 8): the streaming kernels of
-round 6 (tl_lstm_hwt, tl_lstm_gw) against the MFMA forms they replace (tl_gemm_nt_window with 32-row tiles + slab sum,
-tl_gemm_tn_window skinny form + slab sum) and a library GEMM on the same operands.  HIP events, 10 launches each."""
+"""The recurrent products of the label LSTM at the north-star shape (W_hh 73 728 x 18 432, U = 8): the streaming kernel of round 6
+(tl_lstm_gw: dgates . W) for several row-block sizes, and a library GEMM on the same operands for both products as the yardstick
+(the MFMA forms: 1.03 ms forward, 1.05 ms backward, profiles/r06_c3_step_summary.md).  HIP events, 10 launches each."""
 import ctypes as C
 import os
 import sys
@@ -32,14 +32,8 @@ def timed(fn, n=10):
     return e0.elapsed_time(e1) / n
 
 
-ref_f = (h.double() @ W.double().t())
-out = torch.empty(U, N, device=dev)
-t = timed(lambda: check(lib.tl_lstm_hwt(ptr(h), ptr(W), ptr(out), U, N, K, K, K, N, st), "hwt"))
-err = float((out.double() - ref_f).abs().max() / ref_f.abs().max())
-print(f"tl_lstm_hwt                         {t:7.3f} ms  {gb / t:5.2f} TB/s   max rel err vs fp64 {err:.1e}")
 t = timed(lambda: h @ W.t())
 print(f"library GEMM  h @ W^T               {t:7.3f} ms  {gb / t:5.2f} TB/s")
-del ref_f
 ref_b = (g.double() @ W.double())
 for rpb in (256, 512, 1024):
     nb = -(-N // rpb)
