@@ -263,10 +263,10 @@ class CnnEngine:
         return int(max(1, min(ksteps, (target + tiles - 1) // tiles, 1024)))
 
     @staticmethod
-    def _splitk_rounds(tiles: int, ksteps: int, slots: int = 512, max_sk: int = 32) -> int:
+    def _splitk_rounds(tiles: int, ksteps: int, slots: int = 512, max_sk: int = 32, min_rounds: float = 1.9) -> int:
         """Split-K factor for the HBM-streaming GEMMs over W_hh: the workgroup count should fill whole
         rounds of the 512 resident workgroup slots (256 CUs x 2) - a partial last round streams at a
-        fraction of the bandwidth.  Smallest factor whose last round is >= 95 % full with about two
+        fraction of the bandwidth.  Smallest factor whose last round is >= 95 % full with ``min_rounds``
         rounds or more; failing that the fullest."""
         cands = []
         for sk in range(1, max(1, min(max_sk, ksteps)) + 1):
@@ -274,7 +274,7 @@ class CnnEngine:
             cands.append((sk, n, n / (-(-n // slots) * slots)))
         full = [c for c in cands if c[2] >= 0.95]
         for sk, n, _ in full:
-            if n >= 1.9 * slots:
+            if n >= min_rounds * slots:
                 return sk
         if full:
             return full[-1][0]
@@ -875,7 +875,9 @@ class CnnEngine:
             rk, wd = self.lstm_shard
             self._sh = (rk * (4 * H // wd), 4 * H // wd, wd)
         nloc = self._sh[1] if self._sh else 4 * H
-        sk_f = self._splitk_rounds(((U + bm - 1) // bm) * ((nloc + 127) // 128), (H + 31) // 32) if L > 1 else 1
+        # (measured at the north-star shape, 576 column tiles: 7 splits 1.048 ms, 8 0.996, 16 0.990, 32 1.017 - the 32-row kernel
+        # keeps three workgroups per CU, so nine rounds of 512 are six whole rounds of 768: profiles/r06_kernel_notes.md 7)
+        sk_f = self._splitk_rounds(((U + bm - 1) // bm) * ((nloc + 127) // 128), (H + 31) // 32, min_rounds=8.9) if L > 1 else 1
         slab_f = torch.empty(sk_f, U, nloc, **f32) if sk_f > 1 else None
         if self._sh:
             from . import parallel
