@@ -3,7 +3,7 @@
 single-GPU `rank_batch_probe` of a default bench line (train-step time at the per-rank batches 128 / 64 / 32, whole LSTM on the
 rank, no exchange) - machine-readable form of DESIGN.md section 7 (review item 9c).  NOTHING here is measured on N > 1 GPUs.
 
-    python scripts/make_scaling_prediction.py profiles/r06_default_bench_line.log
+    python scripts/make_scaling_prediction.py profiles/r06_c3_bench_line.log
 
 Model: per-rank step(N) = probe[256 / N] - whh_ms (N - 1) / N  (the row-sharded label LSTM divides the W_hh passes and its NAdam pass)
                         + exchange(N) + small_collectives (ten dependent ones of the sharded LSTM) ; exchange = ring all-reduce of
@@ -13,11 +13,11 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_default_bench_line.log")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_c3_bench_line.log")
 line = json.loads([l for l in open(src) if l.startswith("{")][-1])
 probe = {int(k): float(v) for k, v in line["rank_batch_probe"]["ms_per_step_at_batch"].items()}
 probe[256] = float(line["ms_per_step"])
-WHH_MS = 7 * 1.03 + 5.7            # seven 5.4 GB passes over W_hh + the NAdam pass (profiles/r06_c3_step_summary.md)
+WHH_MS = 4 * 0.96 + 3 * 0.94 + 5.7            # seven 5.4 GB passes over W_hh + the NAdam pass (profiles/r06_c3_step_summary.md)
 EXCH_BYTES = 72e6                  # every gradient except W_hh
 LINK = 100e9                       # achieved per direction on one xGMI link (assumption; the spec is ~153 GB/s)
 rows = []
