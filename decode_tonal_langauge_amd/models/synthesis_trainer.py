@@ -378,6 +378,8 @@ class SynthesisTrainer:
                 rows = p.shape[0] // self.world
                 r0 = self.rank * rows
                 for key in ("exp_avg", "exp_avg_sq"):
+                    if p.is_cuda:
+                        torch.cuda.empty_cache()              # (a fresh allocation per moment tensor: optim.FusedNAdam._state_for)
                     if want is not None:                      # whole -> this rank's rows
                         st[key] = st[key][r0:r0 + rows].clone()
                     else:                                     # row shards -> the whole matrix on every rank
